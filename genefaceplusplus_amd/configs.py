@@ -1,0 +1,85 @@
+"""Merged hyper-parameters of the reference's shipped "May" configurations.
+
+These are *data*: the model/render-relevant subset of what the reference's yaml chain
+(egs/egs_bases/radnerf/base.yaml -> lm3d_radnerf.yaml -> egs/datasets/May/*.yaml, resolved by
+utils/commons/hparams.py:53-190) produces.  tests/golden/make_golden.py re-derives them with the
+reference's own loader and the result is pinned in tests/golden/may_hparams.json.
+
+A real deployment passes the checkpoint's own ``config.yaml`` dict instead; every key the renderer reads
+is listed here so that a synthetic model of the same shape can be built without the reference tree.
+"""
+import copy
+
+_BASE = {
+    # NeRF geometry / marching (base.yaml:53-82)
+    "cuda_ray": True,
+    "max_steps": 16,
+    "min_near": 0.05,
+    "bound": 1,
+    "camera_scale": 4.0,
+    "camera_offset": [0, 0, 0],
+    "grid_size": 128,
+    "desired_resolution": 2048,
+    "log2_hashmap_size": 16,
+    "dt_gamma": 0.00390625,
+    "density_thresh": 10,
+    "density_thresh_torso": 0.01,
+    "torso_shrink": 0.8,
+    "near": 0.3,
+    "far": 0.9,
+    # network (base.yaml:86-103, lm3d_radnerf.yaml)
+    "grid_type": "tiledgrid",
+    "grid_interpolation_type": "linear",
+    "with_att": True,
+    "use_window_cond": True,
+    "torso_head_aware": False,
+    "num_layers_sigma": 3,
+    "hidden_dim_sigma": 128,
+    "geo_feat_dim": 128,
+    "num_layers_color": 2,
+    "hidden_dim_color": 128,
+    "cond_out_dim": 64,
+    "num_layers_ambient": 3,
+    "hidden_dim_ambient": 128,
+    "ambient_coord_dim": 3,
+    "individual_embedding_num": 13000,
+    "individual_embedding_dim": 4,
+    "torso_individual_embedding_dim": 8,
+    "cond_type": "idexp_lm3d_normalized",
+    "nerf_keypoint_mode": "lm68",
+    "cond_win_size": 1,
+    "smo_win_size": 5,
+    "cond_dropout_rate": 0.0,
+    "amp": True,
+    "seed": 9999,
+    "video_id": "May",
+}
+
+_VARIANTS = {
+    # egs/datasets/May/lm3d_radnerf.yaml
+    "may_head": {},
+    # egs/datasets/May/lm3d_radnerf_sr.yaml
+    "may_head_sr": {"with_sr": True, "smo_win_size": 3, "add_eye_blink_cond": True, "eye_blink_dim": 2},
+    # egs/datasets/May/lm3d_radnerf_torso.yaml
+    "may_torso": {},
+    # egs/datasets/May/lm3d_radnerf_torso_sr.yaml
+    "may_torso_sr": {"with_sr": True, "smo_win_size": 3, "add_eye_blink_cond": True, "eye_blink_dim": 4,
+                     "torso_head_aware": True},
+}
+
+#: reference yaml each variant was derived from (relative to the reference root)
+VARIANT_YAML = {
+    "may_head": "egs/datasets/May/lm3d_radnerf.yaml",
+    "may_head_sr": "egs/datasets/May/lm3d_radnerf_sr.yaml",
+    "may_torso": "egs/datasets/May/lm3d_radnerf_torso.yaml",
+    "may_torso_sr": "egs/datasets/May/lm3d_radnerf_torso_sr.yaml",
+}
+
+
+def may_hparams(variant="may_torso"):
+    """Return a fresh hparams dict for one of: may_head, may_head_sr, may_torso, may_torso_sr."""
+    if variant not in _VARIANTS:
+        raise KeyError(f"unknown variant {variant!r}; choose from {sorted(_VARIANTS)}")
+    hp = copy.deepcopy(_BASE)
+    hp.update(copy.deepcopy(_VARIANTS[variant]))
+    return hp

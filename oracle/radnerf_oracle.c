@@ -1,0 +1,393 @@
+/*
+ * radnerf_oracle.c -- CPU restatement of the GeneFace++ radnerfs native kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product package may import, link or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY STATUS: "kernel level unpinned" -- the reference ships no tests / golden vectors and its
+ * CUDA kernels cannot be run here (no nvcc, no NVIDIA GPU).  Each function below restates one
+ * reference kernel line by line (citations are into /root/reference) and is pinned by
+ *   (1) the self-derived invariants of SURVEY.md section 8c (tests/test_oracle_invariants.py) and
+ *   (2) the reference's own *Python* layer run on top of this file (tests/golden/make_golden.py),
+ * never by an execution of the reference CUDA code.
+ *
+ * Floating-point policy (the reference is compiled by nvcc with default -fmad=true): every
+ * a*b+c pattern in the reference source is written here as an explicit fmaf(); this file must be
+ * compiled with -ffp-contract=off so that nothing else is fused.  For the shipped geometry
+ * (cascade 1, H = 128, base resolution 16: all powers of two) the only place where fused vs
+ * unfused arithmetic can differ in the marcher is the sample position o + t*d.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * helpers -- modules/radnerfs/raymarching/src/raymarching.cu:19-81
+ * ---------------------------------------------------------------------------------------- */
+static const float ORC_SQRT3 = 1.7320508075688772f; /* raymarching.cu:19 */
+
+static inline float orc_clampf(float x, float lo, float hi) { /* raymarching.cu:34-36 */
+    return fminf(hi, fmaxf(lo, x));
+}
+static inline float orc_signf(float x) { return copysignf(1.0f, x); } /* raymarching.cu:30-32 */
+
+static inline int orc_mip_from_pos(float x, float y, float z, float max_cascade) { /* :42-47 */
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1.0f, fmaxf(0.0f, (float)exponent));
+}
+static inline int orc_mip_from_dt(float dt, float H, float max_cascade) { /* :49-54 */
+    const float mx = (float)((double)(dt * H) * 0.5);
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1.0f, fmaxf(0.0f, (float)exponent));
+}
+static inline uint32_t orc_expand_bits(uint32_t v) { /* :56-63 */
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+ORC_API uint32_t orc_morton3D(uint32_t x, uint32_t y, uint32_t z) { /* :65-71 */
+    return orc_expand_bits(x) | (orc_expand_bits(y) << 1) | (orc_expand_bits(z) << 2);
+}
+ORC_API uint32_t orc_morton3D_invert(uint32_t x) { /* :73-81 */
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+/* raymarching.cu:214-241 (kernel_morton3D / kernel_morton3D_invert): coords [N,3] i32 <-> indices [N] */
+ORC_API void orc_morton3D_batch(const int32_t *coords, uint32_t N, int32_t *indices) {
+    for (uint32_t n = 0; n < N; n++)
+        indices[n] = (int32_t)orc_morton3D((uint32_t)coords[3 * n], (uint32_t)coords[3 * n + 1], (uint32_t)coords[3 * n + 2]);
+}
+ORC_API void orc_morton3D_invert_batch(const int32_t *indices, uint32_t N, int32_t *coords) {
+    for (uint32_t n = 0; n < N; n++) {
+        const uint32_t i = (uint32_t)indices[n];
+        coords[3 * n] = (int32_t)orc_morton3D_invert(i);
+        coords[3 * n + 1] = (int32_t)orc_morton3D_invert(i >> 1);
+        coords[3 * n + 2] = (int32_t)orc_morton3D_invert(i >> 2);
+    }
+}
+
+/* raymarching.cu:267-289 kernel_packbits: grid [N*8] float -> bitfield [N] u8, bit i <-> grid[8n+i] > thresh */
+ORC_API void orc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield) {
+    for (uint32_t n = 0; n < N; n++) {
+        uint8_t bits = 0;
+        for (int i = 0; i < 8; i++)
+            bits |= (grid[(size_t)n * 8 + i] > density_thresh) ? ((uint8_t)1 << i) : 0;
+        bitfield[n] = bits;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * near_far_from_aabb -- raymarching.cu:91-145
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                                    uint32_t N, float min_near, float *nears, float *fars) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+        const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        float t;
+
+        float near = (aabb[0] - ox) * rdx;
+        float far = (aabb[3] - ox) * rdx;
+        if (near > far) { t = near; near = far; far = t; }
+
+        float near_y = (aabb[1] - oy) * rdy;
+        float far_y = (aabb[4] - oy) * rdy;
+        if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
+
+        if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+
+        float near_z = (aabb[2] - oz) * rdz;
+        float far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
+
+        if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_z > near) near = near_z;
+        if (far_z < far) far = far_z;
+
+        if (near < min_near) near = min_near;
+        nears[n] = near;
+        fars[n] = far;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * march_rays (inference) -- raymarching.cu:827-929.  Outputs must be zero-initialised by the
+ * caller (raymarching.py:384-386); slot layout n*n_step + s.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
+                            const float *rays_t, const float *rays_o_, const float *rays_d_,
+                            float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                            const uint8_t *grid, const float *nears, const float *fars,
+                            float *xyzs_, float *dirs_, float *deltas_, const float *noises) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)n_alive; n++) {
+        const int index = rays_alive[n];
+        const float noise = noises[n];
+        const float *rays_o = rays_o_ + (size_t)index * 3;
+        const float *rays_d = rays_d_ + (size_t)index * 3;
+        float *xyzs = xyzs_ + (size_t)n * n_step * 3;
+        float *dirs = dirs_ + (size_t)n * n_step * 3;
+        float *deltas = deltas_ + (size_t)n * n_step * 2;
+
+        const float ox = rays_o[0], oy = rays_o[1], oz = rays_o[2];
+        const float dx = rays_d[0], dy = rays_d[1], dz = rays_d[2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        const float rH = 1 / (float)H;
+        const float H3 = (float)(H * H * H);
+
+        float t = rays_t[index];
+        const float far = fars[index];
+        (void)nears;
+
+        const float dt_max = 2 * ORC_SQRT3 * (float)(1 << (C - 1)) / (float)H;     /* :866 */
+        const float dt_min = fminf(dt_max, 2 * ORC_SQRT3 / (float)max_steps);       /* :867 */
+
+        uint32_t step = 0;
+        t = fmaf(orc_clampf(t * dt_gamma, dt_min, dt_max), noise, t);               /* :873 */
+
+        while (t < far && step < n_step) {
+            const float x = orc_clampf(fmaf(t, dx, ox), -bound, bound);             /* :877-879 */
+            const float y = orc_clampf(fmaf(t, dy, oy), -bound, bound);
+            const float z = orc_clampf(fmaf(t, dz, oz), -bound, bound);
+
+            const float dt = orc_clampf(t * dt_gamma, dt_min, dt_max);
+
+            const int lvl_p = orc_mip_from_pos(x, y, z, (float)C);
+            const int lvl_d = orc_mip_from_dt(dt, (float)H, (float)C);
+            const int level = lvl_p > lvl_d ? lvl_p : lvl_d;
+
+            const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+            const float mip_rbound = 1 / mip_bound;
+
+            /* :890-892 -- the literal 0.5 is a double: fp64 product, rounded to fp32 by clamp(),
+             * then truncated to int. */
+            const int nx = (int)orc_clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+            const int ny = (int)orc_clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+            const int nz = (int)orc_clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+
+            /* :894 -- index arithmetic happens in float (H3 is const float) */
+            const uint32_t gidx = (uint32_t)fmaf((float)level, H3, (float)orc_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+            const int occ = grid[gidx / 8] & (1 << (gidx % 8));
+
+            if (occ) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+                t += dt;
+                deltas[0] = dt;
+                deltas[1] = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+                step++;
+            } else {
+                /* :919-921 */
+                const float tx = fmaf(fmaf(((float)nx + 0.5f + 0.5f * orc_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
+                const float ty = fmaf(fmaf(((float)ny + 0.5f + 0.5f * orc_signf(dy)) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
+                const float tz = fmaf(fmaf(((float)nz + 0.5f + 0.5f * orc_signf(dz)) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
+                const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+                do {
+                    t += orc_clampf(t * dt_gamma, dt_min, dt_max);
+                } while (t < tt);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * composite_rays (inference) -- raymarching.cu:942-1029.  The reference uses the __expf fast
+ * intrinsic (:984); libm expf here => tolerance, not bit equality, on the composited values.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                                float *rays_t_, const float *sigmas_, const float *rgbs_,
+                                const float *deltas_, float *weights_sum_, float *depth_, float *image_) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)n_alive; n++) {
+        const int index = rays_alive[n];
+        const float *sigmas = sigmas_ + (size_t)n * n_step;
+        const float *rgbs = rgbs_ + (size_t)n * n_step * 3;
+        const float *deltas = deltas_ + (size_t)n * n_step * 2;
+
+        float t = rays_t_[index];
+        float weight_sum = weights_sum_[index];
+        float d = depth_[index];
+        float r = image_[(size_t)index * 3], g = image_[(size_t)index * 3 + 1], b = image_[(size_t)index * 3 + 2];
+
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (deltas[0] == 0) break;
+            const float alpha = 1.0f - expf(-sigmas[0] * deltas[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t = deltas[1];
+            d = fmaf(weight, t, d);
+            r = fmaf(weight, rgbs[0], r);
+            g = fmaf(weight, rgbs[1], g);
+            b = fmaf(weight, rgbs[2], b);
+            if (T < T_thresh) break;
+            sigmas++; rgbs += 3; deltas += 2; step++;
+        }
+        if (step < n_step) rays_alive[n] = -1;
+        else rays_t_[index] = t;
+
+        weights_sum_[index] = weight_sum;
+        depth_[index] = d;
+        image_[(size_t)index * 3] = r; image_[(size_t)index * 3 + 1] = g; image_[(size_t)index * 3 + 2] = b;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * grid encoder forward -- modules/radnerfs/encoders/gridencoder/src/gridencoder.cu:50-196
+ * inputs [B,D] in [0,1]; embeddings [sum,C] f32; offsets [L+1]; outputs [L,B,C] (level-major)
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t orc_fast_hash(const uint32_t *pos_grid, uint32_t D) { /* gridencoder.cu:50-63 */
+    static const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+static inline uint32_t orc_grid_index(uint32_t D, uint32_t C, uint32_t gridtype, int align_corners, uint32_t ch,
+                                      uint32_t hashmap_size, uint32_t resolution, const uint32_t *pos_grid) { /* :66-84 */
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= align_corners ? resolution : (resolution + 1);
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = orc_fast_hash(pos_grid, D);
+    return (index % hashmap_size) * C + ch;
+}
+/* level scale / resolution as the device computes them (gridencoder.cu:138-139) */
+ORC_API void orc_grid_level_params(uint32_t level, float S, uint32_t H, float *scale, uint32_t *resolution) {
+    const float sc = fmaf(exp2f((float)level * S), (float)H, -1.0f);
+    *scale = sc;
+    *resolution = (uint32_t)ceil((double)sc) + 1;
+}
+
+ORC_API int orc_grid_encode_forward(const float *inputs_, const float *embeddings, const int32_t *offsets,
+                                    float *outputs_, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp) {
+    if (D < 1 || D > 7 || C < 1 || C > 8) return -1;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t level = 0; level < (int64_t)L; level++) {
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+            const float *inputs = inputs_ + (size_t)b * D;
+            float *outputs = outputs_ + (size_t)level * B * C + (size_t)b * C;
+
+            int flag_oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (inputs[d] < 0 || inputs[d] > 1) flag_oob = 1;
+            if (flag_oob) {
+                for (uint32_t ch = 0; ch < C; ch++) outputs[ch] = 0;
+                continue;
+            }
+
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            float scale; uint32_t resolution;
+            orc_grid_level_params((uint32_t)level, S, H, &scale, &resolution);
+
+            float pos[7]; uint32_t pos_grid[7];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * fmaf(-2.0f, pos[d], 3.0f); /* smoothstep :40-42 */
+            }
+
+            float results[8] = {0};
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pos_grid_local[7];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pos_grid_local[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pos_grid_local[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pos_grid_local);
+                for (uint32_t ch = 0; ch < C; ch++) results[ch] = fmaf(w, grid[index + ch], results[ch]);
+            }
+            for (uint32_t ch = 0; ch < C; ch++) outputs[ch] = results[ch];
+        }
+    }
+    return 0;
+}
+
+/* exposes the raw table row index of one corner (for the index-level known-answer tests) */
+ORC_API uint32_t orc_grid_corner_row(uint32_t D, uint32_t gridtype, int align_corners, uint32_t hashmap_size,
+                                     uint32_t resolution, const uint32_t *pos_grid) {
+    return orc_grid_index(D, 1, gridtype, align_corners, 0, hashmap_size, resolution, pos_grid);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * spherical harmonics, degree <= 4 -- modules/radnerfs/encoders/shencoder/src/shencoder.cu:28-68
+ * inputs [B,3], outputs [B,degree^2]
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_sh_encode_forward(const float *inputs, float *outputs_, uint32_t B, uint32_t degree) {
+    if (degree < 1 || degree > 4) return -1;
+    const uint32_t C2 = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        float *o = outputs_ + (size_t)b * C2;
+        const float x = inputs[3 * b], y = inputs[3 * b + 1], z = inputs[3 * b + 2];
+        const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+        o[0] = 0.28209479177387814f;
+        if (degree <= 1) continue;
+        o[1] = -0.48860251190291987f * y;
+        o[2] = 0.48860251190291987f * z;
+        o[3] = -0.48860251190291987f * x;
+        if (degree <= 2) continue;
+        o[4] = 1.0925484305920792f * xy;
+        o[5] = -1.0925484305920792f * yz;
+        o[6] = fmaf(0.94617469575755997f, z2, -0.31539156525251999f);
+        o[7] = -1.0925484305920792f * xz;
+        o[8] = fmaf(0.54627421529603959f, x2, -(0.54627421529603959f * y2));
+        if (degree <= 3) continue;
+        o[9] = 0.59004358992664352f * y * fmaf(-3.0f, x2, y2);
+        o[10] = 2.8906114426405538f * xy * z;
+        o[11] = 0.45704579946446572f * y * fmaf(-5.0f, z2, 1.0f);
+        o[12] = 0.3731763325901154f * z * fmaf(5.0f, z2, -3.0f);
+        o[13] = 0.45704579946446572f * x * fmaf(-5.0f, z2, 1.0f);
+        o[14] = 1.4453057213202769f * z * (x2 - y2);
+        o[15] = 0.59004358992664352f * x * fmaf(3.0f, y2, -x2);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * frequency encoder -- modules/radnerfs/encoders/freqencoder/src/freqencoder.cu:30-58
+ * outputs [B,C], C = D + 2*D*deg; layout [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...];
+ * cos is sin(x + pi/2) (:55-56).  Reference uses __sinf (fast math) => tolerance.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs) {
+    (void)deg;
+    const float PI = 3.14159265358979323846f;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * C; t++) {
+        const uint32_t b = (uint32_t)(t / C);
+        const uint32_t c = (uint32_t)(t - (int64_t)b * C);
+        const float *in = inputs + (size_t)b * D;
+        if (c < D) {
+            outputs[t] = in[c];
+        } else {
+            const uint32_t col = c / D - 1;
+            const uint32_t d = c % D;
+            const uint32_t freq = col / 2;
+            const float phase_shift = (float)(col % 2) * (PI / 2);
+            outputs[t] = sinf(scalbnf(in[d], (int)freq) + phase_shift);
+        }
+    }
+}

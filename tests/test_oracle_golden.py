@@ -1,0 +1,114 @@
+"""The CPU oracle (oracle/oracle.py) against fixtures produced by the reference's own Python layer
+(tests/golden/make_golden.py).  Pins the host-level restatement: yaml chain, checkpoint layout, camera helpers,
+conditioning nets, per-sample forward wiring, march/eval/composite loop, torso pass."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from genefaceplusplus_amd import synthetic as syn
+from genefaceplusplus_amd.configs import may_hparams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_hparams_match_reference_yaml_chain():
+    ref = json.load(open(os.path.join(HERE, "golden", "may_hparams.json")))
+    for variant, hp in ref.items():
+        assert may_hparams(variant) == hp
+
+
+def test_state_dict_layout_matches_reference_modules():
+    man = json.load(open(os.path.join(HERE, "golden", "state_manifest.json")))
+    for variant, keys in man.items():
+        sd = syn.synthetic_state_dict(may_hparams(variant), variant)
+        assert set(sd) == set(keys)
+        for k, (shape, dtype) in keys.items():
+            assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, k
+
+
+def test_grid_offsets(golden, oracle_mod):
+    for D in (2, 3):
+        off, pls = oracle_mod.grid_offsets(D, 16, 2, 2, 16, 16, 2048)
+        assert np.array_equal(off, golden[f"grid_offsets_D{D}"])
+        assert pls == golden[f"grid_per_level_scale_D{D}"][0]
+        off2, pls2 = syn.grid_offsets(D)
+        assert np.array_equal(off2, off) and pls2 == pls
+    assert int(golden["grid_offsets_D3"][-1]) == 903480 and int(golden["grid_offsets_D2"][-1]) == 555520
+
+
+def test_camera_helpers(golden, oracle_mod):
+    orc = oracle_mod
+    pose = golden["rays_pose"]
+    rays = orc.get_rays(pose[None], syn.intrinsics_for(16, 16), 16, 16)
+    np.testing.assert_allclose(rays["rays_d"], golden["rays_d_16"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(rays["rays_o"], golden["rays_o_16"])
+    np.testing.assert_array_equal(orc.get_bg_coords(16, 16), golden["bg_coords_16"])
+    np.testing.assert_allclose(orc.convert_poses(pose[None]), golden["convert_poses"], atol=1e-6)
+    np.testing.assert_array_equal(orc.nerf_matrix_to_ngp(golden["c2w"]), golden["ngp_pose"])
+    feats = golden["audio_features_in"]
+    for idx in (0, 1, 5, 9):
+        np.testing.assert_array_equal(orc.get_audio_features(feats, 2, idx, 5), golden[f"audio_features_mode2_{idx}"])
+    np.testing.assert_allclose(np.exp(np.array([-3.0, 0.0, 2.5, 20.0], np.float32)), golden["trunc_exp"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["may_head", "may_torso", "may_torso_sr"])
+def test_cond_feat(golden, oracle_mod, variant):
+    hp = may_hparams(variant)
+    sd = syn.synthetic_state_dict(hp, variant)
+    fi = syn.synthetic_frame_inputs(hp, 0)
+    cf = oracle_mod.cal_cond_feat(fi["cond"], sd, hp, fi["eye_area_percent"])
+    np.testing.assert_allclose(cf, golden[f"{variant}.cond_feat"], rtol=1e-4, atol=2e-6)
+
+
+def test_head_forward(golden, oracle_mod):
+    hp = may_hparams("may_head")
+    sd = syn.synthetic_state_dict(hp, "may_head")
+    cf = golden["may_head.cond_feat"]
+    sigma, color, amb = oracle_mod.head_forward(golden["fwd.position"], golden["fwd.direction"], cf,
+                                                sd["individual_embeddings"][0], sd, hp)
+    np.testing.assert_allclose(amb, golden["fwd.ambient"], atol=2e-5)
+    np.testing.assert_allclose(sigma, golden["fwd.sigma"], rtol=5e-4)
+    np.testing.assert_allclose(color, golden["fwd.color"], atol=2e-5)
+    dens = oracle_mod.head_density(golden["fwd.position"], cf, sd, hp)
+    np.testing.assert_allclose(dens["sigma"], golden["fwd.density_sigma"], rtol=5e-4)
+    np.testing.assert_allclose(dens["geo_feat"].sum(axis=1), golden["fwd.geo_feat_sum"], rtol=1e-3, atol=1e-3)
+    # out-of-range position (row 0 = box corner, inside [0,1] after normalisation) still encodes; sigma finite
+    assert np.isfinite(sigma).all()
+
+
+def _render(orc, variant, HW):
+    hp = may_hparams(variant)
+    sd = syn.synthetic_state_dict(hp, variant)
+    fi = syn.synthetic_frame_inputs(hp, 0)
+    pose = syn.synthetic_pose(0)[None]
+    rays = orc.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+    bg = np.full((1, HW * HW, 3), 0.5, np.float32)
+    kw = dict(bg_color=bg, dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=0.01,
+              eye_area_percent=fi["eye_area_percent"])
+    if variant == "may_head":
+        return orc.render_head(rays["rays_o"], rays["rays_d"], fi["cond"], sd, hp, **kw)
+    return orc.render_torso(rays["rays_o"], rays["rays_d"], fi["cond"], orc.get_bg_coords(HW, HW), orc.convert_poses(pose),
+                            sd, hp, lm68=fi["lm68"], sr_variant=(variant == "may_torso_sr"), **kw)
+
+
+@pytest.mark.parametrize("variant,HW", [("may_head", 64), ("may_torso", 64), ("may_torso_sr", 256)])
+def test_render_matches_reference_python(golden, oracle_mod, variant, HW):
+    res = _render(oracle_mod, variant, HW)
+    sel = golden[f"{variant}.render.sel"]
+    rgb = res["rgb_map"].reshape(1, -1, 3)
+    ref = golden[f"{variant}.render.rgb"]
+    err = np.abs(rgb[:, sel] - ref)
+    # torch-CPU vs OpenBLAS GEMM summation order: allow a handful of threshold-crossing rays
+    assert (err > 2e-4).mean() < 5e-4, (err.max(), (err > 2e-4).mean())
+    np.testing.assert_allclose(rgb.astype(np.float64).sum(axis=(0, 1)), golden[f"{variant}.render.rgb_sum"], rtol=2e-5)
+    d = res["depth_map"].reshape(1, -1)[:, sel]
+    dref = golden[f"{variant}.render.depth"]
+    ok = np.isfinite(dref)
+    assert (np.abs(d[ok] - dref[ok]) > 1e-3).mean() < 5e-4
+    if variant != "may_head":
+        ta = res["torso_alpha_map"].reshape(-1)
+        assert np.abs(ta[sel] - golden[f"{variant}.render.torso_alpha"]).max() < 2e-4
+        np.testing.assert_allclose(ta.astype(np.float64).sum(), golden[f"{variant}.render.torso_alpha_sum"][0], rtol=2e-5)
+        np.testing.assert_allclose(np.abs(res["deform"]).astype(np.float64).sum(), golden[f"{variant}.render.deform_abs_sum"][0], rtol=2e-5)
