@@ -1,0 +1,90 @@
+"""ctypes binding of libgfpp_radnerf.so (the C ABI declared in include/gfpp_radnerf.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the product raises.  The CPU
+oracle under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgfpp_radnerf.so")
+_lib = None
+
+c_u32 = ctypes.c_uint32
+c_f = ctypes.c_float
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "gfpp_abi_version": [],
+    "gfpp_last_error": [],
+    "gfpp_near_far_from_aabb": [c_p, c_p, c_p, c_u32, c_f, c_p, c_p, c_p],
+    "gfpp_morton3D": [c_p, c_u32, c_p, c_p],
+    "gfpp_morton3D_invert": [c_p, c_u32, c_p, c_p],
+    "gfpp_packbits": [c_p, c_u32, c_f, c_p, c_p],
+    "gfpp_march_rays": [c_u32, c_u32, c_p, c_p, c_p, c_p, c_f, c_f, c_u32, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gfpp_composite_rays": [c_u32, c_u32, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gfpp_grid_encode_forward": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_u32, c_i, c_u32, c_i, c_p],
+    "gfpp_sh_encode_forward": [c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p],
+    "gfpp_freq_encode_forward": [c_p, c_u32, c_u32, c_u32, c_u32, c_p, c_p],
+    "gfpp_get_rays": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_p],
+}
+_RESTYPES = {"gfpp_last_error": ctypes.c_char_p}
+
+
+class GfppError(RuntimeError):
+    """A C-ABI call returned non-zero (the reference surfaces these as RuntimeError from C++ exceptions)."""
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libgfpp_radnerf.so (in-tree; hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def register(name, argtypes, restype=ctypes.c_int):
+    """Used by the fused-pipeline bindings to add their entry points to the table."""
+    _SIGNATURES[name] = argtypes
+    if restype is not ctypes.c_int:
+        _RESTYPES[name] = restype
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built -- never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GfppError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"(or `make -C genefaceplusplus_amd/csrc`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        got = handle.gfpp_abi_version()
+        if got != 1:
+            raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected 1")
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Invoke one entry point and raise GfppError on a non-zero return."""
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        msg = handle.gfpp_last_error()
+        raise GfppError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")

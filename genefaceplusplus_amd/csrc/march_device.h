@@ -1,0 +1,149 @@
+// march_device.h -- per-ray device routines shared by the stand-alone kernels (raymarch.hip) and the fused frame
+// pipeline (frame_head.hip): slab test, occupancy-guided stepping, and the per-sample compositing update.
+//
+// Semantics follow the reference kernels kernel_near_far_from_aabb (raymarching.cu:91-145), kernel_march_rays
+// (:827-929) and kernel_composite_rays (:942-1029); structure and code are our own.
+#pragma once
+
+#include <float.h>
+
+#include "gfpp_common.h"
+
+namespace gfpp {
+
+struct RayBox {
+    float near, far;
+};
+
+// Slab test of one ray against an axis-aligned box.  A miss reports near = far = FLT_MAX.
+__device__ __forceinline__ RayBox ray_box(float ox, float oy, float oz, float dx, float dy, float dz, const float *__restrict__ aabb,
+                                          float min_near) {
+    const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;
+    RayBox r;
+    float n = (aabb[0] - ox) * rdx, f = (aabb[3] - ox) * rdx;
+    if (n > f) { float t = n; n = f; f = t; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { float t = ny; ny = fy; fy = t; }
+    if (n > fy || ny > f) { r.near = r.far = FLT_MAX; return r; }
+    if (ny > n) n = ny;
+    if (fy < f) f = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { float t = nz; nz = fz; fz = t; }
+    if (n > fz || nz > f) { r.near = r.far = FLT_MAX; return r; }
+    if (nz > n) n = nz;
+    if (fz < f) f = fz;
+    if (n < min_near) n = min_near;
+    r.near = n;
+    r.far = f;
+    return r;
+}
+
+// Constants of one march launch (identical for every ray).
+struct MarchParams {
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf;
+    uint32_t C, H;
+};
+
+__host__ __device__ inline MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    MarchParams p;
+    p.bound = bound;
+    p.dt_gamma = dt_gamma;
+    p.dt_max = 2 * 1.7320508075688772f * (float)(1u << (C - 1)) / (float)H;
+    const float alt = 2 * 1.7320508075688772f / (float)max_steps;
+    p.dt_min = p.dt_max < alt ? p.dt_max : alt;
+    p.rH = 1.0f / (float)H;
+    p.H3 = (float)(H * H * H);
+    p.Hf = (float)H;
+    p.Cf = (float)C;
+    p.C = C;
+    p.H = H;
+    return p;
+}
+
+__device__ __forceinline__ int cascade_of(float x, float y, float z, float dt, const MarchParams &p) {
+    if (p.C == 1) return 0;
+    int e_pos, e_dt;
+    frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+    frexpf((float)((double)(dt * p.Hf) * 0.5), &e_dt);
+    const int lp = (int)fminf(p.Cf - 1.0f, fmaxf(0.0f, (float)e_pos));
+    const int ld = (int)fminf(p.Cf - 1.0f, fmaxf(0.0f, (float)e_dt));
+    return lp > ld ? lp : ld;
+}
+
+// Voxel coordinate along one axis: fp64 product (the reference multiplies by the double literal 0.5), rounded to
+// fp32, clamped, truncated.
+__device__ __forceinline__ int voxel_of(float v, float rbound, const MarchParams &p) {
+    const float g = (float)(0.5 * (double)fmaf(v, rbound, 1.0f) * (double)p.H);
+    return (int)clampf(g, 0.0f, (float)(p.H - 1));
+}
+
+// Distance (in t) from position v to the face of voxel n that the ray leaves through, along one axis.
+__device__ __forceinline__ float exit_distance(int n, float v, float d, float rd, float mip_bound, const MarchParams &p) {
+    const float face = ((float)n + 0.5f + 0.5f * copysignf(1.0f, d)) * p.rH;
+    return fmaf(fmaf(face, 2.0f, -1.0f), mip_bound, -v) * rd;
+}
+
+// One sample produced by the marcher.
+struct Sample {
+    float x, y, z, dt, t_end;
+};
+
+// Advance one ray from t, emitting up to n_step occupied samples through `emit(step, Sample)`.
+// Returns the number of samples emitted; `t` is left at the position after the last emitted sample (or >= far).
+template <typename Emit>
+__device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, float dx, float dy, float dz, float &t, float far,
+                                                  uint32_t n_step, const uint8_t *__restrict__ bitfield, const MarchParams &p,
+                                                  Emit &&emit) {
+    const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        const float x = clampf(fmaf(t, dx, ox), -p.bound, p.bound);
+        const float y = clampf(fmaf(t, dy, oy), -p.bound, p.bound);
+        const float z = clampf(fmaf(t, dz, oz), -p.bound, p.bound);
+        const float dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
+        const int level = cascade_of(x, y, z, dt, p);
+        const float mip_bound = fminf(scalbnf(1.0f, level), p.bound);
+        const float mip_rbound = 1.0f / mip_bound;
+        const int nx = voxel_of(x, mip_rbound, p), ny = voxel_of(y, mip_rbound, p), nz = voxel_of(z, mip_rbound, p);
+        // the reference forms this index in fp32 (exact below 2^24)
+        const uint32_t cell = (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occupied = (bitfield[cell >> 3] >> (cell & 7u)) & 1u;
+        if (occupied) {
+            t += dt;
+            Sample s{x, y, z, dt, t};
+            emit(step, s);
+            ++step;
+        } else {
+            const float tx = exit_distance(nx, x, dx, rdx, mip_bound, p);
+            const float ty = exit_distance(ny, y, dy, rdy, mip_bound, p);
+            const float tz = exit_distance(nz, z, dz, rdz, mip_bound, p);
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do {
+                t += clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
+            } while (t < tt);
+        }
+    }
+    return step;
+}
+
+// Running compositing state of one ray.
+struct RayAccum {
+    float wsum, depth, r, g, b;
+};
+
+// Fold one sample into the accumulators.  Returns true if the ray must stop AFTER this sample (the test uses the
+// transmittance from before the sample, as the reference does).
+__device__ __forceinline__ bool composite_sample(RayAccum &a, float sigma, float dt, float t_end, float cr, float cg, float cb,
+                                                 float T_thresh) {
+    const float alpha = 1.0f - __expf(-sigma * dt);
+    const float T = 1.0f - a.wsum;
+    const float w = alpha * T;
+    a.wsum += w;
+    a.depth = fmaf(w, t_end, a.depth);
+    a.r = fmaf(w, cr, a.r);
+    a.g = fmaf(w, cg, a.g);
+    a.b = fmaf(w, cb, a.b);
+    return T < T_thresh;
+}
+
+}  // namespace gfpp

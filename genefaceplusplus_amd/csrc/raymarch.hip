@@ -1,0 +1,199 @@
+// raymarch.hip -- stand-alone ray kernels behind the reference's `_raymarching_face` extension API
+// (near_far_from_aabb, morton3D(_invert), packbits, march_rays, composite_rays) plus on-device ray generation.
+// One thread per ray; 256-thread workgroups (4 wavefronts) so that a 262 144-ray frame is 1024 workgroups.
+#include <stdarg.h>
+
+#include "march_device.h"
+
+namespace gfpp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                    const float *__restrict__ aabb, uint32_t N, float min_near,
+                                                    float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;
+    const RayBox rb = ray_box(o[0], o[1], o[2], d[0], d[1], d[2], aabb, min_near);
+    nears[n] = rb.near;
+    fars[n] = rb.far;
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3((uint32_t)coords[3ull * n], (uint32_t)coords[3ull * n + 1], (uint32_t)coords[3ull * n + 2]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t code = (uint32_t)indices[n];
+    coords[3ull * n] = (int32_t)compact3(code);
+    coords[3ull * n + 1] = (int32_t)compact3(code >> 1);
+    coords[3ull * n + 2] = (int32_t)compact3(code >> 2);
+}
+
+// One thread packs one output byte from 8 consecutive floats (two 16-byte loads).
+__global__ __launch_bounds__(kBlock) void k_packbits(const float4 *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = grid[2ull * n], b = grid[2ull * n + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+__global__ __launch_bounds__(kBlock) void k_march(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                 const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                 const float *__restrict__ rays_d, MarchParams p, const uint8_t *__restrict__ bitfield,
+                                                 const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                 float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t ray = (uint32_t)rays_alive[n];
+    const float *o = rays_o + 3ull * ray, *d = rays_d + 3ull * ray;
+    const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+    float t = rays_t[ray];
+    t = fmaf(clampf(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    float *px = xyzs + 3ull * n * n_step, *pd = dirs + 3ull * n * n_step, *pl = deltas + 2ull * n * n_step;
+    march_one_ray(ox, oy, oz, dx, dy, dz, t, fars[ray], n_step, bitfield, p, [&](uint32_t s, const Sample &smp) {
+        px[3 * s] = smp.x; px[3 * s + 1] = smp.y; px[3 * s + 2] = smp.z;
+        pd[3 * s] = dx; pd[3 * s + 1] = dy; pd[3 * s + 2] = dz;
+        pl[2 * s] = smp.dt; pl[2 * s + 1] = smp.t_end;
+    });
+}
+
+__global__ __launch_bounds__(kBlock) void k_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                                                     float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                     const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t ray = (uint32_t)rays_alive[n];
+    const float *sg = sigmas + (size_t)n * n_step, *cl = rgbs + 3ull * n * n_step, *dl = deltas + 2ull * n * n_step;
+    RayAccum a{weights_sum[ray], depth[ray], image[3ull * ray], image[3ull * ray + 1], image[3ull * ray + 2]};
+    float t = rays_t[ray];
+    uint32_t s = 0;
+    for (; s < n_step; ++s) {
+        const float dt = dl[2 * s];
+        if (dt == 0.0f) break;  // never-written slot: the ray ran out of samples
+        t = dl[2 * s + 1];
+        if (composite_sample(a, sg[s], dt, t, cl[3 * s], cl[3 * s + 1], cl[3 * s + 2], T_thresh)) break;
+    }
+    if (s < n_step) rays_alive[n] = -1;
+    else rays_t[ray] = t;
+    weights_sum[ray] = a.wsum;
+    depth[ray] = a.depth;
+    image[3ull * ray] = a.r; image[3ull * ray + 1] = a.g; image[3ull * ray + 2] = a.b;
+}
+
+__global__ __launch_bounds__(kBlock) void k_get_rays(const float *__restrict__ pose, float fx, float fy, float cx, float cy, uint32_t H,
+                                                    uint32_t W, float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= H * W) return;
+    const uint32_t h = n / W, w = n - h * W;
+    const float xs = ((float)w + 0.5f - cx) / fx;
+    const float ys = ((float)h + 0.5f - cy) / fy;
+    const float norm = sqrtf(fmaf(xs, xs, fmaf(ys, ys, 1.0f)));
+    const float ux = xs / norm, uy = ys / norm, uz = 1.0f / norm;
+    // rays_d = dir @ R^T  ==  R @ dir
+    for (int r = 0; r < 3; ++r) {
+        rays_d[3ull * n + r] = fmaf(pose[4 * r + 2], uz, fmaf(pose[4 * r + 1], uy, pose[4 * r] * ux));
+        rays_o[3ull * n + r] = pose[4 * r + 3];
+    }
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_abi_version(void) { return GFPP_ABI_VERSION; }
+GFPP_API const char *gfpp_last_error(void) { return gfpp::g_err; }
+
+#define GFPP_REQUIRE(cond, what)                                  \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            gfpp::set_error("%s: invalid argument (%s)", what, #cond); \
+            return GFPP_EINVAL;                                   \
+        }                                                         \
+    } while (0)
+
+GFPP_API int gfpp_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                                     float *nears, float *fars, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    GFPP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "gfpp_near_far_from_aabb");
+    hipLaunchKernelGGL(k_near_far, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch("gfpp_near_far_from_aabb");
+}
+
+GFPP_API int gfpp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    GFPP_REQUIRE(coords && indices, "gfpp_morton3D");
+    hipLaunchKernelGGL(k_morton, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coords, N, indices);
+    return check_launch("gfpp_morton3D");
+}
+
+GFPP_API int gfpp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    GFPP_REQUIRE(coords && indices, "gfpp_morton3D_invert");
+    hipLaunchKernelGGL(k_morton_invert, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, indices, N, coords);
+    return check_launch("gfpp_morton3D_invert");
+}
+
+GFPP_API int gfpp_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    GFPP_REQUIRE(grid && bitfield, "gfpp_packbits");
+    GFPP_REQUIRE(((uintptr_t)grid & 15u) == 0, "gfpp_packbits");
+    hipLaunchKernelGGL(k_packbits, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)grid, N, density_thresh, bitfield);
+    return check_launch("gfpp_packbits");
+}
+
+GFPP_API int gfpp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                             const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                             const float *noises, gfpp_stream_t stream) {
+    (void)nears;
+    if (n_alive == 0) return 0;
+    GFPP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, "gfpp_march_rays");
+    GFPP_REQUIRE(n_step >= 1 && C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, "gfpp_march_rays");
+    const MarchParams p = make_march_params(bound, dt_gamma, max_steps, C, H);
+    hipLaunchKernelGGL(k_march, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises);
+    return check_launch("gfpp_march_rays");
+}
+
+GFPP_API int gfpp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                                 const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                                 float *image, gfpp_stream_t stream) {
+    if (n_alive == 0) return 0;
+    GFPP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "gfpp_composite_rays");
+    GFPP_REQUIRE(n_step >= 1, "gfpp_composite_rays");
+    hipLaunchKernelGGL(k_composite, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return check_launch("gfpp_composite_rays");
+}
+
+GFPP_API int gfpp_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
+                           float *rays_d, gfpp_stream_t stream) {
+    if (H == 0 || W == 0) return 0;
+    GFPP_REQUIRE(pose && rays_o && rays_d, "gfpp_get_rays");
+    hipLaunchKernelGGL(k_get_rays, dim3(div_up(H * W, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, H, W, rays_o, rays_d);
+    return check_launch("gfpp_get_rays");
+}

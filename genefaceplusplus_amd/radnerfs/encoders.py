@@ -1,0 +1,155 @@
+"""Input encodings of the radiance fields: multiresolution grid, spherical harmonics, frequency.
+
+Same constructor arguments, attributes, parameter/buffer names (``embeddings``, ``offsets``) and output layouts as the
+reference's encoders/gridencoder/grid.py:96-164, encoders/shencoder/sphere_harmonics.py:61-87,
+encoders/freqencoder/freq.py:54-78 and the factory encoders/encoding.py:6-35 -- so reference checkpoints load
+unchanged -- but forward() runs our HIP kernels through the C ABI.  Forward only (no autograd).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .._lib import call, GfppError
+
+_GRIDTYPE = {"hash": 0, "tiled": 1}
+_INTERP = {"linear": 0, "smoothstep": 1}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def grid_encode_raw(inputs01, embeddings, offsets, per_level_scale, base_resolution, gridtype_id, align_corners, interp_id):
+    """Level-major lookup: inputs01 [B,D] f32 in [0,1] -> [L,B,C] in the table's dtype."""
+    if not inputs01.is_cuda:
+        raise GfppError("grid_encode: inputs must be on the GPU (no CPU path)")
+    inputs01 = inputs01.float().contiguous()
+    B, D = inputs01.shape
+    L = offsets.shape[0] - 1
+    C = embeddings.shape[1]
+    if embeddings.dtype == torch.float32:
+        dtype = 0
+    elif embeddings.dtype == torch.float16:
+        dtype = 1
+    else:
+        raise GfppError(f"grid tables must be float32 or float16, got {embeddings.dtype}")
+    out = torch.empty(L, B, C, device=inputs01.device, dtype=embeddings.dtype)
+    S = float(np.log2(per_level_scale))
+    call("gfpp_grid_encode_forward", inputs01.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S,
+         int(base_resolution), None, int(gridtype_id), int(bool(align_corners)), int(interp_id), dtype, _stream())
+    return out
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False, interpolation="linear"):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _GRIDTYPE[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _INTERP[interpolation]
+        self.align_corners = align_corners
+        self.max_params = 2 ** log2_hashmap_size
+
+        rows = []
+        for lvl in range(num_levels):
+            res = int(np.ceil(base_resolution * per_level_scale ** lvl))
+            n = min(self.max_params, (res if align_corners else res + 1) ** input_dim)
+            rows.append(int(np.ceil(n / 8) * 8))          # level sizes are rounded up to multiples of 8
+        offsets = np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+        self.register_buffer("offsets", torch.from_numpy(offsets))
+        self.n_params = int(offsets[-1]) * level_dim
+        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
+
+    def __repr__(self):
+        return (f"GridEncoder(hip): input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"base={self.base_resolution} per_level_scale={self.per_level_scale:.4f} rows={tuple(self.embeddings.shape)} "
+                f"gridtype={self.gridtype} interpolation={self.interpolation}")
+
+    def table(self):
+        """Table in the dtype the lookup will use: half under autocast when level_dim is even (grid.py:43-44)."""
+        emb = self.embeddings
+        if torch.is_autocast_enabled() and self.level_dim % 2 == 0:
+            emb = emb.to(torch.half)
+        return emb
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)
+        prefix = list(inputs.shape[:-1])
+        flat = inputs.reshape(-1, self.input_dim)
+        out = grid_encode_raw(flat, self.table(), self.offsets, self.per_level_scale, self.base_resolution, self.gridtype_id,
+                              self.align_corners, self.interp_id)
+        B = flat.shape[0]
+        return out.permute(1, 0, 2).reshape(B, self.output_dim).view(prefix + [self.output_dim])
+
+
+class SHEncoder(nn.Module):
+    def __init__(self, input_dim=3, degree=4):
+        super().__init__()
+        if input_dim != 3:
+            raise AssertionError("SH encoder only support input dim == 3")
+        if not 1 <= degree <= 4:
+            raise GfppError("SH encoder: this build supports degree 1..4 (the reference allows up to 8; the render path uses 4)")
+        self.input_dim = input_dim
+        self.degree = degree
+        self.output_dim = degree ** 2
+
+    def forward(self, inputs, size=1):
+        inputs = inputs / size
+        prefix = list(inputs.shape[:-1])
+        flat = inputs.reshape(-1, 3).float().contiguous()
+        if not flat.is_cuda:
+            raise GfppError("sh_encode: inputs must be on the GPU (no CPU path)")
+        out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
+        call("gfpp_sh_encode_forward", flat.data_ptr(), out.data_ptr(), flat.shape[0], 3, self.degree, None, _stream())
+        return out.view(prefix + [self.output_dim])
+
+
+class FreqEncoder(nn.Module):
+    def __init__(self, input_dim=3, degree=4):
+        super().__init__()
+        self.input_dim = input_dim
+        self.degree = degree
+        self.output_dim = input_dim + input_dim * 2 * degree
+
+    def forward(self, inputs, **kwargs):
+        prefix = list(inputs.shape[:-1])
+        flat = inputs.reshape(-1, self.input_dim).float().contiguous()
+        if not flat.is_cuda:
+            raise GfppError("freq_encode: inputs must be on the GPU (no CPU path)")
+        out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
+        call("gfpp_freq_encode_forward", flat.data_ptr(), flat.shape[0], self.input_dim, self.degree, self.output_dim,
+             out.data_ptr(), _stream())
+        return out.view(prefix + [self.output_dim])
+
+
+def get_encoder(encoding, input_dim=3, multires=6, degree=4, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                desired_resolution=2048, align_corners=False, interpolation="linear", **kwargs):
+    """Factory with the reference's names (encoders/encoding.py:6-35). Returns (encoder, output_dim)."""
+    if encoding == "None":
+        return (lambda x, **kw: x), input_dim
+    if encoding == "frequency":
+        enc = FreqEncoder(input_dim=input_dim, degree=multires)
+    elif encoding == "spherical_harmonics":
+        enc = SHEncoder(input_dim=input_dim, degree=degree)
+    elif encoding in ("hashgrid", "tiledgrid"):
+        enc = GridEncoder(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, base_resolution=base_resolution,
+                          log2_hashmap_size=log2_hashmap_size, desired_resolution=desired_resolution,
+                          gridtype="hash" if encoding == "hashgrid" else "tiled", align_corners=align_corners,
+                          interpolation=interpolation, **kwargs)
+    else:
+        raise NotImplementedError("Unknown encoding mode, choose from [None, frequency, spherical_harmonics, hashgrid, tiledgrid]")
+    return enc, enc.output_dim

@@ -1,0 +1,240 @@
+"""Head radiance field: ``NeRFRenderer`` (state + render entry point) and ``RADNeRF`` (networks).
+
+Drop-in for the reference's modules/radnerfs/renderer.py:66-399 and radnerf.py:13-166: same constructor
+(``Model(hparams: dict)``), attributes (``.hparams``), parameter/buffer names, ``render / forward / density /
+cal_cond_feat`` signatures and result keys.  What differs is the execution: ``render()`` hands the frame to the fused
+HIP pipeline (frame_pipeline.py: device-side loop control, no host syncs); the reference-shaped ``staged`` executor below
+(one march / evaluate / composite round trip per loop iteration, MLPs through rocBLAS) is kept as a debugging aid and as
+the "unfused" baseline for measurements.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from . import raymarching
+from .cond_nets import AudioNet, AudioAttNet, MLP
+from .encoders import get_encoder
+from .camera import trunc_exp
+
+_COND_DIMS = {"esperanto": 44, "deepspeech": 29}
+_KEYPOINT_DIMS = {"lm68": 68 * 3, "lm131": 131 * 3, "lm468": 468 * 3}
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.bound = hparams["bound"]
+        self.cascade = 1 + math.ceil(math.log2(hparams["bound"]))
+        self.grid_size = hparams["grid_size"]
+        self.density_scale = 1
+        self.min_near = hparams["min_near"]
+        self.density_thresh = hparams["density_thresh"]
+        self.cuda_ray = hparams["cuda_ray"]
+
+        b = float(self.bound)
+        aabb = torch.tensor([-b, -b / 2, -b, b, b / 2, b], dtype=torch.float32)
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+
+        self.individual_embedding_num = hparams["individual_embedding_num"]
+        self.individual_embedding_dim = hparams["individual_embedding_dim"]
+        if self.individual_embedding_dim > 0:
+            self.individual_embeddings = nn.Parameter(torch.randn(self.individual_embedding_num, self.individual_embedding_dim) * 0.1)
+
+        cells = self.grid_size ** 3
+        self.register_buffer("density_grid", torch.zeros(self.cascade, cells))
+        self.register_buffer("density_bitfield", torch.zeros(self.cascade * cells // 8, dtype=torch.uint8))
+        self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+        # not persisted, exactly like the reference (renderer.py:97-104)
+        self.mean_density = 0
+        self.iter_density = 0
+        self.mean_count = 0
+        self.local_step = 0
+        #: 'fused' (default) or 'staged'; see module docstring
+        self.executor = "fused"
+        self._pipeline = None
+
+    # -- to be provided by the model ------------------------------------------------------------------------
+    def cal_cond_feat(self, cond, **kwargs):
+        raise NotImplementedError()
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.step_counter.zero_()
+        self.mean_density = self.iter_density = self.mean_count = self.local_step = 0
+
+    # -- shared pieces of render() ------------------------------------------------------------------------
+    def _individual_code(self, index):
+        if self.individual_embedding_dim <= 0:
+            return None
+        return self.individual_embeddings[index if self.training else 0]
+
+    def _require_inference(self):
+        if self.training:
+            raise NotImplementedError("training-time rendering (march_rays_train / composite_rays_train) is not built yet "
+                                      "(SURVEY.md 8f-2); call .eval() first")
+
+    def pipeline(self):
+        """Lazily build the fused frame pipeline (packs weights for the HIP kernels; rebuilt if parameters move)."""
+        from .frame_pipeline import FramePipeline
+        if self._pipeline is None or not self._pipeline.matches(self):
+            self._pipeline = FramePipeline(self)
+        return self._pipeline
+
+    def _march_eval_composite_staged(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, max_steps, T_thresh,
+                                     perturb=False, cond_mask=None, trace=None):
+        """Reference-shaped loop (renderer.py:341-384): one host-visible trip per iteration."""
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        rays_alive = torch.arange(N, dtype=torch.int32, device=dev)
+        rays_t = nears.clone()
+        step = 0
+        while step < max_steps:
+            n_alive = rays_alive.shape[0]
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
+                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
+                                                        perturb if step == 0 else False, dt_gamma, max_steps)
+            if cond_mask is not None:
+                sigmas, rgbs, _ = self(xyzs, dirs, cond_feat, ind_code, cond_mask=cond_mask[rays_alive])
+            else:
+                sigmas, rgbs, _ = self(xyzs, dirs, cond_feat, ind_code)
+            sigmas = self.density_scale * sigmas
+            if trace is not None:
+                trace.append((n_alive, n_step))
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+            rays_alive = rays_alive[rays_alive >= 0].contiguous()
+            step += n_step
+        return weights_sum, depth, image
+
+    def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False,
+               force_all_rays=False, max_steps=1024, T_thresh=1e-4, cond_mask=None, eye_area_percent=None, **kwargs):
+        """Head-only frame: rays [B,N,3] (B == 1) -> {'rgb_map' [B,N,3], 'depth_map' [B,N]} (renderer.py:286-399)."""
+        self._require_inference()
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
+        ind_code = self._individual_code(index)
+        if self.executor == "fused" and cond_mask is None and not perturb:
+            out = self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
+            return {"depth_map": out["depth"].view(*prefix), "rgb_map": out["image"].view(*prefix, 3)}
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma,
+                                                                      max_steps, T_thresh, perturb, cond_mask)
+        if bg_color is None:
+            bg_color = 1
+        image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3).clamp(0, 1)
+        depth = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+        return {"depth_map": depth, "rgb_map": image}
+
+
+class RADNeRF(NeRFRenderer):
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        self.hparams = copy.deepcopy(hparams)
+        cond_type = hparams["cond_type"]
+        if cond_type in _COND_DIMS:
+            self.cond_in_dim = _COND_DIMS[cond_type]
+        elif cond_type == "idexp_lm3d_normalized":
+            mode = hparams.get("nerf_keypoint_mode", "lm68")
+            if mode not in _KEYPOINT_DIMS:
+                raise NotImplementedError()
+            self.cond_in_dim = _KEYPOINT_DIMS[mode]
+        else:
+            raise NotImplementedError()
+
+        self.cond_out_dim = hparams["cond_out_dim"] // 2 * 2
+        self.cond_win_size = hparams["cond_win_size"]
+        self.smo_win_size = hparams["smo_win_size"]
+        self.cond_prenet = AudioNet(self.cond_in_dim, self.cond_out_dim, win_size=self.cond_win_size)
+        if hparams.get("add_eye_blink_cond", False):
+            half = self.cond_out_dim // 2
+            self.blink_embedding = nn.Embedding(1, half)
+            self.blink_encoder = nn.Sequential(nn.Linear(half, half), nn.Linear(half, hparams["eye_blink_dim"]))
+        self.with_att = hparams["with_att"]
+        if self.with_att:
+            self.cond_att_net = AudioAttNet(self.cond_out_dim, seq_len=self.smo_win_size)
+
+        self.grid_type = hparams["grid_type"]
+        self.grid_interpolation_type = hparams["grid_interpolation_type"]
+        grid_kw = dict(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=hparams["log2_hashmap_size"],
+                       interpolation=self.grid_interpolation_type)
+        self.position_embedder, self.position_embedding_dim = get_encoder(
+            self.grid_type, input_dim=3, desired_resolution=hparams["desired_resolution"] * self.bound, **grid_kw)
+        self.num_layers_ambient = hparams["num_layers_ambient"]
+        self.hidden_dim_ambient = hparams["hidden_dim_ambient"]
+        self.ambient_coord_dim = hparams["ambient_coord_dim"]
+        self.ambient_net = MLP(self.position_embedding_dim + self.cond_out_dim, self.ambient_coord_dim, self.hidden_dim_ambient,
+                               self.num_layers_ambient)
+        self.ambient_embedder, self.ambient_embedding_dim = get_encoder(
+            self.grid_type, input_dim=self.ambient_coord_dim, desired_resolution=hparams["desired_resolution"], **grid_kw)
+
+        self.num_layers_sigma = hparams["num_layers_sigma"]
+        self.hidden_dim_sigma = hparams["hidden_dim_sigma"]
+        self.geo_feat_dim = hparams["geo_feat_dim"]
+        self.sigma_net = MLP(self.position_embedding_dim + self.ambient_embedding_dim, 1 + self.geo_feat_dim, self.hidden_dim_sigma,
+                             self.num_layers_sigma)
+
+        self.num_layers_color = hparams["num_layers_color"]
+        self.hidden_dim_color = hparams["hidden_dim_color"]
+        self.direction_embedder, self.direction_embedding_dim = get_encoder("spherical_harmonics")
+        self.color_net = MLP(self.direction_embedding_dim + self.geo_feat_dim + self.individual_embedding_dim, 3, self.hidden_dim_color,
+                             self.num_layers_color)
+        self.dropout = nn.Dropout(p=hparams["cond_dropout_rate"], inplace=False)
+
+    # -- conditioning ---------------------------------------------------------------------------------------
+    def cal_cond_feat(self, cond, eye_area_percent=None):
+        """cond [smo_win, t_window, cond_in] -> cond_feat [cond_out] (radnerf.py:88-106)."""
+        hp = self.hparams
+        feat = self.cond_prenet(cond)
+        if hp.get("add_eye_blink_cond", False):
+            if eye_area_percent is None:
+                eye_area_percent = torch.zeros(1, 1, dtype=feat.dtype)
+            k = hp["eye_blink_dim"]
+            blink = self.blink_embedding.weight[0].reshape(1, -1) * eye_area_percent.reshape(1, 1).to(feat.device)
+            blink = self.blink_encoder(blink)
+            feat = torch.cat([feat[..., :k] + blink.expand(feat.shape[0], k), feat[..., k:]], dim=-1)
+        if self.with_att:
+            feat = self.cond_att_net(feat)
+        return feat
+
+    # -- per-sample evaluation (stand-alone API; render() uses the fused kernels) ----------------------------
+    def _sigma_trunk(self, position, cond_feat):
+        n = position.shape[0]
+        pos_feat = self.position_embedder(position, bound=self.bound)
+        ambient_in = torch.cat([pos_feat, cond_feat.reshape(1, -1).expand(n, -1).to(pos_feat.dtype)], dim=1)
+        ambient_pos = torch.tanh(self.ambient_net(ambient_in).float())
+        ambient_feat = self.ambient_embedder(ambient_pos, bound=1)
+        h = self.sigma_net(torch.cat([pos_feat, ambient_feat], dim=-1))
+        return trunc_exp(h[..., 0]), h[..., 1:], ambient_pos
+
+    def forward(self, position, direction, cond_feat, individual_code, cond_mask=None):
+        """-> sigma [M] f32, color [M,3], ambient_pos [M, ambient_coord_dim] f32 (radnerf.py:108-141)."""
+        sigma, geo_feat, ambient_pos = self._sigma_trunk(position, cond_feat)
+        parts = [self.direction_embedder(direction).to(geo_feat.dtype), geo_feat]
+        if individual_code is not None:
+            parts.append(individual_code.reshape(1, -1).expand(position.shape[0], -1).to(geo_feat.dtype))
+        color = torch.sigmoid(self.color_net(torch.cat(parts, dim=-1)))
+        return sigma, color, ambient_pos
+
+    def density(self, position, cond_feat, e=None, cond_mask=None):
+        """-> {'sigma', 'geo_feat'} (radnerf.py:143-166)."""
+        assert self.hparams.get("to_heatmap", False) is False
+        sigma, geo_feat, _ = self._sigma_trunk(position, cond_feat)
+        return {"sigma": sigma, "geo_feat": geo_feat}

@@ -1,0 +1,204 @@
+"""Head + torso two-pass models: ``RADNeRFTorso`` and ``RADNeRFTorsowithSR``.
+
+Drop-ins for the reference's modules/radnerfs/radnerf_torso.py:17-199 and radnerf_torso_sr.py:17-244 (constructor,
+parameter/buffer names incl. the ``torso_canonicial_net`` spelling, ``forward_torso`` / ``render`` signatures and result
+keys).  The torso is a 2-D deformation field over the background pixel grid: frequency-encode the pixel, predict an
+offset, look the displaced pixel up in a 2-D tiled grid, decode (alpha, rgb), then composite
+head over torso over background.
+"""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import raymarching
+from .cond_nets import MLP
+from .encoders import get_encoder
+from .head import RADNeRF
+
+_CHIN_LANDMARKS = [5, 6, 7, 8, 9, 10, 11]   # the 7 of 68 landmarks the SR variant conditions on (radnerf_torso_sr.py:86)
+
+
+def _head_aware_encoder():
+    return nn.Sequential(nn.Linear(4, 16, bias=True), nn.LeakyReLU(0.02, True), nn.Linear(16, 32, bias=True),
+                         nn.LeakyReLU(0.02, True), nn.Linear(32, 16, bias=True))
+
+
+class _TorsoBase(RADNeRF):
+    """State and compositing shared by both torso variants."""
+
+    #: True for RADNeRFTorsowithSR: landmark conditioning, no pose encoding in the MLP input, no host coin flip
+    landmark_conditioned = False
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        self.register_buffer("density_grid_torso", torch.zeros(self.grid_size ** 2))
+        self.mean_density_torso = 0      # plain attribute, NOT in the checkpoint => 0 at inference (radnerf_torso.py:22)
+        self.density_thresh_torso = hparams["density_thresh_torso"]
+        self.torso_individual_embedding_num = hparams["individual_embedding_num"]
+        self.torso_individual_embedding_dim = hparams["torso_individual_embedding_dim"]
+        if self.torso_individual_embedding_dim > 0:
+            self.torso_individual_codes = nn.Parameter(torch.randn(self.torso_individual_embedding_num, self.torso_individual_embedding_dim) * 0.1)
+
+    def _build_torso_nets(self, hparams, cond_dim):
+        self.torso_pose_embedder, self.pose_embedding_dim = get_encoder("frequency", input_dim=6, multires=4)
+        self.torso_deform_pos_embedder, self.torso_deform_pos_dim = get_encoder("frequency", input_dim=2, multires=10)
+        self.torso_embedder, self.torso_in_dim = get_encoder("tiledgrid", input_dim=2, num_levels=16, level_dim=2, base_resolution=16,
+                                                             log2_hashmap_size=16, desired_resolution=2048)
+        deform_in = self.torso_deform_pos_dim + cond_dim + self.torso_individual_embedding_dim
+        canon_in = self.torso_in_dim + deform_in
+        if hparams["torso_head_aware"]:
+            self.head_color_weights_encoder = _head_aware_encoder()
+            deform_in += 16
+            canon_in += 16
+        self.torso_deform_net = MLP(deform_in, 2, 64, 3)
+        self.torso_canonicial_net = MLP(canon_in, 4, 32, 3)
+
+    # -- the per-pixel torso field, stand-alone API (render() uses the fused kernel) ---------------------------
+    def _frame_constant_columns(self, poses, c, lm68):
+        raise NotImplementedError
+
+    def _forward_torso(self, x, poses, c, image, weights_sum, lm68):
+        hp = self.hparams
+        x = x * hp["torso_shrink"]
+        n = x.shape[0]
+        cols = [self.torso_deform_pos_embedder(x)] + [v.reshape(1, -1).expand(n, -1) for v in self._frame_constant_columns(poses, c, lm68)]
+        h = torch.cat(cols, dim=-1)
+        if hp["torso_head_aware"]:
+            if image is None:
+                image = torch.zeros(n, 3, dtype=h.dtype, device=h.device)
+                weights_sum = torch.zeros(n, 1, dtype=h.dtype, device=h.device)
+            h = torch.cat([h, self.head_color_weights_encoder(torch.cat([image, weights_sum], dim=-1))], dim=-1)
+        dx = self.torso_deform_net(h)
+        moved = (x + dx).clamp(-1, 1).float()
+        feat = self.torso_embedder(moved, bound=1)
+        out = self.torso_canonicial_net(torch.cat([feat.to(h.dtype), h], dim=-1))
+        return torch.sigmoid(out[..., :1]), torch.sigmoid(out[..., 1:]), dx
+
+    def _torso_code(self, index):
+        if self.torso_individual_embedding_dim <= 0:
+            return None
+        return self.torso_individual_codes[index if self.training else 0]
+
+    def _torso_mask(self, bg_coords):
+        thresh = min(self.density_thresh_torso, self.mean_density_torso)
+        occ = F.grid_sample(self.density_grid_torso.view(1, 1, self.grid_size, self.grid_size), bg_coords.view(1, -1, 1, 2),
+                            align_corners=True).view(-1)
+        return occ > thresh
+
+    def _render_staged(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                       eye_area_percent, use_head_for_torso):
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        with torch.no_grad():
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+            cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
+            weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, self._individual_code(index),
+                                                                          dt_gamma, max_steps, T_thresh, perturb)
+        if bg_color is None:
+            bg_color = 1
+        code = self._torso_code(index)
+        mask = self._torso_mask(bg_coords)
+        torso_alpha = torch.zeros(N, 1, device=dev)
+        torso_color = torch.zeros(N, 3, device=dev)
+        deform = None
+        if mask.any():
+            if self.hparams["torso_head_aware"] and use_head_for_torso:
+                a, col, deform = self._forward_torso(bg_coords[mask], poses, code, image[mask], weights_sum.unsqueeze(-1)[mask], lm68)
+            else:
+                a, col, deform = self._forward_torso(bg_coords[mask], poses, code, None, None, lm68)
+            torso_alpha[mask] = a.float()
+            torso_color[mask] = col.float()
+        torso_bg = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
+        image = (image + (1 - weights_sum).unsqueeze(-1) * torso_bg)
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"image": image.clamp(0, 1), "depth": depth, "torso_alpha": torso_alpha, "torso_bg": torso_bg, "deform": deform}
+
+    def _render_common(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                       eye_area_percent, use_head_for_torso):
+        self._require_inference()
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        bg_coords = bg_coords.contiguous().view(-1, 2)
+        if self.executor == "fused" and not perturb:
+            with torch.no_grad():
+                cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
+            return self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, self._individual_code(index), bg_coords, poses,
+                                                     self._torso_code(index), lm68, dt_gamma, max_steps, T_thresh, bg_color,
+                                                     use_head_for_torso)
+        return self._render_staged(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                                   eye_area_percent, use_head_for_torso)
+
+
+class RADNeRFTorso(_TorsoBase):
+    """Pose-conditioned torso (non-SR configs, 512x512 rays)."""
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        self._build_torso_nets(hparams, cond_dim=6 + 6 * 2 * 4)
+
+    def _frame_constant_columns(self, poses, c, lm68):
+        cols = [self.torso_pose_embedder(poses)]
+        if c is not None:
+            cols.append(c)
+        return cols
+
+    def forward_torso(self, x, poses, c=None, image=None, weights_sum=None):
+        """x [P,2] in [-1,1], poses [1,6] -> alpha [P,1], color [P,3], dx [P,2] (radnerf_torso.py:51-84)."""
+        return self._forward_torso(x, poses, c, image, weights_sum, None)
+
+    def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
+               max_steps=1024, T_thresh=1e-4, **kwargs):
+        prefix = rays_o.shape[:-1]
+        # the reference flips a host coin per frame when torso_head_aware (radnerf_torso.py:177-180); same RNG stream here
+        use_head = random.random() < 0.5 if self.hparams["torso_head_aware"] else False
+        # NB: this variant calls cal_cond_feat(cond) without eye_area_percent (radnerf_torso.py:106)
+        out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, None,
+                                  None, use_head)
+        res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"], "depth_map": out["depth"].view(*prefix),
+               "rgb_map": out["image"].view(*prefix, 3)}
+        if out["deform"] is not None:
+            res["deform"] = out["deform"]
+        return res
+
+
+class RADNeRFTorsowithSR(_TorsoBase):
+    """Landmark-conditioned, head-aware torso of the released May checkpoint (256x256 rays + super-resolution)."""
+
+    landmark_conditioned = True
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        self.lm68_embedder, self.lm68_embedding_dim = get_encoder("frequency", input_dim=7 * 2, multires=4)
+        self._build_torso_nets(hparams, cond_dim=self.lm68_embedding_dim)
+        from .superres import Superresolution
+        self.sr_net = Superresolution(channels=3)
+
+    def _frame_constant_columns(self, poses, c, lm68):
+        # the reference also encodes `poses` here but never uses the result (radnerf_torso_sr.py:84,89-96)
+        chin = lm68.reshape(1, 68, 2)[:, _CHIN_LANDMARKS].reshape(1, -1)
+        cols = [c] if c is not None else []
+        cols.append(self.lm68_embedder(chin))
+        return cols
+
+    def forward_torso(self, x, poses, c=None, image=None, weights_sum=None, lm68=None):
+        """(radnerf_torso_sr.py:75-114)."""
+        return self._forward_torso(x, poses, c, image, weights_sum, lm68)
+
+    def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
+               max_steps=1024, T_thresh=1e-4, upscale_torso=False, lm68=None, eye_area_percent=None, **kwargs):
+        out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                                  eye_area_percent, True)
+        side = self.sr_net.input_resolution          # 256: the reference hard-codes [1,256,256,3] (radnerf_torso_sr.py:219,229)
+        rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
+        torso_bg = out["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
+        res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": torso_bg, "depth_map": out["depth"].view(*rays_o.shape[:-1]),
+               "rgb_map": rgb}
+        if out["deform"] is not None:
+            res["deform"] = out["deform"]
+        if self.sr_net.ready:
+            res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
+            if upscale_torso:
+                res["sr_torso_rgb_map"] = self.sr_net(torso_bg.clone()).clamp(0, 1)
+        return res

@@ -1,0 +1,81 @@
+"""Shared scaffolding for frame-level parity tests: one synthetic May-shaped model + one frame of driving inputs,
+rendered by the CPU oracle and by the product on the GPU from identical numpy arrays."""
+import numpy as np
+import torch
+
+from genefaceplusplus_amd import synthetic as syn
+from genefaceplusplus_amd.configs import may_hparams
+
+CLASSES = {"may_head": "RADNeRF", "may_torso": "RADNeRFTorso", "may_torso_sr": "RADNeRFTorsowithSR"}
+
+
+def frame_case(variant, HW, frame_idx=0, **sd_kw):
+    hp = may_hparams(variant)
+    sd = syn.synthetic_state_dict(hp, variant, **sd_kw)
+    fi = syn.synthetic_frame_inputs(hp, frame_idx)
+    pose = syn.synthetic_pose(frame_idx)[None]
+    return {"variant": variant, "hp": hp, "sd": sd, "HW": HW, "pose": pose, "intr": syn.intrinsics_for(HW, HW), **fi,
+            "bg_color": np.full((1, HW * HW, 3), 0.5, np.float32), "T_thresh": 0.01}
+
+
+def oracle_render(orc, case, trace=None):
+    hp, sd, HW = case["hp"], case["sd"], case["HW"]
+    rays = orc.get_rays(case["pose"], case["intr"], HW, HW)
+    kw = dict(bg_color=case["bg_color"], dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=case["T_thresh"],
+              eye_area_percent=case["eye_area_percent"], trace=trace)
+    if case["variant"] == "may_head":
+        return orc.render_head(rays["rays_o"], rays["rays_d"], case["cond"], sd, hp, **kw)
+    return orc.render_torso(rays["rays_o"], rays["rays_d"], case["cond"], orc.get_bg_coords(HW, HW), orc.convert_poses(case["pose"]),
+                            sd, hp, lm68=case["lm68"], sr_variant=(case["variant"] == "may_torso_sr"), **kw)
+
+
+def build_model(case, device, executor):
+    from genefaceplusplus_amd import radnerfs
+    model = getattr(radnerfs, CLASSES[case["variant"]])(case["hp"])
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in case["sd"].items()}, strict=True)
+    model = model.to(device).eval()
+    model.executor = executor
+    return model
+
+
+def product_render(model, case, device, rays_from="oracle", orc=None):
+    """Call render() exactly like inference/genefacepp_infer.py:461-463 does (whole hparams dict splatted in)."""
+    from genefaceplusplus_amd.radnerfs import camera
+    HW = case["HW"]
+    pose = torch.from_numpy(case["pose"]).to(device)
+    if rays_from == "oracle":
+        r = orc.get_rays(case["pose"], case["intr"], HW, HW)
+        rays_o, rays_d = torch.from_numpy(r["rays_o"]).to(device), torch.from_numpy(r["rays_d"]).to(device)
+    else:
+        r = camera.get_rays(pose, case["intr"], HW, HW)
+        rays_o, rays_d = r["rays_o"], r["rays_d"]
+    with torch.no_grad():
+        return model.render(rays_o, rays_d, torch.from_numpy(case["cond"]).to(device), camera.get_bg_coords(HW, HW, device),
+                            camera.convert_poses(pose), index=0, staged=False, bg_color=torch.from_numpy(case["bg_color"]).to(device),
+                            lm68=torch.from_numpy(case["lm68"]).to(device), perturb=False, force_all_rays=False,
+                            T_thresh=case["T_thresh"], eye_area_percent=torch.from_numpy(case["eye_area_percent"]).to(device),
+                            **case["hp"])
+
+
+def compare_frames(res, ref, variant, HW, rgb_tol=2e-4, depth_tol=1e-3, frac=5e-4):
+    """SURVEY 8c tolerance: max-abs <= 2e-4 on rgb / 1e-3 on depth, allowing <= 0.05 % of pixels to exceed (rays whose
+    transmittance crosses T_thresh within rounding)."""
+    rgb = res["rgb_map"].float().cpu().numpy()
+    if variant == "may_torso_sr":
+        rgb = np.transpose(rgb, (0, 2, 3, 1))
+    rgb = rgb.reshape(-1, 3)
+    err = np.abs(rgb - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
+    stats = {"rgb_max": float(err.max()), "rgb_frac_over": float((err > rgb_tol).mean())}
+    assert stats["rgb_frac_over"] <= frac, stats
+    d = res["depth_map"].float().cpu().numpy().reshape(-1)
+    dref = ref["depth_map"].reshape(-1)
+    ok = np.isfinite(dref)
+    derr = np.abs(d[ok] - dref[ok])
+    stats["depth_frac_over"] = float((derr > depth_tol).mean())
+    assert stats["depth_frac_over"] <= frac, stats
+    if variant != "may_head":
+        ta = res["torso_alpha_map"].float().cpu().numpy().reshape(-1)
+        taerr = np.abs(ta - ref["torso_alpha_map"].reshape(-1))
+        stats["alpha_max"] = float(taerr.max())
+        assert (taerr > rgb_tol).mean() <= frac, stats
+    return stats

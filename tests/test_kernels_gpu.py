@@ -1,0 +1,235 @@
+"""HIP kernels (through the C ABI) against the CPU oracle, kernel by kernel.  Needs an MI355X.
+
+Bars: bit-exact for integer / index work (Morton codes, bitfield, marcher sample positions and counts, alive flags)
+and for the fp32 grid lookup (same fmaf sequence on both sides); stated tolerances where the reference itself uses
+fast-math intrinsics (__expf in compositing, __sinf in the frequency encoding).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from genefaceplusplus_amd import synthetic as syn
+from genefaceplusplus_amd.configs import may_hparams
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_library_loaded_is_in_tree():
+    from genefaceplusplus_amd import _lib
+    _lib.lib()
+    assert _lib.LIB_PATH.endswith("genefaceplusplus_amd/libgfpp_radnerf.so")
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = (rng.uniform(-1, 1, (n, 3)) * np.array([0.3, 0.3, 0.3]) + np.array([0, 4.0, 0])).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32) * np.array([0.2, 0.2, 0.2], np.float32) + np.array([0, -1, 0], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # edge cases: axis-parallel rays (zero components => inf reciprocals), rays that miss, origin inside the box
+    d[0] = [0, -1, 0]
+    d[1] = [1, 0, 0]
+    d[2] = [0, 0, 1]
+    o[3] = [0, 0, 0]
+    d[4] = [0, 1, 0]
+    o[5] = [-1.0, 4.0, 0.0]; d[5] = [0, -1, 0]     # exactly on a slab plane: (aabb - o) * inf = nan path
+    return o, d.astype(np.float32)
+
+
+def test_near_far(dev, oracle_mod):
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    o, d = _rays(5000, 1)
+    aabb = np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32)
+    n_ref, f_ref = oracle_mod.near_far_from_aabb(o, d, aabb, 0.05)
+    n, f = rm.near_far_from_aabb(t(o, dev), t(d, dev), t(aabb, dev), 0.05)
+    np.testing.assert_array_equal(n.cpu().numpy(), n_ref)
+    np.testing.assert_array_equal(f.cpu().numpy(), f_ref)
+    assert (n_ref == np.finfo(np.float32).max).any() and (n_ref < 10).any()
+
+
+def test_morton_and_packbits(dev, oracle_mod):
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    rng = np.random.default_rng(2)
+    coords = rng.integers(0, 128, (4096, 3)).astype(np.int32)
+    idx = rm.morton3D(t(coords, dev))
+    ref = np.array([oracle_mod.morton3D(*c) for c in coords], np.int32)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    back = rm.morton3D_invert(idx)
+    np.testing.assert_array_equal(back.cpu().numpy(), coords)
+    grid = rng.uniform(0, 20, (1, 128 ** 3 // 16)).astype(np.float32)
+    bits = rm.packbits(t(grid, dev), 10.0)
+    np.testing.assert_array_equal(bits.cpu().numpy(), oracle_mod.packbits(grid, 10.0))
+
+
+@pytest.mark.parametrize("n_step", [1, 2, 3, 8])
+def test_march_rays_bit_exact(dev, oracle_mod, n_step):
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    hp = may_hparams("may_head")
+    sd = syn.synthetic_state_dict(hp, "may_head")
+    HW = 96
+    pose = syn.synthetic_pose(1)[None]
+    rays = oracle_mod.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+    o, d = rays["rays_o"][0], rays["rays_d"][0]
+    nears, fars = oracle_mod.near_far_from_aabb(o, d, sd["aabb_infer"], hp["min_near"])
+    N = o.shape[0]
+    rng = np.random.default_rng(3)
+    alive = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+    rays_t = nears + rng.uniform(0, 0.6, N).astype(np.float32)     # continue from arbitrary positions
+    ref = oracle_mod.march_rays(len(alive), n_step, alive, rays_t, o, d, 1, sd["density_bitfield"], 1, 128, nears, fars, 128, False,
+                                hp["dt_gamma"], 16)
+    got = rm.march_rays(len(alive), n_step, t(alive, dev), t(rays_t, dev), t(o, dev), t(d, dev), 1, t(sd["density_bitfield"], dev), 1, 128,
+                        t(nears, dev), t(fars, dev), 128, False, hp["dt_gamma"], 16)
+    for g, r, name in zip(got, ref, ("xyzs", "dirs", "deltas")):
+        assert g.shape == r.shape
+        np.testing.assert_array_equal(g.cpu().numpy(), r, err_msg=name)
+    assert (ref[2][:, 0] > 0).sum() > 1000
+
+
+def test_march_rays_all_ones_and_all_zero_bitfield(dev, oracle_mod):
+    """SURVEY 8c invariant 7."""
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    o = np.tile(np.array([[0.1, 4.0, -0.2]], np.float32), (256, 1))
+    d = np.tile(np.array([[0.0, -1.0, 0.0]], np.float32), (256, 1))
+    aabb = np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32)
+    nears, fars = oracle_mod.near_far_from_aabb(o, d, aabb, 0.05)
+    alive = np.arange(256, dtype=np.int32)
+    ones = np.full(128 ** 3 // 8, 255, np.uint8)
+    x, _, dl = rm.march_rays(256, 8, t(alive, dev), t(nears, dev), t(o, dev), t(d, dev), 1, t(ones, dev), 1, 128, t(nears, dev), t(fars, dev),
+                             -1, False, 1 / 256, 16)
+    dt = np.float32(2 * np.float32(1.7320508075688772) / np.float32(128))
+    dl = dl.cpu().numpy().reshape(256, 8, 2)
+    assert np.all(dl[:, :, 0] == dt)
+    tk = nears[0]
+    for k in range(8):
+        tk = np.float32(tk + dt)
+        assert dl[0, k, 1] == tk
+    zeros = np.zeros(128 ** 3 // 8, np.uint8)
+    x, _, dl = rm.march_rays(256, 8, t(alive, dev), t(nears, dev), t(o, dev), t(d, dev), 1, t(zeros, dev), 1, 128, t(nears, dev), t(fars, dev),
+                             -1, False, 1 / 256, 16)
+    assert float(dl.abs().sum()) == 0.0 and float(x.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("n_step", [1, 4])
+def test_composite_rays(dev, oracle_mod, n_step):
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    rng = np.random.default_rng(5)
+    N, n_alive = 4000, 1500
+    alive = np.sort(rng.choice(N, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step
+    sig = np.exp(rng.uniform(-2, 6, M)).astype(np.float32)
+    rgb = rng.uniform(0, 1, (M, 3)).astype(np.float32)
+    deltas = np.stack([np.full(M, 0.027063, np.float32), rng.uniform(3.5, 4.5, M).astype(np.float32)], 1)
+    deltas[rng.random(M) < 0.1] = 0          # exhausted rays
+    ws = rng.uniform(0, 0.995, N).astype(np.float32)
+    dep = rng.uniform(0, 4, N).astype(np.float32)
+    img = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    rt = rng.uniform(3.5, 4.5, N).astype(np.float32)
+    ref = [alive.copy(), rt.copy(), ws.copy(), dep.copy(), img.copy()]
+    oracle_mod.composite_rays(n_alive, n_step, ref[0], ref[1], sig, rgb, deltas, ref[2], ref[3], ref[4], 0.01)
+    g = [t(alive, dev), t(rt, dev), t(ws, dev), t(dep, dev), t(img, dev)]
+    rm.composite_rays(n_alive, n_step, g[0], g[1], t(sig, dev), t(rgb, dev), t(deltas, dev), g[2], g[3], g[4], 0.01)
+    got = [x.cpu().numpy() for x in g]
+    # alive flags: exact except rays whose transmittance sits within rounding of the threshold
+    mism = got[0] != ref[0]
+    assert mism.mean() < 2e-3
+    ok = ~np.isin(np.arange(N), alive[mism])
+    np.testing.assert_allclose(got[2][ok], ref[2][ok], atol=2e-6)       # v_exp_f32 vs libm expf
+    np.testing.assert_allclose(got[3][ok], ref[3][ok], atol=2e-5)
+    np.testing.assert_allclose(got[4][ok], ref[4][ok], atol=2e-6)
+    np.testing.assert_array_equal(got[1][ok], ref[1][ok])
+
+
+def _grid_case(oracle_mod, D, gridtype, rng, C=2, log2_hashmap=16, desired=2048):
+    off, pls = oracle_mod.grid_offsets(D, 16, C, 2, 16, log2_hashmap, desired)
+    emb = rng.uniform(-1, 1, (int(off[-1]), C)).astype(np.float32)
+    return off, pls, emb
+
+
+@pytest.mark.parametrize("D,gridtype,interp,C", [(3, "tiled", "linear", 2), (2, "tiled", "linear", 2), (3, "hash", "linear", 2),
+                                                 (3, "tiled", "smoothstep", 2), (2, "hash", "smoothstep", 4), (3, "hash", "linear", 1),
+                                                 (3, "tiled", "linear", 8)])
+def test_grid_encode_fp32_bit_exact(dev, oracle_mod, D, gridtype, interp, C):
+    from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw
+    rng = np.random.default_rng(11)
+    off, pls, emb = _grid_case(oracle_mod, D, gridtype, rng, C)
+    B = 20011                                                   # ragged: not a multiple of the block size
+    u = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    u[0] = 0.0; u[1] = 1.0                                       # box corners
+    u[2] = -0.001; u[3, 0] = 1.0001                              # out of range -> zeros
+    u[4] = 0.5
+    S = np.log2(pls)
+    sc, res = oracle_mod.grid_level_params(7, S, 16)
+    u[5] = np.float32((np.float32(3.0) - np.float32(0.5)) / sc)  # lands (nearly) on a lattice vertex of level 7
+    ref = oracle_mod.grid_encode_raw(u, emb, off, S, 16, oracle_mod.GRIDTYPE[gridtype], False, oracle_mod.INTERP[interp])
+    got = grid_encode_raw(t(u, dev), t(emb, dev), t(off, dev), pls, 16, oracle_mod.GRIDTYPE[gridtype], False, oracle_mod.INTERP[interp])
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape == (16, B, C)
+    assert np.all(got[:, 2] == 0) and np.all(got[:, 3] == 0)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_grid_encode_empty_and_half(dev, oracle_mod):
+    from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw
+    rng = np.random.default_rng(12)
+    off, pls, emb = _grid_case(oracle_mod, 3, "tiled", rng)
+    out = grid_encode_raw(torch.empty(0, 3, device=dev), t(emb, dev), t(off, dev), pls, 16, 1, False, 0)
+    assert out.shape == (16, 0, 2)
+    u = rng.uniform(0, 1, (5000, 3)).astype(np.float32)
+    ref = oracle_mod.grid_encode_raw(u, emb.astype(np.float16).astype(np.float32), off, np.log2(pls), 16, 1, False, 0)
+    got = grid_encode_raw(t(u, dev), t(emb, dev).half(), t(off, dev), pls, 16, 1, False, 0)
+    assert got.dtype == torch.float16
+    # fp16 tables, fp32 accumulate, one rounding on store (the reference accumulates in half: looser still)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=1e-3)
+
+
+def test_grid_unsupported_raises(dev):
+    from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw
+    from genefaceplusplus_amd._lib import GfppError
+    emb = torch.zeros(64, 3, device=dev)
+    off = torch.tensor([0, 64], dtype=torch.int32, device=dev)
+    with pytest.raises(GfppError):
+        grid_encode_raw(torch.rand(8, 3, device=dev), emb, off, 2.0, 16, 0, False, 0)     # C = 3
+    with pytest.raises(GfppError):
+        grid_encode_raw(torch.rand(8, 5, device=dev), torch.zeros(64, 2, device=dev), off, 2.0, 16, 0, False, 0)   # D = 5
+
+
+def test_sh_and_freq(dev, oracle_mod):
+    from genefaceplusplus_amd.radnerfs.encoders import SHEncoder, FreqEncoder
+    rng = np.random.default_rng(13)
+    d = rng.standard_normal((3001, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for deg in (1, 2, 3, 4):
+        got = SHEncoder(degree=deg)(t(d, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, oracle_mod.sh_encode(d, deg), atol=1e-6)
+    assert np.all(got[:, 0] == np.float32(0.28209479177387814))
+    for D, deg, scale in ((2, 10, 0.8), (6, 4, 4.0), (14, 4, 1.0)):
+        x = (rng.uniform(-1, 1, (777, D)) * scale).astype(np.float32)
+        got = FreqEncoder(input_dim=D, degree=deg)(t(x, dev)).cpu().numpy()
+        ref = oracle_mod.freq_encode(x, deg)
+        assert got.shape == ref.shape == (777, D + 2 * D * deg)
+        np.testing.assert_array_equal(got[:, :D], x)
+        np.testing.assert_allclose(got, ref, atol=2e-6)
+
+
+def test_get_rays(dev, oracle_mod):
+    from genefaceplusplus_amd.radnerfs.camera import get_rays, get_bg_coords, convert_poses
+    pose = syn.synthetic_pose(2)
+    H = W = 48
+    intr = syn.intrinsics_for(H, W)
+    ref = oracle_mod.get_rays(pose[None], intr, H, W)
+    got = get_rays(t(pose, dev)[None], intr, H, W)
+    np.testing.assert_array_equal(got["rays_o"].cpu().numpy(), ref["rays_o"])
+    np.testing.assert_allclose(got["rays_d"].cpu().numpy(), ref["rays_d"], atol=2e-7)
+    # torch on the GPU divides by a host scalar as a multiplication by its reciprocal (1 ulp from numpy's true division);
+    # the reference computes bg_coords with the very same torch expression on its GPU
+    np.testing.assert_allclose(get_bg_coords(H, W, dev).cpu().numpy(), oracle_mod.get_bg_coords(H, W), atol=1.5e-7)
+    np.testing.assert_allclose(convert_poses(t(pose, dev)[None]).cpu().numpy(), oracle_mod.convert_poses(pose[None]), atol=1e-6)
