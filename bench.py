@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- rendered 512x512 head+torso frames/s of the GeneFace++ motion2video NeRF path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one frame (one pass of the hot path over one frame of synthetic driving input) per rank.  Frames are
+independent units, so ranks render disjoint frames with no data-path collective ("weak" scaling: per-GPU work fixed); the
+only exchange is the RCCL all_gather of the finished uint8 frames, which is inside the timed region.  Inputs (rays, conditioning
+windows, poses, background) are resident in HBM before the timed region starts, exactly like the reference keeps them
+(inference/genefacepp_infer.py:246-275).  Rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (k_head_trip: march + grid encode + MFMA MLPs + composite, fused).  bound "mfma";
+                achieved = evaluated samples x 161 536 FLOP (SURVEY 8d "folded" per-sample figure) / time of the trip
+                launches measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32-input MFMA, exact fp32)
+  grid_stage    the stand-alone hash/tiled-grid kernel on 2^22 uniform points: achieved = B x 1164 B / t vs 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (kind "port": the reference has no CPU path) on a bounded sample, rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 161536          # head MLPs after folding the per-frame-constant input columns
+GRID_BYTES_PER_POINT = 1164       # 3-D, 16 levels x 8 corners x 8 B + 12 B in + 128 B out
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--hw", type=int, default=512, help="frame side (rays = hw*hw)")
+    ap.add_argument("--variant", default="may_torso", choices=["may_head", "may_torso", "may_torso_sr"])
+    ap.add_argument("--executor", default="fused", choices=["fused", "staged"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid-stage", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(variant, hw_sample=256, hw_full=512):
+    """Oracle (CPU restatement of the reference path) on one hw_sample^2 frame, scaled to frames/s at hw_full^2."""
+    threads = min(os.cpu_count() or 1, 64)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    from oracle import oracle as orc
+    from tests.helpers import frame_case, oracle_render
+    orc.build()
+    with threadpool_limits(limits=threads):
+        case = frame_case(variant, 64)
+        oracle_render(orc, case)                                  # warm-up (page in tables, spin up thread pools)
+        case = frame_case(variant, hw_sample)
+        t0 = time.perf_counter()
+        trace = []
+        oracle_render(orc, case, trace=trace)
+        dt = time.perf_counter() - t0
+    scale = (hw_full / hw_sample) ** 2
+    return {"value": round(1.0 / (dt * scale), 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 {variant} frame at {hw_sample}x{hw_sample} ({hw_sample * hw_sample} rays) in {dt:.2f} s on {threads} threads "
+                      f"(OpenMP C kernels + BLAS fp32 GEMMs), scaled x1/{scale:.0f} to {hw_full}x{hw_full}",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import camera
+    from genefaceplusplus_amd import radnerfs, frames
+    from tests.helpers import CLASSES
+
+    HW, K, W = args.hw, args.steps, args.warmup
+    N = HW * HW
+    hp = may_hparams(args.variant)
+    if args.variant == "may_torso_sr":
+        assert HW == 256, "the *_sr models render 256x256 rays"
+    sd = syn.synthetic_state_dict(hp, args.variant)
+    model = getattr(radnerfs, CLASSES[args.variant])(hp)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    model.executor = args.executor
+
+    # ---- this rank's frames: global frame index = step * world + rank (frame-parallel sharding) ----------------------------
+    total = K + W
+    my_frames = frames.shard_frames(total * world, rank, world, interleaved=True)
+    intr = syn.intrinsics_for(HW, HW)
+    bg_coords = camera.get_bg_coords(HW, HW, dev)
+    bg_color = torch.full((1, N, 3), 0.5, device=dev)
+    inputs = []
+    for fidx in my_frames:
+        pose = torch.from_numpy(syn.synthetic_pose(fidx)).to(dev)[None]
+        rays = camera.get_rays(pose, intr, HW, HW)
+        fi = syn.synthetic_frame_inputs(hp, fidx)
+        inputs.append({"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose),
+                       "cond": torch.from_numpy(fi["cond"]).to(dev), "lm68": torch.from_numpy(fi["lm68"]).to(dev),
+                       "eye": torch.from_numpy(fi["eye_area_percent"]).to(dev)})
+    out_u8 = torch.empty(K, HW, HW, 3, dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(out_u8) for _ in range(world)] if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+
+    def render(i, slot=None, timed=False):
+        x = inputs[i]
+        with torch.no_grad():
+            res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=i, staged=False, bg_color=bg_color,
+                               lm68=x["lm68"], perturb=False, force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
+        rgb = res["rgb_map"]
+        if args.variant == "may_torso_sr":
+            rgb = rgb.permute(0, 2, 3, 1)
+        if slot is not None:
+            frames.to_uint8_hwc(rgb.reshape(HW, HW, 3), out_u8[slot])
+        return res
+
+    for i in range(W):
+        render(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        render(W + k, slot=k)
+    if world > 1:
+        dist.all_gather(gathered, out_u8)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    result = None
+    if rank == 0:
+        fps = world * K / elapsed
+        result = {"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+                  "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame, max_steps 16, T_thresh 0.01, "
+                                         f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
+                             "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (" + RCCL all_gather of uint8 frames" if world > 1 else ""),
+                             "executor": args.executor}}
+
+    # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
+    if rank == 0 and args.executor == "fused":
+        pipe = model.pipeline()
+        x = inputs[W]
+        with torch.no_grad():
+            cond_feat = model.cal_cond_feat(x["cond"]) if args.variant != "may_torso_sr" else model.cal_cond_feat(x["cond"], eye_area_percent=x["eye"])
+        reps = 5
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t_march, samples, launches = 0.0, 0, 0
+        import ctypes
+        from genefaceplusplus_amd._lib import call
+        for _ in range(reps):
+            ro, rd = x["rays_o"].view(-1, 3), x["rays_d"].view(-1, 3)
+            ws, tbuf = pipe.workspace(N)
+            st = torch.cuda.current_stream().cuda_stream
+            ind = model.individual_embeddings[0].detach().float().contiguous()
+            cf = cond_feat.detach().float().contiguous()
+            call("gfpp_head_frame_begin", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), cf.data_ptr(), ind.data_ptr(), st)
+            e0.record()
+            call("gfpp_head_frame_march", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
+                 int(hp["max_steps"]), 0.01, st)
+            e1.record()
+            torch.cuda.synchronize()
+            t_march += e0.elapsed_time(e1) * 1e-3
+            alive, smp = pipe.trip_counters(N)
+            samples += int(smp.sum())
+            launches += int((smp > 0).sum())
+        flops = samples * FLOP_PER_SAMPLE
+        achieved = flops / t_march / 1e12
+        result["roofline"] = {"kernel": "k_head_trip<3> (fused march + grid encode + MFMA MLP + composite)", "bound": "mfma",
+                              "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                              "samples_per_frame": samples // reps, "nonempty_trips_per_frame": launches // reps,
+                              "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4),
+                              "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4), "alive_per_trip": [int(v) for v in alive[:17] if v > 0]}
+
+    if rank == 0 and not args.no_grid_stage:
+        from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw
+        B = 1 << 22
+        u = torch.rand(B, 3, device=dev)
+        enc = model.position_embedder
+        emb = enc.embeddings.detach()
+        for _ in range(2):
+            grid_encode_raw(u, emb, enc.offsets, enc.per_level_scale, 16, enc.gridtype_id, False, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 5
+        for _ in range(reps):
+            grid_encode_raw(u, emb, enc.offsets, enc.per_level_scale, 16, enc.gridtype_id, False, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        gbps = B * GRID_BYTES_PER_POINT / t / 1e9
+        result["grid_stage"] = {"kernel": "k_grid_encode<3,2,float>", "bound": "hbm", "points": B, "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+                                "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4), "ms": round(t * 1e3, 4), "input": "uniform random in [0,1]^3"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args.variant if args.variant != "may_torso_sr" else "may_torso_sr",
+                                                  hw_sample=256, hw_full=HW)
+        except Exception as exc:  # the oracle is optional equipment for the bench, never for the product
+            result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

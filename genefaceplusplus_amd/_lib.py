@@ -30,6 +30,7 @@ _SIGNATURES = {
     "gfpp_sh_encode_forward": [c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p],
     "gfpp_freq_encode_forward": [c_p, c_u32, c_u32, c_u32, c_u32, c_p, c_p],
     "gfpp_get_rays": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_p],
+    "gfpp_rgb_to_u8": [c_p, ctypes.c_uint64, c_p, c_p],
 }
 _RESTYPES = {"gfpp_last_error": ctypes.c_char_p}
 

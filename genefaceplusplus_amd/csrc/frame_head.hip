@@ -1,0 +1,486 @@
+// frame_head.hip -- fused head-NeRF frame pipeline for gfx950.
+//
+// One "trip" kernel = one iteration of the reference's render loop (renderer.py:354-384), entirely on the device:
+//   phase 1  march      : one thread per alive ray emits up to n_step occupied samples into LDS (march_device.h)
+//   phase 2  evaluate   : occupied samples are compacted inside the tile; each wavefront takes 32 of them and runs
+//                         position grid -> ambient MLP -> tanh -> ambient grid -> sigma MLP -> exp -> SH -> colour MLP
+//                         -> sigmoid with v_mfma_f32_32x32x2_f32 (exact fp32 fma chains).  Weights are the A operand
+//                         (pre-packed in fragment order, see gfpp_radnerf.h), the 32 samples are the B columns, so the
+//                         accumulator registers of one layer ARE the B operands of the next: activations never leave
+//                         the register file and nothing is written to HBM between encode and composite.
+//   phase 3  composite  : one thread per ray folds its samples into (weight_sum, depth, rgb), decides alive/dead, and the
+//                         survivors are appended to the next trip's list (one atomicAdd per tile).
+// Loop control (n_alive -> n_step, cumulative step, exit) is recomputed by every workgroup from the counters that the
+// previous trips left in memory, so the host never synchronises.
+#include <hip/hip_runtime.h>
+
+#include "grid_device.h"
+#include "march_device.h"
+#include "sh_device.h"
+
+namespace gfpp {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 128;     // sample slots per workgroup tile (4 wavefronts x 32 columns)
+constexpr int kThreads = 256;
+constexpr int kMaxTrips = 63;      // counters[0..63] alive counts, counters[64..127] evaluated samples
+
+struct GridDev {
+    const void *table;
+    const gfpp_grid_level *levels;
+    uint32_t gridtype, interp, align_corners;
+};
+
+struct HeadWeights {
+    const float4 *amb_w0, *amb_w1, *sig_w0, *sig_w1, *sig_w2_geo, *col_w0;
+    const float *amb_w2, *sig_w2_sig, *col_w1;
+};
+
+struct TripArgs {
+    MarchParams mp;
+    GridDev pos, amb;
+    HeadWeights w;
+    const uint8_t *bitfield;
+    const float *rays_o, *rays_d, *fars;
+    float *rays_t, *weights_sum, *depth, *image;
+    const int32_t *alive_in;
+    int32_t *alive_out;
+    int32_t *counters;
+    const float *frame_consts;  // [0,128): ambient bias frag, [128,256): colour bias frag
+    float T_thresh, density_scale;
+    uint32_t N, trip, max_steps;
+};
+
+__device__ __forceinline__ v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// acc[m] (4 output tiles of 32 rows) += W_packed * b ;  NS rank-2 steps, b[s] is this lane's B element of step s.
+// Weight fragments stream from L2 one quad (4 steps x 4 tiles = 16 MFMAs ~ 1k cycles) ahead of their use; the
+// sched_barrier keeps the compiler from hoisting a whole layer's loads (which would spill the accumulators).
+template <int NS>
+__device__ __forceinline__ void mfma_layer(v16f (&acc)[4], const float4 *__restrict__ w, const float (&b)[NS], int lane) {
+    static_assert(NS % 4 == 0, "steps are packed in quads");
+    const uint32_t l = (uint32_t)lane;   // uniform base (SGPR pair) + 32-bit lane offset => global_load saddr form
+    float4 a0 = w[l], a1 = w[64u + l], a2 = w[128u + l], a3 = w[192u + l];
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) {
+        float4 n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+        if (q + 1 < NS / 4) {
+            const float4 *wq = w + (q + 1) * 256;
+            n0 = wq[l];
+            n1 = wq[64u + l];
+            n2 = wq[128u + l];
+            n3 = wq[192u + l];
+        }
+        acc[0] = mfma32(a0.x, b[4 * q], acc[0]); acc[1] = mfma32(a1.x, b[4 * q], acc[1]);
+        acc[2] = mfma32(a2.x, b[4 * q], acc[2]); acc[3] = mfma32(a3.x, b[4 * q], acc[3]);
+        acc[0] = mfma32(a0.y, b[4 * q + 1], acc[0]); acc[1] = mfma32(a1.y, b[4 * q + 1], acc[1]);
+        acc[2] = mfma32(a2.y, b[4 * q + 1], acc[2]); acc[3] = mfma32(a3.y, b[4 * q + 1], acc[3]);
+        acc[0] = mfma32(a0.z, b[4 * q + 2], acc[0]); acc[1] = mfma32(a1.z, b[4 * q + 2], acc[1]);
+        acc[2] = mfma32(a2.z, b[4 * q + 2], acc[2]); acc[3] = mfma32(a3.z, b[4 * q + 2], acc[3]);
+        acc[0] = mfma32(a0.w, b[4 * q + 3], acc[0]); acc[1] = mfma32(a1.w, b[4 * q + 3], acc[1]);
+        acc[2] = mfma32(a2.w, b[4 * q + 3], acc[2]); acc[3] = mfma32(a3.w, b[4 * q + 3], acc[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+    }
+}
+
+__device__ __forceinline__ void load_bias(v16f (&acc)[4], const float *__restrict__ bias_frag, int hi) {
+    const float4 *p = reinterpret_cast<const float4 *>(bias_frag + hi * 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = p[m * 4 + q];
+            acc[m][4 * q] = v.x; acc[m][4 * q + 1] = v.y; acc[m][4 * q + 2] = v.z; acc[m][4 * q + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(v16f (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+}
+
+template <bool RELU>
+__device__ __forceinline__ void acc_to_b(const v16f (&acc)[4], float (&b)[64]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b[m * 16 + r] = RELU ? fmaxf(acc[m][r], 0.0f) : acc[m][r];
+}
+
+// Skinny output layer on the VALU: out[c] = sum over this lane's 64 activations, then the two half-waves are added.
+template <int C>
+__device__ __forceinline__ void valu_rows(const float *__restrict__ wv, const float (&b)[64], int hi, float (&out)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float4 *p = reinterpret_cast<const float4 *>(wv + (hi * C + c) * 64);
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = p[q];
+            s = fmaf(v.x, b[4 * q], s); s = fmaf(v.y, b[4 * q + 1], s); s = fmaf(v.z, b[4 * q + 2], s); s = fmaf(v.w, b[4 * q + 3], s);
+        }
+        out[c] = s + __shfl_xor(s, 32);
+    }
+}
+
+// This lane's half of a 16-level, 2-channel grid encoding: levels hi*8 .. hi*8+7 -> 16 features.
+template <int D>
+__device__ __forceinline__ void encode_half(const float (&u)[D], const GridDev &g, int hi, bool valid, float (&f)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f[i] = 0.0f;
+    if (!valid) return;
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) inside = inside && !(u[d] < 0.0f || u[d] > 1.0f);
+    if (!inside) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const gfpp_grid_level lv = g.levels[hi * 8 + i];
+        float o[2];
+        grid_level_lookup<D, 2, float>(u, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype,
+                                       g.align_corners != 0, g.interp, o);
+        f[2 * i] = o[0];
+        f[2 * i + 1] = o[1];
+    }
+}
+
+struct TileShared {
+    float px[kTile], py[kTile], pz[kTile], dt[kTile], tend[kTile];  // by slot = ray_local * n_step + s
+    float sigma[kTile], cr[kTile], cg[kTile], cb[kTile];            // by slot
+    float dx[kTile], dy[kTile], dz[kTile];                          // by ray_local
+    uint32_t order[kTile];                                          // compact index -> slot
+    uint32_t wave_tot[4];
+    uint32_t n_valid;
+    uint32_t out_base;
+};
+
+// Evaluate RADNeRF.forward for the 32 occupied samples [first, first+32) of the tile.
+template <int AMB_D>
+__device__ __forceinline__ void evaluate_block(const TripArgs &a, TileShared &sh, uint32_t first, uint32_t n_step, int lane_in) {
+    int lane = lane_in;
+    // launder the lane id: keeps the (tile-loop-invariant) per-lane weight addresses from being hoisted out of the
+    // tile loop and spilled
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 31, hi = lane >> 5;
+    const uint32_t c = first + j;
+    const bool valid = c < sh.n_valid;
+    const uint32_t slot = valid ? sh.order[c] : 0u;
+    const uint32_t ray_local = slot / n_step;
+
+    // ---- position grid (each half-wave does 8 of the 16 levels) ------------------------------------------------
+    float u3[3];
+    const float b2 = 2.0f * a.mp.bound;
+    u3[0] = (sh.px[slot] + a.mp.bound) / b2;
+    u3[1] = (sh.py[slot] + a.mp.bound) / b2;
+    u3[2] = (sh.pz[slot] + a.mp.bound) / b2;
+    float fpos[16];
+    encode_half<3>(u3, a.pos, hi, valid, fpos);
+
+    v16f acc[4];
+    float bs[64];
+
+    // ---- ambient net -----------------------------------------------------------------------------------------
+    load_bias(acc, a.frame_consts, hi);
+    mfma_layer<16>(acc, a.w.amb_w0, fpos, lane);
+    acc_to_b<true>(acc, bs);
+    zero_acc(acc);
+    mfma_layer<64>(acc, a.w.amb_w1, bs, lane);
+    acc_to_b<true>(acc, bs);
+    float amb[AMB_D];
+    valu_rows<AMB_D>(a.w.amb_w2, bs, hi, amb);
+    float ua[AMB_D];
+#pragma unroll
+    for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
+    float famb[16];
+    encode_half<AMB_D>(ua, a.amb, hi, valid, famb);
+
+    // ---- sigma net -------------------------------------------------------------------------------------------
+    zero_acc(acc);
+    {
+        float b32[32];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { b32[i] = fpos[i]; b32[16 + i] = famb[i]; }
+        mfma_layer<32>(acc, a.w.sig_w0, b32, lane);
+    }
+    acc_to_b<true>(acc, bs);
+    zero_acc(acc);
+    mfma_layer<64>(acc, a.w.sig_w1, bs, lane);
+    acc_to_b<true>(acc, bs);
+    float logit[1];
+    valu_rows<1>(a.w.sig_w2_sig, bs, hi, logit);
+    const float sigma = a.density_scale * expf(logit[0]);
+    zero_acc(acc);
+    mfma_layer<64>(acc, a.w.sig_w2_geo, bs, lane);   // geo_feat: no activation
+
+    // ---- colour net --------------------------------------------------------------------------------------------
+    {
+        float b72[72];
+        float shv[16];
+        sh_basis4(sh.dx[ray_local], sh.dy[ray_local], sh.dz[ray_local], shv);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b72[s] = hi ? shv[8 + s] : shv[s];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b72[8 + m * 16 + r] = acc[m][r];
+        load_bias(acc, a.frame_consts + 128, hi);
+        mfma_layer<72>(acc, a.w.col_w0, b72, lane);
+    }
+    acc_to_b<true>(acc, bs);
+    float rgb[3];
+    valu_rows<3>(a.w.col_w1, bs, hi, rgb);
+
+    if (valid && hi == 0) {
+        sh.sigma[slot] = sigma;
+        sh.cr[slot] = 1.0f / (1.0f + expf(-rgb[0]));
+        sh.cg[slot] = 1.0f / (1.0f + expf(-rgb[1]));
+        sh.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = __shfl_up(v, off);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+template <int AMB_D>
+__global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
+    __shared__ TileShared sh;
+    // ---- loop state, recomputed from the per-trip counters (renderer.py:354-384) ----------------------------------
+    uint32_t step_before = 0;
+    for (uint32_t k = 0; k < a.trip; ++k) {
+        const uint32_t na = (uint32_t)a.counters[k];
+        if (na == 0) return;
+        uint32_t ns = a.N / na;
+        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
+        step_before += ns;
+    }
+    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
+    if (n_alive == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N / n_alive;
+    n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+
+    const uint32_t rays_per_tile = kTile / n_step;
+    const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // ---- phase 1: march ---------------------------------------------------------------------------------------
+        const uint32_t n = tile * rays_per_tile + tid;
+        const bool has_ray = (uint32_t)tid < rays_per_tile && n < n_alive;
+        uint32_t ray = 0, cnt = 0;
+        float t = 0.0f;
+        if (has_ray) {
+            ray = a.trip == 0 ? n : (uint32_t)a.alive_in[n];
+            const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+            const float dx = d[0], dy = d[1], dz = d[2];
+            sh.dx[tid] = dx; sh.dy[tid] = dy; sh.dz[tid] = dz;
+            t = a.rays_t[ray];
+            const uint32_t base = tid * n_step;
+            cnt = march_one_ray(o[0], o[1], o[2], dx, dy, dz, t, a.fars[ray], n_step, a.bitfield, a.mp, [&](uint32_t s, const Sample &smp) {
+                sh.px[base + s] = smp.x; sh.py[base + s] = smp.y; sh.pz[base + s] = smp.z;
+                sh.dt[base + s] = smp.dt; sh.tend[base + s] = smp.t_end;
+            });
+        }
+        // tile-level compaction of the occupied samples (rays live in waves 0 and 1 only)
+        const uint32_t incl = wave_inclusive_scan(cnt, lane);
+        if (lane == 63) sh.wave_tot[wave] = incl;
+        __syncthreads();
+        {
+            uint32_t before = 0;
+            for (int w = 0; w < wave; ++w) before += sh.wave_tot[w];
+            uint32_t pos = before + incl - cnt;
+            for (uint32_t s = 0; s < cnt; ++s) sh.order[pos + s] = tid * n_step + s;
+            if (tid == kThreads - 1) {
+                sh.n_valid = before + incl;
+                if (before + incl) atomicAdd(&a.counters[64 + a.trip], (int)(before + incl));   // evaluated samples of this trip
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: evaluate the radiance field on the occupied samples, 32 per wavefront -------------------------
+        const uint32_t n_valid = sh.n_valid;
+        for (uint32_t first = wave * 32; first < n_valid; first += 4 * 32) evaluate_block<AMB_D>(a, sh, first, n_step, lane);
+        __syncthreads();
+
+        // ---- phase 3: composite, ray state update, survivor compaction -------------------------------------------------
+        bool survives = false;
+        if (has_ray) {
+            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            const uint32_t base = tid * n_step;
+            uint32_t s = 0;
+            float t_last = t;
+            for (; s < cnt; ++s) {
+                const uint32_t k = base + s;
+                t_last = sh.tend[k];
+                if (composite_sample(acc, sh.sigma[k], sh.dt[k], t_last, sh.cr[k], sh.cg[k], sh.cb[k], a.T_thresh)) break;
+            }
+            // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
+            survives = (s == n_step);
+            if (survives) a.rays_t[ray] = t_last;
+            a.weights_sum[ray] = acc.wsum;
+            a.depth[ray] = acc.depth;
+            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+        }
+        const unsigned long long ballot = __ballot(survives);
+        const uint32_t wave_cnt = (uint32_t)__popcll(ballot);
+        if (lane == 0) sh.wave_tot[wave] = wave_cnt;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t total = sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+            sh.out_base = total ? (uint32_t)atomicAdd(&a.counters[a.trip + 1], (int)total) : 0u;
+        }
+        __syncthreads();
+        if (survives) {
+            uint32_t before = sh.out_base;
+            for (int w = 0; w < wave; ++w) before += sh.wave_tot[w];
+            const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+            a.alive_out[before + rank] = (int32_t)ray;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- frame begin: slab test + state reset + constant folding ------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, uint32_t N,
+                                                         float min_near, float ax0, float ay0, float az0, float ax1, float ay1, float az1,
+                                                         float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ rays_t,
+                                                         float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                                         int32_t *__restrict__ counters) {
+    const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 128) counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)N : 0;
+    if (n >= N) return;
+    const float aabb[6] = {ax0, ay0, az0, ax1, ay1, az1};
+    const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;
+    const RayBox rb = ray_box(o[0], o[1], o[2], d[0], d[1], d[2], aabb, min_near);
+    nears[n] = rb.near;
+    fars[n] = rb.far;
+    rays_t[n] = rb.near;
+    weights_sum[n] = 0.0f;
+    depth[n] = 0.0f;
+    image[3ull * n] = 0.0f; image[3ull * n + 1] = 0.0f; image[3ull * n + 2] = 0.0f;
+}
+
+// out[row] = sum_k W[row, k] * v[k] for 128 rows, written in bias-fragment order Bf[h][16*m+r] <- row 32*m+rr(r)+4*h.
+__global__ __launch_bounds__(128) void k_fold_constants(const float *__restrict__ w_cond, const float *__restrict__ cond, uint32_t cond_dim,
+                                                       const float *__restrict__ w_ind, const float *__restrict__ ind, uint32_t ind_dim,
+                                                       float *__restrict__ frame_consts) {
+    const int row = threadIdx.x;  // 0..127
+    const float *w = blockIdx.x == 0 ? w_cond : w_ind;
+    const float *v = blockIdx.x == 0 ? cond : ind;
+    const uint32_t K = blockIdx.x == 0 ? cond_dim : ind_dim;
+    float s = 0.0f;
+    if (w && v)
+        for (uint32_t k = 0; k < K; ++k) s = fmaf(w[(size_t)row * K + k], v[k], s);
+    const int m = row >> 5, i = row & 31;
+    const int h = (i >> 2) & 1;
+    const int r = (i & 3) + 4 * (i >> 3);
+    frame_consts[blockIdx.x * 128 + h * 64 + m * 16 + r] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_head_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
+                                                         const float *__restrict__ weights_sum, const float *__restrict__ depth,
+                                                         const float *__restrict__ image, const float *__restrict__ bg_color, float bg_scalar,
+                                                         float *__restrict__ out_image, float *__restrict__ out_depth) {
+    const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const float T = 1.0f - weights_sum[n];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float bg = bg_color ? bg_color[3ull * n + c] : bg_scalar;
+        out_image[3ull * n + c] = clampf(image[3ull * n + c] + T * bg, 0.0f, 1.0f);
+    }
+    out_depth[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+}
+
+static bool grid_ok(const gfpp_grid_desc &g, uint32_t D) {
+    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_grid_level_table(uint32_t L, float S, uint32_t H, float *scale_out, uint32_t *resolution_out) {
+    if (!scale_out || !resolution_out || L > (uint32_t)kMaxLevels) { set_error("gfpp_grid_level_table: bad arguments"); return GFPP_EINVAL; }
+    GridLevels g;
+    fill_level_scales(g, L, S, H);
+    for (uint32_t l = 0; l < L; ++l) { scale_out[l] = g.scale[l]; resolution_out[l] = g.resolution[l]; }
+    return 0;
+}
+
+GFPP_API int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                   const float *cond_feat, const float *ind_code, gfpp_stream_t stream) {
+    if (!model || !ws || !rays_o || !rays_d || !cond_feat) { set_error("gfpp_head_frame_begin: null argument"); return GFPP_EINVAL; }
+    if (!ws->nears || !ws->fars || !ws->rays_t || !ws->weights_sum || !ws->depth || !ws->image || !ws->counters || !ws->frame_consts || ws->N == 0) {
+        set_error("gfpp_head_frame_begin: incomplete workspace");
+        return GFPP_EINVAL;
+    }
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_frame_begin, dim3(div_up(ws->N, kThreads)), dim3(kThreads), 0, st, rays_o, rays_d, ws->N, model->min_near, model->aabb[0],
+                       model->aabb[1], model->aabb[2], model->aabb[3], model->aabb[4], model->aabb[5], ws->nears, ws->fars, ws->rays_t,
+                       ws->weights_sum, ws->depth, ws->image, ws->counters);
+    int rc = check_launch("gfpp_head_frame_begin(init)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fold_constants, dim3(2), dim3(128), 0, st, model->amb_w0_cond, cond_feat, model->cond_dim, model->col_w0_ind,
+                       model->ind_dim ? ind_code : nullptr, model->ind_dim, ws->frame_consts);
+    return check_launch("gfpp_head_frame_begin(fold)");
+}
+
+GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                   float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_march: null argument"); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("gfpp_head_frame_march: max_steps must be in 1..%d", kMaxTrips); return GFPP_EUNSUPPORTED; }
+    if (!grid_ok(model->pos_grid, 3) || !(grid_ok(model->amb_grid, 2) || grid_ok(model->amb_grid, 3))) {
+        set_error("gfpp_head_frame_march: grids must be 16-level fp32, position D=3, ambient D in {2,3}");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (model->cascade < 1 || model->cascade > 8 || !model->density_bitfield || !ws->alive[0] || !ws->alive[1]) {
+        set_error("gfpp_head_frame_march: bad model/workspace");
+        return GFPP_EINVAL;
+    }
+    TripArgs a;
+    a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
+    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
+                      (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
+    a.bitfield = model->density_bitfield;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
+    a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.counters = ws->counters;
+    a.frame_consts = ws->frame_consts;
+    a.T_thresh = T_thresh; a.density_scale = model->density_scale;
+    a.N = ws->N; a.max_steps = max_steps;
+    // enough workgroups for the worst trip (ceil(N / floor(128/n_step)) tiles), capped: tiles are taken grid-stride
+    uint32_t grid = div_up(ws->N, 120);
+    if (grid > 4096u) grid = 4096u;
+    const hipStream_t st = (hipStream_t)stream;
+    for (uint32_t trip = 0; trip < max_steps; ++trip) {
+        a.trip = trip;
+        a.alive_in = ws->alive[trip & 1];
+        a.alive_out = ws->alive[(trip + 1) & 1];
+        if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip<3>, dim3(grid), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL(k_head_trip<2>, dim3(grid), dim3(kThreads), 0, st, a);
+        const int rc = check_launch("gfpp_head_frame_march");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+GFPP_API int gfpp_head_frame_finish(const gfpp_frame_ws *ws, const float *bg_color, float bg_scalar, float *out_image, float *out_depth,
+                                    gfpp_stream_t stream) {
+    if (!ws || !out_image || !out_depth || ws->N == 0) { set_error("gfpp_head_frame_finish: null argument"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_head_finish, dim3(div_up(ws->N, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, ws->N, ws->nears, ws->fars,
+                       ws->weights_sum, ws->depth, ws->image, bg_color, bg_scalar, out_image, out_depth);
+    return check_launch("gfpp_head_frame_finish");
+}

@@ -120,6 +120,20 @@ __global__ __launch_bounds__(kBlock) void k_get_rays(const float *__restrict__ p
     }
 }
 
+// float -> uint8 with truncation (x * 255 then int cast), 4 values per thread
+__global__ __launch_bounds__(kBlock) void k_rgb_to_u8(const float *__restrict__ rgb, size_t n, uint8_t *__restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(rgb + i);
+        uchar4 o;
+        o.x = (uint8_t)clampf(v.x * 255.0f, 0.0f, 255.0f); o.y = (uint8_t)clampf(v.y * 255.0f, 0.0f, 255.0f);
+        o.z = (uint8_t)clampf(v.z * 255.0f, 0.0f, 255.0f); o.w = (uint8_t)clampf(v.w * 255.0f, 0.0f, 255.0f);
+        *reinterpret_cast<uchar4 *>(out + i) = o;
+    } else {
+        for (size_t k = i; k < n; ++k) out[k] = (uint8_t)clampf(rgb[k] * 255.0f, 0.0f, 255.0f);
+    }
+}
+
 }  // namespace gfpp
 
 using namespace gfpp;
@@ -196,4 +210,13 @@ GFPP_API int gfpp_get_rays(const float *pose, float fx, float fy, float cx, floa
     GFPP_REQUIRE(pose && rays_o && rays_d, "gfpp_get_rays");
     hipLaunchKernelGGL(k_get_rays, dim3(div_up(H * W, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, H, W, rays_o, rays_d);
     return check_launch("gfpp_get_rays");
+}
+
+GFPP_API int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_stream_t stream) {
+    if (n_values == 0) return 0;
+    GFPP_REQUIRE(rgb && out, "gfpp_rgb_to_u8");
+    GFPP_REQUIRE(((uintptr_t)rgb & 15u) == 0 && ((uintptr_t)out & 3u) == 0, "gfpp_rgb_to_u8");
+    const uint64_t threads = (n_values + 3) / 4;
+    hipLaunchKernelGGL(k_rgb_to_u8, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, rgb, (size_t)n_values, out);
+    return check_launch("gfpp_rgb_to_u8");
 }

@@ -1,0 +1,67 @@
+"""Frame-parallel sharding of a clip across the GPUs of one node (new work -- the reference renders
+frames serially on one device, inference/genefacepp_infer.py:460-485).
+
+Frames are independent units (each needs only its own pose, conditioning window, landmarks; the weights are replicated), so
+the data path has no collective.  The single exchange step is the all_gather of finished uint8 frames (786 432 B per 512x512
+frame) over RCCL / xGMI -- backend "nccl" on ROCm; the same code runs on "gloo" for the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import call
+
+
+def shard_frames(n_frames, rank, world, interleaved=False):
+    """Frame indices owned by `rank`.
+
+    contiguous (default): blocks of ceil(n/world) frames keep video order inside a rank (what a clip renderer wants);
+    interleaved: frame i -> rank i % world (what a streaming server wants: every rank works on the "current" second)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    if interleaved:
+        return list(range(rank, n_frames, world))
+    per = -(-n_frames // world)
+    return list(range(min(rank * per, n_frames), min((rank + 1) * per, n_frames)))
+
+
+def frame_owner(frame_idx, n_frames, world, interleaved=False):
+    if interleaved:
+        return frame_idx % world
+    per = -(-n_frames // world)
+    return frame_idx // per
+
+
+def to_uint8_hwc(rgb, out=None):
+    """float [..,3] in [0,1] -> uint8 (truncating, like `(x * 255.).int()` in genefacepp_infer.py:468); one HIP launch."""
+    rgb = rgb.contiguous()
+    if out is None:
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+    if rgb.is_cuda:
+        call("gfpp_rgb_to_u8", rgb.data_ptr(), rgb.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    else:  # host-side convenience for the gloo tests only (no kernel involved)
+        out.copy_((rgb * 255.0).to(torch.int32).clamp_(0, 255).to(torch.uint8))
+    return out
+
+
+def gather_clip(local_frames, n_frames, interleaved=False, group=None):
+    """all_gather the per-rank uint8 frame stacks [F_local, H, W, 3] and reassemble the clip in frame order on every rank.
+    Ranks may own different numbers of frames (last block shorter): stacks are padded to the longest."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_frames
+    rank = dist.get_rank(group)
+    counts = [len(shard_frames(n_frames, r, world, interleaved)) for r in range(world)]
+    longest = max(counts)
+    if local_frames.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local_frames.shape[0]} frames, expected {counts[rank]}")
+    if local_frames.shape[0] < longest:
+        pad = torch.zeros(longest - local_frames.shape[0], *local_frames.shape[1:], dtype=local_frames.dtype, device=local_frames.device)
+        local_frames = torch.cat([local_frames, pad], dim=0)
+    parts = [torch.empty_like(local_frames) for _ in range(world)]
+    dist.all_gather(parts, local_frames.contiguous(), group=group)
+    clip = torch.empty(n_frames, *local_frames.shape[1:], dtype=local_frames.dtype, device=local_frames.device)
+    for r in range(world):
+        idx = shard_frames(n_frames, r, world, interleaved)
+        if idx:
+            clip[torch.tensor(idx, device=clip.device)] = parts[r][:len(idx)]
+    return clip

@@ -1,0 +1,323 @@
+"""Host side of the fused frame pipeline (Section B of include/gfpp_radnerf.h).
+
+``FramePipeline`` is built once per model: it re-packs the MLP weights into MFMA fragment order, uploads the per-level
+grid tables, fills the C descriptor structs, and owns the per-resolution device workspaces.  ``render_head`` /
+``render_head_torso`` then issue a fixed sequence of C-ABI calls on torch's current stream -- no allocation (after the first
+frame of a resolution), no host synchronisation, hence capturable in a hipGraph (see ``GraphedFrame``).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import call, GfppError
+
+c_p = ctypes.c_void_p
+c_u32 = ctypes.c_uint32
+c_f = ctypes.c_float
+
+
+class GridLevel(ctypes.Structure):
+    _fields_ = [("scale", c_f), ("resolution", c_u32), ("offset", c_u32), ("size", c_u32)]
+
+
+class GridDesc(ctypes.Structure):
+    _fields_ = [("table", c_p), ("levels", c_p), ("dtype", ctypes.c_int32), ("D", c_u32), ("L", c_u32), ("gridtype", c_u32),
+                ("interp", c_u32), ("align_corners", c_u32)]
+
+
+class HeadModel(ctypes.Structure):
+    _fields_ = [("aabb", c_f * 6), ("min_near", c_f), ("bound", c_f), ("density_scale", c_f), ("cascade", c_u32), ("grid_size", c_u32),
+                ("density_bitfield", c_p), ("pos_grid", GridDesc), ("amb_grid", GridDesc),
+                ("amb_w0", c_p), ("amb_w0_cond", c_p), ("amb_w1", c_p), ("amb_w2", c_p),
+                ("sig_w0", c_p), ("sig_w1", c_p), ("sig_w2_geo", c_p), ("sig_w2_sig", c_p),
+                ("col_w0", c_p), ("col_w0_ind", c_p), ("col_w1", c_p), ("cond_dim", c_u32), ("ind_dim", c_u32)]
+
+
+class FrameWs(ctypes.Structure):
+    _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("rays_t", c_p), ("weights_sum", c_p), ("depth", c_p), ("image", c_p),
+                ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p)]
+
+
+class TorsoModel(ctypes.Structure):
+    _fields_ = [("density_grid", c_p), ("grid_size", c_u32), ("density_thresh", c_f), ("torso_shrink", c_f), ("variant", c_u32),
+                ("code_dim", c_u32), ("const_dim", c_u32), ("head_aware", c_u32), ("grid", GridDesc),
+                ("def_w0_x", c_p), ("def_w0_c", c_p), ("def_w0_h", c_p), ("def_w1", c_p), ("def_w2", c_p),
+                ("can_w0_g", c_p), ("can_w0_x", c_p), ("can_w0_c", c_p), ("can_w0_h", c_p), ("can_w1", c_p), ("can_w2", c_p),
+                ("ha_w0", c_p), ("ha_b0", c_p), ("ha_w1", c_p), ("ha_b1", c_p), ("ha_w2", c_p), ("ha_b2", c_p)]
+
+
+_lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
+                                   c_p, c_p, c_p])
+_lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
+_lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
+_lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# weight packing (layout documented at gfpp_head_model in include/gfpp_radnerf.h)
+# ---------------------------------------------------------------------------------------------------------------------
+def _rr(r):
+    return (r & 3) + 8 * (r >> 2)
+
+
+def activation_pairs(width=128):
+    """K-step -> (input index fed by lanes 0-31, by lanes 32-63) when the inputs are the previous layer's accumulators."""
+    return [(32 * m + _rr(r), 32 * m + _rr(r) + 4) for m in range(width // 32) for r in range(16)]
+
+
+def encoder_pairs(base, count):
+    """Inputs produced by an encoder whose `count` values are split between the two half-waves."""
+    half = count // 2
+    return [(base + s, base + half + s) for s in range(half)]
+
+
+def pack_mfma(weight, pairs, shift=0):
+    """weight [128, in] (nn.Linear layout) -> float32 [S/4, 4, 64, 4]; `shift` offsets activation indices into `weight`."""
+    W = weight.detach().float()
+    assert W.shape[0] == 128, "the MFMA path is built for 128-wide layers (4 tiles of 32 rows)"
+    S = len(pairs)
+    assert S % 4 == 0
+    idx = torch.tensor(pairs, dtype=torch.long, device=W.device) + shift          # [S, 2]
+    Wk = W[:, idx]                                                                  # [128, S, 2]
+    P = Wk.view(4, 32, S, 2).permute(2, 0, 3, 1)                                    # [S, m, half, i]
+    P = P.reshape(S // 4, 4, 4, 64).permute(0, 2, 3, 1)                             # [S/4, m, lane, sub]
+    return P.contiguous()
+
+
+def pack_valu(weight):
+    """weight [C, 128] -> float32 [2, C, 64] with V[h][c][16*m+r] = W[c][32*m + rr(r) + 4*h]."""
+    W = weight.detach().float()
+    C = W.shape[0]
+    cols = torch.tensor([[32 * m + _rr(r) + 4 * h for m in range(4) for r in range(16)] for h in range(2)], dtype=torch.long, device=W.device)
+    return W[:, cols].permute(1, 0, 2).contiguous().view(2, C, 64)
+
+
+def supports(model):
+    """The MFMA kernels are specialised for the shipped architecture family (hidden 128, 3/3/2 layers, 16x2 grids)."""
+    hp = model.hparams
+    ok = (hp["hidden_dim_ambient"] == 128 and hp["hidden_dim_sigma"] == 128 and hp["hidden_dim_color"] == 128 and hp["geo_feat_dim"] == 128
+          and hp["num_layers_ambient"] == 3 and hp["num_layers_sigma"] == 3 and hp["num_layers_color"] == 2
+          and hp["ambient_coord_dim"] in (2, 3) and model.position_embedder.num_levels == 16 and model.position_embedder.level_dim == 2)
+    return ok
+
+
+class FramePipeline:
+    def __init__(self, model):
+        if not supports(model):
+            raise GfppError("fused pipeline: unsupported architecture (needs hidden 128, layers 3/3/2, 16x2 grids); "
+                            "set model.executor = 'staged'")
+        self.device = model.density_bitfield.device
+        if self.device.type != "cuda":
+            raise GfppError("fused pipeline: the model must live on the GPU (there is no CPU path)")
+        _lib.lib()
+        self._keep = []            # device tensors referenced by raw pointers in the descriptors
+        self._versions = self._fingerprint(model)
+        self.head = self._build_head(model)
+        self.torso = self._build_torso(model) if hasattr(model, "torso_deform_net") else None
+        self._ws = {}
+
+    # -- change detection ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _fingerprint(model):
+        return tuple((p.data_ptr(), p._version) for p in list(model.parameters()) + list(model.buffers()))
+
+    def matches(self, model):
+        return model.density_bitfield.device == self.device and self._fingerprint(model) == self._versions
+
+    # -- descriptors ---------------------------------------------------------------------------------------------
+    def _hold(self, t):
+        t = t.contiguous()
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _grid_desc(self, enc):
+        if enc.level_dim != 2 or enc.num_levels != 16:
+            raise GfppError("fused pipeline: grids must have 16 levels x 2 channels")
+        L = enc.num_levels
+        scale = (c_f * L)()
+        res = (c_u32 * L)()
+        call("gfpp_grid_level_table", L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), scale, res)
+        off = enc.offsets.cpu().numpy()
+        lv = np.zeros(L, dtype=[("scale", np.float32), ("resolution", np.uint32), ("offset", np.uint32), ("size", np.uint32)])
+        lv["scale"] = np.frombuffer(scale, dtype=np.float32)
+        lv["resolution"] = np.frombuffer(res, dtype=np.uint32)
+        lv["offset"] = off[:-1]
+        lv["size"] = off[1:] - off[:-1]
+        levels = torch.from_numpy(lv.view(np.uint8).reshape(L, 16).copy()).to(self.device)
+        d = GridDesc()
+        d.table = self._hold(enc.embeddings.detach().float())
+        d.levels = self._hold(levels)
+        d.dtype = 0
+        d.D, d.L = enc.input_dim, L
+        d.gridtype, d.interp, d.align_corners = enc.gridtype_id, enc.interp_id, int(enc.align_corners)
+        return d
+
+    def _build_head(self, m):
+        hm = HeadModel()
+        aabb = m.aabb_infer.detach().cpu().numpy().astype(np.float32)
+        for i in range(6):
+            hm.aabb[i] = float(aabb[i])
+        hm.min_near, hm.bound, hm.density_scale = float(m.min_near), float(m.bound), float(m.density_scale)
+        hm.cascade, hm.grid_size = int(m.cascade), int(m.grid_size)
+        hm.density_bitfield = self._hold(m.density_bitfield)
+        hm.pos_grid = self._grid_desc(m.position_embedder)
+        hm.amb_grid = self._grid_desc(m.ambient_embedder)
+        act = activation_pairs()
+        enc32 = encoder_pairs(0, 32)
+        A0, A1, A2 = (l.weight for l in m.ambient_net.net)
+        S0, S1, S2 = (l.weight for l in m.sigma_net.net)
+        C0, C1 = (l.weight for l in m.color_net.net)
+        hm.amb_w0 = self._hold(pack_mfma(A0, enc32))
+        hm.amb_w0_cond = self._hold(A0.detach().float()[:, 32:])
+        hm.amb_w1 = self._hold(pack_mfma(A1, act))
+        hm.amb_w2 = self._hold(pack_valu(A2))
+        hm.sig_w0 = self._hold(pack_mfma(S0, enc32 + encoder_pairs(32, 32)))
+        hm.sig_w1 = self._hold(pack_mfma(S1, act))
+        hm.sig_w2_geo = self._hold(pack_mfma(S2[1:], act))
+        hm.sig_w2_sig = self._hold(pack_valu(S2[:1]))
+        hm.col_w0 = self._hold(pack_mfma(C0, encoder_pairs(0, 16) + [(16 + a, 16 + b) for a, b in act]))
+        ind_dim = int(m.individual_embedding_dim)
+        hm.col_w0_ind = self._hold(C0.detach().float()[:, 144:]) if ind_dim > 0 else None
+        hm.col_w1 = self._hold(pack_valu(C1))
+        hm.cond_dim, hm.ind_dim = int(A0.shape[1] - 32), ind_dim
+        return hm
+
+    def _build_torso(self, m):
+        hp = m.hparams
+        tm = TorsoModel()
+        tm.density_grid = self._hold(m.density_grid_torso.detach().float())
+        tm.grid_size = int(m.grid_size)
+        tm.density_thresh = float(min(m.density_thresh_torso, m.mean_density_torso))
+        tm.torso_shrink = float(hp["torso_shrink"])
+        tm.variant = 1 if m.landmark_conditioned else 0
+        tm.code_dim = int(m.torso_individual_embedding_dim)
+        tm.const_dim = (126 if m.landmark_conditioned else 54) + tm.code_dim
+        tm.head_aware = int(bool(hp["torso_head_aware"]))
+        tm.grid = self._grid_desc(m.torso_embedder)
+        D0, D1, D2 = (l.weight.detach().float() for l in m.torso_deform_net.net)
+        K0, K1, K2 = (l.weight.detach().float() for l in m.torso_canonicial_net.net)
+        if D0.shape[0] != 64 or K0.shape[0] != 32 or D0.shape[1] != 42 + tm.const_dim + 16 * tm.head_aware:
+            raise GfppError("fused pipeline: unexpected torso MLP shapes")
+        c0, c1 = 42, 42 + tm.const_dim
+        kt = lambda w: w.t().contiguous()           # [out,in] -> k-major [in,out]
+        tm.def_w0_x = self._hold(kt(D0[:, :c0]))
+        tm.def_w0_c = self._hold(D0[:, c0:c1])
+        tm.def_w1 = self._hold(kt(D1))
+        tm.def_w2 = self._hold(kt(D2))
+        tm.can_w0_g = self._hold(kt(K0[:, :32]))
+        tm.can_w0_x = self._hold(kt(K0[:, 32:32 + c0]))
+        tm.can_w0_c = self._hold(K0[:, 32 + c0:32 + c1])
+        tm.can_w1 = self._hold(kt(K1))
+        tm.can_w2 = self._hold(kt(K2))
+        if tm.head_aware:
+            tm.def_w0_h = self._hold(kt(D0[:, c1:]))
+            tm.can_w0_h = self._hold(kt(K0[:, 32 + c1:]))
+            enc = m.head_color_weights_encoder
+            for i, name in zip((0, 2, 4), ("0", "1", "2")):
+                setattr(tm, "ha_w" + name, self._hold(kt(enc[i].weight.detach().float())))
+                setattr(tm, "ha_b" + name, self._hold(enc[i].bias.detach().float()))
+        return tm
+
+    # -- per-resolution workspace ------------------------------------------------------------------------------------
+    def workspace(self, N):
+        ent = self._ws.get(N)
+        if ent is None:
+            dev = self.device
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            t = {"nears": f(N), "fars": f(N), "rays_t": f(N), "weights_sum": f(N), "depth": f(N), "image": f(N, 3),
+                 "alive0": torch.empty(N, dtype=torch.int32, device=dev), "alive1": torch.empty(N, dtype=torch.int32, device=dev),
+                 "counters": torch.zeros(128, dtype=torch.int32, device=dev), "frame_consts": f(256),
+                 "out_image": f(N, 3), "out_depth": f(N)}
+            self._ws_bytes = sum(v.numel() * v.element_size() for v in t.values())
+            ws = FrameWs()
+            ws.N = N
+            for k in ("nears", "fars", "rays_t", "weights_sum", "depth", "image", "counters", "frame_consts"):
+                setattr(ws, k, t[k].data_ptr())
+            ws.alive[0], ws.alive[1] = t["alive0"].data_ptr(), t["alive1"].data_ptr()
+            ent = (ws, t)
+            self._ws[N] = ent
+        return ent
+
+    # -- frames ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _dev_f32(t, name):
+        if not t.is_cuda:
+            raise GfppError(f"{name} must be on the GPU")
+        return t.detach().float().contiguous()
+
+    def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh):
+        """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace."""
+        rays_o = self._dev_f32(rays_o, "rays_o")
+        rays_d = self._dev_f32(rays_d, "rays_d")
+        N = rays_o.shape[0]
+        ws, t = self.workspace(N)
+        cond_feat = self._dev_f32(cond_feat.reshape(-1), "cond_feat")
+        if cond_feat.numel() != self.head.cond_dim:
+            raise GfppError(f"cond_feat must have {self.head.cond_dim} values, got {cond_feat.numel()}")
+        ind = self._dev_f32(ind_code.reshape(-1), "ind_code") if ind_code is not None else None
+        st = torch.cuda.current_stream().cuda_stream
+        call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), cond_feat.data_ptr(),
+             ind.data_ptr() if ind is not None else None, st)
+        call("gfpp_head_frame_march", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
+             int(max_steps), float(T_thresh), st)
+        return ws, t
+
+    def render_head(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color):
+        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh)
+        st = torch.cuda.current_stream().cuda_stream
+        bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, ws.N)
+        out_image, out_depth = torch.empty_like(t["out_image"]), torch.empty_like(t["out_depth"])
+        call("gfpp_head_frame_finish", ctypes.byref(ws), bg_ptr, bg_scalar, out_image.data_ptr(), out_depth.data_ptr(), st)
+        return {"image": out_image, "depth": out_depth}
+
+    def _bg(self, bg_color, N):
+        if bg_color is None:
+            return None, 1.0, None
+        if torch.is_tensor(bg_color):
+            bg = self._dev_f32(bg_color, "bg_color").reshape(-1, 3)
+            if bg.shape[0] == 1:
+                bg = bg.expand(N, 3).contiguous()
+            return bg.data_ptr(), 1.0, bg
+        return None, float(bg_color), None
+
+    def render_head_torso(self, rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma, max_steps, T_thresh,
+                          bg_color, use_head_for_torso):
+        """Head pass + torso pass + compositing -> dict(image [N,3], depth [N], torso_alpha [N,1], torso_bg [N,3],
+        deform_dense [N,2], torso_mask [N] u8, deform=None)."""
+        if self.torso is None:
+            raise GfppError("this model has no torso networks")
+        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh)
+        N = ws.N
+        dev = self.device
+        bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
+        if self.torso.variant == 1:
+            if lm68 is None:
+                raise GfppError("RADNeRFTorsowithSR.render needs lm68")
+            cond_in = self._dev_f32(lm68.reshape(-1), "lm68")
+            if cond_in.numel() != 136:
+                raise GfppError("lm68 must hold 68 x 2 values")
+        else:
+            cond_in = self._dev_f32(poses.reshape(-1), "poses")
+            if cond_in.numel() != 6:
+                raise GfppError("poses must hold 6 values")
+        code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
+        bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
+               "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
+        call("gfpp_torso_frame", ctypes.byref(self.torso), ctypes.byref(ws), bg_coords.data_ptr(), cond_in.data_ptr(),
+             code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
+             out["depth"].data_ptr(), out["torso_alpha"].data_ptr(), out["torso_bg"].data_ptr(), out["deform_dense"].data_ptr(),
+             out["torso_mask"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    MAX_TRIPS = 63
+
+    def trip_counters(self, N):
+        """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises."""
+        c = self.workspace(N)[1]["counters"].cpu().numpy()
+        return c[:64], c[64:]

@@ -131,7 +131,7 @@ class NeRFRenderer(nn.Module):
         rays_d = rays_d.contiguous().view(-1, 3)
         cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
         ind_code = self._individual_code(index)
-        if self.executor == "fused" and cond_mask is None and not perturb:
+        if self.executor == "fused" and cond_mask is None and not perturb and max_steps <= 63:
             out = self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
             return {"depth_map": out["depth"].view(*prefix), "rgb_map": out["image"].view(*prefix, 3)}
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)

@@ -30,6 +30,8 @@ class _TorsoBase(RADNeRF):
 
     #: True for RADNeRFTorsowithSR: landmark conditioning, no pose encoding in the MLP input, no host coin flip
     landmark_conditioned = False
+    #: fused executor only: also return result['deform'] ([P,2], masked pixels) like the reference; costs one host sync
+    return_deform = False
 
     def __init__(self, hparams):
         super().__init__(hparams)
@@ -121,12 +123,16 @@ class _TorsoBase(RADNeRF):
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
-        if self.executor == "fused" and not perturb:
+        if self.executor == "fused" and not perturb and max_steps <= 63:
             with torch.no_grad():
                 cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
-            return self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, self._individual_code(index), bg_coords, poses,
-                                                     self._torso_code(index), lm68, dt_gamma, max_steps, T_thresh, bg_color,
-                                                     use_head_for_torso)
+            out = self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, self._individual_code(index), bg_coords, poses,
+                                                    self._torso_code(index), lm68, dt_gamma, max_steps, T_thresh, bg_color,
+                                                    use_head_for_torso)
+            if self.return_deform:
+                # the reference returns dx of the masked pixels only ([P,2]); compacting needs a host sync, hence opt-in
+                out["deform"] = out["deform_dense"][out["torso_mask"].bool()]
+            return out
         return self._render_staged(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
                                    eye_area_percent, use_head_for_torso)
 

@@ -114,6 +114,160 @@ int gfpp_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32
 int gfpp_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
                   float *rays_d, gfpp_stream_t stream);
 
+/* replaces the per-frame `(pred_rgb * 255.).int() ... astype(np.uint8)` host conversion of the caller
+ * (inference/genefacepp_infer.py:468): rgb [n_values] f32 in [0,1] -> out [n_values] u8, truncating. rgb 16-byte aligned. */
+int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Section B -- fused frame pipeline (no native counterpart in the reference; replaces the Python loop of
+ * NeRFRenderer.render, modules/radnerfs/renderer.py:341-397, its copies radnerf_torso.py:128-151 /
+ * radnerf_torso_sr.py:158-181, RADNeRF.forward radnerf.py:108-141 evaluated per trip, and the torso pass
+ * radnerf_torso.py:156-197 / radnerf_torso_sr.py:186-231 incl. forward_torso :51-84 / :75-114).
+ *
+ * Loop control lives on the device: trip k reads the alive-ray count that trip k-1 produced, derives
+ * n_step = clamp(N / n_alive, 1, 8) and the cumulative step exactly like renderer.py:354-384, and exits by itself when
+ * the reference's loop would have ended -- so a frame is a fixed sequence of launches with no host synchronisation.
+ *
+ * All descriptor structs live in HOST memory and hold DEVICE pointers; they are read at call time only.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* replaces the per-thread level setup of kernel_grid (gridencoder.cu:137-139) with a host-side table (no GPU needed):
+ * per-level scale = exp2f(level*S)*H - 1 and resolution = ceil(scale) + 1, computed in
+ * fp32 exactly as the device code of gridencoder.cu:138-139 states them. */
+int gfpp_grid_level_table(uint32_t L, float S, uint32_t H, float *scale_out, uint32_t *resolution_out);
+
+typedef struct gfpp_grid_level { /* one entry per level, uploaded to device memory by the caller */
+    float scale;
+    uint32_t resolution;
+    uint32_t offset; /* first table row of the level */
+    uint32_t size;   /* rows in the level (the reference's hashmap_size) */
+} gfpp_grid_level;
+
+typedef struct gfpp_grid_desc {
+    const void *table;             /* [rows, 2] f32 or f16 (level_dim is 2 on this path) */
+    const gfpp_grid_level *levels; /* [L] in device memory */
+    int32_t dtype;                 /* GFPP_F32 | GFPP_F16 */
+    uint32_t D;                    /* 2 or 3 */
+    uint32_t L;                    /* 16 */
+    uint32_t gridtype;             /* 0 hash, 1 tiled */
+    uint32_t interp;               /* 0 linear, 1 smoothstep */
+    uint32_t align_corners;
+} gfpp_grid_desc;
+
+/* MLP weight packing for the MFMA kernels ("fragment order", fp32):
+ *   a dense layer out[128] = W[128,K] x  is evaluated as a sequence of K/2 rank-2 updates with
+ *   v_mfma_f32_32x32x2_f32; update `s` consumes the input pair (k0[s], k1[s]).  Packed array P[s/4][m][lane][s%4] =
+ *   W[32*m + (lane & 31)][ (lane < 32) ? k0[s] : k1[s] ],  m = 0..3 (32-row output tiles), lane = 0..63.
+ *   Pair orders (rr(r) = (r&3) + 8*(r>>2)):
+ *     encoder features (32 values in two halves of 16):  (s, 16+s), s = 0..15   [SH, 16 values: (s, 8+s), s = 0..7]
+ *     previous-layer activations (128):  step 16*m'+r -> (32*m'+rr(r), 32*m'+rr(r)+4), m' = 0..3, r = 0..15
+ *   which is exactly how the accumulator registers of one layer line up as B operands of the next, so activations
+ *   never leave the register file.  Skinny layers (3 or 1 outputs) are packed for VALU dot products:
+ *   V[h][c][16*m'+r] = W[c][32*m'+rr(r)+4*h], h = 0,1.  Bias vectors in the same order: Bf[h][16*m+r] = b[32*m+rr(r)+4*h]. */
+typedef struct gfpp_head_model {
+    float aabb[6];
+    float min_near;
+    float bound;
+    float density_scale;
+    uint32_t cascade;   /* C */
+    uint32_t grid_size; /* H */
+    const uint8_t *density_bitfield;
+    gfpp_grid_desc pos_grid; /* D = 3 */
+    gfpp_grid_desc amb_grid; /* D = ambient_coord_dim (2 or 3) */
+    /* ambient_net 96->128->128->amb_D (cond columns folded into a per-frame bias) */
+    const float *amb_w0;      /* packed, 16 steps (position features) */
+    const float *amb_w0_cond; /* [128, cond_dim] row-major = W0[:, 32:] */
+    const float *amb_w1;      /* packed, 64 steps */
+    const float *amb_w2;      /* VALU pack [2][amb_D][64] */
+    /* sigma_net 64->128->128->129 */
+    const float *sig_w0;     /* packed, 32 steps: 16 position + 16 ambient feature pairs */
+    const float *sig_w1;     /* packed, 64 steps */
+    const float *sig_w2_geo; /* packed, 64 steps: rows 1..128 of the last layer */
+    const float *sig_w2_sig; /* VALU pack [2][1][64]: row 0 (density logit) */
+    /* color_net 148->128->3 (individual-code columns folded into a per-frame bias) */
+    const float *col_w0;     /* packed, 72 steps: 8 SH pairs + 64 geo-feature pairs */
+    const float *col_w0_ind; /* [128, ind_dim] row-major = W0[:, 144:] (NULL if ind_dim == 0) */
+    const float *col_w1;     /* VALU pack [2][3][64] */
+    uint32_t cond_dim;       /* 64 */
+    uint32_t ind_dim;        /* 4 */
+} gfpp_head_model;
+
+/* per-frame device workspace (caller-allocated, reusable across frames) */
+typedef struct gfpp_frame_ws {
+    uint32_t N;          /* rays in the frame */
+    float *nears;        /* [N] */
+    float *fars;         /* [N] */
+    float *rays_t;       /* [N] */
+    float *weights_sum;  /* [N] */
+    float *depth;        /* [N] */
+    float *image;        /* [N,3] premultiplied head colour */
+    int32_t *alive[2];   /* [N] each: ping-pong lists of alive ray ids */
+    int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated */
+    float *frame_consts; /* [256] f32: folded biases of ambient_net.0 and color_net.0 in fragment order */
+} gfpp_frame_ws;
+
+/* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state
+ * setup, and the per-sample cond_feat.repeat / individual_code.repeat + cat of radnerf.py:115-136):
+ * slab test for every ray (= near_far_from_aabb), zeroes the accumulators, rays_t = near, resets the trip
+ * counters (counters[0] = N), and folds cond_feat [cond_dim] / ind_code [ind_dim] into the two per-frame bias vectors. */
+int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                          const float *cond_feat, const float *ind_code, gfpp_stream_t stream);
+
+/* Runs the whole march -> evaluate -> composite loop of renderer.py:354-384 (kernels raymarching.cu:827-929, :942-1029;
+ * networks radnerf.py:108-141; encoders gridencoder.cu:87-196, shencoder.cu:28-68): `max_steps` fused trip launches, each of
+ * which marches its alive rays (kernel_march_rays semantics), evaluates RADNeRF.forward on MFMA for the occupied samples
+ * only, composites (kernel_composite_rays semantics) and compacts the survivors for the next trip. */
+int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                          float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
+/* Head-only epilogue (renderer.py:385-397): image = clamp(image + (1 - weights_sum) * bg, 0, 1),
+ * depth = clamp(depth - near, 0) / (far - near).  bg_color [N,3] or NULL (then bg_scalar is used; reference default 1). */
+int gfpp_head_frame_finish(const gfpp_frame_ws *ws, const float *bg_color, float bg_scalar, float *out_image, float *out_depth,
+                           gfpp_stream_t stream);
+
+/* Torso field + final compositing.  Weight matrices are stored K-MAJOR ([in][out], i.e. nn.Linear.weight transposed) so
+ * that one input feeds a contiguous row of outputs; the *_c blocks (columns multiplying per-frame constants) stay row-major
+ * [out][const_dim] and are folded into biases on the device at the start of every launch.
+ * Input column order of torso_deform_net (and, after the 32 grid features, of torso_canonicial_net):
+ *   variant 0, RADNeRFTorso        (radnerf_torso.py:51-84):   [freq(x,10) 42 | freq(pose,4) 54 | code | head-aware 16]
+ *   variant 1, RADNeRFTorsowithSR  (radnerf_torso_sr.py:75-114): [freq(x,10) 42 | code | freq(chin lm,4) 126 | head-aware 16] */
+typedef struct gfpp_torso_model {
+    const float *density_grid;  /* [G*G] f32, density_grid_torso */
+    uint32_t grid_size;         /* G = 128 */
+    float density_thresh;       /* min(density_thresh_torso, mean_density_torso) -- 0 for a loaded checkpoint */
+    float torso_shrink;         /* 0.8 */
+    uint32_t variant;           /* 0 pose-conditioned, 1 landmark-conditioned */
+    uint32_t code_dim;          /* torso_individual_embedding_dim (8) */
+    uint32_t const_dim;         /* 54 + code_dim or 126 + code_dim */
+    uint32_t head_aware;        /* hparams['torso_head_aware'] */
+    gfpp_grid_desc grid;        /* D = 2, tiled, linear */
+    const float *def_w0_x;      /* [42][64]  */
+    const float *def_w0_c;      /* [64][const_dim] row-major */
+    const float *def_w0_h;      /* [16][64] or NULL */
+    const float *def_w1;        /* [64][64] */
+    const float *def_w2;        /* [64][2] */
+    const float *can_w0_g;      /* [32][32] grid-feature columns */
+    const float *can_w0_x;      /* [42][32] */
+    const float *can_w0_c;      /* [32][const_dim] row-major */
+    const float *can_w0_h;      /* [16][32] or NULL */
+    const float *can_w1;        /* [32][32] */
+    const float *can_w2;        /* [32][4] */
+    const float *ha_w0, *ha_b0; /* head_color_weights_encoder: [4][16],[16] */
+    const float *ha_w1, *ha_b1; /* [16][32],[32] */
+    const float *ha_w2, *ha_b2; /* [32][16],[16] */
+} gfpp_torso_model;
+
+/* Replaces the torso pass + epilogue of RADNeRFTorso.render / RADNeRFTorsowithSR.render (radnerf_torso.py:156-197,
+ * radnerf_torso_sr.py:186-231) on top of a finished head pass (ws->image / weights_sum / depth / nears / fars):
+ * occupancy mask = F.grid_sample(density_grid_torso)(bg_coords) > thresh; forward_torso on the masked pixels;
+ * torso_bg = rgb*alpha + bg*(1-alpha); image = clamp(head + (1-weights_sum)*torso_bg, 0, 1); depth normalised.
+ * cond_in = poses [6] (variant 0) or lm68 [136] (variant 1); code [code_dim]; use_head != 0 feeds (head rgb, alpha) to the
+ * head-aware encoder (else zeros, like passing image=None).  Outputs: out_image, torso_bg [N,3]; out_depth, torso_alpha [N];
+ * deform [N,2] (zero outside the mask); mask [N] u8. */
+int gfpp_torso_frame(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *cond_in,
+                     const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
+                     float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
