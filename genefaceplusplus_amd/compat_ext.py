@@ -1,0 +1,97 @@
+"""Drop-in replacements for the reference's four *native extension modules*, so that the reference's own Python shims
+(modules/radnerfs/raymarching/raymarching.py, encoders/gridencoder/grid.py, encoders/shencoder/sphere_harmonics.py,
+encoders/freqencoder/freq.py) run on MI355X without touching them:
+
+    import genefaceplusplus_amd.compat_ext as ext; ext.install()
+    # `import _raymarching_face as _backend` etc. now bind to libgfpp_radnerf.so
+
+Function names, argument order and in-place output convention are those of the pybind modules
+(raymarching/src/bindings.cpp:7-20, gridencoder/src/bindings.cpp, shencoder/src/bindings.cpp, freqencoder/src/bindings.cpp);
+arguments are torch CUDA(=HIP) tensors, converted to raw pointers for the C ABI.  Kernels run on torch's current stream.
+Inference entry points only; the training-only functions raise NotImplementedError.
+"""
+import sys
+import types
+
+import torch
+
+from ._lib import call
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ---- _raymarching_face -------------------------------------------------------------------------------------------
+def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+    call("gfpp_near_far_from_aabb", _p(rays_o), _p(rays_d), _p(aabb), int(N), float(min_near), _p(nears), _p(fars), _st())
+
+
+def morton3D(coords, N, indices):
+    call("gfpp_morton3D", _p(coords), int(N), _p(indices), _st())
+
+
+def morton3D_invert(indices, N, coords):
+    call("gfpp_morton3D_invert", _p(indices), int(N), _p(coords), _st())
+
+
+def packbits(grid, N, density_thresh, bitfield):
+    call("gfpp_packbits", _p(grid), int(N), float(density_thresh), _p(bitfield), _st())
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs,
+               deltas, noises):
+    call("gfpp_march_rays", int(n_alive), int(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d), float(bound), float(dt_gamma),
+         int(max_steps), int(C), int(H), _p(grid), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises), _st())
+
+
+def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+    call("gfpp_composite_rays", int(n_alive), int(n_step), float(T_thresh), _p(rays_alive), _p(rays_t), _p(sigmas), _p(rgbs), _p(deltas),
+         _p(weights_sum), _p(depth), _p(image), _st())
+
+
+def _training_only(name):
+    def fn(*a, **k):
+        raise NotImplementedError(f"{name}: training kernels are not built yet (SURVEY.md 8f-2)")
+    return fn
+
+
+# ---- _gridencoder / _shencoder / _freqencoder ------------------------------------------------------------------------
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
+    dtype = {torch.float32: 0, torch.float16: 1}[embeddings.dtype]
+    call("gfpp_grid_encode_forward", _p(inputs), _p(embeddings), _p(offsets), _p(outputs), int(B), int(D), int(C), int(L), float(S), int(H),
+         _p(dy_dx), int(gridtype), int(bool(align_corners)), int(interp), dtype, _st())
+
+
+def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
+    call("gfpp_sh_encode_forward", _p(inputs), _p(outputs), int(B), int(D), int(C), _p(dy_dx), _st())
+
+
+def freq_encode_forward(inputs, B, D, deg, C, outputs):
+    call("gfpp_freq_encode_forward", _p(inputs), int(B), int(D), int(deg), int(C), _p(outputs), _st())
+
+
+def _module(name, fns):
+    m = types.ModuleType(name)
+    m.__dict__.update(fns)
+    return m
+
+
+def install():
+    rm = dict(near_far_from_aabb=near_far_from_aabb, morton3D=morton3D, morton3D_invert=morton3D_invert, packbits=packbits,
+              march_rays=march_rays, composite_rays=composite_rays)
+    for n in ("sph_from_ray", "morton3D_dilation", "march_rays_train", "march_rays_train_backward", "composite_rays_train_forward",
+              "composite_rays_train_backward"):
+        rm[n] = _training_only(n)
+    sys.modules["_raymarching_face"] = _module("_raymarching_face", rm)
+    sys.modules["_gridencoder"] = _module("_gridencoder", dict(grid_encode_forward=grid_encode_forward,
+                                                                 grid_encode_backward=_training_only("grid_encode_backward"),
+                                                                 grad_total_variation=_training_only("grad_total_variation")))
+    sys.modules["_shencoder"] = _module("_shencoder", dict(sh_encode_forward=sh_encode_forward, sh_encode_backward=_training_only("sh_encode_backward")))
+    sys.modules["_freqencoder"] = _module("_freqencoder", dict(freq_encode_forward=freq_encode_forward,
+                                                                 freq_encode_backward=_training_only("freq_encode_backward")))

@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's ``modules/radnerfs`` package (see compat.py for the import-path shim)."""
 from .head import NeRFRenderer, RADNeRF
-from .torso import RADNeRFTorso, RADNeRFTorsowithSR
+from .torso import RADNeRFTorso, RADNeRFTorsowithSR, RADNeRFwithSR
 from .cond_nets import AudioNet, AudioAttNet, MLP
 from .encoders import GridEncoder, SHEncoder, FreqEncoder, get_encoder
 

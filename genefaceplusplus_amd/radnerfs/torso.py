@@ -208,3 +208,25 @@ class RADNeRFTorsowithSR(_TorsoBase):
             if upscale_torso:
                 res["sr_torso_rgb_map"] = self.sr_net(torso_bg.clone()).clamp(0, 1)
         return res
+
+
+class RADNeRFwithSR(RADNeRF):
+    """Head-only model of the *_sr configs (reference: modules/radnerfs/radnerf_sr.py:45-210, which repeats RADNeRF's
+    networks and adds ``sr_net`` + the ``lambda_ambient`` scalar).  Renders 256x256 rays; the SR stage is "next"."""
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        from .superres import Superresolution
+        self.sr_net = Superresolution(channels=3)
+        self.lambda_ambient = nn.Parameter(torch.tensor([1.0]), requires_grad=False)
+
+    def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
+               max_steps=1024, T_thresh=1e-4, cond_mask=None, eye_area_percent=None, **kwargs):
+        res = super().render(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, force_all_rays, max_steps, T_thresh,
+                             cond_mask, eye_area_percent=eye_area_percent, **kwargs)
+        side = self.sr_net.input_resolution
+        rgb = res["rgb_map"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
+        res["rgb_map"] = rgb
+        if self.sr_net.ready:
+            res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
+        return res

@@ -1,0 +1,71 @@
+"""Frame-parallel sharding + clip gather on the `gloo` backend, world_size 2 (the N>1 path of bench.py / frames.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from genefaceplusplus_amd import frames
+
+
+def test_shard_frames_partitions():
+    for n in (0, 1, 7, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            for inter in (False, True):
+                parts = [frames.shard_frames(n, r, world, inter) for r in range(world)]
+                flat = sorted(i for p in parts for i in p)
+                assert flat == list(range(n))
+                for r, p in enumerate(parts):
+                    assert all(frames.frame_owner(i, n, world, inter) == r for i in p)
+                assert max(len(p) for p in parts) - min(len(p) for p in parts) <= (1 if inter else -(-n // world))
+    with pytest.raises(ValueError):
+        frames.shard_frames(4, 2, 2)
+
+
+def test_to_uint8_truncates():
+    x = torch.tensor([[0.0, 0.5, 1.0], [0.999, 0.0039, 0.00392157]])
+    assert frames.to_uint8_hwc(x).tolist() == [[0, 127, 255], [254, 0, 1]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, inter, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = frames.shard_frames(n_frames, rank, world, inter)
+    # a "rendered frame" whose every pixel encodes its global frame index
+    local = torch.stack([torch.full((4, 4, 3), i % 256, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
+    clip = frames.gather_clip(local, n_frames, inter)
+    ok = clip.shape == (n_frames, 4, 4, 3) and all(int(clip[i, 0, 0, 0]) == i % 256 for i in range(n_frames))
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, bool(ok), float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,inter", [(7, False), (8, True), (5, True)])
+def test_gather_clip_world2_gloo(n_frames, inter):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, inter, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in results) == [0, 1]
+    assert all(ok for _, ok, _ in results) and all(t == 2.0 for _, _, t in results)
