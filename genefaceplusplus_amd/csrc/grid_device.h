@@ -80,8 +80,37 @@ struct TableIO<__half> {
     }
 };
 
+// Two x-adjacent table rows in one load.  Rows r and r+1 are contiguous in memory (C values each); the pair is only
+// C*sizeof(T)-aligned, so the vector type carries a reduced alignment (gfx950 global loads handle it natively).
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef _Float16 f16x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int C, typename T>
+__device__ __forceinline__ void load_row_pair(const T *__restrict__ p, float (&lo)[C], float (&hi)[C]) {
+    if constexpr (C == 2 && sizeof(T) == 4) {
+        const f32x4_a8 v = *reinterpret_cast<const f32x4_a8 *>(p);
+        lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
+    } else if constexpr (C == 1 && sizeof(T) == 4) {
+        const f32x2_a4 v = *reinterpret_cast<const f32x2_a4 *>(p);
+        lo[0] = v[0]; hi[0] = v[1];
+    } else if constexpr (C == 2 && sizeof(T) == 2) {
+        const f16x4_a4 v = *reinterpret_cast<const f16x4_a4 *>(p);
+        lo[0] = (float)v[0]; lo[1] = (float)v[1]; hi[0] = (float)v[2]; hi[1] = (float)v[3];
+    } else {
+        TableIO<T>::template load<C>(p, lo);
+        TableIO<T>::template load<C>(p + C, hi);
+    }
+}
+
 // d-linear (or smoothstep) interpolation of one level for one point; `u` in [0,1]^D.  Accumulates in fp32
 // (for f16 tables the reference accumulates in half, gridencoder.cu:163 -- documented tolerance, not bit parity).
+//
+// The 2^D corners are visited in the reference's order (corner bit d selects +1 along dimension d), but the two corners
+// that differ only in x are fetched together: dimension 0 always enters the linear index with stride 1
+// (gridencoder.cu:70-75), so unless the level is hashed or the row wraps at the end of the level they are adjacent
+// table rows -- one 16-byte gather instead of two 8-byte ones, which halves the number of cache lines the texture
+// path has to look up (the bound of this kernel is tag-lookup rate, not bytes).
 template <int D, int C, typename T>
 __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *__restrict__ table, uint32_t level_offset,
                                                   uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
@@ -100,20 +129,56 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = 0.0f;
     const T *level_table = table + (size_t)level_offset * C;
+
+    // is the level addressed by the hash?  (stride after all D dimensions > level size, hash grid type)
+    // does the tiled index drop the last dimension?  (stride already > level size before dimension D-1 is reached:
+    // gridencoder.cu:72 stops the loop, so corners that differ only in that dimension alias the same row)
+    uint32_t stride = 1;
+    bool last_dim_dropped = false;
 #pragma unroll
-    for (int corner = 0; corner < (1 << D); ++corner) {
-        float w = 1.0f;
+    for (int d = 0; d < D; ++d) {
+        if (stride <= hashmap_size) stride *= align_corners ? resolution : (resolution + 1u);
+        else if (d == D - 1) last_dim_dropped = true;
+    }
+    const bool hashed = gridtype == 0 && stride > hashmap_size;
+    const bool reuse_upper = D == 3 && last_dim_dropped && !hashed;
+
+    constexpr int kPairs = 1 << (D - 1);
+    float keep0[kPairs / 2 > 0 ? kPairs / 2 : 1][C], keep1[kPairs / 2 > 0 ? kPairs / 2 : 1][C];
+#pragma unroll
+    for (int pair = 0; pair < kPairs; ++pair) {
+        // weights of the two corners (x bit clear / set), products in the reference's order d = 0, 1, ...
+        float w0 = 1.0f - frac[0], w1 = frac[0];
         uint32_t pg[D];
+        pg[0] = base[0];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (corner & (1 << d)) { w *= frac[d]; pg[d] = base[d] + 1u; }
-            else { w *= 1.0f - frac[d]; pg[d] = base[d]; }
+        for (int d = 1; d < D; ++d) {
+            if (pair & (1 << (d - 1))) { w0 *= frac[d]; w1 *= frac[d]; pg[d] = base[d] + 1u; }
+            else { w0 *= 1.0f - frac[d]; w1 *= 1.0f - frac[d]; pg[d] = base[d]; }
         }
-        const uint32_t row = grid_row<D>(pg, gridtype, align_corners, hashmap_size, resolution);
-        float v[C];
-        TableIO<T>::template load<C>(level_table + (size_t)row * C, v);
+        float v0[C], v1[C];
+        const bool upper = D == 3 && pair >= kPairs / 2;
+        if (upper && reuse_upper) {
+            // same rows as pair - kPairs/2 (z ignored by the index): reuse the values, keep the accumulation order
 #pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = fmaf(w, v[c], out[c]);
+            for (int c = 0; c < C; ++c) { v0[c] = keep0[pair - kPairs / 2][c]; v1[c] = keep1[pair - kPairs / 2][c]; }
+        } else {
+            const uint32_t row0 = grid_row<D>(pg, gridtype, align_corners, hashmap_size, resolution);
+            if (!hashed && row0 + 1u < hashmap_size) {
+                load_row_pair<C, T>(level_table + (size_t)row0 * C, v0, v1);
+            } else {
+                pg[0] = base[0] + 1u;
+                const uint32_t row1 = grid_row<D>(pg, gridtype, align_corners, hashmap_size, resolution);
+                TableIO<T>::template load<C>(level_table + (size_t)row0 * C, v0);
+                TableIO<T>::template load<C>(level_table + (size_t)row1 * C, v1);
+            }
+            if (D == 3 && !upper) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) { keep0[pair][c] = v0[c]; keep1[pair][c] = v1[c]; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = fmaf(w1, v1[c], fmaf(w0, v0[c], out[c]));
     }
 }
 
