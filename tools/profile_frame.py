@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Render a few synthetic 512x512 head+torso frames (nothing else) -- the target process for rocprofv3 runs."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import frame_case, build_model, product_render
+
+variant = sys.argv[1] if len(sys.argv) > 1 else "may_torso"
+HW = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dev = torch.device("cuda:0")
+case = frame_case(variant, HW)
+model = build_model(case, dev, "fused")
+for _ in range(frames):
+    product_render(model, case, dev, "hip")
+torch.cuda.synchronize()
+alive, smp = model.pipeline().trip_counters(HW * HW)
+print("alive", alive[:8], "samples", smp[:8], "total", smp.sum())
