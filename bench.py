@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 161536          # head MLPs after folding the per-frame-constant input columns
+FLOP_PER_SAMPLE_LP = 128768       # 16-bit kernel: additionally sigma_net.2 (geo rows) x color_net.0 merged into one 128x128 layer
+GATHER_BYTES_PER_SAMPLE = 2060    # fused pipeline: 12 B position + 2 encodes x 16 levels x 8 corners x 8 B
+PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense f16 / bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 GRID_BYTES_PER_POINT = 1164       # 3-D, 16 levels x 8 corners x 8 B + 12 B in + 128 B out
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
@@ -40,6 +43,8 @@ def parse():
     ap.add_argument("--hw", type=int, default=512, help="frame side (rays = hw*hw)")
     ap.add_argument("--variant", default="may_torso", choices=["may_head", "may_torso", "may_torso_sr"])
     ap.add_argument("--executor", default="fused", choices=["fused", "staged"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"],
+                    help="arithmetic of the five wide head layers: exact-fp32 MFMA, or 16-bit MFMA operands with fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-stage", action="store_true")
     return ap.parse_args()
@@ -102,6 +107,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     model.executor = args.executor
+    model.precision = args.precision
 
     # ---- this rank's frames: global frame index = step * world + rank (frame-parallel sharding) ----------------------------
     total = K + W
@@ -160,7 +166,8 @@ def main():
         fps = world * K / elapsed
         result = {"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
                   "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16 operands / f32 accumulate", "bf16": "bf16 operands / f32 accumulate"}[args.precision],
+                  "data": "synthetic",
                   "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame, max_steps 16, T_thresh 0.01, "
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (" + RCCL all_gather of uint8 frames" if world > 1 else ""),
@@ -185,22 +192,32 @@ def main():
             cf = cond_feat.detach().float().contiguous()
             call("gfpp_head_frame_begin", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), cf.data_ptr(), ind.data_ptr(), st)
             e0.record()
-            call("gfpp_head_frame_march", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
-                 int(hp["max_steps"]), 0.01, st)
+            call("gfpp_head_frame_march" if args.precision == "fp32" else "gfpp_head_frame_march_lp", ctypes.byref(pipe.head), ctypes.byref(ws),
+                 ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), int(hp["max_steps"]), 0.01, st)
             e1.record()
             torch.cuda.synchronize()
             t_march += e0.elapsed_time(e1) * 1e-3
             alive, smp = pipe.trip_counters(N)
             samples += int(smp.sum())
             launches += int((smp > 0).sum())
-        flops = samples * FLOP_PER_SAMPLE
-        achieved = flops / t_march / 1e12
-        result["roofline"] = {"kernel": "k_head_trip<3> (fused march + grid encode + MFMA MLP + composite)", "bound": "mfma",
-                              "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                              "samples_per_frame": samples // reps, "nonempty_trips_per_frame": launches // reps,
-                              "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4),
-                              "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4), "alive_per_trip": [int(v) for v in alive[:17] if v > 0]}
+        common = {"samples_per_frame": samples // reps, "nonempty_trips_per_frame": launches // reps,
+                  "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4), "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4),
+                  "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
+        if args.precision == "fp32":
+            achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
+            result["roofline"] = {"kernel": "k_head_trip<3> (fused march + grid encode + fp32 MFMA MLP + composite)", "bound": "mfma",
+                                  "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
+        else:
+            # the 16-bit kernel is bound by the hash-grid gathers (L2 / texture path), not by the matrix pipe: quote the gather stream against the
+            # HBM peak (the north star's yardstick for the hash-grid stage) and the MFMA fraction beside it
+            gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
+            tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
+            result["roofline"] = {"kernel": f"k_head_trip_lp<3,{args.precision}> (fused march + grid encode + 16-bit MFMA MLP + composite)", "bound": "hbm",
+                                  "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                                  "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
+                                  "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP}, **common}
 
     if rank == 0 and not args.no_grid_stage:
         from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw

@@ -14,23 +14,9 @@
 // previous trips left in memory, so the host never synchronises.
 #include <hip/hip_runtime.h>
 
-#include "grid_device.h"
-#include "march_device.h"
-#include "sh_device.h"
+#include "head_eval_device.h"
 
 namespace gfpp {
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-constexpr int kTile = 128;     // sample slots per workgroup tile (4 wavefronts x 32 columns)
-constexpr int kThreads = 256;
-constexpr int kMaxTrips = 63;      // counters[0..63] alive counts, counters[64..127] evaluated samples
-
-struct GridDev {
-    const void *table;
-    const gfpp_grid_level *levels;
-    uint32_t gridtype, interp, align_corners;
-};
 
 struct HeadWeights {
     const float4 *amb_w0, *amb_w1, *sig_w0, *sig_w1, *sig_w2_geo, *col_w0;
@@ -82,70 +68,6 @@ __device__ __forceinline__ void mfma_layer(v16f (&acc)[4], const float4 *__restr
         acc[2] = mfma32(a2.w, b[4 * q + 3], acc[2]); acc[3] = mfma32(a3.w, b[4 * q + 3], acc[3]);
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-    }
-}
-
-__device__ __forceinline__ void load_bias(v16f (&acc)[4], const float *__restrict__ bias_frag, int hi) {
-    const float4 *p = reinterpret_cast<const float4 *>(bias_frag + hi * 64);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = p[m * 4 + q];
-            acc[m][4 * q] = v.x; acc[m][4 * q + 1] = v.y; acc[m][4 * q + 2] = v.z; acc[m][4 * q + 3] = v.w;
-        }
-    }
-}
-
-__device__ __forceinline__ void zero_acc(v16f (&acc)[4]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-}
-
-template <bool RELU>
-__device__ __forceinline__ void acc_to_b(const v16f (&acc)[4], float (&b)[64]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) b[m * 16 + r] = RELU ? fmaxf(acc[m][r], 0.0f) : acc[m][r];
-}
-
-// Skinny output layer on the VALU: out[c] = sum over this lane's 64 activations, then the two half-waves are added.
-template <int C>
-__device__ __forceinline__ void valu_rows(const float *__restrict__ wv, const float (&b)[64], int hi, float (&out)[C]) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float4 *p = reinterpret_cast<const float4 *>(wv + (hi * C + c) * 64);
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 v = p[q];
-            s = fmaf(v.x, b[4 * q], s); s = fmaf(v.y, b[4 * q + 1], s); s = fmaf(v.z, b[4 * q + 2], s); s = fmaf(v.w, b[4 * q + 3], s);
-        }
-        out[c] = s + __shfl_xor(s, 32);
-    }
-}
-
-// This lane's half of a 16-level, 2-channel grid encoding: levels hi*8 .. hi*8+7 -> 16 features.
-template <int D>
-__device__ __forceinline__ void encode_half(const float (&u)[D], const GridDev &g, int hi, bool valid, float (&f)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) f[i] = 0.0f;
-    if (!valid) return;
-    bool inside = true;
-#pragma unroll
-    for (int d = 0; d < D; ++d) inside = inside && !(u[d] < 0.0f || u[d] > 1.0f);
-    if (!inside) return;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const gfpp_grid_level lv = g.levels[hi * 8 + i];
-        float o[2];
-        grid_level_lookup<D, 2, float>(u, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype,
-                                       g.align_corners != 0, g.interp, o);
-        f[2 * i] = o[0];
-        f[2 * i + 1] = o[1];
     }
 }
 
@@ -241,15 +163,6 @@ __device__ __forceinline__ void evaluate_block(const TripArgs &a, TileShared &sh
         sh.cg[slot] = 1.0f / (1.0f + expf(-rgb[1]));
         sh.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
     }
-}
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t n = __shfl_up(v, off);
-        if (lane >= off) v += n;
-    }
-    return v;
 }
 
 template <int AMB_D>
@@ -415,6 +328,35 @@ GFPP_API int gfpp_grid_level_table(uint32_t L, float S, uint32_t H, float *scale
     GridLevels g;
     fill_level_scales(g, L, S, H);
     for (uint32_t l = 0; l < L; ++l) { scale_out[l] = g.scale[l]; resolution_out[l] = g.resolution[l]; }
+    return 0;
+}
+
+GFPP_API int gfpp_grid_levels_fill(uint32_t D, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, const int32_t *offsets,
+                                   uint32_t row_pad, gfpp_grid_level *levels) {
+    if (!offsets || !levels || L > (uint32_t)kMaxLevels || D < 2 || D > 3 || gridtype > 1) { set_error("gfpp_grid_levels_fill: bad arguments"); return GFPP_EINVAL; }
+    GridLevels g;
+    fill_level_scales(g, L, S, H);
+    for (uint32_t l = 0; l < L; ++l) {
+        gfpp_grid_level &lv = levels[l];
+        lv.scale = g.scale[l];
+        lv.resolution = g.resolution[l];
+        lv.offset = (uint32_t)offsets[l] + l * row_pad;
+        lv.size = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const uint32_t r1 = align_corners ? lv.resolution : lv.resolution + 1u;
+        // the loop of get_grid_index: a dimension enters the index only while stride <= hashmap_size (uint32 arithmetic)
+        uint32_t stride = 1, st[3] = {0, 0, 0};
+        for (uint32_t d = 0; d < D; ++d) {
+            if (stride <= lv.size) { st[d] = stride; stride *= r1; }
+        }
+        lv.sy = st[1];
+        lv.sz = st[2];
+        const bool pow2 = lv.size != 0 && (lv.size & (lv.size - 1u)) == 0;
+        const bool hashed = gridtype == 0 && stride > lv.size;
+        // a non-power-of-two size needs no modulo iff every index stays below it: sum over kept dims of res*stride < stride_total <= size
+        const bool exact = stride <= lv.size;
+        lv.mask = pow2 ? lv.size - 1u : 0xFFFFFFFFu;
+        lv.flags = (hashed || (!pow2 && (!exact || align_corners)) || lv.size >= (1u << 24) || r1 >= (1u << 12)) ? GFPP_LEVEL_SLOW : 0u;
+    }
     return 0;
 }
 

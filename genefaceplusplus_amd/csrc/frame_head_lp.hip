@@ -1,0 +1,590 @@
+// frame_head_lp.hip -- the fused head trip kernel with 16-bit MFMA operands (f16 or bf16 inputs, fp32 accumulation).
+//
+// Same loop semantics as frame_head.hip (renderer.py:354-384, one launch per loop iteration, loop state on the device), but
+// the arithmetic of the five wide layers runs on v_mfma_f32_32x32x16_{f16,bf16} -- 16x the rate of the exact-fp32 MFMA -- which
+// moves the bound of the kernel from the matrix pipe to the hash-grid gathers.  This is the mode that corresponds to the
+// reference's own inference precision: genefacepp_infer.py renders under torch.autocast(fp16), i.e. nn.Linear in half with
+// fp32 accumulation (and half activations BETWEEN layers, which this kernel avoids: accumulators stay fp32 in registers and
+// are rounded once, when they become the next layer's operand).
+//
+// Differences of structure from the fp32 kernel, all consequences of the 16x shorter MFMA phase:
+//   * The weights (124 KB in 16 bit) are RESIDENT IN LDS for the whole launch: one 512-thread workgroup per CU copies
+//     them once, then every wavefront streams its A operands with ds_read_b128 (1 KB per MFMA; from L2 the matrix pipe
+//     would starve at 64 B/clk/CU).  The three skinny output layers (3+1+3 rows, fp32, VALU) and the per-frame folded
+//     biases sit in LDS too.
+//   * sigma_net's last layer (geo_feat rows, no activation) and color_net's first layer are ONE matrix:
+//     relu(C0_sh sh + C0_geo (S2_geo h) + b) = relu(C0_sh sh + (C0_geo S2_geo) h + b); the product is formed on the host in
+//     fp64.  One 128x128 layer less per sample (128 768 FLOP instead of 161 536) and one rounding of activations less.
+//   * Wavefronts are autonomous: a wavefront marches 64 / 32 / 16 rays (<= 128 sample slots), compacts, evaluates 32 samples
+//     per pass, composites and appends its survivors -- no workgroup barrier after the weight copy, so one wavefront's
+//     gathers overlap another's MFMAs on the same SIMD.
+#include "head_eval_device.h"
+
+namespace gfpp {
+
+constexpr int kLpThreads = 512;
+constexpr int kLpWaves = kLpThreads / 64;
+constexpr int kLpSlots = 128;   // sample slots of one wavefront tile
+constexpr int kLpRays = 64;     // rays of one wavefront tile (at most)
+// K = 16 steps of the five MFMA layers, in LDS order
+constexpr int kStepAmb0 = 0;    // 2 steps: 32 position features
+constexpr int kStepAmb1 = 2;    // 8 steps: 128 activations
+constexpr int kStepSig0 = 10;   // 4 steps: 32 position + 32 ambient features
+constexpr int kStepSig1 = 14;   // 8 steps
+constexpr int kStepCol = 22;    // 9 steps: 16 SH + 128 activations (merged geo layer)
+constexpr int kLpSteps = 31;
+constexpr int kLpWeightChunks = kLpSteps * 4 * 64;   // 16-byte chunks: [step][tile m][lane]
+constexpr int kSkinnyAmb = 0, kSkinnySig = 384, kSkinnyCol = 512, kSkinnyFloats = 896;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename H>
+struct LpTraits;
+template <>
+struct LpTraits<_Float16> {
+    typedef f16x8 vec;
+    static constexpr bool kPackedMax = true;
+    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct LpTraits<__bf16> {
+    typedef bf16x8 vec;
+    static constexpr bool kPackedMax = false;
+    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct LpWaveTile {
+    float px[kLpSlots], py[kLpSlots], pz[kLpSlots];   // sample position; after evaluation: sigma, r, g of the slot
+    float cb[kLpSlots], dt[kLpSlots], tend[kLpSlots]; // b of the slot; step length; t after the sample
+    uint32_t ray[kLpRays];                            // ray id by local ray (direction is re-read from rays_d for the SH basis)
+    uint8_t order[kLpSlots];                          // compact index -> slot
+};
+
+struct LpShared {
+    uint4 w[kLpWeightChunks];      // 126 976 B
+    float skinny[kSkinnyFloats];   //   3 584 B
+    float bias[256];               //   1 024 B
+    LpWaveTile tile[kLpWaves];     //  27 648 B
+};
+static_assert(sizeof(LpShared) <= 163840, "one workgroup per CU: everything must fit the 160 KiB LDS");
+
+struct LpGrid {
+    const gfpp_grid_level *levels;   // [16] device memory, read with scalar loads
+    const float *table;
+    uint32_t gridtype, interp, align_corners, any_slow;
+};
+
+struct LpTripArgs {
+    MarchParams mp;
+    LpGrid pos, amb;
+    const uint4 *w16;
+    const float *amb_w2, *sig_w2_sig, *col_w1;
+    const float *rays_o, *rays_d;
+    const float *sample_t;        // [N, sample_stride]: t of every occupied sample of the ray, in march order (k_premarch)
+    const uint32_t *sample_cnt;   // [N]: how many of them exist (capped at max_steps + 7, more can never be consumed)
+    uint32_t *consumed;           // [N]: how many the previous trips used up (the role of rays_t)
+    uint32_t sample_stride;
+    float *weights_sum, *depth, *image;
+    const int32_t *alive_in;
+    int32_t *alive_out;
+    int32_t *counters;
+    const float *frame_consts;
+    float T_thresh, density_scale;
+    uint32_t N, trip, max_steps;
+    unsigned long long *phase_cycles;   // optional [trips][4]: shader cycles summed over wavefronts (weights copy, march, evaluate, composite)
+};
+
+// LDS traffic of one wavefront is executed in program order; this only stops the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc[m] += W[32m.., 16 s..] * b[s]  for NS steps of K = 16; A operands come from the LDS-resident weight image, one step
+// (4 x ds_read_b128) ahead of their use.  The sched_barrier keeps the compiler from hoisting a whole layer's reads, which
+// would spill the accumulators.
+template <typename H, int NS>
+__device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
+    typedef typename LpTraits<H>::vec vec;
+    const vec *p = reinterpret_cast<const vec *>(w) + step0 * 256 + lane;
+    vec a0 = p[0], a1 = p[64], a2 = p[128], a3 = p[192];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        vec n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+        if (s + 1 < NS) {
+            const vec *q = p + (s + 1) * 256;
+            n0 = q[0]; n1 = q[64]; n2 = q[128]; n3 = q[192];
+        }
+        acc[0] = LpTraits<H>::mfma(a0, b[s], acc[0]);
+        acc[1] = LpTraits<H>::mfma(a1, b[s], acc[1]);
+        acc[2] = LpTraits<H>::mfma(a2, b[s], acc[2]);
+        acc[3] = LpTraits<H>::mfma(a3, b[s], acc[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+    }
+}
+
+// relu(accumulators) -> the next layer's 8 operand registers-quads (step s takes rows of tile s>>1, registers 8(s&1)..+7)
+template <typename H>
+__device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTraits<H>::vec (&b)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if constexpr (sizeof(H) == 2 && LpTraits<H>::kPackedMax) {
+            // round first, clamp the packed pairs afterwards (v_pk_max_f16): relu(round(x)) == round(relu(x))
+            typename LpTraits<H>::vec t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (H)acc[s >> 1][8 * (s & 1) + e];
+            b[s] = __builtin_elementwise_max(t, (typename LpTraits<H>::vec)(H)0.0f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[s][e] = (H)fmaxf(acc[s >> 1][8 * (s & 1) + e], 0.0f);
+        }
+    }
+}
+
+// ---- grid encoding, straight-line ---------------------------------------------------------------------------------------
+// One level of the lookup with the index arithmetic resolved on the host (gfpp_grid_levels_fill) and no branch: tables are the
+// per-level padded copy (row `size` repeats row 0), so the x+1 neighbour of the last row needs no wrap-around case, and a dropped
+// z coordinate (sz == 0) simply fetches the same rows again.  Same corner order, weight products and fma chain as
+// grid_level_lookup => bit-identical features.
+struct LevelU {   // one level's descriptor in scalar registers
+    float scale;
+    uint32_t sy, sz, mask, offset;
+};
+
+// Level descriptors are read through the constant address space with uniform addresses => scalar loads (s_load_dwordx8) straight
+// into SGPRs, no vector registers involved.
+typedef const __attribute__((address_space(4))) gfpp_grid_level *LevelsK;
+
+__device__ __forceinline__ LevelU load_level(LevelsK lv, int l) {
+    LevelU r;
+    r.scale = lv[l].scale;
+    r.sy = lv[l].sy;
+    r.sz = lv[l].sz;
+    r.mask = lv[l].mask;
+    r.offset = lv[l].offset;
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
+                                                   bool smooth, float (&out)[2]) {
+    float frac[D];
+    uint32_t base[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float pos = fmaf(u[d], lv.scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos);
+        base[d] = (uint32_t)fl;
+        float f = pos - fl;
+        if (smooth) f = f * f * fmaf(-2.0f, f, 3.0f);
+        frac[d] = f;
+    }
+    const float *lt = table + 2ull * lv.offset;
+    const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
+    uint32_t z0 = 0, z1 = 0;
+    if constexpr (D == 3) { z0 = __umul24(base[2], lv.sz); z1 = z0 + lv.sz; }
+    out[0] = 0.0f;
+    out[1] = 0.0f;
+    constexpr int kPairs = 1 << (D - 1);
+    f32x4_a8 v[kPairs];
+#pragma unroll
+    for (int pair = 0; pair < kPairs; ++pair) {
+        uint32_t row = base[0] + ((pair & 1) ? y1 : y0);
+        if constexpr (D == 3) row += (pair & 2) ? z1 : z0;   // sz == 0 (z dropped by the tiled index): the same rows again, an L1 hit
+        row &= lv.mask;
+        v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * row);
+    }
+#pragma unroll
+    for (int pair = 0; pair < kPairs; ++pair) {
+        float w0 = 1.0f - frac[0], w1 = frac[0];
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            if (pair & (1 << (d - 1))) { w0 *= frac[d]; w1 *= frac[d]; }
+            else { w0 *= 1.0f - frac[d]; w1 *= 1.0f - frac[d]; }
+        }
+        out[0] = fmaf(w1, v[pair][2], fmaf(w0, v[pair][0], out[0]));
+        out[1] = fmaf(w1, v[pair][3], fmaf(w0, v[pair][1], out[1]));
+    }
+}
+
+// This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..:
+// the two descriptors of iteration i (levels 2i, 2i+1) are fetched with ONE scalar load and selected per lane, and the lookup is
+// straight-line code, so the gathers of several levels are in flight together.  Value k (= 8 s + e) of the lane is level 2 (k/2) + hi,
+// channel k % 2.
+template <int D, typename H, bool SLOW>
+__device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, LevelsK lvk, int hi, bool valid, typename LpTraits<H>::vec (&b)[2]) {
+    bool ok = valid;
+    float uc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ok = ok && !(u[d] < 0.0f || u[d] > 1.0f);
+        uc[d] = fminf(fmaxf(u[d], 0.0f), 1.0f);
+    }
+    const bool smooth = g.interp == 1, ac = g.align_corners != 0;
+    float f[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float o[2];
+        if constexpr (SLOW) {
+            // hash-addressed (or true-modulo) levels present: the generic lookup (separate kernel instantiation)
+            const gfpp_grid_level lv = g.levels[2 * i + hi];
+            grid_level_lookup<D, 2, float>(uc, g.table, lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
+        } else {
+            const LevelU e = load_level(lvk, 2 * i), q = load_level(lvk, 2 * i + 1);
+            LevelU lv;
+            lv.scale = hi ? q.scale : e.scale;
+            lv.sy = hi ? q.sy : e.sy;
+            lv.sz = hi ? q.sz : e.sz;
+            lv.mask = hi ? q.mask : e.mask;
+            lv.offset = hi ? q.offset : e.offset;
+            level_fast_uniform<D>(uc, g.table, lv, ac, smooth, o);
+        }
+        f[2 * i] = ok ? o[0] : 0.0f;
+        f[2 * i + 1] = ok ? o[1] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[s][e] = (H)f[8 * s + e];
+}
+
+// ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves
+template <int AMB_D, typename H>
+__device__ __forceinline__ void ambient_block(const LpShared &sh, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi, float (&amb)[AMB_D]) {
+    v16f acc[4];
+    typename LpTraits<H>::vec bh[8];
+    float bs[64];
+    load_bias(acc, sh.bias, hi);
+    mfma_steps<H, 2>(acc, sh.w, kStepAmb0, bpos, lane);
+    relu_pack<H>(acc, bh);
+    zero_acc(acc);
+    mfma_steps<H, 8>(acc, sh.w, kStepAmb1, bh, lane);
+    acc_to_b<true>(acc, bs);
+    valu_rows<AMB_D>(sh.skinny + kSkinnyAmb, bs, hi, amb);
+}
+
+// sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
+template <typename H>
+__device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, const typename LpTraits<H>::vec (&bpos)[2],
+                                               const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi) {
+    typedef typename LpTraits<H>::vec vec;
+    const bool valid = c < n_valid;
+    const uint32_t slot = valid ? wt.order[c] : 0u;
+    const uint32_t ray_local = slot / n_step;
+    v16f acc[4];
+    vec bh[8];
+    float bs[64];
+    zero_acc(acc);
+    mfma_steps<H, 2>(acc, sh.w, kStepSig0, bpos, lane);
+    mfma_steps<H, 2>(acc, sh.w, kStepSig0 + 2, bamb, lane);
+    relu_pack<H>(acc, bh);
+    zero_acc(acc);
+    mfma_steps<H, 8>(acc, sh.w, kStepSig1, bh, lane);
+    acc_to_b<true>(acc, bs);
+    float logit[1];
+    valu_rows<1>(sh.skinny + kSkinnySig, bs, hi, logit);
+    const float sigma = a.density_scale * expf(logit[0]);
+    {
+        vec bcol[9];
+        float shv[16];
+        const float *dir = a.rays_d + 3ull * wt.ray[ray_local];
+        sh_basis4(dir[0], dir[1], dir[2], shv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bcol[0][e] = (H)(hi ? shv[8 + e] : shv[e]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bcol[1 + s][e] = (H)bs[8 * s + e];   // bs[16 m + r] = relu(acc[m][r]): same order as relu_pack
+        load_bias(acc, sh.bias + 128, hi);
+        mfma_steps<H, 9>(acc, sh.w, kStepCol, bcol, lane);
+    }
+    acc_to_b<true>(acc, bs);
+    float rgb[3];
+    valu_rows<3>(sh.skinny + kSkinnyCol, bs, hi, rgb);
+    if (valid && hi == 0) {
+        wt.px[slot] = sigma;
+        wt.py[slot] = 1.0f / (1.0f + expf(-rgb[0]));
+        wt.pz[slot] = 1.0f / (1.0f + expf(-rgb[1]));
+        wt.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
+    }
+}
+
+// RADNeRF.forward for the 32 occupied samples [first, first+32) of this wavefront's tile.
+template <int AMB_D, typename H, bool SLOW>
+__device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, uint32_t first, uint32_t n_valid,
+                                                  uint32_t n_step, int lane_in) {
+    typedef typename LpTraits<H>::vec vec;
+    int lane = lane_in;
+    // launder the lane id: keeps tile-loop-invariant per-lane LDS addresses from being hoisted out of the tile loop and spilled
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 31, hi = lane >> 5;
+    const uint32_t c = first + (uint32_t)j;
+    const bool valid = c < n_valid;
+    const uint32_t slot = valid ? wt.order[c] : 0u;
+    // launder the descriptor pointers too (uniform, but opaque to LICM: hoisting 32 descriptors out of the tile loop would spill them)
+    LevelsK lv_pos = (LevelsK)a.pos.levels, lv_amb = (LevelsK)a.amb.levels;
+    asm volatile("" : "+s"(lv_pos), "+s"(lv_amb));
+
+    vec bpos[2], bamb[2];
+    {
+        float u3[3];
+        const float b2 = 2.0f * a.mp.bound;
+        u3[0] = (wt.px[slot] + a.mp.bound) / b2;
+        u3[1] = (wt.py[slot] + a.mp.bound) / b2;
+        u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
+        encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
+    }
+    {
+        float amb[AMB_D], ua[AMB_D];
+        ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
+#pragma unroll
+        for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
+        encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
+    }
+    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi);
+}
+
+template <int AMB_D, typename H, bool SLOW>
+__global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
+    __shared__ LpShared sh;
+    // ---- loop state, recomputed from the per-trip counters (renderer.py:354-384) ----------------------------------
+    uint32_t step_before = 0;
+    for (uint32_t k = 0; k < a.trip; ++k) {
+        const uint32_t na = (uint32_t)a.counters[k];
+        if (na == 0) return;
+        uint32_t ns = a.N / na;
+        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
+        step_before += ns;
+    }
+    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
+    if (n_alive == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N / n_alive;
+    n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t rays_per_tile = (uint32_t)kLpSlots / n_step < (uint32_t)kLpRays ? (uint32_t)kLpSlots / n_step : (uint32_t)kLpRays;
+    const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
+    if ((uint32_t)blockIdx.x * kLpWaves >= n_tiles) return;   // no tile for any wavefront of this workgroup
+
+    const bool prof = a.phase_cycles != nullptr;
+    unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull, cyc[4] = {0ull, 0ull, 0ull, 0ull};
+    auto lap = [&](int phase) {
+        if (prof) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            cyc[phase] += now - t_mark;
+            t_mark = now;
+        }
+    };
+    // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
+    for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
+    for (int i = tid; i < kSkinnyFloats; i += kLpThreads) {
+        float v = 0.0f;
+        if (i < kSkinnySig) { if (i < 2 * AMB_D * 64) v = a.amb_w2[i]; }
+        else if (i < kSkinnyCol) v = a.sig_w2_sig[i - kSkinnySig];
+        else v = a.col_w1[i - kSkinnyCol];
+        sh.skinny[i] = v;
+    }
+    if (tid < 256) sh.bias[tid] = a.frame_consts[tid];
+    __syncthreads();
+    lap(0);
+
+    LpWaveTile &wt = sh.tile[wave];
+    const uint32_t gw = blockIdx.x * kLpWaves + wave, nw = gridDim.x * kLpWaves;
+    uint32_t evaluated = 0;
+    for (uint32_t tile = gw; tile < n_tiles; tile += nw) {
+        // ---- phase 1: this trip's samples of every ray (one lane per ray), from the frame's pre-marched list -----------------
+        const uint32_t n = tile * rays_per_tile + lane;
+        const bool has_ray = (uint32_t)lane < rays_per_tile && n < n_alive;
+        uint32_t ray = 0, cnt = 0, used = 0;
+        if (has_ray) {
+            ray = a.trip == 0 ? n : (uint32_t)a.alive_in[n];
+            used = a.trip == 0 ? 0u : a.consumed[ray];
+            const uint32_t avail = a.sample_cnt[ray] - used;
+            cnt = avail < n_step ? avail : n_step;
+            wt.ray[lane] = ray;
+            if (cnt) {
+                const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+                const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+                const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
+                const uint32_t base = lane * n_step;
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    // the same expressions as march_one_ray (raymarching.cu:873-882, 905-913) evaluated at the stored t
+                    const float t0 = ts[s];
+                    const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);
+                    wt.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                    wt.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                    wt.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                    wt.dt[base + s] = dt;
+                    wt.tend[base + s] = t0 + dt;
+                }
+            }
+        }
+        // compaction of the occupied samples inside the wavefront
+        const uint32_t incl = wave_inclusive_scan(cnt, lane);
+        const uint32_t n_valid = (uint32_t)__shfl((int)incl, 63);
+        {
+            const uint32_t pos = incl - cnt;
+            for (uint32_t s = 0; s < cnt; ++s) wt.order[pos + s] = (uint8_t)(lane * n_step + s);
+        }
+        wave_sync();
+        lap(1);
+
+        // ---- phase 2: evaluate the radiance field on the occupied samples, 32 per pass --------------------------------
+        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW>(a, sh, wt, first, n_valid, n_step, lane);
+        evaluated += n_valid;
+        wave_sync();
+        lap(2);
+
+        // ---- phase 3: composite, ray state update, survivor compaction -------------------------------------------------
+        bool survives = false;
+        if (has_ray) {
+            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            const uint32_t base = lane * n_step;
+            uint32_t s = 0;
+            for (; s < cnt; ++s) {
+                const uint32_t k = base + s;
+                if (composite_sample(acc, wt.px[k], wt.dt[k], wt.tend[k], wt.py[k], wt.pz[k], wt.cb[k], a.T_thresh)) break;
+            }
+            // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
+            survives = (s == n_step);
+            if (survives) a.consumed[ray] = used + n_step;
+            a.weights_sum[ray] = acc.wsum;
+            a.depth[ray] = acc.depth;
+            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+        }
+        const unsigned long long ballot = __ballot(survives);
+        const uint32_t total = (uint32_t)__popcll(ballot);
+        uint32_t out_base = 0;
+        if (lane == 0 && total) out_base = (uint32_t)atomicAdd(&a.counters[a.trip + 1], (int)total);
+        out_base = (uint32_t)__shfl((int)out_base, 0);
+        if (survives) a.alive_out[out_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (int32_t)ray;
+        wave_sync();
+        lap(3);
+    }
+    if (prof && lane == 0)
+        for (int ph = 0; ph < 4; ++ph) atomicAdd(&a.phase_cycles[4 * a.trip + ph], cyc[ph]);
+    if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + a.trip], (int)evaluated);   // evaluated samples of this trip
+}
+
+// The sample positions of a ray do not depend on the radiance field (only on the occupancy bitfield), and the reference's marcher
+// carries nothing but t from one loop iteration to the next (raymarching.cu:857, renderer.py:366), so the whole per-ray sample
+// sequence can be marched ONCE per frame, at full occupancy, instead of piecewise inside the register- and LDS-heavy trip kernel:
+// trip k then just takes the next n_step entries.  A ray can consume at most max_steps + 7 samples (cumulative step < max_steps
+// before the last trip, n_step <= 8).
+struct PremarchArgs {
+    MarchParams mp;
+    const uint8_t *bitfield;
+    const float *rays_o, *rays_d, *nears, *fars;
+    float *sample_t;
+    uint32_t *sample_cnt;
+    uint32_t N, stride, max_samples;
+};
+
+__global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= p.N) return;
+    const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
+    float t = p.nears[n];
+    float *out = p.sample_t + (size_t)n * p.stride;
+    p.sample_cnt[n] = march_one_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, p.fars[n], p.max_samples, p.bitfield, p.mp,
+                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+}
+
+template <int AMB_D, typename H, bool SLOW>
+static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
+    hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
+}
+
+static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {
+    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
+}
+
+static int lp_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                      float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_march_lp: null argument"); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("gfpp_head_frame_march_lp: max_steps must be in 1..%d", kMaxTrips); return GFPP_EUNSUPPORTED; }
+    if (!model->lp_weights || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
+        set_error("gfpp_head_frame_march_lp: the model carries no 16-bit weight image (lp_weights / lp_dtype)");
+        return GFPP_EINVAL;
+    }
+    if (!lp_grid_ok(model->pos_grid, 3) || !(lp_grid_ok(model->amb_grid, 2) || lp_grid_ok(model->amb_grid, 3))) {
+        set_error("gfpp_head_frame_march_lp: grids must be 16-level fp32 tables, position D=3, ambient D in {2,3}");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (model->cascade < 1 || model->cascade > 8 || !model->density_bitfield || !ws->alive[0] || !ws->alive[1]) {
+        set_error("gfpp_head_frame_march_lp: bad model/workspace");
+        return GFPP_EINVAL;
+    }
+    LpTripArgs a;
+    a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("gfpp_head_frame_march_lp: grid descriptors carry no host level table (levels_host)"); return GFPP_EINVAL; }
+    for (int which = 0; which < 2; ++which) {
+        const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
+        LpGrid &g = which ? a.amb : a.pos;
+        g.any_slow = 0;
+        g.levels = gd.levels;
+        for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
+        if (!g.any_slow && !gd.row_padded) { set_error("gfpp_head_frame_march_lp: tables must be the per-level padded copy (row_padded)"); return GFPP_EINVAL; }
+        g.table = (const float *)gd.table;
+        g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
+    }
+    a.w16 = (const uint4 *)model->lp_weights;
+    a.amb_w2 = model->amb_w2; a.sig_w2_sig = model->sig_w2_sig; a.col_w1 = model->col_w1;
+    if (!ws->sample_t || !ws->sample_cnt || ws->sample_stride < max_steps + 7u) {
+        set_error("gfpp_head_frame_march_lp: the workspace needs sample_t [N, sample_stride >= max_steps + 7] and sample_cnt [N]");
+        return GFPP_EINVAL;
+    }
+    a.rays_o = rays_o; a.rays_d = rays_d;
+    a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
+    a.consumed = (uint32_t *)ws->rays_t;   // the per-ray cursor takes the place of rays_t
+    a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.counters = ws->counters;
+    a.frame_consts = ws->frame_consts;
+    a.T_thresh = T_thresh; a.density_scale = model->density_scale;
+    a.N = ws->N; a.max_steps = max_steps;
+    a.phase_cycles = (unsigned long long *)ws->phase_cycles;
+    const hipStream_t st0 = (hipStream_t)stream;
+    {
+        PremarchArgs p;
+        p.mp = a.mp;
+        p.bitfield = model->density_bitfield;
+        p.rays_o = rays_o; p.rays_d = rays_d; p.nears = ws->nears; p.fars = ws->fars;
+        p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
+        p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
+        hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, st0, p);
+        const int rc = check_launch("gfpp_head_frame_march_lp(premarch)");
+        if (rc) return rc;
+    }
+    const uint32_t grid = (uint32_t)lp_cu_count();   // one resident workgroup per CU (LDS-bound), tiles are taken wave-stride
+    const hipStream_t st = (hipStream_t)stream;
+    const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
+    void (*launch)(uint32_t, hipStream_t, const LpTripArgs &) =
+        amb3 ? (bf ? (slow ? launch_lp<3, __bf16, true> : launch_lp<3, __bf16, false>) : (slow ? launch_lp<3, _Float16, true> : launch_lp<3, _Float16, false>))
+             : (bf ? (slow ? launch_lp<2, __bf16, true> : launch_lp<2, __bf16, false>) : (slow ? launch_lp<2, _Float16, true> : launch_lp<2, _Float16, false>));
+    for (uint32_t trip = 0; trip < max_steps; ++trip) {
+        a.trip = trip;
+        a.alive_in = ws->alive[trip & 1];
+        a.alive_out = ws->alive[(trip + 1) & 1];
+        launch(grid, st, a);
+        const int rc = check_launch("gfpp_head_frame_march_lp");
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -182,4 +182,12 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
     }
 }
 
+// ---- resolved index arithmetic for the fused kernels --------------------------------------------------------------------
+// gfpp_grid_level carries, besides the reference's per-level quantities, the index arithmetic resolved on the host
+// (gfpp_grid_levels_fill): sy / sz = stride of the y / z coordinate in the level's linear index, 0 where the reference's
+// `stride <= hashmap_size` test (gridencoder.cu:72) drops the dimension; mask = size - 1 where the level size is a power
+// of two, ~0 where the index provably stays below the size, so `index % hashmap_size` (gridencoder.cu:82) is one AND.
+// Levels that need the hash (or a true modulo) are flagged GFPP_LEVEL_SLOW and go through grid_level_lookup above.
+// The user of these fields is level_fast_uniform in frame_head_lp.hip.
+
 }  // namespace gfpp

@@ -1,0 +1,98 @@
+// head_eval_device.h -- device helpers shared by the fp32 (frame_head.hip) and 16-bit (frame_head_lp.hip) head trip kernels:
+// grid-encoder halves, fragment-order bias load, accumulator -> operand moves, skinny VALU output rows, wave scan.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "grid_device.h"
+#include "march_device.h"
+#include "sh_device.h"
+
+namespace gfpp {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 128;     // sample slots per workgroup tile (4 wavefronts x 32 columns)
+constexpr int kThreads = 256;
+constexpr int kMaxTrips = 63;      // counters[0..63] alive counts, counters[64..127] evaluated samples
+
+struct GridDev {
+    const void *table;
+    const gfpp_grid_level *levels;
+    uint32_t gridtype, interp, align_corners;
+};
+
+__device__ __forceinline__ void load_bias(v16f (&acc)[4], const float *__restrict__ bias_frag, int hi) {
+    const float4 *p = reinterpret_cast<const float4 *>(bias_frag + hi * 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = p[m * 4 + q];
+            acc[m][4 * q] = v.x; acc[m][4 * q + 1] = v.y; acc[m][4 * q + 2] = v.z; acc[m][4 * q + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(v16f (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+}
+
+template <bool RELU>
+__device__ __forceinline__ void acc_to_b(const v16f (&acc)[4], float (&b)[64]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b[m * 16 + r] = RELU ? fmaxf(acc[m][r], 0.0f) : acc[m][r];
+}
+
+// Skinny output layer on the VALU: out[c] = sum over this lane's 64 activations, then the two half-waves are added.
+template <int C>
+__device__ __forceinline__ void valu_rows(const float *__restrict__ wv, const float (&b)[64], int hi, float (&out)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float4 *p = reinterpret_cast<const float4 *>(wv + (hi * C + c) * 64);
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = p[q];
+            s = fmaf(v.x, b[4 * q], s); s = fmaf(v.y, b[4 * q + 1], s); s = fmaf(v.z, b[4 * q + 2], s); s = fmaf(v.w, b[4 * q + 3], s);
+        }
+        out[c] = s + __shfl_xor(s, 32);
+    }
+}
+
+// This lane's half of a 16-level, 2-channel grid encoding: levels hi*8 .. hi*8+7 -> 16 features.
+template <int D>
+__device__ __forceinline__ void encode_half(const float (&u)[D], const GridDev &g, int hi, bool valid, float (&f)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f[i] = 0.0f;
+    if (!valid) return;
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) inside = inside && !(u[d] < 0.0f || u[d] > 1.0f);
+    if (!inside) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const gfpp_grid_level lv = g.levels[hi * 8 + i];
+        float o[2];
+        grid_level_lookup<D, 2, float>(u, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype,
+                                       g.align_corners != 0, g.interp, o);
+        f[2 * i] = o[0];
+        f[2 * i + 1] = o[1];
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = __shfl_up(v, off);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+}  // namespace gfpp

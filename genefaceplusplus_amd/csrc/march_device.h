@@ -86,6 +86,7 @@ __device__ __forceinline__ float exit_distance(int n, float v, float d, float rd
 // One sample produced by the marcher.
 struct Sample {
     float x, y, z, dt, t_end;
+    float t0;   // t at which the sample was taken (t_end = t0 + dt)
 };
 
 // Advance one ray from t, emitting up to n_step occupied samples through `emit(step, Sample)`.
@@ -109,8 +110,9 @@ __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, 
         const uint32_t cell = (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
         const bool occupied = (bitfield[cell >> 3] >> (cell & 7u)) & 1u;
         if (occupied) {
+            const float t0 = t;
             t += dt;
-            Sample s{x, y, z, dt, t};
+            Sample s{x, y, z, dt, t, t0};
             emit(step, s);
             ++step;
         } else {

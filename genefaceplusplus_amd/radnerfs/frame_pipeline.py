@@ -20,12 +20,13 @@ c_f = ctypes.c_float
 
 
 class GridLevel(ctypes.Structure):
-    _fields_ = [("scale", c_f), ("resolution", c_u32), ("offset", c_u32), ("size", c_u32)]
+    _fields_ = [("scale", c_f), ("resolution", c_u32), ("offset", c_u32), ("size", c_u32),
+                ("sy", c_u32), ("sz", c_u32), ("mask", c_u32), ("flags", c_u32)]
 
 
 class GridDesc(ctypes.Structure):
     _fields_ = [("table", c_p), ("levels", c_p), ("dtype", ctypes.c_int32), ("D", c_u32), ("L", c_u32), ("gridtype", c_u32),
-                ("interp", c_u32), ("align_corners", c_u32)]
+                ("interp", c_u32), ("align_corners", c_u32), ("levels_host", c_p), ("row_padded", c_u32)]
 
 
 class HeadModel(ctypes.Structure):
@@ -33,12 +34,14 @@ class HeadModel(ctypes.Structure):
                 ("density_bitfield", c_p), ("pos_grid", GridDesc), ("amb_grid", GridDesc),
                 ("amb_w0", c_p), ("amb_w0_cond", c_p), ("amb_w1", c_p), ("amb_w2", c_p),
                 ("sig_w0", c_p), ("sig_w1", c_p), ("sig_w2_geo", c_p), ("sig_w2_sig", c_p),
-                ("col_w0", c_p), ("col_w0_ind", c_p), ("col_w1", c_p), ("cond_dim", c_u32), ("ind_dim", c_u32)]
+                ("col_w0", c_p), ("col_w0_ind", c_p), ("col_w1", c_p), ("cond_dim", c_u32), ("ind_dim", c_u32),
+                ("lp_weights", c_p), ("lp_dtype", ctypes.c_int32)]
 
 
 class FrameWs(ctypes.Structure):
     _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("rays_t", c_p), ("weights_sum", c_p), ("depth", c_p), ("image", c_p),
-                ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p)]
+                ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
+                ("sample_stride", c_u32), ("phase_cycles", c_p)]
 
 
 class TorsoModel(ctypes.Structure):
@@ -52,8 +55,10 @@ class TorsoModel(ctypes.Structure):
 _lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p])
 _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
+_lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
 _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
 
 
@@ -96,6 +101,51 @@ def pack_valu(weight):
     return W[:, cols].permute(1, 0, 2).contiguous().view(2, C, 64)
 
 
+# ---- 16-bit operand image (layout documented at gfpp_head_model.lp_weights) -----------------------------------------------
+GFPP_F16, GFPP_BF16 = 1, 2
+LP_DTYPES = {"fp16": (GFPP_F16, torch.float16), "bf16": (GFPP_BF16, torch.bfloat16)}
+
+
+def lp_cols_encoder(base):
+    """32 encoder features as 2 steps of K = 16: col[s][h][e].  Half-wave h holds the levels h, h+2, ... (encode_half_lp), so its
+    k-th value (k = 8 s + e) is level 2 (k // 2) + h, channel k % 2 = feature 2 level + channel."""
+    return [[[base + 2 * (2 * ((8 * s + e) // 2) + h) + (e % 2) for e in range(8)] for h in range(2)] for s in range(2)]
+
+
+def lp_cols_act(base=0):
+    """128 previous-layer activations as 8 steps: step s takes accumulator tile s>>1, registers 8(s&1)..+7."""
+    return [[[base + 32 * (s >> 1) + _rr(8 * (s & 1) + e) + 4 * h for e in range(8)] for h in range(2)] for s in range(8)]
+
+
+def lp_cols_sh():
+    return [[[8 * h + e for e in range(8)] for h in range(2)]]
+
+
+def pack_lp(weight, cols):
+    """weight [128, K] (nn.Linear layout, any float dtype) -> [S, 4, 64, 8] with P[s][m][lane][e] = W[32m + (lane&31)][cols[s][lane>>5][e]]."""
+    W = weight.detach().double()
+    assert W.shape[0] == 128
+    idx = torch.tensor(cols, dtype=torch.long, device=W.device)            # [S, 2, 8]
+    S = idx.shape[0]
+    Wk = W[:, idx]                                                          # [128, S, 2, 8]
+    P = Wk.view(4, 32, S, 2, 8).permute(2, 0, 3, 1, 4)                      # [S, m, h, i, e]
+    return P.reshape(S, 4, 64, 8).contiguous()
+
+
+def lp_weight_image(model, dtype):
+    """The five wide layers of the head as one [31, 4, 64, 8] tensor of `dtype` (steps: amb0 2 | amb1 8 | sig0 4 | sig1 8 | colour 9)."""
+    A0, A1, _ = (l.weight.detach().double() for l in model.ambient_net.net)
+    S0, S1, S2 = (l.weight.detach().double() for l in model.sigma_net.net)
+    C0 = model.color_net.net[0].weight.detach().double()
+    merged = torch.cat([C0[:, :16], C0[:, 16:144] @ S2[1:129, :]], dim=1)    # [128, 144]: SH columns | geo columns through sigma_net.2
+    parts = [pack_lp(A0[:, :32], lp_cols_encoder(0)), pack_lp(A1, lp_cols_act()),
+             pack_lp(S0, lp_cols_encoder(0) + lp_cols_encoder(32)), pack_lp(S1, lp_cols_act()),
+             pack_lp(merged, lp_cols_sh() + lp_cols_act(16))]
+    img = torch.cat(parts, dim=0)
+    assert img.shape == (31, 4, 64, 8)
+    return img.to(dtype).contiguous()
+
+
 def supports(model):
     """The MFMA kernels are specialised for the shipped architecture family (hidden 128, 3/3/2 layers, 16x2 grids)."""
     hp = model.hparams
@@ -115,6 +165,8 @@ class FramePipeline:
             raise GfppError("fused pipeline: the model must live on the GPU (there is no CPU path)")
         _lib.lib()
         self._keep = []            # device tensors referenced by raw pointers in the descriptors
+        self._lp_images = {}
+        self.precision = "fp32"
         self._versions = self._fingerprint(model)
         self.head = self._build_head(model)
         self.torso = self._build_torso(model) if hasattr(model, "torso_deform_net") else None
@@ -138,18 +190,21 @@ class FramePipeline:
         if enc.level_dim != 2 or enc.num_levels != 16:
             raise GfppError("fused pipeline: grids must have 16 levels x 2 channels")
         L = enc.num_levels
-        scale = (c_f * L)()
-        res = (c_u32 * L)()
-        call("gfpp_grid_level_table", L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), scale, res)
-        off = enc.offsets.cpu().numpy()
-        lv = np.zeros(L, dtype=[("scale", np.float32), ("resolution", np.uint32), ("offset", np.uint32), ("size", np.uint32)])
-        lv["scale"] = np.frombuffer(scale, dtype=np.float32)
-        lv["resolution"] = np.frombuffer(res, dtype=np.uint32)
-        lv["offset"] = off[:-1]
-        lv["size"] = off[1:] - off[:-1]
-        levels = torch.from_numpy(lv.view(np.uint8).reshape(L, 16).copy()).to(self.device)
+        off = np.ascontiguousarray(enc.offsets.cpu().numpy().astype(np.int32))
+        lv = (GridLevel * L)()
+        call("gfpp_grid_levels_fill", int(enc.input_dim), L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id),
+             int(enc.align_corners), off.ctypes.data, 1, lv)
+        levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
         d = GridDesc()
-        d.table = self._hold(enc.embeddings.detach().float())
+        # padded copy: every level is followed by a repeat of its first row (see gfpp_grid_desc.row_padded)
+        emb = enc.embeddings.detach().float()
+        parts = []
+        for l in range(L):
+            parts += [emb[off[l]:off[l + 1]], emb[off[l]:off[l] + 1]]
+        d.table = self._hold(torch.cat(parts, dim=0))
+        self._keep.append(lv)
+        d.levels_host = ctypes.addressof(lv)
+        d.row_padded = 1
         d.levels = self._hold(levels)
         d.dtype = 0
         d.D, d.L = enc.input_dim, L
@@ -184,7 +239,21 @@ class FramePipeline:
         hm.col_w0_ind = self._hold(C0.detach().float()[:, 144:]) if ind_dim > 0 else None
         hm.col_w1 = self._hold(pack_valu(C1))
         hm.cond_dim, hm.ind_dim = int(A0.shape[1] - 32), ind_dim
+        hm.lp_weights, hm.lp_dtype = None, 0
         return hm
+
+    def set_precision(self, model, precision):
+        """'fp32' (exact-fp32 MFMA) | 'fp16' | 'bf16' (16-bit MFMA operands, fp32 accumulation; weights repacked on first use)."""
+        if precision == "fp32":
+            self.precision = "fp32"
+            return
+        if precision not in LP_DTYPES:
+            raise GfppError(f"precision must be 'fp32', 'fp16' or 'bf16', got {precision!r}")
+        if precision not in self._lp_images:
+            self._lp_images[precision] = lp_weight_image(model, LP_DTYPES[precision][1]).to(self.device)
+        self.head.lp_weights = self._lp_images[precision].data_ptr()
+        self.head.lp_dtype = LP_DTYPES[precision][0]
+        self.precision = precision
 
     def _build_torso(self, m):
         hp = m.hparams
@@ -238,6 +307,8 @@ class FramePipeline:
             for k in ("nears", "fars", "rays_t", "weights_sum", "depth", "image", "counters", "frame_consts"):
                 setattr(ws, k, t[k].data_ptr())
             ws.alive[0], ws.alive[1] = t["alive0"].data_ptr(), t["alive1"].data_ptr()
+            ws.phase_cycles = None
+            ws.sample_t, ws.sample_cnt, ws.sample_stride = None, None, 0
             ent = (ws, t)
             self._ws[N] = ent
         return ent
@@ -262,8 +333,13 @@ class FramePipeline:
         st = torch.cuda.current_stream().cuda_stream
         call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), cond_feat.data_ptr(),
              ind.data_ptr() if ind is not None else None, st)
-        call("gfpp_head_frame_march", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
-             int(max_steps), float(T_thresh), st)
+        if self.precision != "fp32" and ws.sample_stride < int(max_steps) + 7:
+            stride = (int(max_steps) + 7 + 7) // 8 * 8
+            t["sample_t"] = torch.empty(N, stride, dtype=torch.float32, device=self.device)
+            t["sample_cnt"] = torch.empty(N, dtype=torch.int32, device=self.device)
+            ws.sample_t, ws.sample_cnt, ws.sample_stride = t["sample_t"].data_ptr(), t["sample_cnt"].data_ptr(), stride
+        call("gfpp_head_frame_march" if self.precision == "fp32" else "gfpp_head_frame_march_lp", ctypes.byref(self.head), ctypes.byref(ws),
+             rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
         return ws, t
 
     def render_head(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color):
@@ -316,6 +392,18 @@ class FramePipeline:
         return out
 
     MAX_TRIPS = 63
+
+    def enable_phase_cycles(self, N, on=True):
+        """Profiling aid of the 16-bit kernel: per-trip shader cycles by phase (see gfpp_frame_ws.phase_cycles)."""
+        ws, t = self.workspace(N)
+        if on:
+            t["phase_cycles"] = torch.zeros(64, 4, dtype=torch.int64, device=self.device)
+            ws.phase_cycles = t["phase_cycles"].data_ptr()
+        else:
+            ws.phase_cycles = None
+            ws.sample_t, ws.sample_cnt, ws.sample_stride = None, None, 0
+            t.pop("phase_cycles", None)
+        return t.get("phase_cycles")
 
     def trip_counters(self, N):
         """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises."""

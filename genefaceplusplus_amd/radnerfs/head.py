@@ -54,6 +54,10 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
         #: 'fused' (default) or 'staged'; see module docstring
         self.executor = "fused"
+        #: arithmetic of the five wide head layers in the fused executor: 'fp32' (exact-fp32 MFMA), 'fp16' / 'bf16' (16-bit MFMA
+        #: operands, fp32 accumulation), or 'auto' = follow the caller's torch.autocast context like nn.Linear does in the
+        #: reference (genefacepp_infer.py renders under autocast -> fp16; no autocast -> fp32)
+        self.precision = "auto"
         self._pipeline = None
 
     # -- to be provided by the model ------------------------------------------------------------------------
@@ -89,7 +93,17 @@ class NeRFRenderer(nn.Module):
         from .frame_pipeline import FramePipeline
         if self._pipeline is None or not self._pipeline.matches(self):
             self._pipeline = FramePipeline(self)
+        want = self.resolved_precision()
+        if self._pipeline.precision != want:
+            self._pipeline.set_precision(self, want)
         return self._pipeline
+
+    def resolved_precision(self):
+        if self.precision != "auto":
+            return self.precision
+        if torch.is_autocast_enabled():
+            return "bf16" if torch.get_autocast_gpu_dtype() == torch.bfloat16 else "fp16"
+        return "fp32"
 
     def _march_eval_composite_staged(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, max_steps, T_thresh,
                                      perturb=False, cond_mask=None, trace=None):

@@ -41,6 +41,7 @@ typedef void *gfpp_stream_t; /* hipStream_t */
 /* dtype codes for grid tables / encoder outputs */
 #define GFPP_F32 0
 #define GFPP_F16 1
+#define GFPP_BF16 2 /* MFMA operand type of the 16-bit head kernel only */
 
 int gfpp_abi_version(void);
 const char *gfpp_last_error(void);
@@ -136,12 +137,25 @@ int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_strea
  * fp32 exactly as the device code of gridencoder.cu:138-139 states them. */
 int gfpp_grid_level_table(uint32_t L, float S, uint32_t H, float *scale_out, uint32_t *resolution_out);
 
+#define GFPP_LEVEL_SLOW 1u /* flags: the level is addressed by the hash, or needs a true modulo -> generic lookup */
+
 typedef struct gfpp_grid_level { /* one entry per level, uploaded to device memory by the caller */
     float scale;
     uint32_t resolution;
     uint32_t offset; /* first table row of the level */
     uint32_t size;   /* rows in the level (the reference's hashmap_size) */
+    /* index arithmetic of get_grid_index (gridencoder.cu:66-84) resolved per level, see gfpp_grid_levels_fill */
+    uint32_t sy;    /* stride of coordinate 1 in the linear index, 0 if the `stride <= hashmap_size` test drops it */
+    uint32_t sz;    /* stride of coordinate 2, 0 if dropped (or D == 2) */
+    uint32_t mask;  /* index % size == index & mask: size - 1 for power-of-two sizes, 0xFFFFFFFF where index < size always */
+    uint32_t flags; /* GFPP_LEVEL_SLOW */
 } gfpp_grid_level;
+
+/* Fills all fields of `levels[0..L)` (HOST memory) from the encoder's hyper-parameters and its `offsets` array (HOST copy of
+ * GridEncoder.offsets, L+1 entries; grid.py:121-132): scale / resolution as gfpp_grid_level_table, offset / size from the
+ * offsets, and the resolved index arithmetic of get_grid_index (gridencoder.cu:66-84) for D in {2,3}. */
+int gfpp_grid_levels_fill(uint32_t D, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, const int32_t *offsets,
+                          uint32_t row_pad, gfpp_grid_level *levels); /* row_pad: rows of padding after every level (0 or 1) */
 
 typedef struct gfpp_grid_desc {
     const void *table;             /* [rows, 2] f32 or f16 (level_dim is 2 on this path) */
@@ -152,6 +166,10 @@ typedef struct gfpp_grid_desc {
     uint32_t gridtype;             /* 0 hash, 1 tiled */
     uint32_t interp;               /* 0 linear, 1 smoothstep */
     uint32_t align_corners;
+    const gfpp_grid_level *levels_host; /* the same [L] entries in HOST memory (the 16-bit kernel passes them as kernel arguments) */
+    uint32_t row_padded;           /* 1: `table` is the padded copy -- level l starts at row offsets[l] + l and is followed by one row that
+                                    * repeats its first row, so that the x+1 neighbour of a level's last row (index modulo, gridencoder.cu:82)
+                                    * is the next row in memory; levels[l].offset already includes the padding */
 } gfpp_grid_desc;
 
 /* MLP weight packing for the MFMA kernels ("fragment order", fp32):
@@ -190,6 +208,18 @@ typedef struct gfpp_head_model {
     const float *col_w1;     /* VALU pack [2][3][64] */
     uint32_t cond_dim;       /* 64 */
     uint32_t ind_dim;        /* 4 */
+    /* 16-bit operand image for gfpp_head_frame_march_lp (NULL if not built): the five wide layers as K = 16 MFMA steps,
+     * 31 steps x 4 row tiles x 64 lanes x 8 halves (126 976 B), L[step][m][lane][e] = W[32*m + (lane & 31)][col(step, lane >> 5, e)]:
+     *   steps  0- 1  ambient_net.0, position features:            col = 2*(2*((8*s + e)/2) + h) + e%2  (half-wave h encodes levels h, h+2, ..)
+     *   steps  2- 9  ambient_net.1, activations:                  col = act(s) = 32*(s>>1) + rr(8*(s&1) + e) + 4*h
+     *   steps 10-13  sigma_net.0:  s<2 position features as above, s>=2 ambient features 32 + (the same formula with s-2)
+     *   steps 14-21  sigma_net.1, activations
+     *   steps 22-30  MERGED colour layer  [ C0[:, :16] | C0[:, 16:144] @ S2[1:129, :] ]  (color_net.0 x sigma_net.2 geo rows,
+     *                no activation lies between them, radnerf.py:126-137): step 22 SH col = 8*h + e, steps 23-30 16 + act(s-23)
+     * with h = lane >> 5, rr(r) = (r&3) + 8*(r>>2).  lp_dtype = GFPP_F16 (what the reference's autocast inference uses) or
+     * GFPP_BF16.  The skinny rows (amb_w2, sig_w2_sig, col_w1), the folded biases and all accumulation stay fp32. */
+    const void *lp_weights;
+    int32_t lp_dtype;
 } gfpp_head_model;
 
 /* per-frame device workspace (caller-allocated, reusable across frames) */
@@ -204,6 +234,11 @@ typedef struct gfpp_frame_ws {
     int32_t *alive[2];   /* [N] each: ping-pong lists of alive ray ids */
     int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated */
     float *frame_consts; /* [256] f32: folded biases of ambient_net.0 and color_net.0 in fragment order */
+    float *sample_t;        /* 16-bit kernel only: [N, sample_stride] f32, t of every occupied sample of each ray in march order */
+    uint32_t *sample_cnt;   /* 16-bit kernel only: [N] u32 */
+    uint32_t sample_stride; /* >= max_steps + 7 */
+    uint64_t *phase_cycles; /* optional (NULL = off), [64][4] u64, caller-zeroed: gfpp_head_frame_march_lp adds, per trip, the shader
+                             * cycles its wavefronts spent in {weight copy, march, evaluate, composite} -- a profiling aid */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state
@@ -219,6 +254,15 @@ int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws,
  * only, composites (kernel_composite_rays semantics) and compacts the survivors for the next trip. */
 int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                           float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
+/* Same loop as gfpp_head_frame_march (renderer.py:354-384, raymarching.cu:827-929, :942-1029, radnerf.py:108-141) with the five
+ * wide layers on 16-bit MFMA operands (model->lp_weights), fp32 accumulation -- the precision class of the reference's own
+ * inference path (inference/genefacepp_infer.py:433-486 renders under torch.autocast: nn.Linear in fp16).  March, grid interpolation, tanh / exp / sigmoid, SH and compositing are fp32 and
+ * identical to the fp32 entry point, so sample positions and the trip schedule do not depend on the mode except through
+ * sigma (rays whose transmittance crosses T_thresh).  Stated tolerance vs the fp32 oracle: PSNR >= 45 dB, max-abs <= 2e-2
+ * (SURVEY.md 8c).  One 512-thread workgroup per CU keeps the weight image resident in LDS. */
+int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                             float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
 
 /* Head-only epilogue (renderer.py:385-397): image = clamp(image + (1 - weights_sum) * bg, 0, 1),
  * depth = clamp(depth - near, 0) / (far - near).  bg_color [N,3] or NULL (then bg_scalar is used; reference default 1). */

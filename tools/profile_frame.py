@@ -13,11 +13,22 @@ from helpers import frame_case, build_model, product_render
 variant = sys.argv[1] if len(sys.argv) > 1 else "may_torso"
 HW = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+precision = sys.argv[4] if len(sys.argv) > 4 else "fp32"
 dev = torch.device("cuda:0")
 case = frame_case(variant, HW)
 model = build_model(case, dev, "fused")
+model.precision = precision
 for _ in range(frames):
     product_render(model, case, dev, "hip")
 torch.cuda.synchronize()
+if precision != "fp32" and os.environ.get("GFPP_PHASES"):
+    pc = model.pipeline().enable_phase_cycles(HW * HW)
+    product_render(model, case, dev, "hip")
+    torch.cuda.synchronize()
+    pc = pc.cpu().numpy()
+    print("trip: cycles summed over wavefronts (k = 1e3) copy / march / evaluate / composite")
+    for k in range(16):
+        if pc[k].sum():
+            print(k, [int(v // 1000) for v in pc[k]])
 alive, smp = model.pipeline().trip_counters(HW * HW)
 print("alive", alive[:8], "samples", smp[:8], "total", smp.sum())
