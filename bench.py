@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--executor", default="fused", choices=["fused", "staged"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="arithmetic of the five wide head layers: exact-fp32 MFMA, or 16-bit MFMA operands with fp32 accumulation")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying the per-frame hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-stage", action="store_true")
     return ap.parse_args()
@@ -108,6 +109,7 @@ def main():
     model = model.to(dev).eval()
     model.executor = args.executor
     model.precision = args.precision
+    model.use_graph = not args.no_graph and args.executor == "fused"
 
     # ---- this rank's frames: global frame index = step * world + rank (frame-parallel sharding) ----------------------------
     total = K + W
@@ -171,7 +173,8 @@ def main():
                   "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame, max_steps 16, T_thresh 0.01, "
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (" + RCCL all_gather of uint8 frames" if world > 1 else ""),
-                             "executor": args.executor}}
+                             "executor": args.executor,
+                             "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 
     # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
     if rank == 0 and args.executor == "fused":

@@ -92,7 +92,7 @@ struct LpTripArgs {
     const float *frame_consts;
     float T_thresh, density_scale;
     uint32_t N, trip, max_steps;
-    unsigned long long *phase_cycles;   // optional [trips][4]: shader cycles summed over wavefronts (weights copy, march, evaluate, composite)
+    unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
 
 // LDS traffic of one wavefront is executed in program order; this only stops the compiler from moving accesses across.
@@ -117,6 +117,7 @@ __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int s
             const vec *q = p + (s + 1) * 256;
             n0 = q[0]; n1 = q[64]; n2 = q[128]; n3 = q[192];
         }
+        __builtin_amdgcn_sched_barrier(0);   // the next step's LDS reads go out BEFORE this step's MFMAs occupy the issue slots
         acc[0] = LpTraits<H>::mfma(a0, b[s], acc[0]);
         acc[1] = LpTraits<H>::mfma(a1, b[s], acc[1]);
         acc[2] = LpTraits<H>::mfma(a2, b[s], acc[2]);
@@ -315,7 +316,16 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 // RADNeRF.forward for the 32 occupied samples [first, first+32) of this wavefront's tile.
 template <int AMB_D, typename H, bool SLOW>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, uint32_t first, uint32_t n_valid,
-                                                  uint32_t n_step, int lane_in) {
+                                                  uint32_t n_step, int lane_in, unsigned long long (&sub)[4]) {
+    const bool prof = a.phase_cycles != nullptr;
+    unsigned long long tm = prof ? __builtin_readcyclecounter() : 0ull;
+    auto lap = [&](int k) {
+        if (prof) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            sub[k] += now - tm;
+            tm = now;
+        }
+    };
     typedef typename LpTraits<H>::vec vec;
     int lane = lane_in;
     // launder the lane id: keeps tile-loop-invariant per-lane LDS addresses from being hoisted out of the tile loop and spilled
@@ -337,14 +347,18 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
         encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
     }
+    lap(0);
     {
         float amb[AMB_D], ua[AMB_D];
         ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
+        lap(1);
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
+    lap(2);
     radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi);
+    lap(3);
 }
 
 template <int AMB_D, typename H, bool SLOW>
@@ -394,6 +408,7 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
     LpWaveTile &wt = sh.tile[wave];
     const uint32_t gw = blockIdx.x * kLpWaves + wave, nw = gridDim.x * kLpWaves;
     uint32_t evaluated = 0;
+    unsigned long long sub[4] = {0ull, 0ull, 0ull, 0ull};   // profiling: position encode, ambient MLP, ambient encode, sigma + colour
     for (uint32_t tile = gw; tile < n_tiles; tile += nw) {
         // ---- phase 1: this trip's samples of every ray (one lane per ray), from the frame's pre-marched list -----------------
         const uint32_t n = tile * rays_per_tile + lane;
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
         lap(1);
 
         // ---- phase 2: evaluate the radiance field on the occupied samples, 32 per pass --------------------------------
-        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW>(a, sh, wt, first, n_valid, n_step, lane);
+        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW>(a, sh, wt, first, n_valid, n_step, lane, sub);
         evaluated += n_valid;
         wave_sync();
         lap(2);
@@ -465,7 +480,10 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
         lap(3);
     }
     if (prof && lane == 0)
-        for (int ph = 0; ph < 4; ++ph) atomicAdd(&a.phase_cycles[4 * a.trip + ph], cyc[ph]);
+        for (int ph = 0; ph < 4; ++ph) {
+            atomicAdd(&a.phase_cycles[8 * a.trip + ph], cyc[ph]);
+            atomicAdd(&a.phase_cycles[8 * a.trip + 4 + ph], sub[ph]);
+        }
     if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + a.trip], (int)evaluated);   // evaluated samples of this trip
 }
 

@@ -44,6 +44,13 @@ class FrameWs(ctypes.Structure):
                 ("sample_stride", c_u32), ("phase_cycles", c_p)]
 
 
+class CondModel(ctypes.Structure):
+    _fields_ = [("smo", c_u32), ("t_win", c_u32), ("c_in", c_u32), ("dim_aud", c_u32), ("strides", c_u32 * 4),
+                ("conv_w", c_p * 4), ("conv_b", c_p * 4), ("fc_w", c_p * 2), ("fc_b", c_p * 2),
+                ("blink_dim", c_u32), ("blink_emb", c_p), ("blink_w", c_p * 2), ("blink_b", c_p * 2),
+                ("with_att", c_u32), ("att_conv_w", c_p * 5), ("att_conv_b", c_p * 5), ("att_fc_w", c_p), ("att_fc_b", c_p)]
+
+
 class TorsoModel(ctypes.Structure):
     _fields_ = [("density_grid", c_p), ("grid_size", c_u32), ("density_thresh", c_f), ("torso_shrink", c_f), ("variant", c_u32),
                 ("code_dim", c_u32), ("const_dim", c_u32), ("head_aware", c_u32), ("grid", GridDesc),
@@ -54,6 +61,7 @@ class TorsoModel(ctypes.Structure):
 
 _lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p])
+_lib.register("gfpp_cond_feat", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p])
 _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
 _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
 _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
@@ -155,6 +163,47 @@ def supports(model):
     return ok
 
 
+class GraphedFrame:
+    """One frame of C-ABI launches captured in a hipGraph (torch.cuda.CUDAGraph is a hipGraph on ROCm) and replayed.
+
+    The per-frame inputs (rays, conditioning window, landmarks, pose, background) are copied into static device buffers, the graph
+    is replayed, and the result tensors are the graph's static outputs: they are overwritten by the next frame of the same shape,
+    which is how the reference's caller uses them (it moves every frame to the host right away, genefacepp_infer.py:465-469).
+    Host cost per frame: a handful of small device-to-device copies + one graph launch instead of ~25 launches and their Python."""
+
+    def __init__(self, fn, inputs):
+        self.fn = fn
+        self.static = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream), torch.no_grad():
+            for _ in range(2):                       # warm-up: allocates the workspaces, packs weights, loads code objects
+                fn(**self.static)
+        torch.cuda.current_stream().wait_stream(stream)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = fn(**self.static)
+
+    def matches(self, inputs):
+        for k, v in inputs.items():
+            sv = self.static.get(k)
+            if torch.is_tensor(v) != torch.is_tensor(sv):
+                return False
+            if torch.is_tensor(v):
+                if v.shape != sv.shape or v.dtype != sv.dtype:
+                    return False
+            elif v != sv:
+                return False
+        return True
+
+    def __call__(self, inputs):
+        for k, v in inputs.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 class FramePipeline:
     def __init__(self, model):
         if not supports(model):
@@ -167,9 +216,11 @@ class FramePipeline:
         self._keep = []            # device tensors referenced by raw pointers in the descriptors
         self._lp_images = {}
         self.precision = "fp32"
+        self._graphs = {}
         self._versions = self._fingerprint(model)
         self.head = self._build_head(model)
         self.torso = self._build_torso(model) if hasattr(model, "torso_deform_net") else None
+        self.cond = self._build_cond(model)
         self._ws = {}
 
     # -- change detection ----------------------------------------------------------------------------------------
@@ -254,6 +305,50 @@ class FramePipeline:
         self.head.lp_weights = self._lp_images[precision].data_ptr()
         self.head.lp_dtype = LP_DTYPES[precision][0]
         self.precision = precision
+
+    def _build_cond(self, m):
+        """Descriptor of cal_cond_feat's networks (None if the shape is outside what the one-workgroup kernel covers)."""
+        from .cond_nets import _STRIDES
+        hp = m.hparams
+        pre = m.cond_prenet
+        cm = CondModel()
+        cm.smo, cm.t_win, cm.c_in, cm.dim_aud = int(m.smo_win_size), int(m.cond_win_size), int(m.cond_in_dim), int(m.cond_out_dim)
+        if cm.dim_aud > 64 or cm.smo > 64 or cm.smo * 64 * cm.t_win > 8192:
+            return None
+        f = lambda t: self._hold(t.detach().float())
+        for i, s_ in enumerate(_STRIDES[pre.win_size]):
+            cm.strides[i] = s_
+            conv = pre.encoder_conv[2 * i]
+            cm.conv_w[i], cm.conv_b[i] = f(conv.weight), f(conv.bias)
+        for i, j in enumerate((0, 2)):
+            cm.fc_w[i], cm.fc_b[i] = f(pre.encoder_fc1[j].weight), f(pre.encoder_fc1[j].bias)
+        if hp.get("add_eye_blink_cond", False):
+            cm.blink_dim = int(hp["eye_blink_dim"])
+            cm.blink_emb = f(m.blink_embedding.weight[0])
+            for i in range(2):
+                cm.blink_w[i], cm.blink_b[i] = f(m.blink_encoder[i].weight), f(m.blink_encoder[i].bias)
+        cm.with_att = int(bool(m.with_att))
+        if m.with_att:
+            att = m.cond_att_net
+            for i in range(5):
+                conv = att.attentionConvNet[2 * i]
+                cm.att_conv_w[i], cm.att_conv_b[i] = f(conv.weight), f(conv.bias)
+            cm.att_fc_w, cm.att_fc_b = f(att.attentionNet[0].weight), f(att.attentionNet[0].bias)
+        return cm
+
+    def cond_feat(self, cond, eye_area_percent=None):
+        """cal_cond_feat on the device in one launch -> [cond_out_dim] (or [smo, cond_out_dim] without the attention net)."""
+        cond = self._dev_f32(cond, "cond")
+        cm = self.cond
+        if tuple(cond.shape) != (cm.smo, cm.t_win, cm.c_in):
+            raise GfppError(f"cond must be [{cm.smo}, {cm.t_win}, {cm.c_in}], got {tuple(cond.shape)}")
+        eye = None
+        if cm.blink_dim and eye_area_percent is not None:
+            eye = self._dev_f32(eye_area_percent.reshape(-1)[:1], "eye_area_percent")
+        out = torch.empty(cm.dim_aud if cm.with_att else (cm.smo, cm.dim_aud), dtype=torch.float32, device=self.device)
+        call("gfpp_cond_feat", ctypes.byref(cm), cond.data_ptr(), eye.data_ptr() if eye is not None else None, out.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        return out
 
     def _build_torso(self, m):
         hp = m.hparams
@@ -391,13 +486,22 @@ class FramePipeline:
              out["torso_mask"].data_ptr(), torch.cuda.current_stream().cuda_stream)
         return out
 
+    def graphed(self, key, fn, inputs):
+        """Run `fn(**inputs)` through a per-`key` captured graph (captured on first use, re-captured if shapes change)."""
+        key = (key, self.precision)
+        g = self._graphs.get(key)
+        if g is None or not g.matches(inputs):
+            g = GraphedFrame(fn, inputs)
+            self._graphs[key] = g
+        return g(inputs)
+
     MAX_TRIPS = 63
 
     def enable_phase_cycles(self, N, on=True):
         """Profiling aid of the 16-bit kernel: per-trip shader cycles by phase (see gfpp_frame_ws.phase_cycles)."""
         ws, t = self.workspace(N)
         if on:
-            t["phase_cycles"] = torch.zeros(64, 4, dtype=torch.int64, device=self.device)
+            t["phase_cycles"] = torch.zeros(64, 8, dtype=torch.int64, device=self.device)
             ws.phase_cycles = t["phase_cycles"].data_ptr()
         else:
             ws.phase_cycles = None

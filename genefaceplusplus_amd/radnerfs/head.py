@@ -58,6 +58,9 @@ class NeRFRenderer(nn.Module):
         #: operands, fp32 accumulation), or 'auto' = follow the caller's torch.autocast context like nn.Linear does in the
         #: reference (genefacepp_infer.py renders under autocast -> fp16; no autocast -> fp32)
         self.precision = "auto"
+        #: replay each frame from a captured hipGraph (frame_pipeline.GraphedFrame).  The returned tensors are then the graph's
+        #: static outputs, valid until the next render() of the same shape -- fine for the reference's caller, opt-in otherwise
+        self.use_graph = False
         self._pipeline = None
 
     # -- to be provided by the model ------------------------------------------------------------------------
@@ -143,11 +146,18 @@ class NeRFRenderer(nn.Module):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
-        cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
         ind_code = self._individual_code(index)
         if self.executor == "fused" and cond_mask is None and not perturb and max_steps <= 63:
-            out = self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
+            def frame(rays_o, rays_d, cond, eye, bg_color):
+                cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye)
+                return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
+            inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_color": bg_color}
+            if self.use_graph and not torch.is_grad_enabled():
+                out = self.pipeline().graphed(("head", float(dt_gamma), int(max_steps), float(T_thresh)), frame, inputs)
+            else:
+                out = frame(**inputs)
             return {"depth_map": out["depth"].view(*prefix), "rgb_map": out["image"].view(*prefix, 3)}
+        cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma,
                                                                       max_steps, T_thresh, perturb, cond_mask)
@@ -216,6 +226,13 @@ class RADNeRF(NeRFRenderer):
     def cal_cond_feat(self, cond, eye_area_percent=None):
         """cond [smo_win, t_window, cond_in] -> cond_feat [cond_out] (radnerf.py:88-106)."""
         hp = self.hparams
+        if (self.executor == "fused" and not self.training and torch.is_tensor(cond) and cond.is_cuda and not torch.is_grad_enabled()
+                and (eye_area_percent is None or torch.is_tensor(eye_area_percent))):
+            from .frame_pipeline import supports
+            if supports(self):
+                pipe = self.pipeline()
+                if pipe.cond is not None:
+                    return pipe.cond_feat(cond, eye_area_percent if hp.get("add_eye_blink_cond", False) else None)
         feat = self.cond_prenet(cond)
         if hp.get("add_eye_blink_cond", False):
             if eye_area_percent is None:

@@ -124,11 +124,19 @@ class _TorsoBase(RADNeRF):
         rays_d = rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
         if self.executor == "fused" and not perturb and max_steps <= 63:
-            with torch.no_grad():
-                cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
-            out = self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, self._individual_code(index), bg_coords, poses,
-                                                    self._torso_code(index), lm68, dt_gamma, max_steps, T_thresh, bg_color,
-                                                    use_head_for_torso)
+            ind_code, torso_code = self._individual_code(index), self._torso_code(index)
+
+            def frame(rays_o, rays_d, cond, eye, bg_coords, poses, lm68, bg_color):
+                with torch.no_grad():
+                    cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye)
+                return self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
+                                                         max_steps, T_thresh, bg_color, use_head_for_torso)
+            inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_coords": bg_coords, "poses": poses,
+                      "lm68": lm68, "bg_color": bg_color}
+            if self.use_graph and not torch.is_grad_enabled():
+                out = self.pipeline().graphed(("torso", float(dt_gamma), int(max_steps), float(T_thresh), bool(use_head_for_torso)), frame, inputs)
+            else:
+                out = frame(**inputs)
             if self.return_deform:
                 # the reference returns dx of the masked pixels only ([P,2]); compacting needs a host sync, hence opt-in
                 out["deform"] = out["deform_dense"][out["torso_mask"].bool()]

@@ -172,6 +172,29 @@ typedef struct gfpp_grid_desc {
                                     * is the next row in memory; levels[l].offset already includes the padding */
 } gfpp_grid_desc;
 
+/* Per-frame conditioning: replaces RADNeRF.cal_cond_feat (radnerf.py:88-106 = AudioNet cond_encoder.py:98-143, the blink branch
+ * radnerf.py:97-103, AudioAttNet cond_encoder.py:146-180).  All weights in PyTorch layout (Conv1d [out,in,3], Linear [out,in]), fp32,
+ * device memory.  One launch of one workgroup; cond_feat stays on the device for gfpp_head_frame_begin. */
+typedef struct gfpp_cond_model {
+    uint32_t smo;        /* smo_win_size: windows per frame (the batch of AudioNet, the sequence of AudioAttNet) */
+    uint32_t t_win;      /* cond_win_size: time steps per window (1 for the lm3d configs, 16 for the audio ones) */
+    uint32_t c_in;       /* 204 (lm68 x 3), 29 or 44 */
+    uint32_t dim_aud;    /* cond_out_dim (<= 64) */
+    uint32_t strides[4]; /* cond_encoder.py:103-114 */
+    const float *conv_w[4], *conv_b[4]; /* channels c_in -> 32 -> 32 -> 64 -> 64 */
+    const float *fc_w[2], *fc_b[2];     /* 64 -> 64 -> dim_aud */
+    uint32_t blink_dim;                 /* eye_blink_dim, 0 = no blink branch */
+    const float *blink_emb;             /* blink_embedding.weight[0], [dim_aud/2] */
+    const float *blink_w[2], *blink_b[2];
+    uint32_t with_att;
+    const float *att_conv_w[5], *att_conv_b[5]; /* channels dim_aud -> 16 -> 8 -> 4 -> 2 -> 1 over the smo axis */
+    const float *att_fc_w, *att_fc_b;           /* [smo, smo] */
+} gfpp_cond_model;
+
+/* replaces RADNeRF.cal_cond_feat (radnerf.py:88-106).  cond [smo, t_win, c_in] f32; eye_area [1] f32 or NULL (= 0, like
+ * eye_area_percent=None); cond_feat [dim_aud] f32 out ([smo, dim_aud] when with_att == 0). */
+int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, const float *eye_area, float *cond_feat, gfpp_stream_t stream);
+
 /* MLP weight packing for the MFMA kernels ("fragment order", fp32):
  *   a dense layer out[128] = W[128,K] x  is evaluated as a sequence of K/2 rank-2 updates with
  *   v_mfma_f32_32x32x2_f32; update `s` consumes the input pair (k0[s], k1[s]).  Packed array P[s/4][m][lane][s%4] =
@@ -237,8 +260,9 @@ typedef struct gfpp_frame_ws {
     float *sample_t;        /* 16-bit kernel only: [N, sample_stride] f32, t of every occupied sample of each ray in march order */
     uint32_t *sample_cnt;   /* 16-bit kernel only: [N] u32 */
     uint32_t sample_stride; /* >= max_steps + 7 */
-    uint64_t *phase_cycles; /* optional (NULL = off), [64][4] u64, caller-zeroed: gfpp_head_frame_march_lp adds, per trip, the shader
-                             * cycles its wavefronts spent in {weight copy, march, evaluate, composite} -- a profiling aid */
+    uint64_t *phase_cycles; /* optional (NULL = off), [64][8] u64, caller-zeroed: gfpp_head_frame_march_lp adds, per trip, the shader
+                             * cycles its wavefronts spent in {weight copy, sample fetch, evaluate, composite} and, splitting evaluate,
+                             * {position encode, ambient MLP, ambient encode, sigma + colour MLP} -- a profiling aid */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

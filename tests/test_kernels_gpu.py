@@ -233,3 +233,21 @@ def test_get_rays(dev, oracle_mod):
     # the reference computes bg_coords with the very same torch expression on its GPU
     np.testing.assert_allclose(get_bg_coords(H, W, dev).cpu().numpy(), oracle_mod.get_bg_coords(H, W), atol=1.5e-7)
     np.testing.assert_allclose(convert_poses(t(pose, dev)[None]).cpu().numpy(), oracle_mod.convert_poses(pose[None]), atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["may_head", "may_torso_sr"])
+def test_cond_feat_kernel_matches_oracle(dev, oracle_mod, variant):
+    """gfpp_cond_feat (one launch) vs the oracle's cal_cond_feat (radnerf.py:88-106) and vs the PyTorch modules it replaces."""
+    from helpers import frame_case, build_model
+    case = frame_case(variant, 64)
+    model = build_model(case, dev, "fused")
+    cond = torch.from_numpy(case["cond"]).to(dev)
+    eye = torch.from_numpy(case["eye_area_percent"]).to(dev)
+    ref = oracle_mod.cal_cond_feat(case["cond"], case["sd"], case["hp"], case["eye_area_percent"])
+    with torch.no_grad():
+        got = model.cal_cond_feat(cond, eye_area_percent=eye)
+        model.executor = "staged"
+        torch_path = model.cal_cond_feat(cond, eye_area_percent=eye)
+    assert got.shape == torch_path.shape
+    np.testing.assert_allclose(got.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), torch_path.cpu().numpy(), rtol=2e-5, atol=2e-6)

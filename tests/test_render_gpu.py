@@ -82,3 +82,24 @@ def test_staged_trip_schedule_matches_oracle(dev, oracle_mod):
                                            0.01, trace=tr)
     assert [s for _, s in tr] == [s for _, s in tr_ref]
     assert max(abs(a - b) for (a, _), (b, _) in zip(tr, tr_ref)) <= 2, (tr, tr_ref)
+
+
+@pytest.mark.parametrize("variant,HW", [("may_head", 64), ("may_torso", 64)])
+def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
+    """use_graph=True replays a captured hipGraph; results must equal the eager launches bit for bit, also for a second,
+    different frame pushed through the same graph."""
+    import numpy as np
+    outs = {}
+    for mode in ("eager", "graph"):
+        model = build_model(frame_case(variant, HW), dev, "fused")
+        model.use_graph = mode == "graph"
+        res = []
+        for fidx in (0, 3, 0):
+            case = frame_case(variant, HW, frame_idx=fidx)
+            r = product_render(model, case, dev, "oracle", oracle_mod)
+            res.append({k: v.detach().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)})
+        outs[mode] = res
+    for a, b in zip(outs["eager"], outs["graph"]):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert not np.array_equal(outs["graph"][0]["rgb_map"], outs["graph"][1]["rgb_map"])

@@ -26,7 +26,7 @@ if precision != "fp32" and os.environ.get("GFPP_PHASES"):
     product_render(model, case, dev, "hip")
     torch.cuda.synchronize()
     pc = pc.cpu().numpy()
-    print("trip: cycles summed over wavefronts (k = 1e3) copy / march / evaluate / composite")
+    print("trip: cycles summed over wavefronts (k = 1e3) copy / samples / evaluate / composite | pos-enc / amb-MLP / amb-enc / sigma+colour")
     for k in range(16):
         if pc[k].sum():
             print(k, [int(v // 1000) for v in pc[k]])
