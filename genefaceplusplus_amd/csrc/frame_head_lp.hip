@@ -20,6 +20,10 @@
 //     gathers overlap another's MFMAs on the same SIMD.
 #include "head_eval_device.h"
 
+#ifndef GFPP_LP_LDS_LEVELS
+#define GFPP_LP_LDS_LEVELS 1   // level descriptors: 0 = scalar loads + per-lane select, 1 = per-lane LDS reads
+#endif
+
 namespace gfpp {
 
 constexpr int kLpThreads = 512;
@@ -34,7 +38,8 @@ constexpr int kStepSig1 = 14;   // 8 steps
 constexpr int kStepCol = 22;    // 9 steps: 16 SH + 128 activations (merged geo layer)
 constexpr int kLpSteps = 31;
 constexpr int kLpWeightChunks = kLpSteps * 4 * 64;   // 16-byte chunks: [step][tile m][lane]
-constexpr int kSkinnyAmb = 0, kSkinnySig = 384, kSkinnyCol = 512, kSkinnyFloats = 896;
+constexpr int kSkinnyRows = 7;   // ambient_net.2 (3, padded), sigma_net.2 row 0, color_net.1 (3): rows 0-2, 3, 4-6
+constexpr int kSkinnyWords = 2 * kSkinnyRows * 32;   // [half][row][32 pairs of 16-bit weights]
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,13 +50,17 @@ template <>
 struct LpTraits<_Float16> {
     typedef f16x8 vec;
     static constexpr bool kPackedMax = true;
+    typedef _Float16 pair __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 };
 template <>
 struct LpTraits<__bf16> {
     typedef bf16x8 vec;
     static constexpr bool kPackedMax = false;
+    typedef __bf16 pair __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
 };
 
 struct LpWaveTile {
@@ -63,7 +72,8 @@ struct LpWaveTile {
 
 struct LpShared {
     uint4 w[kLpWeightChunks];      // 126 976 B
-    float skinny[kSkinnyFloats];   //   3 584 B
+    uint32_t skinny[kSkinnyWords]; //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
+    gfpp_grid_level lv[2][16];     //   1 024 B  level descriptors of the position / ambient grid
     float bias[256];               //   1 024 B
     LpWaveTile tile[kLpWaves];     //  27 648 B
 };
@@ -79,7 +89,7 @@ struct LpTripArgs {
     MarchParams mp;
     LpGrid pos, amb;
     const uint4 *w16;
-    const float *amb_w2, *sig_w2_sig, *col_w1;
+    const uint32_t *skinny16;
     const float *rays_o, *rays_d;
     const float *sample_t;        // [N, sample_stride]: t of every occupied sample of the ray, in march order (k_premarch)
     const uint32_t *sample_cnt;   // [N]: how many of them exist (capped at max_steps + 7, more can never be consumed)
@@ -108,22 +118,30 @@ __device__ __forceinline__ void wave_sync() {
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
     typedef typename LpTraits<H>::vec vec;
+    constexpr int kAhead = NS >= 3 ? 2 : 1;   // LDS read-ahead in steps: the reads of 8 wavefronts queue up, one step (128 MFMA cycles) does not cover them
     const vec *p = reinterpret_cast<const vec *>(w) + step0 * 256 + lane;
-    vec a0 = p[0], a1 = p[64], a2 = p[128], a3 = p[192];
+    vec ring[kAhead + 1][4];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+        if (k < NS) {
+            const vec *q = p + k * 256;
+            ring[k][0] = q[0]; ring[k][1] = q[64]; ring[k][2] = q[128]; ring[k][3] = q[192];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        vec n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-        if (s + 1 < NS) {
-            const vec *q = p + (s + 1) * 256;
-            n0 = q[0]; n1 = q[64]; n2 = q[128]; n3 = q[192];
+        if (s + kAhead < NS) {
+            const vec *q = p + (s + kAhead) * 256;
+            vec (&r)[4] = ring[(s + kAhead) % (kAhead + 1)];
+            r[0] = q[0]; r[1] = q[64]; r[2] = q[128]; r[3] = q[192];
         }
-        __builtin_amdgcn_sched_barrier(0);   // the next step's LDS reads go out BEFORE this step's MFMAs occupy the issue slots
-        acc[0] = LpTraits<H>::mfma(a0, b[s], acc[0]);
-        acc[1] = LpTraits<H>::mfma(a1, b[s], acc[1]);
-        acc[2] = LpTraits<H>::mfma(a2, b[s], acc[2]);
-        acc[3] = LpTraits<H>::mfma(a3, b[s], acc[3]);
+        __builtin_amdgcn_sched_barrier(0);   // the read-ahead goes out BEFORE this step's MFMAs occupy the issue slots
+        const vec (&a)[4] = ring[s % (kAhead + 1)];
+        acc[0] = LpTraits<H>::mfma(a[0], b[s], acc[0]);
+        acc[1] = LpTraits<H>::mfma(a[1], b[s], acc[1]);
+        acc[2] = LpTraits<H>::mfma(a[2], b[s], acc[2]);
+        acc[3] = LpTraits<H>::mfma(a[3], b[s], acc[3]);
         __builtin_amdgcn_sched_barrier(0);
-        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
     }
 }
 
@@ -154,20 +172,6 @@ struct LevelU {   // one level's descriptor in scalar registers
     float scale;
     uint32_t sy, sz, mask, offset;
 };
-
-// Level descriptors are read through the constant address space with uniform addresses => scalar loads (s_load_dwordx8) straight
-// into SGPRs, no vector registers involved.
-typedef const __attribute__((address_space(4))) gfpp_grid_level *LevelsK;
-
-__device__ __forceinline__ LevelU load_level(LevelsK lv, int l) {
-    LevelU r;
-    r.scale = lv[l].scale;
-    r.sy = lv[l].sy;
-    r.sz = lv[l].sz;
-    r.mask = lv[l].mask;
-    r.offset = lv[l].offset;
-    return r;
-}
 
 template <int D>
 __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
@@ -212,11 +216,11 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
 }
 
 // This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..:
-// the two descriptors of iteration i (levels 2i, 2i+1) are fetched with ONE scalar load and selected per lane, and the lookup is
-// straight-line code, so the gathers of several levels are in flight together.  Value k (= 8 s + e) of the lane is level 2 (k/2) + hi,
+// the level descriptors sit in LDS and the lookup is straight-line code, so the gathers of several levels are in flight together.  Value k (= 8 s + e) of the lane is level 2 (k/2) + hi,
 // channel k % 2.
 template <int D, typename H, bool SLOW>
-__device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, LevelsK lvk, int hi, bool valid, typename LpTraits<H>::vec (&b)[2]) {
+__device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, const gfpp_grid_level *lvl, int hi, bool valid,
+                                               typename LpTraits<H>::vec (&b)[2]) {
     bool ok = valid;
     float uc[D];
 #pragma unroll
@@ -234,13 +238,20 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
             const gfpp_grid_level lv = g.levels[2 * i + hi];
             grid_level_lookup<D, 2, float>(uc, g.table, lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
         } else {
-            const LevelU e = load_level(lvk, 2 * i), q = load_level(lvk, 2 * i + 1);
+#if GFPP_LP_LDS_LEVELS
+            const gfpp_grid_level &d = lvl[2 * i + hi];   // LDS, two distinct addresses per wavefront
+            const LevelU lv{d.scale, d.sy, d.sz, d.mask, d.offset};
+#else
+            // both descriptors of the iteration with one scalar load (uniform address, constant address space), selected per lane
+            typedef const __attribute__((address_space(4))) gfpp_grid_level *LevelsK;
+            const LevelsK lk = (LevelsK)lvl;
             LevelU lv;
-            lv.scale = hi ? q.scale : e.scale;
-            lv.sy = hi ? q.sy : e.sy;
-            lv.sz = hi ? q.sz : e.sz;
-            lv.mask = hi ? q.mask : e.mask;
-            lv.offset = hi ? q.offset : e.offset;
+            lv.scale = hi ? lk[2 * i + 1].scale : lk[2 * i].scale;
+            lv.sy = hi ? lk[2 * i + 1].sy : lk[2 * i].sy;
+            lv.sz = hi ? lk[2 * i + 1].sz : lk[2 * i].sz;
+            lv.mask = hi ? lk[2 * i + 1].mask : lk[2 * i].mask;
+            lv.offset = hi ? lk[2 * i + 1].offset : lk[2 * i].offset;
+#endif
             level_fast_uniform<D>(uc, g.table, lv, ac, smooth, o);
         }
         f[2 * i] = ok ? o[0] : 0.0f;
@@ -252,19 +263,40 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         for (int e = 0; e < 8; ++e) b[s][e] = (H)f[8 * s + e];
 }
 
+// Skinny output rows on packed 16-bit dot products: out[c] = sum over this lane's 64 activations (the operand registers of
+// relu_pack) of w * x with fp32 accumulation (v_dot2c_f32_{f16,bf16}); the two half-waves are added.  Weights: LDS, 32 pairs per row.
+template <int C, typename H>
+__device__ __forceinline__ void skinny_rows(const uint32_t *__restrict__ wrow, const typename LpTraits<H>::vec (&b)[8], int hi, float (&out)[C]) {
+    typedef typename LpTraits<H>::vec vec;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const vec *p = reinterpret_cast<const vec *>(wrow + (hi * kSkinnyRows + c) * 32);
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const vec w = p[s], x = b[s];
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), s1);
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), s1);
+        }
+        const float t = s0 + s1;
+        out[c] = t + __shfl_xor(t, 32);
+    }
+}
+
 // ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves
 template <int AMB_D, typename H>
 __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi, float (&amb)[AMB_D]) {
     v16f acc[4];
     typename LpTraits<H>::vec bh[8];
-    float bs[64];
     load_bias(acc, sh.bias, hi);
     mfma_steps<H, 2>(acc, sh.w, kStepAmb0, bpos, lane);
     relu_pack<H>(acc, bh);
     zero_acc(acc);
     mfma_steps<H, 8>(acc, sh.w, kStepAmb1, bh, lane);
-    acc_to_b<true>(acc, bs);
-    valu_rows<AMB_D>(sh.skinny + kSkinnyAmb, bs, hi, amb);
+    relu_pack<H>(acc, bh);
+    skinny_rows<AMB_D, H>(sh.skinny, bh, hi, amb);
 }
 
 // sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
@@ -277,16 +309,15 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     const uint32_t ray_local = slot / n_step;
     v16f acc[4];
     vec bh[8];
-    float bs[64];
     zero_acc(acc);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0, bpos, lane);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0 + 2, bamb, lane);
     relu_pack<H>(acc, bh);
     zero_acc(acc);
     mfma_steps<H, 8>(acc, sh.w, kStepSig1, bh, lane);
-    acc_to_b<true>(acc, bs);
+    relu_pack<H>(acc, bh);   // the hidden state feeds both the density row and the (merged) colour layer
     float logit[1];
-    valu_rows<1>(sh.skinny + kSkinnySig, bs, hi, logit);
+    skinny_rows<1, H>(sh.skinny + 3 * 32, bh, hi, logit);
     const float sigma = a.density_scale * expf(logit[0]);
     {
         vec bcol[9];
@@ -296,15 +327,13 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 #pragma unroll
         for (int e = 0; e < 8; ++e) bcol[0][e] = (H)(hi ? shv[8 + e] : shv[e]);
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bcol[1 + s][e] = (H)bs[8 * s + e];   // bs[16 m + r] = relu(acc[m][r]): same order as relu_pack
+        for (int s = 0; s < 8; ++s) bcol[1 + s] = bh[s];
         load_bias(acc, sh.bias + 128, hi);
         mfma_steps<H, 9>(acc, sh.w, kStepCol, bcol, lane);
     }
-    acc_to_b<true>(acc, bs);
+    relu_pack<H>(acc, bh);
     float rgb[3];
-    valu_rows<3>(sh.skinny + kSkinnyCol, bs, hi, rgb);
+    skinny_rows<3, H>(sh.skinny + 4 * 32, bh, hi, rgb);
     if (valid && hi == 0) {
         wt.px[slot] = sigma;
         wt.py[slot] = 1.0f / (1.0f + expf(-rgb[0]));
@@ -334,9 +363,13 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
     const uint32_t c = first + (uint32_t)j;
     const bool valid = c < n_valid;
     const uint32_t slot = valid ? wt.order[c] : 0u;
-    // launder the descriptor pointers too (uniform, but opaque to LICM: hoisting 32 descriptors out of the tile loop would spill them)
-    LevelsK lv_pos = (LevelsK)a.pos.levels, lv_amb = (LevelsK)a.amb.levels;
+    // the descriptor tables are addressed through the laundered lane id too (hoisting 32 descriptors out of the tile loop would spill)
+#if GFPP_LP_LDS_LEVELS
+    const gfpp_grid_level *lv_pos = &sh.lv[0][0] + (lane & 0), *lv_amb = &sh.lv[1][0] + (lane & 0);
+#else
+    const gfpp_grid_level *lv_pos = a.pos.levels, *lv_amb = a.amb.levels;
     asm volatile("" : "+s"(lv_pos), "+s"(lv_amb));
+#endif
 
     vec bpos[2], bamb[2];
     {
@@ -394,14 +427,12 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
     };
     // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
     for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
-    for (int i = tid; i < kSkinnyFloats; i += kLpThreads) {
-        float v = 0.0f;
-        if (i < kSkinnySig) { if (i < 2 * AMB_D * 64) v = a.amb_w2[i]; }
-        else if (i < kSkinnyCol) v = a.sig_w2_sig[i - kSkinnySig];
-        else v = a.col_w1[i - kSkinnyCol];
-        sh.skinny[i] = v;
-    }
+    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
     if (tid < 256) sh.bias[tid] = a.frame_consts[tid];
+    else if (tid < 512) {   // 2 x 16 descriptors x 8 dwords
+        const int k = tid - 256, which = k >> 7, w = k & 127;
+        reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
+    }
     __syncthreads();
     lap(0);
 
@@ -538,7 +569,7 @@ GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_f
                                       float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
     if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_march_lp: null argument"); return GFPP_EINVAL; }
     if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("gfpp_head_frame_march_lp: max_steps must be in 1..%d", kMaxTrips); return GFPP_EUNSUPPORTED; }
-    if (!model->lp_weights || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
+    if (!model->lp_weights || !model->lp_skinny || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
         set_error("gfpp_head_frame_march_lp: the model carries no 16-bit weight image (lp_weights / lp_dtype)");
         return GFPP_EINVAL;
     }
@@ -564,7 +595,7 @@ GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_f
         g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
     }
     a.w16 = (const uint4 *)model->lp_weights;
-    a.amb_w2 = model->amb_w2; a.sig_w2_sig = model->sig_w2_sig; a.col_w1 = model->col_w1;
+    a.skinny16 = (const uint32_t *)model->lp_skinny;
     if (!ws->sample_t || !ws->sample_cnt || ws->sample_stride < max_steps + 7u) {
         set_error("gfpp_head_frame_march_lp: the workspace needs sample_t [N, sample_stride >= max_steps + 7] and sample_cnt [N]");
         return GFPP_EINVAL;

@@ -35,7 +35,7 @@ class HeadModel(ctypes.Structure):
                 ("amb_w0", c_p), ("amb_w0_cond", c_p), ("amb_w1", c_p), ("amb_w2", c_p),
                 ("sig_w0", c_p), ("sig_w1", c_p), ("sig_w2_geo", c_p), ("sig_w2_sig", c_p),
                 ("col_w0", c_p), ("col_w0_ind", c_p), ("col_w1", c_p), ("cond_dim", c_u32), ("ind_dim", c_u32),
-                ("lp_weights", c_p), ("lp_dtype", ctypes.c_int32)]
+                ("lp_weights", c_p), ("lp_skinny", c_p), ("lp_dtype", ctypes.c_int32)]
 
 
 class FrameWs(ctypes.Structure):
@@ -152,6 +152,20 @@ def lp_weight_image(model, dtype):
     img = torch.cat(parts, dim=0)
     assert img.shape == (31, 4, 64, 8)
     return img.to(dtype).contiguous()
+
+
+def lp_skinny_image(model, dtype):
+    """[2, 7, 64] of `dtype`: the skinny output rows in the operand order of the preceding layer's activations."""
+    A2 = model.ambient_net.net[2].weight.detach().double()
+    S2 = model.sigma_net.net[2].weight.detach().double()
+    C1 = model.color_net.net[1].weight.detach().double()
+    rows = torch.zeros(7, 128, dtype=torch.float64, device=A2.device)
+    rows[:A2.shape[0]] = A2
+    rows[3] = S2[0]
+    rows[4:7] = C1
+    cols = torch.tensor(lp_cols_act(), dtype=torch.long, device=A2.device)      # [8 steps, 2 halves, 8]
+    img = rows[:, cols]                                                          # [7, 8, 2, 8]
+    return img.permute(2, 0, 1, 3).reshape(2, 7, 64).to(dtype).contiguous()
 
 
 def supports(model):
@@ -290,7 +304,7 @@ class FramePipeline:
         hm.col_w0_ind = self._hold(C0.detach().float()[:, 144:]) if ind_dim > 0 else None
         hm.col_w1 = self._hold(pack_valu(C1))
         hm.cond_dim, hm.ind_dim = int(A0.shape[1] - 32), ind_dim
-        hm.lp_weights, hm.lp_dtype = None, 0
+        hm.lp_weights, hm.lp_skinny, hm.lp_dtype = None, None, 0
         return hm
 
     def set_precision(self, model, precision):
@@ -301,8 +315,10 @@ class FramePipeline:
         if precision not in LP_DTYPES:
             raise GfppError(f"precision must be 'fp32', 'fp16' or 'bf16', got {precision!r}")
         if precision not in self._lp_images:
-            self._lp_images[precision] = lp_weight_image(model, LP_DTYPES[precision][1]).to(self.device)
-        self.head.lp_weights = self._lp_images[precision].data_ptr()
+            dt = LP_DTYPES[precision][1]
+            self._lp_images[precision] = (lp_weight_image(model, dt).to(self.device), lp_skinny_image(model, dt).to(self.device))
+        self.head.lp_weights = self._lp_images[precision][0].data_ptr()
+        self.head.lp_skinny = self._lp_images[precision][1].data_ptr()
         self.head.lp_dtype = LP_DTYPES[precision][0]
         self.precision = precision
 

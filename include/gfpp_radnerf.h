@@ -240,8 +240,12 @@ typedef struct gfpp_head_model {
      *   steps 22-30  MERGED colour layer  [ C0[:, :16] | C0[:, 16:144] @ S2[1:129, :] ]  (color_net.0 x sigma_net.2 geo rows,
      *                no activation lies between them, radnerf.py:126-137): step 22 SH col = 8*h + e, steps 23-30 16 + act(s-23)
      * with h = lane >> 5, rr(r) = (r&3) + 8*(r>>2).  lp_dtype = GFPP_F16 (what the reference's autocast inference uses) or
-     * GFPP_BF16.  The skinny rows (amb_w2, sig_w2_sig, col_w1), the folded biases and all accumulation stay fp32. */
+     * GFPP_BF16.  The folded biases and all accumulation stay fp32. */
     const void *lp_weights;
+    /* the three skinny output layers for the same kernel, 16-bit, [2 half-waves][7 rows][64]: rows 0-2 ambient_net.2 (zero rows beyond
+     * ambient_coord_dim), row 3 sigma_net.2 row 0 (density logit), rows 4-6 color_net.1; entry k = 8*s + e of half h = W[row][act(s)] as above,
+     * so that a row is a sequence of packed dot products against the operand registers of the preceding layer (1 792 B) */
+    const void *lp_skinny;
     int32_t lp_dtype;
 } gfpp_head_model;
 
