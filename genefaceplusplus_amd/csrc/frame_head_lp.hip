@@ -19,6 +19,7 @@
 //     per pass, composites and appends its survivors -- no workgroup barrier after the weight copy, so one wavefront's
 //     gathers overlap another's MFMAs on the same SIMD.
 #include "head_eval_device.h"
+#include "lp_mfma_device.h"
 
 #ifndef GFPP_LP_LDS_LEVELS
 #define GFPP_LP_LDS_LEVELS 1   // level descriptors: 0 = scalar loads + per-lane select, 1 = per-lane LDS reads
@@ -40,28 +41,6 @@ constexpr int kLpSteps = 31;
 constexpr int kLpWeightChunks = kLpSteps * 4 * 64;   // 16-byte chunks: [step][tile m][lane]
 constexpr int kSkinnyRows = 7;   // ambient_net.2 (3, padded), sigma_net.2 row 0, color_net.1 (3): rows 0-2, 3, 4-6
 constexpr int kSkinnyWords = 2 * kSkinnyRows * 32;   // [half][row][32 pairs of 16-bit weights]
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <typename H>
-struct LpTraits;
-template <>
-struct LpTraits<_Float16> {
-    typedef f16x8 vec;
-    static constexpr bool kPackedMax = true;
-    typedef _Float16 pair __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
-};
-template <>
-struct LpTraits<__bf16> {
-    typedef bf16x8 vec;
-    static constexpr bool kPackedMax = false;
-    typedef __bf16 pair __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
-};
 
 struct LpWaveTile {
     float px[kLpSlots], py[kLpSlots], pz[kLpSlots];   // sample position; after evaluation: sigma, r, g of the slot
@@ -112,55 +91,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// acc[m] += W[32m.., 16 s..] * b[s]  for NS steps of K = 16; A operands come from the LDS-resident weight image, one step
-// (4 x ds_read_b128) ahead of their use.  The sched_barrier keeps the compiler from hoisting a whole layer's reads, which
-// would spill the accumulators.
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
-    typedef typename LpTraits<H>::vec vec;
-    constexpr int kAhead = NS >= 3 ? 2 : 1;   // LDS read-ahead in steps: the reads of 8 wavefronts queue up, one step (128 MFMA cycles) does not cover them
-    const vec *p = reinterpret_cast<const vec *>(w) + step0 * 256 + lane;
-    vec ring[kAhead + 1][4];
-#pragma unroll
-    for (int k = 0; k < kAhead; ++k) {
-        if (k < NS) {
-            const vec *q = p + k * 256;
-            ring[k][0] = q[0]; ring[k][1] = q[64]; ring[k][2] = q[128]; ring[k][3] = q[192];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (s + kAhead < NS) {
-            const vec *q = p + (s + kAhead) * 256;
-            vec (&r)[4] = ring[(s + kAhead) % (kAhead + 1)];
-            r[0] = q[0]; r[1] = q[64]; r[2] = q[128]; r[3] = q[192];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the read-ahead goes out BEFORE this step's MFMAs occupy the issue slots
-        const vec (&a)[4] = ring[s % (kAhead + 1)];
-        acc[0] = LpTraits<H>::mfma(a[0], b[s], acc[0]);
-        acc[1] = LpTraits<H>::mfma(a[1], b[s], acc[1]);
-        acc[2] = LpTraits<H>::mfma(a[2], b[s], acc[2]);
-        acc[3] = LpTraits<H>::mfma(a[3], b[s], acc[3]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);
 }
 
-// relu(accumulators) -> the next layer's 8 operand registers-quads (step s takes rows of tile s>>1, registers 8(s&1)..+7)
 template <typename H>
 __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTraits<H>::vec (&b)[8]) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if constexpr (sizeof(H) == 2 && LpTraits<H>::kPackedMax) {
-            // round first, clamp the packed pairs afterwards (v_pk_max_f16): relu(round(x)) == round(relu(x))
-            typename LpTraits<H>::vec t;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (H)acc[s >> 1][8 * (s & 1) + e];
-            b[s] = __builtin_elementwise_max(t, (typename LpTraits<H>::vec)(H)0.0f);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[s][e] = (H)fmaxf(acc[s >> 1][8 * (s & 1) + e], 0.0f);
-        }
-    }
+    act_pack<H, 4, 1>(acc, b);
 }
 
 // ---- grid encoding, straight-line ---------------------------------------------------------------------------------------
@@ -263,26 +201,9 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         for (int e = 0; e < 8; ++e) b[s][e] = (H)f[8 * s + e];
 }
 
-// Skinny output rows on packed 16-bit dot products: out[c] = sum over this lane's 64 activations (the operand registers of
-// relu_pack) of w * x with fp32 accumulation (v_dot2c_f32_{f16,bf16}); the two half-waves are added.  Weights: LDS, 32 pairs per row.
 template <int C, typename H>
 __device__ __forceinline__ void skinny_rows(const uint32_t *__restrict__ wrow, const typename LpTraits<H>::vec (&b)[8], int hi, float (&out)[C]) {
-    typedef typename LpTraits<H>::vec vec;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const vec *p = reinterpret_cast<const vec *>(wrow + (hi * kSkinnyRows + c) * 32);
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const vec w = p[s], x = b[s];
-            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), s0);
-            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), s1);
-            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), s0);
-            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), s1);
-        }
-        const float t = s0 + s1;
-        out[c] = t + __shfl_xor(t, 32);
-    }
+    skinny_dot<C, 8, H>(wrow, kSkinnyRows, b, hi, out);
 }
 
 // ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves

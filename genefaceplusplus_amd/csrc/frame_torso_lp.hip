@@ -1,0 +1,356 @@
+// frame_torso_lp.hip -- torso pass + final compositing with the torso MLPs on 16-bit MFMA operands (fp32 accumulation).
+//
+// Same function as frame_torso.hip (radnerf_torso.py:156-197 / radnerf_torso_sr.py:186-231 + forward_torso), for the 16-bit
+// precision modes of the head kernel.  The fp32 kernel spends its time streaming ~13 k weights per pixel through scalar loads into
+// v_fmac operands; here a wavefront compacts the masked pixels of its 64-pixel span and pushes them, 32 at a time, through
+//   head-aware encoder 4 -> 16 -> 32 -> 16 (LeakyReLU)      4 MFMAs
+//   deformation MLP   (42 freq + 16 head-aware) -> 64 -> 64  16 MFMAs, -> 2 as packed dot products
+//   2-D tiled grid at the displaced coordinate (each half-wave 8 of the 16 levels, straight-line lookups on the padded table)
+//   canonical MLP     (32 grid + 42 freq + 16 head-aware) -> 32 -> 32   8 MFMAs, -> 4 as packed dot products
+// with the 28 KB weight image resident in LDS.  Columns that are constant over the frame (pose / landmark encoding, individual code)
+// are folded into fp32 bias vectors in the block prologue, exactly as in the fp32 kernel.  Everything outside the MLPs (occupancy
+// test, frequency features, grid interpolation, sigmoid, compositing, depth) is fp32 and shared with frame_torso.hip's semantics.
+#include <hip/hip_runtime.h>
+
+#include "grid_device.h"
+#include "lp_mfma_device.h"
+#include "sh_device.h"
+
+namespace gfpp {
+
+constexpr int kTlThreads = 256;
+constexpr int kTlWaves = kTlThreads / 64;
+constexpr int kTlMaxConst = 160;
+// weight image: [step][tile][lane] 16-byte fragments, layers in this order (steps x tiles)
+constexpr int kTlHa0 = 0;                    // 1 x 1   4 -> 16 (rows padded to 32)
+constexpr int kTlHa1 = kTlHa0 + 1;           // 1 x 1  16 -> 32
+constexpr int kTlHa2 = kTlHa1 + 1;           // 2 x 1  32 -> 16 (padded)
+constexpr int kTlDef0 = kTlHa2 + 2;          // 4 x 2  [freq 42 | pad 6 | head-aware 16] -> 64
+constexpr int kTlDef1 = kTlDef0 + 8;         // 4 x 2  64 -> 64
+constexpr int kTlCan0 = kTlDef1 + 8;         // 6 x 1  [grid 32 | freq 42 | pad 6 | head-aware 16] -> 32
+constexpr int kTlCan1 = kTlCan0 + 6;         // 2 x 1  32 -> 32
+constexpr int kTlFrags = kTlCan1 + 2;        // 28 fragments-of-64-lanes
+constexpr int kTlSkinnyWords = 2 * 2 * 16 + 2 * 4 * 8;   // def2 [2 halves][2 rows][32 values] + can2 [2][4][16], 16-bit pairs
+
+struct TorsoLpArgs {
+    const float *bg_coords, *density_grid, *cond_in, *code, *head_image, *weights_sum, *depth_acc, *nears, *fars, *bg_color;
+    float bg_scalar, shrink, thresh;
+    uint32_t N, G, variant, code_dim, const_dim, head_aware, use_head;
+    const float *table;
+    const gfpp_grid_level *levels;
+    const float *def_w0_c, *can_w0_c;                      // fp32 [64][const_dim], [32][const_dim]: folded in the prologue
+    const float *ha_b0, *ha_b1, *ha_b2;                    // fp32 biases of the head-aware encoder
+    const uint4 *w16;                                      // kTlFrags * 64 fragments
+    const uint32_t *skinny16;                              // kTlSkinnyWords
+    float *out_image, *out_depth, *torso_alpha, *torso_bg, *deform;
+    uint8_t *mask_out;
+};
+
+struct TorsoLpShared {
+    uint4 w[kTlFrags * 64];            // 28 672 B
+    uint32_t skinny[kTlSkinnyWords];   //    512 B
+    float consts[kTlMaxConst];
+    float bdef[64], bcan[32], bha0[32], bha1[32], bha2[32];
+    gfpp_grid_level lv[16];
+    float res[kTlWaves][6][64];        // per wavefront: alpha, r, g, b, dx, dy by local pixel
+    uint8_t order[kTlWaves][64];
+};
+
+__device__ __forceinline__ float tl_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float tl_bilinear_occupancy(const float *__restrict__ grid, uint32_t G, float cx, float cy) {
+    const float ix = ((cx + 1.0f) / 2.0f) * (float)(G - 1);
+    const float iy = ((cy + 1.0f) / 2.0f) * (float)(G - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float wnw = (x1 - ix) * (y1 - iy), wne = (ix - x0) * (y1 - iy), wsw = (x1 - ix) * (iy - y0), wse = (ix - x0) * (iy - y0);
+    auto tap = [&](float yy, float xx) -> float {
+        const bool ok = xx >= 0.0f && xx <= (float)(G - 1) && yy >= 0.0f && yy <= (float)(G - 1);
+        return ok ? grid[(uint32_t)yy * G + (uint32_t)xx] : 0.0f;
+    };
+    return tap(y0, x0) * wnw + tap(y0, x1) * wne + tap(y1, x0) * wsw + tap(y1, x1) * wse;
+}
+
+// bias vector (natural order, LDS) -> accumulator fragment: acc[t][r] = b[32 t + (r&3) + 8 (r>>2) + 4 h]
+template <int T>
+__device__ __forceinline__ void tl_load_bias(v16f (&acc)[T], const float *__restrict__ b, int hi) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi];
+}
+
+// one level of the 2-D tiled grid, index arithmetic resolved on the host, padded table (see frame_head_lp.hip)
+__device__ __forceinline__ void tl_level2(const float (&u)[2], const float *__restrict__ table, const gfpp_grid_level &lv, float (&out)[2]) {
+    float frac[2];
+    uint32_t base[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float pos = fmaf(u[d], lv.scale, 0.5f);
+        const float fl = floorf(pos);
+        base[d] = (uint32_t)fl;
+        frac[d] = pos - fl;
+    }
+    const float *lt = table + 2ull * lv.offset;
+    const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
+    const uint32_t r0 = (base[0] + y0) & lv.mask, r1 = (base[0] + y1) & lv.mask;
+    const f32x4_a8 v0 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r0);
+    const f32x4_a8 v1 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r1);
+    out[0] = 0.0f;
+    out[1] = 0.0f;
+    {
+        const float w0 = (1.0f - frac[0]) * (1.0f - frac[1]), w1 = frac[0] * (1.0f - frac[1]);
+        out[0] = fmaf(w1, v0[2], fmaf(w0, v0[0], out[0]));
+        out[1] = fmaf(w1, v0[3], fmaf(w0, v0[1], out[1]));
+    }
+    {
+        const float w0 = (1.0f - frac[0]) * frac[1], w1 = frac[0] * frac[1];
+        out[0] = fmaf(w1, v1[2], fmaf(w0, v1[0], out[0]));
+        out[1] = fmaf(w1, v1[3], fmaf(w0, v1[1], out[1]));
+    }
+}
+
+template <typename H>
+__global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
+    typedef typename LpTraits<H>::vec vec;
+    __shared__ TorsoLpShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+
+    // ---- this thread's pixel: occupancy test first (most workgroups of a frame have no torso pixel and skip the weights) ----------
+    const uint32_t n = blockIdx.x * kTlThreads + tid;
+    const bool in_frame = n < a.N;
+    float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f;
+    bool masked = false;
+    if (in_frame) {
+        cx = a.bg_coords[2ull * n]; cy = a.bg_coords[2ull * n + 1];
+        masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
+        hr = a.head_image[3ull * n]; hg = a.head_image[3ull * n + 1]; hb = a.head_image[3ull * n + 2];
+        wsum = a.weights_sum[n];
+    }
+    const bool block_has_work = __syncthreads_or(masked ? 1 : 0) != 0;
+
+    float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
+    if (block_has_work) {
+        // ---- prologue: weights -> LDS, per-frame constant columns folded into biases (same arithmetic as frame_torso.hip) ----------
+        for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = a.w16[i];
+        for (int i = tid; i < kTlSkinnyWords; i += kTlThreads) sh.skinny[i] = a.skinny16[i];
+        if (tid < 16 * 8) reinterpret_cast<uint32_t *>(&sh.lv[0])[tid] = reinterpret_cast<const uint32_t *>(a.levels)[tid];
+        if (tid < 32) {
+            sh.bha0[tid] = (a.head_aware && tid < 16) ? a.ha_b0[tid] : 0.0f;
+            sh.bha1[tid] = a.head_aware ? a.ha_b1[tid] : 0.0f;
+            sh.bha2[tid] = (a.head_aware && tid < 16) ? a.ha_b2[tid] : 0.0f;
+        }
+        {
+            const uint32_t enc_D = a.variant == 0 ? 6u : 14u;
+            const uint32_t enc_C = enc_D + 2u * enc_D * 4u;
+            const uint32_t enc_at = a.variant == 0 ? 0u : a.code_dim;
+            const uint32_t code_at = a.variant == 0 ? enc_C : 0u;
+            for (uint32_t c = tid; c < enc_C; c += kTlThreads) {
+                const uint32_t d = c % enc_D;
+                const float v = a.variant == 0 ? a.cond_in[d] : a.cond_in[10 + d];   // landmarks 5..11 -> flat 10..23
+                sh.consts[enc_at + c] = c < enc_D ? v : freq_feature(v, c / enc_D - 1);
+            }
+            for (uint32_t c = tid; c < a.code_dim; c += kTlThreads) sh.consts[code_at + c] = a.code[c];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.0f;
+            for (uint32_t k = 0; k < a.const_dim; ++k) s = fmaf(a.def_w0_c[(size_t)tid * a.const_dim + k], sh.consts[k], s);
+            sh.bdef[tid] = s;
+        } else if (tid < 96) {
+            const int q = tid - 64;
+            float s = 0.0f;
+            for (uint32_t k = 0; k < a.const_dim; ++k) s = fmaf(a.can_w0_c[(size_t)q * a.const_dim + k], sh.consts[k], s);
+            sh.bcan[q] = s;
+        }
+        __syncthreads();
+
+        // ---- compaction of the wavefront's masked pixels -------------------------------------------------------------------------
+        const unsigned long long ballot = __ballot(masked);
+        const uint32_t n_m = (uint32_t)__popcll(ballot);
+        if (masked) sh.order[wave][__popcll(ballot & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const vec *W = reinterpret_cast<const vec *>(sh.w);
+
+        for (uint32_t first = 0; first < n_m; first += 32) {
+            const uint32_t c = first + (uint32_t)j;
+            const bool valid = c < n_m;
+            const int src = valid ? (int)sh.order[wave][c] : 0;   // local pixel this column evaluates
+            const float px = __shfl(cx, src), py = __shfl(cy, src);
+            const float x0 = px * a.shrink, x1 = py * a.shrink;
+
+            // frequency features of the pixel coordinate, this half-wave's 24 of the 48 operand slots (42 used):
+            // slot k = 16 s + 8 h + e  <->  ex[k] = k < 2 ? x_k : freq_feature(x_{k&1}, k/2 - 1)
+            vec bex[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * s + 8 * hi + e;
+                    const float xk = (k & 1) ? x1 : x0;
+                    const float v = k < 2 ? xk : (k < 42 ? freq_feature(xk, (uint32_t)(k / 2 - 1)) : 0.0f);
+                    bex[s][e] = (H)v;
+                }
+
+            // head-aware encoder of (head rgb, head alpha): Linear 4->16, LeakyReLU, 16->32, LeakyReLU, 32->16
+            vec bha[1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bha[0][e] = (H)0.0f;
+            if (a.head_aware) {
+                const float i0 = a.use_head ? __shfl(hr, src) : 0.0f, i1 = a.use_head ? __shfl(hg, src) : 0.0f;
+                const float i2 = a.use_head ? __shfl(hb, src) : 0.0f, i3 = a.use_head ? __shfl(wsum, src) : 0.0f;
+                vec bin[1];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bin[0][e] = (H)0.0f;
+                if (hi == 0) { bin[0][0] = (H)i0; bin[0][1] = (H)i1; bin[0][2] = (H)i2; bin[0][3] = (H)i3; }
+                v16f acc1[1];
+                vec b2[2];
+                tl_load_bias<1>(acc1, sh.bha0, hi);
+                mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa0 * 64, bin, lane);
+                act_pack<H, 1, 2>(acc1, b2);            // rows 0..15 live in b2[0]; b2[1] (rows 16..31) is padding
+                vec b1[1] = {b2[0]};
+                tl_load_bias<1>(acc1, sh.bha1, hi);
+                mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa1 * 64, b1, lane);
+                act_pack<H, 1, 2>(acc1, b2);
+                tl_load_bias<1>(acc1, sh.bha2, hi);
+                mfma_layer_lds<H, 2, 1>(acc1, W + kTlHa2 * 64, b2, lane);
+                act_pack<H, 1, 0>(acc1, b2);
+                bha[0] = b2[0];
+            }
+
+            // deformation MLP
+            float dxy[2];
+            {
+                v16f acc2[2];
+                vec bin[4] = {bex[0], bex[1], bex[2], bha[0]};
+                tl_load_bias<2>(acc2, sh.bdef, hi);
+                mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef0 * 64, bin, lane);
+                vec bh[4];
+                act_pack<H, 2, 1>(acc2, bh);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
+                mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef1 * 64, bh, lane);
+                act_pack<H, 2, 1>(acc2, bh);
+                skinny_dot<2, 4, H>(sh.skinny, 2, bh, hi, dxy);
+            }
+
+            // 2-D tiled grid at the displaced, clamped coordinate; half-wave h encodes the levels h, h+2, ...
+            vec bgrid[2];
+            {
+                float u[2];
+                u[0] = (clampf(x0 + dxy[0], -1.0f, 1.0f) + 1.0f) / 2.0f;
+                u[1] = (clampf(x1 + dxy[1], -1.0f, 1.0f) + 1.0f) / 2.0f;
+                float f[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float o[2];
+                    tl_level2(u, a.table, sh.lv[2 * i + hi], o);
+                    f[2 * i] = o[0];
+                    f[2 * i + 1] = o[1];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bgrid[s][e] = (H)f[8 * s + e];
+            }
+
+            // canonical MLP
+            float o4[4];
+            {
+                v16f acc1[1];
+                vec bin[6] = {bgrid[0], bgrid[1], bex[0], bex[1], bex[2], bha[0]};
+                tl_load_bias<1>(acc1, sh.bcan, hi);
+                mfma_layer_lds<H, 6, 1>(acc1, W + kTlCan0 * 64, bin, lane);
+                vec bh[2];
+                act_pack<H, 1, 1>(acc1, bh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
+                mfma_layer_lds<H, 2, 1>(acc1, W + kTlCan1 * 64, bh, lane);
+                act_pack<H, 1, 1>(acc1, bh);
+                skinny_dot<4, 2, H>(sh.skinny + 2 * 2 * 16, 4, bh, hi, o4);
+            }
+            if (valid && hi == 0) {
+                float *r = &sh.res[wave][0][0];
+                r[0 * 64 + src] = tl_sigmoid(o4[0]);
+                r[1 * 64 + src] = tl_sigmoid(o4[1]);
+                r[2 * 64 + src] = tl_sigmoid(o4[2]);
+                r[3 * 64 + src] = tl_sigmoid(o4[3]);
+                r[4 * 64 + src] = dxy[0];
+                r[5 * 64 + src] = dxy[1];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (masked) {
+            const float *r = &sh.res[wave][0][0];
+            alpha = r[lane]; tr = r[64 + lane]; tg = r[128 + lane]; tb = r[192 + lane]; ddx = r[256 + lane]; ddy = r[320 + lane];
+        }
+    }
+    if (!in_frame) return;
+
+    // ---- torso over background, head over torso (radnerf_torso.py:186-197) ---------------------------------------------------------
+    const float T = 1.0f - wsum;
+    const float tcol[3] = {tr, tg, tb}, hcol[3] = {hr, hg, hb};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float bg = a.bg_color ? a.bg_color[3ull * n + c] : a.bg_scalar;
+        const float tbg = tcol[c] * alpha + bg * (1.0f - alpha);
+        a.torso_bg[3ull * n + c] = tbg;
+        a.out_image[3ull * n + c] = clampf(hcol[c] + T * tbg, 0.0f, 1.0f);
+    }
+    a.torso_alpha[n] = alpha;
+    a.deform[2ull * n] = ddx;
+    a.deform[2ull * n + 1] = ddy;
+    a.mask_out[n] = masked ? 1 : 0;
+    a.out_depth[n] = fmaxf(a.depth_acc[n] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws *ws, const float *bg_coords, const float *cond_in,
+                                 const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
+                                 float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream) {
+    if (!m || !ws || !bg_coords || !cond_in || !out_image || !out_depth || !torso_alpha || !torso_bg || !deform || !mask) {
+        set_error("gfpp_torso_frame_lp: null argument");
+        return GFPP_EINVAL;
+    }
+    if (!m->lp_weights || !m->lp_skinny || (m->lp_dtype != GFPP_F16 && m->lp_dtype != GFPP_BF16)) {
+        set_error("gfpp_torso_frame_lp: the model carries no 16-bit weight image (lp_weights / lp_skinny / lp_dtype)");
+        return GFPP_EINVAL;
+    }
+    if (m->grid.D != 2 || m->grid.L != 16 || m->grid.dtype != GFPP_F32 || m->grid.gridtype != 1 || m->grid.interp != 0 || m->grid.align_corners ||
+        !m->grid.row_padded || !m->grid.levels_host) {
+        set_error("gfpp_torso_frame_lp: the torso grid must be a 16-level fp32 2-D tiled grid (padded table copy) with linear interpolation");
+        return GFPP_EUNSUPPORTED;
+    }
+    for (int l = 0; l < 16; ++l)
+        if (m->grid.levels_host[l].flags & GFPP_LEVEL_SLOW) { set_error("gfpp_torso_frame_lp: level %d needs the generic lookup", l); return GFPP_EUNSUPPORTED; }
+    const uint32_t enc_c = m->variant == 0 ? 54u : 126u;
+    if (m->variant > 1 || m->const_dim != enc_c + m->code_dim || m->const_dim > (uint32_t)kTlMaxConst || (m->code_dim && !code)) {
+        set_error("gfpp_torso_frame_lp: inconsistent constant-column layout");
+        return GFPP_EINVAL;
+    }
+    TorsoLpArgs a;
+    a.bg_coords = bg_coords; a.density_grid = m->density_grid; a.cond_in = cond_in; a.code = code;
+    a.head_image = ws->image; a.weights_sum = ws->weights_sum; a.depth_acc = ws->depth; a.nears = ws->nears; a.fars = ws->fars;
+    a.bg_color = bg_color; a.bg_scalar = bg_scalar; a.shrink = m->torso_shrink; a.thresh = m->density_thresh;
+    a.N = ws->N; a.G = m->grid_size; a.variant = m->variant; a.code_dim = m->code_dim; a.const_dim = m->const_dim;
+    a.head_aware = m->head_aware; a.use_head = use_head;
+    a.table = (const float *)m->grid.table; a.levels = m->grid.levels;
+    a.def_w0_c = m->def_w0_c; a.can_w0_c = m->can_w0_c;
+    a.ha_b0 = m->ha_b0; a.ha_b1 = m->ha_b1; a.ha_b2 = m->ha_b2;
+    a.w16 = (const uint4 *)m->lp_weights; a.skinny16 = (const uint32_t *)m->lp_skinny;
+    a.out_image = out_image; a.out_depth = out_depth; a.torso_alpha = torso_alpha; a.torso_bg = torso_bg; a.deform = deform; a.mask_out = mask;
+    const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
+    if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_torso_lp<_Float16>, grid, block, 0, (hipStream_t)stream, a);
+    return check_launch("gfpp_torso_frame_lp");
+}

@@ -7,10 +7,10 @@
 #include "grid_device.h"
 #include "march_device.h"
 #include "sh_device.h"
+#include "lp_mfma_device.h"   // v16f
 
 namespace gfpp {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 128;     // sample slots per workgroup tile (4 wavefronts x 32 columns)
 constexpr int kThreads = 256;

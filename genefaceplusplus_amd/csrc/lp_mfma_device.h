@@ -1,0 +1,116 @@
+// lp_mfma_device.h -- 16-bit-operand MFMA building blocks shared by the head (frame_head_lp.hip) and torso (frame_torso_lp.hip) kernels:
+// operand traits for f16 / bf16, an LDS-fed layer of K = 16 steps, relu / leaky-relu + repack of the accumulators into the next
+// layer's operands, and skinny output rows as packed dot products.
+//
+// Layout conventions (v_mfma_f32_32x32x16_*): a layer out[32 T] = W[32 T, 16 NS] x is T row tiles x NS steps; the weight image holds
+// 16-byte fragments [step][tile][lane]: lane (i = lane & 31, h = lane >> 5) carries W[32 t + i][col(step, h, 0..7)].  The samples /
+// pixels are the 32 columns; lane (j, h) supplies the 8 K-values of its half for column j.  After a layer, lane (j, h) holds in
+// acc[t][r] the output row 32 t + (r & 3) + 8 (r >> 2) + 4 h of column j, i.e. 16 T values = 2 T operand registers-quads of the next
+// layer (step s = 2 t + (r >> 3), element e = r & 7).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace gfpp {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename H>
+struct LpTraits;
+template <>
+struct LpTraits<_Float16> {
+    typedef f16x8 vec;
+    static constexpr bool kPackedMax = true;
+    typedef _Float16 pair __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+};
+template <>
+struct LpTraits<__bf16> {
+    typedef bf16x8 vec;
+    static constexpr bool kPackedMax = false;
+    typedef __bf16 pair __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+};
+
+// acc[t] += W[32 t.., 16 s..] * b[s] for NS steps; A operands come from the LDS-resident weight image, kAhead steps ahead of
+// their use (the reads of all wavefronts of the workgroup queue up in the LDS; one step = T MFMAs does not cover the latency).
+// The sched_barriers pin the order: read-ahead first, then this step's MFMAs.
+template <typename H, int NS, int T>
+__device__ __forceinline__ void mfma_layer_lds(v16f (&acc)[T], const typename LpTraits<H>::vec *__restrict__ wl, const typename LpTraits<H>::vec (&b)[NS],
+                                               int lane) {
+    typedef typename LpTraits<H>::vec vec;
+    constexpr int kAhead = NS >= 3 ? 2 : 1;
+    const vec *p = wl + lane;
+    vec ring[kAhead + 1][T];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+        if (k < NS) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) ring[k][t] = p[(k * T + t) * 64];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + kAhead < NS) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) ring[(s + kAhead) % (kAhead + 1)][t] = p[((s + kAhead) * T + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = LpTraits<H>::mfma(ring[s % (kAhead + 1)][t], b[s], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// act(accumulators) -> the next layer's 2 T operand registers-quads.  ACT: 0 none, 1 relu, 2 leaky relu (slope 0.02)
+template <typename H, int T, int ACT>
+__device__ __forceinline__ void act_pack(const v16f (&acc)[T], typename LpTraits<H>::vec (&b)[2 * T]) {
+#pragma unroll
+    for (int s = 0; s < 2 * T; ++s) {
+        if constexpr (ACT == 1 && LpTraits<H>::kPackedMax) {
+            // round first, clamp the packed pairs afterwards (v_pk_max_f16): relu(round(x)) == round(relu(x))
+            typename LpTraits<H>::vec t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (H)acc[s >> 1][8 * (s & 1) + e];
+            b[s] = __builtin_elementwise_max(t, (typename LpTraits<H>::vec)(H)0.0f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = acc[s >> 1][8 * (s & 1) + e];
+                b[s][e] = (H)(ACT == 1 ? fmaxf(v, 0.0f) : (ACT == 2 ? (v >= 0.0f ? v : v * 0.02f) : v));
+            }
+        }
+    }
+}
+
+// Skinny output rows on packed 16-bit dot products: out[c] = sum over this lane's 8 NV activations (operand registers b) of w * x,
+// fp32 accumulation (v_dot2c_f32_{f16,bf16}); the two half-waves are added.  `wrow`: LDS, rows of 4 NV 32-bit words, row index
+// hi * rows_per_half + c.  (Operand pairs are taken with shufflevector: bit-casting vector ELEMENTS to pairs is miscompiled by
+// ROCm 7.2's clang -- every element collapses to element 0.)
+template <int C, int NV, typename H>
+__device__ __forceinline__ void skinny_dot(const uint32_t *__restrict__ wrow, int rows_per_half, const typename LpTraits<H>::vec (&b)[NV], int hi,
+                                           float (&out)[C]) {
+    typedef typename LpTraits<H>::vec vec;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const vec *p = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half + c) * 4 * NV);
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const vec w = p[s], x = b[s];
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), s1);
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), s1);
+        }
+        const float t = s0 + s1;
+        out[c] = t + __shfl_xor(t, 32);
+    }
+}
+
+}  // namespace gfpp

@@ -56,12 +56,15 @@ class TorsoModel(ctypes.Structure):
                 ("code_dim", c_u32), ("const_dim", c_u32), ("head_aware", c_u32), ("grid", GridDesc),
                 ("def_w0_x", c_p), ("def_w0_c", c_p), ("def_w0_h", c_p), ("def_w1", c_p), ("def_w2", c_p),
                 ("can_w0_g", c_p), ("can_w0_x", c_p), ("can_w0_c", c_p), ("can_w0_h", c_p), ("can_w1", c_p), ("can_w2", c_p),
-                ("ha_w0", c_p), ("ha_b0", c_p), ("ha_w1", c_p), ("ha_b1", c_p), ("ha_w2", c_p), ("ha_b2", c_p)]
+                ("ha_w0", c_p), ("ha_b0", c_p), ("ha_w1", c_p), ("ha_b1", c_p), ("ha_w2", c_p), ("ha_b2", c_p),
+                ("lp_weights", c_p), ("lp_skinny", c_p), ("lp_dtype", ctypes.c_int32)]
 
 
 _lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p])
 _lib.register("gfpp_cond_feat", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p])
+_lib.register("gfpp_torso_frame_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
+                                      c_p, c_p, c_p])
 _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
 _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
 _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
@@ -152,6 +155,58 @@ def lp_weight_image(model, dtype):
     img = torch.cat(parts, dim=0)
     assert img.shape == (31, 4, 64, 8)
     return img.to(dtype).contiguous()
+
+
+def pack_frag(weight, cols, tiles):
+    """weight [M <= 32*tiles, K] -> [S, tiles, 64, 8] float64 fragments; cols[s][h][e] = input column, -1 = padding (zero)."""
+    W = weight.detach().double()
+    Wp = torch.zeros(32 * tiles, W.shape[1] + 1, dtype=torch.float64, device=W.device)
+    Wp[:W.shape[0], :W.shape[1]] = W
+    idx = torch.tensor(cols, dtype=torch.long, device=W.device)              # [S, 2, 8]
+    idx = torch.where(idx < 0, torch.full_like(idx, W.shape[1]), idx)
+    S = idx.shape[0]
+    Wk = Wp[:, idx]                                                          # [32*tiles, S, 2, 8]
+    return Wk.view(tiles, 32, S, 2, 8).permute(2, 0, 3, 1, 4).reshape(S, tiles, 64, 8).contiguous()
+
+
+def _act_cols(n_steps, base=0):
+    """previous-layer activations as operands: step s, half h, element e -> row 32 (s>>1) + rr(8 (s&1) + e) + 4 h."""
+    return [[[base + 32 * (s >> 1) + _rr(8 * (s & 1) + e) + 4 * h for e in range(8)] for h in range(2)] for s in range(n_steps)]
+
+
+def torso_lp_images(m, dtype):
+    """(weights [28, 64, 8], skinny [128 x 2]) of `dtype` for gfpp_torso_frame_lp; layout documented at gfpp_torso_model.lp_weights."""
+    hp = m.hparams
+    D0, D1, D2 = (l.weight.detach().double() for l in m.torso_deform_net.net)
+    K0, K1, K2 = (l.weight.detach().double() for l in m.torso_canonicial_net.net)
+    head_aware = bool(hp["torso_head_aware"])
+    const_dim = D0.shape[1] - 42 - (16 if head_aware else 0)
+    dev = D0.device
+    freq = lambda base: [[[(base + 16 * s + 8 * h + e) if 16 * s + 8 * h + e < 42 else -1 for e in range(8)] for h in range(2)] for s in range(3)]
+    ha_in = lambda base: [[[(base + _rr(e) + 4 * h) if head_aware else -1 for e in range(8)] for h in range(2)]]
+    grid = [[[2 * (2 * ((8 * s + e) // 2) + h) + (e % 2) for e in range(8)] for h in range(2)] for s in range(2)]
+    frags = []
+    if head_aware:
+        enc = m.head_color_weights_encoder
+        H0, H1, H2 = (enc[i].weight.detach().double() for i in (0, 2, 4))
+        frags.append(pack_frag(H0, [[[e if (h == 0 and e < 4) else -1 for e in range(8)] for h in range(2)]], 1))
+        frags.append(pack_frag(H1, [[[_rr(e) + 4 * h for e in range(8)] for h in range(2)]], 1))
+        frags.append(pack_frag(H2, _act_cols(2), 1))
+    else:
+        frags.append(torch.zeros(4, 1, 64, 8, dtype=torch.float64, device=dev))
+    frags.append(pack_frag(D0, freq(0) + ha_in(42 + const_dim), 2))
+    frags.append(pack_frag(D1, _act_cols(4), 2))
+    frags.append(pack_frag(K0, grid + freq(32) + ha_in(32 + 42 + const_dim), 1))
+    frags.append(pack_frag(K1, _act_cols(2), 1))
+    img = torch.cat([f.reshape(-1, 64, 8) for f in frags], dim=0)
+    assert img.shape == (28, 64, 8), img.shape
+    a4 = torch.tensor(_act_cols(4), dtype=torch.long, device=dev)              # [4, 2, 8]
+    a2 = torch.tensor(_act_cols(2), dtype=torch.long, device=dev)
+    sk_def = D2[:, a4].permute(2, 0, 1, 3).reshape(2, 2, 32)                   # [h, row, 8 s + e]
+    sk_can = K2[:, a2].permute(2, 0, 1, 3).reshape(2, 4, 16)
+    skinny = torch.cat([sk_def.reshape(-1), sk_can.reshape(-1)])
+    assert skinny.numel() == 256
+    return img.to(dtype).contiguous(), skinny.to(dtype).contiguous()
 
 
 def lp_skinny_image(model, dtype):
@@ -319,6 +374,14 @@ class FramePipeline:
             self._lp_images[precision] = (lp_weight_image(model, dt).to(self.device), lp_skinny_image(model, dt).to(self.device))
         self.head.lp_weights = self._lp_images[precision][0].data_ptr()
         self.head.lp_skinny = self._lp_images[precision][1].data_ptr()
+        if self.torso is not None:
+            key = "torso_" + precision
+            if key not in self._lp_images:
+                w, sk = torso_lp_images(model, LP_DTYPES[precision][1])
+                self._lp_images[key] = (w.to(self.device), sk.to(self.device))
+            self.torso.lp_weights = self._lp_images[key][0].data_ptr()
+            self.torso.lp_skinny = self._lp_images[key][1].data_ptr()
+            self.torso.lp_dtype = LP_DTYPES[precision][0]
         self.head.lp_dtype = LP_DTYPES[precision][0]
         self.precision = precision
 
@@ -400,6 +463,7 @@ class FramePipeline:
             for i, name in zip((0, 2, 4), ("0", "1", "2")):
                 setattr(tm, "ha_w" + name, self._hold(kt(enc[i].weight.detach().float())))
                 setattr(tm, "ha_b" + name, self._hold(enc[i].bias.detach().float()))
+        tm.lp_weights, tm.lp_skinny, tm.lp_dtype = None, None, 0
         return tm
 
     # -- per-resolution workspace ------------------------------------------------------------------------------------
@@ -496,7 +560,8 @@ class FramePipeline:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
                "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
-        call("gfpp_torso_frame", ctypes.byref(self.torso), ctypes.byref(ws), bg_coords.data_ptr(), cond_in.data_ptr(),
+        call("gfpp_torso_frame" if self.precision == "fp32" else "gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws),
+             bg_coords.data_ptr(), cond_in.data_ptr(),
              code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
              out["depth"].data_ptr(), out["torso_alpha"].data_ptr(), out["torso_bg"].data_ptr(), out["deform_dense"].data_ptr(),
              out["torso_mask"].data_ptr(), torch.cuda.current_stream().cuda_stream)

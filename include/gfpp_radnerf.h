@@ -327,6 +327,17 @@ typedef struct gfpp_torso_model {
     const float *ha_w0, *ha_b0; /* head_color_weights_encoder: [4][16],[16] */
     const float *ha_w1, *ha_b1; /* [16][32],[32] */
     const float *ha_w2, *ha_b2; /* [32][16],[16] */
+    /* 16-bit operand image for gfpp_torso_frame_lp (NULL if not built): 28 fragments of [tile][lane] x 8 halves, K = 16 MFMA steps,
+     * F[step][t][lane][e] = W[32*t + (lane & 31)][col(step, lane >> 5, e)] (zero where the column is padding), layers in this order:
+     *   head-aware encoder  ha0 1 step x 1 tile (4 -> 16, inputs in elements 0..3 of half 0), ha1 1 x 1 (16 -> 32), ha2 2 x 1 (32 -> 16);
+     *   torso_deform_net.0  4 x 2: steps 0-2 = frequency features of the pixel, slot 16*s + 8*h + e (42 used), step 3 = head-aware 16;
+     *   torso_deform_net.1  4 x 2 over the 64 activations;  torso_canonicial_net.0  6 x 1: steps 0-1 = 32 grid features (half-wave h holds
+     *   levels h, h+2, ..), steps 2-4 = frequency features, step 5 = head-aware;  torso_canonicial_net.1  2 x 1.
+     * Activation columns follow the accumulator order act(s) of gfpp_head_model.lp_weights.  lp_skinny: torso_deform_net.2 as
+     * [2 halves][2 rows][32] and torso_canonicial_net.2 as [2][4][16], 16-bit, in the operand order of the preceding activations. */
+    const void *lp_weights;
+    const void *lp_skinny;
+    int32_t lp_dtype;
 } gfpp_torso_model;
 
 /* Replaces the torso pass + epilogue of RADNeRFTorso.render / RADNeRFTorsowithSR.render (radnerf_torso.py:156-197,
@@ -339,6 +350,12 @@ typedef struct gfpp_torso_model {
 int gfpp_torso_frame(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *cond_in,
                      const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
                      float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
+
+/* gfpp_torso_frame with the torso MLPs (radnerf_torso.py:51-84, radnerf_torso_sr.py:75-114) on 16-bit MFMA operands, fp32 accumulation;
+ * same arguments and outputs.  Occupancy test, frequency features, grid interpolation, sigmoid, compositing and depth stay fp32. */
+int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *cond_in,
+                        const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
+                        float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
 
 #ifdef __cplusplus
 }

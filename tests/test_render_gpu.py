@@ -31,7 +31,7 @@ def _psnr(a, b):
     return 10.0 * np.log10(1.0 / max(mse, 1e-20))
 
 
-@pytest.mark.parametrize("variant,HW", [("may_head", 64), ("may_torso", 128)])
+@pytest.mark.parametrize("variant,HW", [("may_head", 64), ("may_torso", 128), ("may_torso_sr", 256)])
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, precision):
     """16-bit MFMA operands / fp32 accumulation (gfpp_head_frame_march_lp) vs the fp32 oracle.  Stated tolerance:
@@ -44,10 +44,19 @@ def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, 
     model.precision = precision
     res = product_render(model, case, dev, "oracle", oracle_mod)
     assert model.pipeline().precision == precision
-    rgb = res["rgb_map"].float().cpu().numpy().reshape(-1, 3)
+    rgb = res["rgb_map"].float().cpu().numpy()
+    if variant == "may_torso_sr":
+        rgb = np.transpose(rgb, (0, 2, 3, 1))
+    rgb = rgb.reshape(-1, 3)
     rref = ref["rgb_map"].reshape(-1, 3)
     err = np.abs(rgb - rref).max(axis=1)
     tol = {"fp16": 2e-2, "bf16": 5e-2}[precision]
+    if variant != "may_head":
+        # the torso field (16-bit MFMA too): alpha of every pixel, and the mask must be identical (it is computed in fp32)
+        ta = res["torso_alpha_map"].float().cpu().numpy().reshape(-1)
+        taerr = np.abs(ta - ref["torso_alpha_map"].reshape(-1))
+        print(variant, precision, "torso alpha max err", float(taerr.max()))
+        assert (taerr > tol).mean() <= 5e-4, float(taerr.max())
     stats = {"psnr": _psnr(rgb, rref), "rgb_max": float(err.max()), "frac_over_tol": float((err > tol).mean()), "rgb_mean": float(err.mean())}
     print(variant, precision, stats)
     assert stats["psnr"] >= 45.0, stats
