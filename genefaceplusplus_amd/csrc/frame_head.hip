@@ -362,7 +362,7 @@ GFPP_API int gfpp_grid_levels_fill(uint32_t D, uint32_t L, float S, uint32_t H, 
 
 GFPP_API int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                    const float *cond_feat, const float *ind_code, gfpp_stream_t stream) {
-    if (!model || !ws || !rays_o || !rays_d || !cond_feat) { set_error("gfpp_head_frame_begin: null argument"); return GFPP_EINVAL; }
+    if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_begin: null argument"); return GFPP_EINVAL; }
     if (!ws->nears || !ws->fars || !ws->rays_t || !ws->weights_sum || !ws->depth || !ws->image || !ws->counters || !ws->frame_consts || ws->N == 0) {
         set_error("gfpp_head_frame_begin: incomplete workspace");
         return GFPP_EINVAL;
@@ -372,10 +372,16 @@ GFPP_API int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_fram
                        model->aabb[1], model->aabb[2], model->aabb[3], model->aabb[4], model->aabb[5], ws->nears, ws->fars, ws->rays_t,
                        ws->weights_sum, ws->depth, ws->image, ws->counters);
     int rc = check_launch("gfpp_head_frame_begin(init)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_fold_constants, dim3(2), dim3(128), 0, st, model->amb_w0_cond, cond_feat, model->cond_dim, model->col_w0_ind,
+    if (rc || !cond_feat) return rc;   // cond_feat == NULL: the caller folds later with gfpp_head_frame_fold (possibly on another stream)
+    return gfpp_head_frame_fold(model, ws, cond_feat, ind_code, stream);
+}
+
+GFPP_API int gfpp_head_frame_fold(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *cond_feat, const float *ind_code,
+                                  gfpp_stream_t stream) {
+    if (!model || !ws || !cond_feat || !ws->frame_consts) { set_error("gfpp_head_frame_fold: null argument"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_fold_constants, dim3(2), dim3(128), 0, (hipStream_t)stream, model->amb_w0_cond, cond_feat, model->cond_dim, model->col_w0_ind,
                        model->ind_dim ? ind_code : nullptr, model->ind_dim, ws->frame_consts);
-    return check_launch("gfpp_head_frame_begin(fold)");
+    return check_launch("gfpp_head_frame_fold");
 }
 
 GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,

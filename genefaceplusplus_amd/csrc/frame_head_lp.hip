@@ -486,41 +486,60 @@ static int lp_cu_count() {
 
 using namespace gfpp;
 
-GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+static int lp_check_common(const char *who, const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                           uint32_t max_steps) {
+    if (!model || !ws || !rays_o || !rays_d) { set_error("%s: null argument", who); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("%s: max_steps must be in 1..%d", who, kMaxTrips); return GFPP_EUNSUPPORTED; }
+    if (model->cascade < 1 || model->cascade > 8 || !model->density_bitfield) { set_error("%s: bad model", who); return GFPP_EINVAL; }
+    if (!ws->sample_t || !ws->sample_cnt || ws->sample_stride < max_steps + 7u || !ws->nears || !ws->fars) {
+        set_error("%s: the workspace needs sample_t [N, sample_stride >= max_steps + 7] and sample_cnt [N]", who);
+        return GFPP_EINVAL;
+    }
+    return 0;
+}
+
+GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                      float dt_gamma, uint32_t max_steps, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_frame_premarch", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    PremarchArgs p;
+    p.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    p.bitfield = model->density_bitfield;
+    p.rays_o = rays_o; p.rays_d = rays_d; p.nears = ws->nears; p.fars = ws->fars;
+    p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
+    p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
+    hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("gfpp_head_frame_premarch");
+}
+
+GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                       float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
-    if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_march_lp: null argument"); return GFPP_EINVAL; }
-    if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("gfpp_head_frame_march_lp: max_steps must be in 1..%d", kMaxTrips); return GFPP_EUNSUPPORTED; }
+    const int bad = lp_check_common("gfpp_head_frame_trips_lp", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
     if (!model->lp_weights || !model->lp_skinny || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
-        set_error("gfpp_head_frame_march_lp: the model carries no 16-bit weight image (lp_weights / lp_dtype)");
+        set_error("gfpp_head_frame_trips_lp: the model carries no 16-bit weight image (lp_weights / lp_skinny / lp_dtype)");
         return GFPP_EINVAL;
     }
     if (!lp_grid_ok(model->pos_grid, 3) || !(lp_grid_ok(model->amb_grid, 2) || lp_grid_ok(model->amb_grid, 3))) {
-        set_error("gfpp_head_frame_march_lp: grids must be 16-level fp32 tables, position D=3, ambient D in {2,3}");
+        set_error("gfpp_head_frame_trips_lp: grids must be 16-level fp32 tables, position D=3, ambient D in {2,3}");
         return GFPP_EUNSUPPORTED;
     }
-    if (model->cascade < 1 || model->cascade > 8 || !model->density_bitfield || !ws->alive[0] || !ws->alive[1]) {
-        set_error("gfpp_head_frame_march_lp: bad model/workspace");
-        return GFPP_EINVAL;
-    }
+    if (!ws->alive[0] || !ws->alive[1] || !ws->rays_t || !ws->counters || !ws->frame_consts) { set_error("gfpp_head_frame_trips_lp: bad workspace"); return GFPP_EINVAL; }
     LpTripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
-    if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("gfpp_head_frame_march_lp: grid descriptors carry no host level table (levels_host)"); return GFPP_EINVAL; }
+    if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("gfpp_head_frame_trips_lp: grid descriptors carry no host level table (levels_host)"); return GFPP_EINVAL; }
     for (int which = 0; which < 2; ++which) {
         const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
         LpGrid &g = which ? a.amb : a.pos;
         g.any_slow = 0;
         g.levels = gd.levels;
         for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
-        if (!g.any_slow && !gd.row_padded) { set_error("gfpp_head_frame_march_lp: tables must be the per-level padded copy (row_padded)"); return GFPP_EINVAL; }
+        if (!g.any_slow && !gd.row_padded) { set_error("gfpp_head_frame_trips_lp: tables must be the per-level padded copy (row_padded)"); return GFPP_EINVAL; }
         g.table = (const float *)gd.table;
         g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
     }
     a.w16 = (const uint4 *)model->lp_weights;
     a.skinny16 = (const uint32_t *)model->lp_skinny;
-    if (!ws->sample_t || !ws->sample_cnt || ws->sample_stride < max_steps + 7u) {
-        set_error("gfpp_head_frame_march_lp: the workspace needs sample_t [N, sample_stride >= max_steps + 7] and sample_cnt [N]");
-        return GFPP_EINVAL;
-    }
     a.rays_o = rays_o; a.rays_d = rays_d;
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
     a.consumed = (uint32_t *)ws->rays_t;   // the per-ray cursor takes the place of rays_t
@@ -530,18 +549,6 @@ GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_f
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
     a.phase_cycles = (unsigned long long *)ws->phase_cycles;
-    const hipStream_t st0 = (hipStream_t)stream;
-    {
-        PremarchArgs p;
-        p.mp = a.mp;
-        p.bitfield = model->density_bitfield;
-        p.rays_o = rays_o; p.rays_d = rays_d; p.nears = ws->nears; p.fars = ws->fars;
-        p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
-        p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
-        hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, st0, p);
-        const int rc = check_launch("gfpp_head_frame_march_lp(premarch)");
-        if (rc) return rc;
-    }
     const uint32_t grid = (uint32_t)lp_cu_count();   // one resident workgroup per CU (LDS-bound), tiles are taken wave-stride
     const hipStream_t st = (hipStream_t)stream;
     const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
@@ -553,8 +560,15 @@ GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_f
         a.alive_in = ws->alive[trip & 1];
         a.alive_out = ws->alive[(trip + 1) & 1];
         launch(grid, st, a);
-        const int rc = check_launch("gfpp_head_frame_march_lp");
+        const int rc = check_launch("gfpp_head_frame_trips_lp");
         if (rc) return rc;
     }
     return 0;
+}
+
+GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                      float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    const int rc = gfpp_head_frame_premarch(model, ws, rays_o, rays_d, dt_gamma, max_steps, stream);
+    if (rc) return rc;
+    return gfpp_head_frame_trips_lp(model, ws, rays_o, rays_d, dt_gamma, max_steps, T_thresh, stream);
 }

@@ -48,7 +48,8 @@ class CondModel(ctypes.Structure):
     _fields_ = [("smo", c_u32), ("t_win", c_u32), ("c_in", c_u32), ("dim_aud", c_u32), ("strides", c_u32 * 4),
                 ("conv_w", c_p * 4), ("conv_b", c_p * 4), ("fc_w", c_p * 2), ("fc_b", c_p * 2),
                 ("blink_dim", c_u32), ("blink_emb", c_p), ("blink_w", c_p * 2), ("blink_b", c_p * 2),
-                ("with_att", c_u32), ("att_conv_w", c_p * 5), ("att_conv_b", c_p * 5), ("att_fc_w", c_p), ("att_fc_b", c_p)]
+                ("with_att", c_u32), ("att_conv_w", c_p * 5), ("att_conv_b", c_p * 5), ("att_fc_w", c_p), ("att_fc_b", c_p),
+                ("center_tap_only", c_u32), ("blob", c_p), ("blob_floats", c_u32)]
 
 
 class TorsoModel(ctypes.Structure):
@@ -69,6 +70,9 @@ _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
 _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
 _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_fold", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p])
+_lib.register("gfpp_head_frame_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
+_lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
 
@@ -286,6 +290,7 @@ class FramePipeline:
         self._lp_images = {}
         self.precision = "fp32"
         self._graphs = {}
+        self._side_stream = None
         self._versions = self._fingerprint(model)
         self.head = self._build_head(model)
         self.torso = self._build_torso(model) if hasattr(model, "torso_deform_net") else None
@@ -394,25 +399,51 @@ class FramePipeline:
         cm.smo, cm.t_win, cm.c_in, cm.dim_aud = int(m.smo_win_size), int(m.cond_win_size), int(m.cond_in_dim), int(m.cond_out_dim)
         if cm.dim_aud > 64 or cm.smo > 64 or cm.smo * 64 * cm.t_win > 8192:
             return None
-        f = lambda t: self._hold(t.detach().float())
+        # all weights go into ONE contiguous blob (the kernel pulls it into LDS in one burst); every piece starts 16-byte aligned
+        pieces = []
+
+        def f(t):
+            t = t.detach().float().reshape(-1)
+            pad = (-t.numel()) % 4
+            pieces.append((t, pad))
+            return len(pieces) - 1
+
+        center = cm.t_win == 1
+        cm.center_tap_only = int(center)
+        slots = {}
         for i, s_ in enumerate(_STRIDES[pre.win_size]):
             cm.strides[i] = s_
             conv = pre.encoder_conv[2 * i]
-            cm.conv_w[i], cm.conv_b[i] = f(conv.weight), f(conv.bias)
+            slots[("conv_w", i)] = f(conv.weight[:, :, 1] if center else conv.weight)
+            slots[("conv_b", i)] = f(conv.bias)
         for i, j in enumerate((0, 2)):
-            cm.fc_w[i], cm.fc_b[i] = f(pre.encoder_fc1[j].weight), f(pre.encoder_fc1[j].bias)
+            slots[("fc_w", i)], slots[("fc_b", i)] = f(pre.encoder_fc1[j].weight), f(pre.encoder_fc1[j].bias)
         if hp.get("add_eye_blink_cond", False):
             cm.blink_dim = int(hp["eye_blink_dim"])
-            cm.blink_emb = f(m.blink_embedding.weight[0])
+            slots[("blink_emb", None)] = f(m.blink_embedding.weight[0])
             for i in range(2):
-                cm.blink_w[i], cm.blink_b[i] = f(m.blink_encoder[i].weight), f(m.blink_encoder[i].bias)
+                slots[("blink_w", i)], slots[("blink_b", i)] = f(m.blink_encoder[i].weight), f(m.blink_encoder[i].bias)
         cm.with_att = int(bool(m.with_att))
         if m.with_att:
             att = m.cond_att_net
             for i in range(5):
                 conv = att.attentionConvNet[2 * i]
-                cm.att_conv_w[i], cm.att_conv_b[i] = f(conv.weight), f(conv.bias)
-            cm.att_fc_w, cm.att_fc_b = f(att.attentionNet[0].weight), f(att.attentionNet[0].bias)
+                slots[("att_conv_w", i)], slots[("att_conv_b", i)] = f(conv.weight), f(conv.bias)
+            slots[("att_fc_w", None)], slots[("att_fc_b", None)] = f(att.attentionNet[0].weight), f(att.attentionNet[0].bias)
+        blob = torch.cat([torch.cat([t, t.new_zeros(pad)]) for t, pad in pieces]).contiguous()
+        self._keep.append(blob)
+        offs, at = [], 0
+        for t, pad in pieces:
+            offs.append(at)
+            at += t.numel() + pad
+        base = blob.data_ptr()
+        for (name, i), k in slots.items():
+            addr = base + 4 * offs[k]
+            if i is None:
+                setattr(cm, name, addr)
+            else:
+                getattr(cm, name)[i] = addr
+        cm.blob, cm.blob_floats = base, int(blob.numel())
         return cm
 
     def cond_feat(self, cond, eye_area_percent=None):
@@ -496,24 +527,50 @@ class FramePipeline:
         return t.detach().float().contiguous()
 
     def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh):
-        """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace."""
+        """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace.
+
+        `cond_feat` is a tensor, or a callable returning it: the callable (the conditioning networks) is then issued on a side
+        stream together with the constant folding, next to the slab test and the pre-march on the main stream, which do not depend
+        on it (fork / join, also inside a captured graph)."""
         rays_o = self._dev_f32(rays_o, "rays_o")
         rays_d = self._dev_f32(rays_d, "rays_d")
         N = rays_o.shape[0]
         ws, t = self.workspace(N)
-        cond_feat = self._dev_f32(cond_feat.reshape(-1), "cond_feat")
-        if cond_feat.numel() != self.head.cond_dim:
-            raise GfppError(f"cond_feat must have {self.head.cond_dim} values, got {cond_feat.numel()}")
         ind = self._dev_f32(ind_code.reshape(-1), "ind_code") if ind_code is not None else None
-        st = torch.cuda.current_stream().cuda_stream
-        call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), cond_feat.data_ptr(),
-             ind.data_ptr() if ind is not None else None, st)
-        if self.precision != "fp32" and ws.sample_stride < int(max_steps) + 7:
+        ind_ptr = ind.data_ptr() if ind is not None else None
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
+        lp = self.precision != "fp32"
+        if lp and ws.sample_stride < int(max_steps) + 7:
             stride = (int(max_steps) + 7 + 7) // 8 * 8
             t["sample_t"] = torch.empty(N, stride, dtype=torch.float32, device=self.device)
             t["sample_cnt"] = torch.empty(N, dtype=torch.int32, device=self.device)
             ws.sample_t, ws.sample_cnt, ws.sample_stride = t["sample_t"].data_ptr(), t["sample_cnt"].data_ptr(), stride
-        call("gfpp_head_frame_march" if self.precision == "fp32" else "gfpp_head_frame_march_lp", ctypes.byref(self.head), ctypes.byref(ws),
+
+        def fold(cf, stream_ptr):
+            cf = self._dev_f32(cf.reshape(-1), "cond_feat")
+            if cf.numel() != self.head.cond_dim:
+                raise GfppError(f"cond_feat must have {self.head.cond_dim} values, got {cf.numel()}")
+            call("gfpp_head_frame_fold", ctypes.byref(self.head), ctypes.byref(ws), cf.data_ptr(), ind_ptr, stream_ptr)
+            return cf
+
+        side = None
+        if callable(cond_feat):
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(main)                      # fork: everything the caller queued so far (input copies) is visible
+            with torch.cuda.stream(side):
+                t["cond_feat"] = fold(cond_feat(), side.cuda_stream)
+        call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), None, None, st)
+        if side is None:
+            fold(cond_feat, st)
+        if lp:
+            call("gfpp_head_frame_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
+                 int(max_steps), st)
+        if side is not None:
+            main.wait_stream(side)                      # join
+        call("gfpp_head_frame_trips_lp" if lp else "gfpp_head_frame_march", ctypes.byref(self.head), ctypes.byref(ws),
              rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
         return ws, t
 

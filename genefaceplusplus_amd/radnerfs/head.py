@@ -149,7 +149,7 @@ class NeRFRenderer(nn.Module):
         ind_code = self._individual_code(index)
         if self.executor == "fused" and cond_mask is None and not perturb and max_steps <= 63:
             def frame(rays_o, rays_d, cond, eye, bg_color):
-                cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye)
+                cond_feat = lambda: self.cal_cond_feat(cond, eye_area_percent=eye)     # runs on the pipeline's side stream
                 return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_color": bg_color}
             if self.use_graph and not torch.is_grad_enabled():

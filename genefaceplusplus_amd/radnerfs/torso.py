@@ -127,8 +127,9 @@ class _TorsoBase(RADNeRF):
             ind_code, torso_code = self._individual_code(index), self._torso_code(index)
 
             def frame(rays_o, rays_d, cond, eye, bg_coords, poses, lm68, bg_color):
-                with torch.no_grad():
-                    cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye)
+                def cond_feat():                                                        # runs on the pipeline's side stream
+                    with torch.no_grad():
+                        return self.cal_cond_feat(cond, eye_area_percent=eye)
                 return self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
                                                          max_steps, T_thresh, bg_color, use_head_for_torso)
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_coords": bg_coords, "poses": poses,

@@ -189,6 +189,10 @@ typedef struct gfpp_cond_model {
     uint32_t with_att;
     const float *att_conv_w[5], *att_conv_b[5]; /* channels dim_aud -> 16 -> 8 -> 4 -> 2 -> 1 over the smo axis */
     const float *att_fc_w, *att_fc_b;           /* [smo, smo] */
+    /* optional accelerators (0 / NULL = plain): */
+    uint32_t center_tap_only; /* t_win == 1 only: conv_w[l] hold the centre taps W[:, :, 1] as [out, in] matrices (the outer taps only see padding) */
+    const float *blob;        /* all weight / bias pointers above point into this one contiguous, 16-byte aligned array: it is copied */
+    uint32_t blob_floats;     /* to LDS in one burst when it fits (multiple of 4) */
 } gfpp_cond_model;
 
 /* replaces RADNeRF.cal_cond_feat (radnerf.py:88-106).  cond [smo, t_win, c_in] f32; eye_area [1] f32 or NULL (= 0, like
@@ -276,6 +280,12 @@ typedef struct gfpp_frame_ws {
 int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                           const float *cond_feat, const float *ind_code, gfpp_stream_t stream);
 
+/* The constant-folding half of gfpp_head_frame_begin on its own (the per-sample cond_feat.repeat / individual_code.repeat + cat of
+ * radnerf.py:115-136 become two bias vectors): pass cond_feat == NULL to gfpp_head_frame_begin and call this once cond_feat exists,
+ * e.g. on a second stream next to the slab test and the pre-march, which do not depend on the conditioning networks. */
+int gfpp_head_frame_fold(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *cond_feat, const float *ind_code,
+                         gfpp_stream_t stream);
+
 /* Runs the whole march -> evaluate -> composite loop of renderer.py:354-384 (kernels raymarching.cu:827-929, :942-1029;
  * networks radnerf.py:108-141; encoders gridencoder.cu:87-196, shencoder.cu:28-68): `max_steps` fused trip launches, each of
  * which marches its alive rays (kernel_march_rays semantics), evaluates RADNeRF.forward on MFMA for the occupied samples
@@ -290,6 +300,16 @@ int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws,
  * sigma (rays whose transmittance crosses T_thresh).  Stated tolerance vs the fp32 oracle: PSNR >= 45 dB, max-abs <= 2e-2
  * (SURVEY.md 8c).  One 512-thread workgroup per CU keeps the weight image resident in LDS. */
 int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                             float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
+/* First stage of gfpp_head_frame_march_lp on its own: marches every ray of the frame once through the occupancy bitfield
+ * (kernel_march_rays semantics, raymarching.cu:827-929) and stores the t of every occupied sample in ws->sample_t / sample_cnt.
+ * Needs only gfpp_head_frame_begin's slab test.  Follow with gfpp_head_frame_trips_lp. */
+int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                             float dt_gamma, uint32_t max_steps, gfpp_stream_t stream);
+
+/* Second stage: the trip launches of gfpp_head_frame_march_lp, consuming the pre-marched lists (renderer.py:354-384 loop). */
+int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                              float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
 
 /* Head-only epilogue (renderer.py:385-397): image = clamp(image + (1 - weights_sum) * bg, 0, 1),
