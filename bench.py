@@ -10,10 +10,19 @@ only exchange is the RCCL all_gather of the finished uint8 frames, which is insi
 windows, poses, background) are resident in HBM before the timed region starts, exactly like the reference keeps them
 (inference/genefacepp_infer.py:246-275).  Rank 0 prints ONE JSON line.
 
+The headline `value` is measured in --precision fp16 by default: MLP layers on 16-bit MFMA operands with fp32 accumulation, the
+precision class the reference itself renders in (torch.autocast(fp16) in genefacepp_infer.py) and of BASELINE config 3 ("bf16 MLP,
+hipGraph-captured per-frame"); `modes` carries the same measurement for the exact-fp32 parity mode and for bf16.
+
 Extra objects in the JSON line:
-  roofline      dominant kernel (k_head_trip: march + grid encode + MFMA MLPs + composite, fused).  bound "mfma";
-                achieved = evaluated samples x 161 536 FLOP (SURVEY 8d "folded" per-sample figure) / time of the trip
-                launches measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32-input MFMA, exact fp32)
+  roofline      dominant kernel = the fused head trip kernel (sample fetch + 2 grid encodes + MLPs + composite).
+                16-bit modes: bound "hbm" -- the kernel is bound by the hash-grid gathers; achieved = evaluated samples x 2 060 B
+                (12 B position + 2 encodes x 16 levels x 8 corners x 8 B) / time of the trip launches (HIP events on the
+                launch stream) vs the 8 TB/s HBM peak (the tables are L2 / Infinity-Cache resident, so the fraction can exceed what
+                DRAM could deliver; `traffic` = fabric bytes per frame from the FETCH_SIZE PMC pass committed under profiles/);
+                the MFMA fraction (128 768 FLOP/sample vs 2.5 PFLOP/s) is reported beside it.
+                fp32 mode: bound "mfma", 161 536 FLOP/sample vs 157.3 TFLOP/s (fp32-input MFMA, exact fp32)
+  modes         frames/s of the other precision modes (short runs of the same pipeline)
   grid_stage    the stand-alone hash/tiled-grid kernel on 2^22 uniform points: achieved = B x 1164 B / t vs 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (kind "port": the reference has no CPU path) on a bounded sample, rank 0 at N=1 only
 """
@@ -43,8 +52,10 @@ def parse():
     ap.add_argument("--hw", type=int, default=512, help="frame side (rays = hw*hw)")
     ap.add_argument("--variant", default="may_torso", choices=["may_head", "may_torso", "may_torso_sr"])
     ap.add_argument("--executor", default="fused", choices=["fused", "staged"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"],
-                    help="arithmetic of the five wide head layers: exact-fp32 MFMA, or 16-bit MFMA operands with fp32 accumulation")
+    ap.add_argument("--precision", default="fp16", choices=["fp32", "fp16", "bf16"],
+                    help="arithmetic of the MLP layers (head + torso): 16-bit MFMA operands with fp32 accumulation (fp16 = what the reference's "
+                         "autocast inference computes in, bf16 = BASELINE config 3), or exact-fp32 MFMA (the parity mode)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the short runs of the other two precision modes")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying the per-frame hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-stage", action="store_true")
@@ -224,6 +235,35 @@ def main():
                                   "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
                                   "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP}, **common}
+
+    # ---- the other precision modes, briefly (same model, same inputs; graphs are kept per precision) -------------------------------
+    if rank == 0 and world == 1 and not args.no_modes:
+        modes = {}
+        for prec in ("fp32", "fp16", "bf16"):
+            if prec == args.precision:
+                continue
+            model.precision = prec
+            for i in range(3):
+                render(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_m = 10
+            for k in range(n_m):
+                render(W + (k % K), slot=k % K)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            modes[prec] = {"value": round(n_m / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_m, 4), "steps": n_m}
+        model.precision = args.precision
+        result["modes"] = modes
+
+    # ---- HBM-side traffic of the trip launches: from the committed rocprofv3 --pmc pass of this same workload ---------------------------
+    if rank == 0 and "roofline" in result:
+        tfile = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.precision}.json")
+        if os.path.exists(tfile):
+            try:
+                result["roofline"]["traffic"] = json.load(open(tfile))
+            except Exception:
+                pass
 
     if rank == 0 and not args.no_grid_stage:
         from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Turn the raw outputs of tools/profile_round.sh (gpurun_out/<tag>_*) into the summaries committed under profiles/:
+   profiles/<tag>_kernel_stats.md   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + the bench JSON line)
+   profiles/<tag>_pmc.md            per-kernel PMC sums of the last rendered frame, per counter pass
+   profiles/r01_pmc_traffic_<precision>.json   fabric-side bytes of the trip launches per frame (read back by bench.py as roofline.traffic)
+Usage: profile_digest.py <tag> <precision>"""
+import csv
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def demangle(name):
+    if name.startswith("_Z"):
+        try:
+            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
+        except OSError:
+            pass
+    if name.startswith("_ZN4gfpp"):   # llvm-cxxfilt of ROCm 7.2 does not know the _Float16 / __bf16 manglings (DF16_, DF16b)
+        m = re.match(r"_ZN4gfpp\d+(k_\w+?)I(.*)EEvNS_", name)
+        if m:
+            args = m.group(2).replace("DF16_", "_Float16, ").replace("DF16b", "__bf16, ").replace("Li", "").replace("Lb0", "false").replace("Lb1", "true").replace("E", ", ")
+            name = "gfpp::" + m.group(1) + "<" + args.strip(", ").replace(", ,", ",") + ">"
+    return name
+
+
+def main(tag, precision):
+    src = os.path.join(ROOT, "gpurun_out")
+    dst = os.path.join(ROOT, "profiles")
+    rows = list(csv.DictReader(open(os.path.join(src, f"{tag}_stats", "bench_kernel_stats.csv"))))
+    bench_line = [l for l in open(os.path.join(src, f"{tag}_bench.log")) if l.startswith('{"metric')][-1].strip()
+    out = [f"# rocprofv3 --kernel-trace --stats -- {tag}",
+           "",
+           f"Command (1x MI355X via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --precision {precision} --no-cpu-baseline --no-modes`",
+           "",
+           "bench line of the profiled run (profiling costs a few % of wall time):", "", "```", bench_line, "```", "",
+           "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:22]:
+        name = demangle(r["Name"])
+        name = name if len(name) < 110 else name[:107] + "..."
+        out.append(f"| `{name}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | {int(r['MinNs']) / 1e3:.2f} | "
+                   f"{int(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.1f} |")
+    d = json.loads(bench_line)
+    rf = d.get("roofline", {})
+    trip = [r for r in rows if "k_head_trip" in r["Name"]]
+    if trip:
+        frames = 20 + 3 + 5          # timed + warm-up + the roofline section's repetitions
+        tot_ms = sum(int(r["TotalDurationNs"]) for r in trip) / 1e6
+        out += ["", f"Trip launches in this trace: {sum(int(r['Calls']) for r in trip)} dispatches, {tot_ms:.3f} ms in total = {tot_ms / frames:.4f} ms per frame over "
+                    f"{frames} frames (20 timed + 3 warm-up + 5 in the roofline section); bench.py's HIP-event measurement of the same launches: "
+                    f"{rf.get('ms_per_frame_all_trips')} ms per frame, {rf.get('avg_launch_ms')} ms per non-empty launch."]
+    open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w").write("\n".join(out) + "\n")
+
+    pmc = open(os.path.join(src, f"{tag}_pmc.txt")).read()
+    pmc = "\n".join(demangle(w) if w.startswith("_Z") else w for w in re.split(r"(\s+)", pmc)) if False else pmc
+    lines = []
+    for line in pmc.splitlines():
+        m = re.match(r"^(_Z\S+)(.*)$", line)
+        lines.append((demangle(m.group(1)).split("(")[0] + m.group(2)) if m else line)
+    head = [f"# rocprofv3 --pmc passes -- {tag}", "",
+            f"Each counter group in its own run (`rocprofv3 --pmc <group> --kernel-trace -- python tools/profile_frame.py may_torso 512 3 {precision}`), summed per kernel over the",
+            "dispatches of the LAST rendered frame (16 trip launches, 6 of them non-empty); `per trip` lists the first 8 trip launches.",
+            "Units as rocprofv3 reports them: FETCH_SIZE / WRITE_SIZE in KiB of fabric-side (L2 <-> Infinity Cache / HBM) traffic -- on gfx950 a wide coalesced read",
+            "is under-reported by 2x and other access shapes are uncalibrated (MI355X_MICROARCH.md, HBM section), so read them as lower bounds and compare runs, not absolutes;",
+            "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles summed over wavefronts; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; GRBM_GUI_ACTIVE in cycles summed over XCDs.", "",
+            "```"]
+    open(os.path.join(dst, f"{tag}_pmc.md"), "w").write("\n".join(head + lines + ["```"]) + "\n")
+
+    def grab(counter):
+        m = re.search(r"k_head_trip\S* \{[^}]*'" + counter + r"': ([0-9.]+)", pmc)
+        return float(m.group(1)) if m else None
+    fetch, write = grab("FETCH_SIZE"), grab("WRITE_SIZE")
+    hit, miss = grab("TCC_HIT_sum"), grab("TCC_MISS_sum")
+    traffic = {"source": f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, one frame = 16 trip launches)",
+               "fetch_MB_per_frame": round(fetch * 1024 / 1e6, 1) if fetch else None, "write_MB_per_frame": round(write * 1024 / 1e6, 1) if write else None,
+               "l2_hit_rate": round(hit / (hit + miss), 4) if hit and miss else None,
+               "note": "fabric-side (L2 <-> Infinity Cache / HBM) KiB as rocprofv3 reports them; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 and is "
+                       "uncalibrated for 16-byte gathers, so this is a lower bound.  Algorithmic gather bytes per frame = samples x 2060 B (~1.9 GB): the tables live in L2 / Infinity Cache"}
+    json.dump(traffic, open(os.path.join(dst, f"r01_pmc_traffic_{precision}.json"), "w"), indent=1)
+    print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])
