@@ -116,6 +116,9 @@ def main():
         assert HW == 256, "the *_sr models render 256x256 rays"
     sd = syn.synthetic_state_dict(hp, args.variant)
     model = getattr(radnerfs, CLASSES[args.variant])(hp)
+    if args.variant == "may_torso_sr":
+        sd = dict(sd)
+        sd.update(syn.synthetic_sr_state())
     model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     model.executor = args.executor
@@ -136,7 +139,8 @@ def main():
         inputs.append({"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose),
                        "cond": torch.from_numpy(fi["cond"]).to(dev), "lm68": torch.from_numpy(fi["lm68"]).to(dev),
                        "eye": torch.from_numpy(fi["eye_area_percent"]).to(dev)})
-    out_u8 = torch.empty(K, HW, HW, 3, dtype=torch.uint8, device=dev)
+    HWO = 512 if args.variant == "may_torso_sr" else HW          # the *_sr models render 256^2 rays and super-resolve to 512^2
+    out_u8 = torch.empty(K, HWO, HWO, 3, dtype=torch.uint8, device=dev)
     gathered = [torch.empty_like(out_u8) for _ in range(world)] if world > 1 else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -148,9 +152,9 @@ def main():
                                lm68=x["lm68"], perturb=False, force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
         rgb = res["rgb_map"]
         if args.variant == "may_torso_sr":
-            rgb = rgb.permute(0, 2, 3, 1)
+            rgb = res["sr_rgb_map"].permute(0, 2, 3, 1)              # [1,3,512,512] view of NHWC memory
         if slot is not None:
-            frames.to_uint8_hwc(rgb.reshape(HW, HW, 3), out_u8[slot])
+            frames.to_uint8_hwc(rgb.reshape(HWO, HWO, 3), out_u8[slot])
         return res
 
     for i in range(W):
@@ -181,7 +185,9 @@ def main():
                   "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
                   "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16 operands / f32 accumulate", "bf16": "bf16 operands / f32 accumulate"}[args.precision],
                   "data": "synthetic",
-                  "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame, max_steps 16, T_thresh 0.01, "
+                  "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame"
+                                         + (" + StyleGAN2 super-resolution to 512x512 (random noise inputs, like the reference)" if args.variant == "may_torso_sr" else "")
+                                         + ", max_steps 16, T_thresh 0.01, "
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (" + RCCL all_gather of uint8 frames" if world > 1 else ""),
                              "executor": args.executor,

@@ -1,0 +1,317 @@
+// superres.hip -- the StyleGAN2 super-resolution stage of the *_sr models (radnerf_sr.py:14-43: SynthesisBlockNoUp 3 -> 128 @ 256^2,
+// SynthesisBlock 128 -> 64 @ 512^2, networks_stylegan2.py:286-478) as four launches of implicit-GEMM convolutions on 16-bit MFMA.
+//
+// Superresolution feeds ws = ones (radnerf_sr.py:32-33), so every style vector is a constant of the checkpoint: modulation and
+// demodulation (networks_stylegan2.py:37-94) are folded into the convolution weights ONCE on the host, in fp64.  What remains per frame:
+//   k_sr_first   conv 3x3,   3 -> 128 @ 256^2 (+ noise + bias, lrelu * sqrt 2, clamp)                      K = 27 (padded to 32)
+//   k_sr_conv3   conv 3x3, 128 -> 128 @ 256^2  + ToRGB 128 -> 3 fused: img256 = rgb_in + clamp(torgb)       K = 1152
+//   k_sr_conv3   up-conv 128 -> 64, 256^2 -> 512^2: the transposed stride-2 convolution AND the [1,3,3,1] FIR of conv2d_resample.py:
+//                117-133 composed on the host into one 3x3 convolution with 4 x 64 output channels (one set per output phase),
+//                written depth-to-space                                                                    K = 1152, N = 256
+//   k_sr_conv3   conv 3x3,  64 -> 64 @ 512^2  + ToRGB 64 -> 3 + upsample2d(img256) fused -> rgb 512^2       K = 576
+// Activations travel as f16 NHWC (the reference runs both blocks in fp16 on the GPU, use_fp16=True), images as fp32; accumulation fp32.
+//
+// Kernel shape: a 256-thread workgroup owns a 16x16 output patch; its 18x18 input halo sits in LDS (pixel stride padded by 16 B so
+// that the 16 pixels of a row hit distinct banks); each wavefront owns 4 rows = 64 pixels = two 32-column MFMA tiles x NT row tiles
+// of output channels.  The weights of one tap (CIN/16 steps x NT fragments, pre-packed in fragment order) are double-buffered
+// through LDS: the next tap's fragments are in flight (global -> registers) while the current tap's MFMAs run.
+#include <hip/hip_runtime.h>
+
+#include "gfpp_common.h"
+#include "lp_mfma_device.h"
+
+namespace gfpp {
+
+constexpr int kSrThreads = 256;
+constexpr int kSrPatch = 16;            // output patch side
+constexpr int kSrHalo = kSrPatch + 2;   // 3x3 convolution
+
+enum SrEpilogue { kSrPlain = 0, kSrRgbAdd = 1, kSrUpPhases = 2, kSrFinal = 3 };
+
+struct SrConvArgs {
+    const _Float16 *x;        // [H][W][CIN] f16
+    const uint4 *w;           // [pass][9 taps][CIN/16][NT][64] fragments
+    const float *noise;       // [Hout][Wout] or null
+    float noise_strength;
+    const float *bias;        // [Cout]
+    float act_gain, clamp;    // sqrt(2), 256
+    _Float16 *y;              // [Hout][Wout][Cout] f16 (null for kSrFinal)
+    uint32_t H, W;            // input = patch-grid resolution
+    // ToRGB fused (kSrRgbAdd, kSrFinal)
+    const float *w_rgb;       // [Cout][3] modulated 1x1 weights
+    const float *b_rgb;       // [3]
+    const float *img_in;      // kSrRgbAdd: [H][W][3] fp32 (the NeRF image);  kSrFinal: [H/2][W/2][3] fp32 (img256)
+    float *img_out;           // kSrRgbAdd: [H][W][3];  kSrFinal: [H][W][3] fp32 (the 512^2 result)
+    float fir[4];             // kSrFinal: 1-D taps of the separable resample filter x up (= [1,3,3,1]/8 * 2)
+};
+
+__device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
+    v = (v >= 0.0f ? v : 0.2f * v) * gain;
+    return fminf(fmaxf(v, -clamp), clamp);
+}
+
+template <int CIN, int NT, int EPI>
+__global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
+    typedef LpTraits<_Float16>::vec vec;
+    constexpr int PS = CIN + 8;                  // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
+    constexpr int STEPS = CIN / 16;
+    constexpr int TAPFRAGS = STEPS * NT * 64;    // 16-byte fragments of one tap
+    constexpr int PER_THREAD = TAPFRAGS / kSrThreads;
+    static_assert(TAPFRAGS % kSrThreads == 0, "tap weights must split evenly over the workgroup");
+    __shared__ __attribute__((aligned(16))) _Float16 patch[kSrHalo * kSrHalo * PS];
+    __shared__ uint4 wbuf[2][TAPFRAGS];
+    __shared__ float s_rgb[(EPI == kSrRgbAdd || EPI == kSrFinal) ? NT * 32 * 3 + 4 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
+    const uint32_t pass = blockIdx.z;
+    const uint4 *wg = a.w + (size_t)pass * 9 * TAPFRAGS;
+
+    // ---- first tap's weights straight to LDS, input halo to LDS (zero padding outside the image) ----------------------------------
+    for (int i = tid; i < TAPFRAGS; i += kSrThreads) wbuf[0][i] = wg[i];
+    for (int i = tid; i < kSrHalo * kSrHalo * (CIN / 8); i += kSrThreads) {
+        const int p = i / (CIN / 8), c8 = i % (CIN / 8);
+        const int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) v = *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + c8 * 8);
+        *reinterpret_cast<uint4 *>(&patch[p * PS + c8 * 8]) = v;
+    }
+    if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
+        for (int i = tid; i < NT * 32 * 3; i += kSrThreads) s_rgb[i] = a.w_rgb[i];
+        if (tid < 3) s_rgb[NT * 32 * 3 + tid] = a.b_rgb[tid];
+    }
+    __syncthreads();
+
+    v16f acc[2][NT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.0f;
+
+    // this lane's two pixels (one per column tile): rows 4 wave + 2 u + (j >> 4), column j & 15 of the patch
+    const int prow = 4 * wave + (j >> 4), pcol = j & 15;
+    int cur = 0;
+    for (int tap = 0; tap < 9; ++tap) {
+        uint4 nxt[PER_THREAD];
+        if (tap + 1 < 9) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; ++q) nxt[q] = wg[(size_t)(tap + 1) * TAPFRAGS + q * kSrThreads + tid];
+        }
+        const int dy = tap / 3, dx = tap % 3;
+        const _Float16 *b0 = &patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi];
+        const _Float16 *b1 = b0 + 2 * kSrHalo * PS;
+        const vec *wl = reinterpret_cast<const vec *>(wbuf[cur]) + lane;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const vec B0 = *reinterpret_cast<const vec *>(b0 + 16 * s), B1 = *reinterpret_cast<const vec *>(b1 + 16 * s);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const vec A = wl[(s * NT + t) * 64];
+                acc[0][t] = LpTraits<_Float16>::mfma(A, B0, acc[0][t]);
+                acc[1][t] = LpTraits<_Float16>::mfma(A, B1, acc[1][t]);
+            }
+        }
+        if (tap + 1 < 9) {
+#pragma unroll
+            for (int q = 0; q < PER_THREAD; ++q) wbuf[cur ^ 1][q * kSrThreads + tid] = nxt[q];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: noise + bias, leaky relu * gain, clamp; store / ToRGB ----------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int Y = y0 + prow + 2 * u, X = x0 + pcol;          // position at the patch-grid (input) resolution
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = 32 * t + 8 * q + 4 * hi;           // channels n0 .. n0+3 are registers 4 q .. 4 q + 3
+                const int ng = (int)pass * NT * 32 + n0;
+                float v[4];
+                int oy = Y, ox = X, oc = ng;
+                uint32_t OW = a.W, OC = NT * 32;
+                if constexpr (EPI == kSrUpPhases) {               // depth to space: 4 phases x 64 channels -> (2Y + py, 2X + px)
+                    const int phase = ng >> 6;
+                    oy = 2 * Y + (phase >> 1); ox = 2 * X + (phase & 1); oc = ng & 63;
+                    OW = 2 * a.W; OC = 64;
+                }
+                const float nz = a.noise ? a.noise[(size_t)oy * OW + ox] * a.noise_strength : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sr_act(acc[u][t][4 * q + e] + nz + a.bias[oc + e], a.act_gain, a.clamp);
+                if constexpr (EPI != kSrFinal) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<h4 *>(a.y + ((size_t)oy * OW + ox) * OC + oc) = o;
+                }
+                if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
+                    // the next stage sees the f16-rounded activation in the reference too (x stays fp16 through ToRGB)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xv = (float)(_Float16)v[e];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) rgb[k] = fmaf(xv, s_rgb[(n0 + e) * 3 + k], rgb[k]);
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
+            if (hi == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float t = fminf(fmaxf(rgb[k] + s_rgb[NT * 32 * 3 + k], -a.clamp), a.clamp);
+                    float base;
+                    if constexpr (EPI == kSrRgbAdd) {
+                        base = a.img_in[((size_t)Y * a.W + X) * 3 + k];
+                    } else {
+                        // upsample2d(img256) at (Y, X): zero insertion, [1,3,3,1] FIR, gain 4 (upfirdn2d.py:330-355) = two taps per axis
+                        const int h2 = (int)a.H / 2, w2 = (int)a.W / 2;
+                        const int ya = (Y & 1) ? (Y - 1) / 2 : Y / 2 - 1, xa = (X & 1) ? (X - 1) / 2 : X / 2 - 1;
+                        const float wy0 = (Y & 1) ? a.fir[1] : a.fir[0], wy1 = (Y & 1) ? a.fir[3] : a.fir[2];
+                        const float wx0 = (X & 1) ? a.fir[1] : a.fir[0], wx1 = (X & 1) ? a.fir[3] : a.fir[2];
+                        auto px = [&](int yy, int xx) -> float {
+                            return (yy >= 0 && yy < h2 && xx >= 0 && xx < w2) ? a.img_in[((size_t)yy * w2 + xx) * 3 + k] : 0.0f;
+                        };
+                        base = wy0 * (wx0 * px(ya, xa) + wx1 * px(ya, xa + 1)) + wy1 * (wx0 * px(ya + 1, xa) + wx1 * px(ya + 1, xa + 1));
+                    }
+                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = base + t;
+                }
+            }
+        }
+    }
+}
+
+// ---- first layer: 3 -> 128, K = 27 padded to 32 --------------------------------------------------------------------------------------
+struct SrFirstArgs {
+    const float *rgb;      // [H][W][3] fp32
+    const uint4 *w;        // [2 steps][4 tiles][64] fragments; k = 16 s + 8 h + e -> (tap = k / 3, channel = k % 3), k >= 27 zero
+    const float *noise;
+    float noise_strength;
+    const float *bias;     // [128]
+    float act_gain, clamp;
+    _Float16 *y;           // [H][W][128]
+    uint32_t H, W;
+};
+
+__global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
+    typedef LpTraits<_Float16>::vec vec;
+    __shared__ float patch[kSrHalo * kSrHalo * 3];
+    __shared__ uint4 wl[2 * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
+    for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) wl[i] = a.w[i];
+    for (int i = tid; i < kSrHalo * kSrHalo * 3; i += kSrThreads) {
+        const int p = i / 3, c = i % 3;
+        const int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
+        // the reference casts the block input to fp16 before the first convolution (superresolution.py:216)
+        patch[i] = (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) ? (float)(_Float16)a.rgb[((size_t)py * a.W + px) * 3 + c] : 0.0f;
+    }
+    __syncthreads();
+    const int prow = 4 * wave + (j >> 4), pcol = j & 15;
+    v16f acc[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.0f;
+    const vec *W = reinterpret_cast<const vec *>(wl) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        vec B[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * s + 8 * hi + e;
+                float v = 0.0f;
+                if (k < 27) {
+                    const int tap = k / 3, c = k % 3;
+                    v = patch[((prow + 2 * u + tap / 3) * kSrHalo + pcol + tap % 3) * 3 + c];
+                }
+                B[u][e] = (_Float16)v;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const vec A = W[(s * 4 + t) * 64];
+            acc[0][t] = LpTraits<_Float16>::mfma(A, B[0], acc[0][t]);
+            acc[1][t] = LpTraits<_Float16>::mfma(A, B[1], acc[1][t]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int Y = y0 + prow + 2 * u, X = x0 + pcol;
+        const float nz = a.noise ? a.noise[(size_t)Y * a.W + X] * a.noise_strength : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = 32 * t + 8 * q + 4 * hi;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)sr_act(acc[u][t][4 * q + e] + nz + a.bias[n0 + e], a.act_gain, a.clamp);
+                *reinterpret_cast<h4 *>(a.y + ((size_t)Y * a.W + X) * 128 + n0) = o;
+            }
+    }
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const float *rgb_in, const float *const noise[4], float *rgb_out,
+                             gfpp_stream_t stream) {
+    if (!m || !ws || !rgb_in || !rgb_out) { set_error("gfpp_sr_forward: null argument"); return GFPP_EINVAL; }
+    if (!m->w_first || !m->w_b0c1 || !m->w_up || !m->w_b1c1 || !m->rgb0_w || !m->rgb1_w || !ws->x0 || !ws->x1 || !ws->x2 || !ws->img256) {
+        set_error("gfpp_sr_forward: incomplete model / workspace");
+        return GFPP_EINVAL;
+    }
+    const hipStream_t st = (hipStream_t)stream;
+    const uint32_t R = 256;
+    const float gain = 1.4142135623730951f, clamp = m->conv_clamp;
+    {
+        SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R};
+        hipLaunchKernelGGL(k_sr_first, dim3(R / kSrPatch, R / kSrPatch), dim3(kSrThreads), 0, st, a);
+        const int rc = check_launch("gfpp_sr_forward(block0.conv0)");
+        if (rc) return rc;
+    }
+    {
+        SrConvArgs a{};
+        a.x = (const _Float16 *)ws->x0; a.w = (const uint4 *)m->w_b0c1; a.noise = noise ? noise[1] : nullptr; a.noise_strength = m->noise_strength[1];
+        a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
+        a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
+        hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
+        const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
+        if (rc) return rc;
+    }
+    {
+        SrConvArgs a{};
+        a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
+        a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
+        hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(kSrThreads), 0, st, a);
+        const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
+        if (rc) return rc;
+    }
+    {
+        SrConvArgs a{};
+        a.x = (const _Float16 *)ws->x2; a.w = (const uint4 *)m->w_b1c1; a.noise = noise ? noise[3] : nullptr; a.noise_strength = m->noise_strength[3];
+        a.bias = m->bias[3]; a.act_gain = gain; a.clamp = clamp; a.y = nullptr; a.H = 2 * R; a.W = 2 * R;
+        a.w_rgb = m->rgb1_w; a.b_rgb = m->rgb1_b; a.img_in = ws->img256; a.img_out = rgb_out;
+        for (int k = 0; k < 4; ++k) a.fir[k] = m->fir[k];
+        hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
+        const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
+        if (rc) return rc;
+    }
+    return 0;
+}

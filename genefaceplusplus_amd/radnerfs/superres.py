@@ -1,22 +1,236 @@
-"""Super-resolution stage of the *_sr models (reference: modules/radnerfs/radnerf_sr.py:14-43 on top of
-modules/eg3ds/models/superresolution.py:159-258 and networks_stylegan2.py:37-94, 286-478).
+"""Super-resolution stage of the *_sr models: drop-in for the reference's ``Superresolution`` (modules/radnerfs/radnerf_sr.py:14-43
+on top of modules/eg3ds/models/superresolution.py:159-258 and networks_stylegan2.py:37-94, 286-478).
 
-SURVEY.md section 8f-1 ranks this stage "next" after the NeRF hot path; until it is built the class below only
-carries the interface (``input_resolution``) and refuses to run, so that the NeRF part of the *_sr models (256x256 rays,
-landmark-conditioned head-aware torso) can be rendered and verified on its own.
+Same constructor, ``state_dict()`` key set / shapes / dtypes (``block{0,1}.{conv0,conv1,torgb}.{weight,bias,affine.*,noise_const,
+noise_strength,resample_filter}``, pinned by tests/golden/sr_state_manifest.json) and ``forward(rgb, noise_mode=...)`` signature.
+Execution differs: ``Superresolution`` feeds ``ws = ones`` (radnerf_sr.py:32-33), so every style vector is a constant of the
+checkpoint -- modulation, demodulation and, for the up-sampling layer, the transposed convolution + FIR filter are folded into plain
+3x3 convolution weights once (fp64, re-done when the parameters change), and a frame is four implicit-GEMM MFMA launches
+(csrc/superres.hip) instead of ~40 PyTorch / cuDNN / plugin launches.  Activations are f16 like the reference's GPU path
+(use_fp16=True); images and accumulation fp32.
 """
+import ctypes
+
+import numpy as np
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .._lib import call, GfppError
+
+c_p = ctypes.c_void_p
+c_f = ctypes.c_float
+
+
+class SrModel(ctypes.Structure):
+    _fields_ = [("w_first", c_p), ("w_b0c1", c_p), ("w_up", c_p), ("w_b1c1", c_p), ("bias", c_p * 4), ("noise_strength", c_f * 4),
+                ("rgb0_w", c_p), ("rgb0_b", c_p), ("rgb1_w", c_p), ("rgb1_b", c_p), ("fir", c_f * 4), ("conv_clamp", c_f)]
+
+
+class SrWs(ctypes.Structure):
+    _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p)]
+
+
+_lib.register("gfpp_sr_forward", [ctypes.POINTER(SrModel), ctypes.POINTER(SrWs), c_p, c_p, c_p, c_p])
+
+
+def _setup_filter():
+    f = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    f = torch.outer(f, f)
+    return f / f.sum()
+
+
+class _Affine(nn.Module):
+    """FullyConnectedLayer(w_dim, in_channels, bias_init=1) (networks_stylegan2.py:99-133); only ever applied to ws = ones."""
+
+    def __init__(self, w_dim, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_features, w_dim))
+        self.bias = nn.Parameter(torch.ones(out_features))
+        self.weight_gain = 1.0 / np.sqrt(w_dim)
+
+    def styles_for_ones(self):
+        return (self.weight.detach().double() * self.weight_gain).sum(dim=1) + self.bias.detach().double()
+
+
+class _SynthesisLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, up=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.resolution, self.up = in_channels, out_channels, resolution, up
+        self.affine = _Affine(w_dim, in_channels)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, 3, 3))
+        self.register_buffer("noise_const", torch.randn(resolution, resolution))
+        self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.register_buffer("resample_filter", _setup_filter())
+
+    def effective_weight(self):
+        """modulate with the constant styles, demodulate (networks_stylegan2.py:60-70) -> [out, in, 3, 3] float64."""
+        w = self.weight.detach().double() * self.affine.styles_for_ones().reshape(1, -1, 1, 1)
+        d = (w.square().sum(dim=[1, 2, 3]) + 1e-8).rsqrt()
+        return w * d.reshape(-1, 1, 1, 1)
+
+
+class _ToRGB(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim):
+        super().__init__()
+        self.affine = _Affine(w_dim, in_channels)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.weight_gain = 1.0 / np.sqrt(in_channels)
+
+    def effective_weight(self):
+        """modulated, NOT demodulated (networks_stylegan2.py:363-366) -> [in, out] float64."""
+        s = self.affine.styles_for_ones() * self.weight_gain
+        return (self.weight.detach().double()[:, :, 0, 0] * s.reshape(1, -1)).t().contiguous()
+
+
+class _Block(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, up):
+        super().__init__()
+        self.register_buffer("resample_filter", _setup_filter())
+        self.conv0 = _SynthesisLayer(in_channels, out_channels, w_dim, resolution, up=up)
+        self.conv1 = _SynthesisLayer(out_channels, out_channels, w_dim, resolution)
+        self.torgb = _ToRGB(out_channels, 3, w_dim)
+
+
+def _pack_conv3(w_eff, nt):
+    """[Cout, Cin, 3, 3] -> f16 fragments [passes, 9, Cin/16, nt, 64, 8]: lane (i, h) of tile t holds W[pass*32nt + 32t + i][16 s + 8 h + e][tap]."""
+    cout, cin = w_eff.shape[:2]
+    per_pass = 32 * nt
+    assert cout % per_pass == 0 and cin % 16 == 0
+    w = w_eff.reshape(cout // per_pass, nt, 32, cin // 16, 2, 8, 9)          # [pass, t, i, s, h, e, tap]
+    w = w.permute(0, 6, 3, 1, 4, 2, 5)                                       # [pass, tap, s, t, h, i, e]
+    return w.reshape(cout // per_pass, 9, cin // 16, nt, 64, 8).to(torch.float16).contiguous()
+
+
+def _pack_first(w_eff):
+    """[128, 3, 3, 3] -> [2 steps, 4 tiles, 64, 8] f16 with k = 3 tap + channel (27 used of 32)."""
+    flat = torch.zeros(128, 32, dtype=torch.float64, device=w_eff.device)
+    flat[:, :27] = w_eff.permute(0, 2, 3, 1).reshape(128, 27)               # [n][ky][kx][c] -> k = (3 ky + kx) 3 + c
+    w = flat.reshape(4, 32, 2, 2, 8).permute(2, 0, 3, 1, 4)                  # [t, i, s, h, e] -> [s, t, h, i, e]
+    return w.reshape(2, 4, 64, 8).to(torch.float16).contiguous()
+
+
+def _compose_up_weights(w_eff, filt):
+    """The up = 2 path of conv2d_resample (conv2d_resample.py:117-133: conv_transpose2d stride 2, then the FIR filter with gain 4) as ONE
+    3x3 convolution at the low resolution with 4 x Cout output channels, channel = 64 phase + o, phase = 2 py + px <-> output pixel
+    (2y + py, 2x + px).  Both operations are linear and shift invariant up to the stride, so the composed taps are read off the response
+    to a unit impulse, once per 3x3 basis kernel (fp64)."""
+    cout, cin = w_eff.shape[:2]
+    f = filt.double()
+    resp = torch.zeros(3, 3, 32, 32, dtype=torch.float64)
+    x = torch.zeros(1, 1, 16, 16, dtype=torch.float64)
+    x[0, 0, 8, 8] = 1.0
+    for ky in range(3):
+        for kx in range(3):
+            k = torch.zeros(1, 1, 3, 3, dtype=torch.float64)
+            k[0, 0, ky, kx] = 1.0
+            # conv2d_resample(up=2, padding=1, flip_weight=False), see oracle/sr_oracle.py::conv2d_resample for the padding arithmetic
+            y = F.conv_transpose2d(x, k.transpose(0, 1), stride=2, padding=0)            # 33 x 33
+            y = F.pad(y, [1, 1, 1, 1])
+            y = F.conv2d(y, (f * 4.0).flip([0, 1])[None, None])                           # 32 x 32
+            resp[ky, kx] = y[0, 0]
+    # output (2y + py, 2x + px) from input (y + dy, x + dx):  resp[2 (8 - dy) + py][2 (8 - dx) + px]
+    C = torch.zeros(3, 3, 2, 2, 3, 3, dtype=torch.float64)                                # [ky, kx, py, px, dy+1, dx+1]
+    covered = torch.zeros(32, 32, dtype=torch.bool)
+    for py in range(2):
+        for px in range(2):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    r, c = 2 * (8 - dy) + py, 2 * (8 - dx) + px
+                    C[:, :, py, px, dy + 1, dx + 1] = resp[:, :, r, c]
+                    covered[r, c] = True
+    assert float(resp[:, :, ~covered].abs().max()) == 0.0, "the composed kernel must fit a 3x3 neighbourhood"
+    w = torch.einsum("oikl,klpqab->pqoiab", w_eff.double().cpu(), C)                      # [py, px, o, i, 3, 3]
+    return w.reshape(4 * cout, cin, 3, 3).to(w_eff.device)
 
 
 class Superresolution(nn.Module):
-    ready = False
+    ready = True
 
     def __init__(self, channels=3, img_resolution=512, sr_antialias=True):
         super().__init__()
         assert img_resolution == 512
+        assert channels == 3, "the radnerfs models instantiate Superresolution(channels=3)"
+        self.sr_antialias = sr_antialias
         self.input_resolution = 256
         self.w_dim = 16
+        self.conv_clamp = 256.0
+        self.block0 = _Block(channels, 128, self.w_dim, 256, up=1)
+        self.block1 = _Block(128, 64, self.w_dim, 512, up=2)
+        self.register_buffer("resample_filter", _setup_filter())
+        self._packed = None
 
-    def forward(self, rgb, **block_kwargs):
-        raise NotImplementedError("the StyleGAN2 super-resolution stage is not built yet (SURVEY.md 8f-1); "
-                                  "use result['rgb_map'] (256x256) of the *_sr models")
+    # -- packing (once per parameter version) -------------------------------------------------------------------------------------
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _pack(self):
+        fp = self._fingerprint()
+        if self._packed is not None and self._packed["fp"] == fp:
+            return self._packed
+        dev = self.resample_filter.device
+        if dev.type != "cuda":
+            raise GfppError("Superresolution: the module must live on the GPU (there is no CPU path)")
+        _lib.lib()
+        b0, b1 = self.block0, self.block1
+        keep = {
+            "w_first": _pack_first(b0.conv0.effective_weight()).to(dev),
+            "w_b0c1": _pack_conv3(b0.conv1.effective_weight(), 4).to(dev),
+            "w_up": _pack_conv3(_compose_up_weights(b1.conv0.effective_weight(), self.resample_filter.detach().cpu()), 4).to(dev),
+            "w_b1c1": _pack_conv3(b1.conv1.effective_weight(), 2).to(dev),
+            "bias": [l.bias.detach().float().contiguous() for l in (b0.conv0, b0.conv1, b1.conv0, b1.conv1)],
+            "rgb0_w": b0.torgb.effective_weight().float().contiguous(), "rgb0_b": b0.torgb.bias.detach().float().contiguous(),
+            "rgb1_w": b1.torgb.effective_weight().float().contiguous(), "rgb1_b": b1.torgb.bias.detach().float().contiguous(),
+            "x0": torch.empty(256, 256, 128, dtype=torch.float16, device=dev), "x1": torch.empty(256, 256, 128, dtype=torch.float16, device=dev),
+            "x2": torch.empty(512, 512, 64, dtype=torch.float16, device=dev), "img256": torch.empty(256, 256, 3, dtype=torch.float32, device=dev),
+        }
+        m = SrModel()
+        for k in ("w_first", "w_b0c1", "w_up", "w_b1c1", "rgb0_w", "rgb0_b", "rgb1_w", "rgb1_b"):
+            setattr(m, k, keep[k].data_ptr())
+        for i, l in enumerate((b0.conv0, b0.conv1, b1.conv0, b1.conv1)):
+            m.bias[i] = keep["bias"][i].data_ptr()
+            m.noise_strength[i] = float(l.noise_strength)
+        f2 = self.resample_filter.detach().double().cpu()
+        f1 = f2.sum(dim=0)                                # the filter is the outer product of its marginals (setup_filter, upfirdn2d.py:106)
+        if not torch.allclose(torch.outer(f1, f1), f2, atol=1e-7):
+            raise GfppError("Superresolution: resample_filter must be separable")
+        for i in range(4):
+            m.fir[i] = float(f1[i] * 2.0)                 # gain up^2 = 4 -> 2 per axis
+        m.conv_clamp = float(self.conv_clamp)
+        ws = SrWs()
+        for k in ("x0", "x1", "x2", "img256"):
+            setattr(ws, k, keep[k].data_ptr())
+        self._packed = {"fp": fp, "keep": keep, "model": m, "ws": ws}
+        return self._packed
+
+    # -- forward ------------------------------------------------------------------------------------------------------------------
+    def forward(self, rgb, noise_mode="random", **block_kwargs):
+        """rgb [1,3,256,256] in [0,1] -> [1,3,512,512] fp32 (radnerf_sr.py:30-43).  noise_mode: 'random' (the reference's default: a fresh
+        unit normal field per layer, scaled by the learned noise_strength), 'const' (the stored noise_const buffers) or 'none'."""
+        assert noise_mode in ("random", "const", "none")
+        if rgb.dim() != 4 or rgb.shape[0] != 1 or rgb.shape[1] != 3:
+            raise GfppError(f"Superresolution: expected rgb [1,3,H,W], got {tuple(rgb.shape)}")
+        if not rgb.is_cuda:
+            raise GfppError("Superresolution: input must be on the GPU (there is no CPU path)")
+        if rgb.shape[-1] < self.input_resolution:
+            rgb = F.interpolate(rgb, size=(self.input_resolution, self.input_resolution), mode="bilinear", align_corners=False,
+                                antialias=self.sr_antialias)
+        if rgb.shape[-1] != self.input_resolution or rgb.shape[-2] != self.input_resolution:
+            raise GfppError("Superresolution: input must be 256x256 (or smaller, then it is interpolated up like in the reference)")
+        P = self._pack()
+        x = rgb.detach().float().permute(0, 2, 3, 1).contiguous()               # NHWC view of the NeRF image: no copy when it came from render()
+        layers = (self.block0.conv0, self.block0.conv1, self.block1.conv0, self.block1.conv1)
+        if noise_mode == "const":
+            noises = [l.noise_const.detach().float().contiguous() for l in layers]
+        elif noise_mode == "random":
+            noises = [torch.randn(l.resolution, l.resolution, device=x.device) for l in layers]
+        else:
+            noises = None
+        arr = (c_p * 4)(*[n.data_ptr() for n in noises]) if noises is not None else None
+        out = torch.empty(512, 512, 3, dtype=torch.float32, device=x.device)
+        call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(P["ws"]), x.data_ptr(), arr, out.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        return out.permute(2, 0, 1).unsqueeze(0)                                # [1,3,512,512] view

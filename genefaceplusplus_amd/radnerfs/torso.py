@@ -203,6 +203,7 @@ class RADNeRFTorsowithSR(_TorsoBase):
 
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, upscale_torso=False, lm68=None, eye_area_percent=None, **kwargs):
+        sr_noise = kwargs.get("sr_noise_mode", "random")     # the reference always renders with the layers' default, 'random'
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
                                   eye_area_percent, True)
         side = self.sr_net.input_resolution          # 256: the reference hard-codes [1,256,256,3] (radnerf_torso_sr.py:219,229)
@@ -213,9 +214,9 @@ class RADNeRFTorsowithSR(_TorsoBase):
         if out["deform"] is not None:
             res["deform"] = out["deform"]
         if self.sr_net.ready:
-            res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
+            res["sr_rgb_map"] = self.sr_net(rgb, noise_mode=sr_noise).clamp(0, 1)
             if upscale_torso:
-                res["sr_torso_rgb_map"] = self.sr_net(torso_bg.clone()).clamp(0, 1)
+                res["sr_torso_rgb_map"] = self.sr_net(torso_bg, noise_mode=sr_noise).clamp(0, 1)
         return res
 
 

@@ -214,3 +214,40 @@ def synthetic_frame_inputs(hp, frame_idx=0, seed=0):
     lm68 = rng.uniform(0.3, 0.7, (136,)).astype(f32)
     eye = np.array([[0.3]], f32)
     return {"cond": cond, "lm68": lm68, "eye_area_percent": eye}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# super-resolution net of the *_sr models (radnerf_sr.py:14-43): same key names / shapes / dtypes as the reference's
+# Superresolution(channels=3).state_dict(), deterministic values.  Kept apart from synthetic_state_dict so that the NeRF
+# fixtures do not depend on it.
+# ---------------------------------------------------------------------------------------------------------------------
+SR_LAYERS = (  # name, out, in, kernel, resolution (None = no noise: ToRGB), up
+    ("block0.conv0", 128, 3, 3, 256), ("block0.conv1", 128, 128, 3, 256), ("block0.torgb", 3, 128, 1, None),
+    ("block1.conv0", 64, 128, 3, 512), ("block1.conv1", 64, 64, 3, 512), ("block1.torgb", 3, 64, 1, None))
+
+
+def sr_resample_filter():
+    """upfirdn2d.setup_filter([1,3,3,1]) (upfirdn2d.py:74-121): outer product, normalised to sum 1."""
+    f = np.array([1, 3, 3, 1], f32)
+    f2 = np.outer(f, f)
+    return (f2 / f2.sum()).astype(f32)
+
+
+def synthetic_sr_state(seed=4321, prefix="sr_net.", w_dim=16):
+    rng = np.random.default_rng(seed)
+    sd = {}
+    filt = sr_resample_filter()
+    sd[prefix + "resample_filter"] = filt.copy()
+    for blk in ("block0", "block1"):
+        sd[prefix + blk + ".resample_filter"] = filt.copy()
+    for name, o, i, k, res in SR_LAYERS:
+        p = prefix + name
+        sd[p + ".weight"] = rng.standard_normal((o, i, k, k)).astype(f32)
+        sd[p + ".bias"] = (0.1 * rng.standard_normal(o)).astype(f32)
+        sd[p + ".affine.weight"] = rng.standard_normal((i, w_dim)).astype(f32)
+        sd[p + ".affine.bias"] = (1.0 + 0.1 * rng.standard_normal(i)).astype(f32)
+        if res is not None:
+            sd[p + ".noise_strength"] = np.array(0.05 + 0.05 * rng.random(), f32)
+            sd[p + ".resample_filter"] = filt.copy()
+            sd[p + ".noise_const"] = rng.standard_normal((res, res)).astype(f32)
+    return sd

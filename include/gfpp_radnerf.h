@@ -377,6 +377,38 @@ int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, 
                         const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
                         float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Super-resolution stage of the *_sr models: replaces Superresolution.forward (modules/radnerfs/radnerf_sr.py:30-43 =
+ * SynthesisBlockNoUp superresolution.py:159-258 + SynthesisBlock networks_stylegan2.py:375-478, layers :286-371, modulated_conv2d
+ * :37-94, conv2d_resample.py:47-147, upfirdn2d.py:330-355, bias_act.py:95-125).  ws = ones there, so the styles are constants: the
+ * caller folds modulation / demodulation (and, for block1.conv0, transposed convolution + FIR) into the weights, packed as f16 MFMA
+ * fragments  F[pass][tap 9][step Cin/16][tile NT][lane][e] = W_eff[pass*32*NT + 32*t + (lane & 31)][16*s + 8*(lane >> 5) + e][tap / 3][tap % 3].
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct gfpp_sr_model {
+    const void *w_first;   /* block0.conv0  3 -> 128: [2 steps][4 tiles][64][8] f16, k = 3*tap + channel (27 of 32 used) */
+    const void *w_b0c1;    /* block0.conv1  128 -> 128: NT = 4, 1 pass */
+    const void *w_up;      /* block1.conv0  128 -> 4 phases x 64 (output pixel (2y + py, 2x + px), channel = 64*(2*py + px) + o): NT = 4, 2 passes */
+    const void *w_b1c1;    /* block1.conv1  64 -> 64: NT = 2, 1 pass */
+    const float *bias[4];  /* per layer, in the order above: [128], [128], [64], [64] */
+    float noise_strength[4];
+    const float *rgb0_w, *rgb0_b; /* block0.torgb: modulated 1x1 weights [128][3], bias [3] */
+    const float *rgb1_w, *rgb1_b; /* block1.torgb: [64][3], [3] */
+    float fir[4];          /* 1-D taps of the (separable) resample filter times the per-axis gain 2: [1,3,3,1]/8 * 2 */
+    float conv_clamp;      /* 256 */
+} gfpp_sr_model;
+
+typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
+    void *x0;      /* [256][256][128] f16 */
+    void *x1;      /* [256][256][128] f16 */
+    void *x2;      /* [512][512][64]  f16 */
+    float *img256; /* [256][256][3]   f32 */
+} gfpp_sr_ws;
+
+/* replaces Superresolution.forward (radnerf_sr.py:30-43).  rgb_in [256][256][3] f32 (NHWC, values in [0,1]) -> rgb_out [512][512][3] f32.  noise: NULL (noise_mode 'none') or 4 device pointers to
+ * the per-layer noise fields [256^2], [256^2], [512^2], [512^2] f32 (noise_const, or fresh unit normals for noise_mode 'random'). */
+int gfpp_sr_forward(const gfpp_sr_model *model, const gfpp_sr_ws *ws, const float *rgb_in, const float *const noise[4], float *rgb_out,
+                    gfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,3 +251,27 @@ def test_cond_feat_kernel_matches_oracle(dev, oracle_mod, variant):
     assert got.shape == torch_path.shape
     np.testing.assert_allclose(got.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(got.cpu().numpy(), torch_path.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("noise_mode", ["const", "none"])
+def test_superresolution_matches_oracle(dev, noise_mode):
+    """gfpp_sr_forward (folded weights, f16 MFMA convolutions) vs the fp32 oracle of the reference's Superresolution.  The reference runs
+    these blocks in fp16 on the GPU; stated tolerance vs fp32: PSNR >= 50 dB over the output range and max-abs <= 4e-2."""
+    from oracle import sr_oracle
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    net = Superresolution(channels=3)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    net = net.to(dev).eval()
+    rng = np.random.default_rng(5)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 256, dtype=np.float32), np.linspace(0, 1, 256, dtype=np.float32), indexing="ij")
+    x = np.stack([0.5 + 0.5 * np.sin(9 * xx + 3 * yy), yy * xx, rng.random((256, 256), dtype=np.float32)], 0)[None].astype(np.float32)
+    ref = sr_oracle.superresolution(x, sd, prefix="", noise_mode=noise_mode)
+    with torch.no_grad():
+        got = net(torch.from_numpy(x).to(dev), noise_mode=noise_mode).cpu().numpy()
+    assert got.shape == ref.shape == (1, 3, 512, 512)
+    err = np.abs(got - ref)
+    span = float(ref.max() - ref.min())
+    psnr = 10 * np.log10(span ** 2 / float(np.mean((got - ref) ** 2)))
+    print("sr", noise_mode, "max", float(err.max()), "mean", float(err.mean()), "psnr", psnr, "range", float(ref.min()), float(ref.max()))
+    assert psnr >= 50.0 and err.max() <= 4e-2, (psnr, float(err.max()))

@@ -112,3 +112,27 @@ def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert not np.array_equal(outs["graph"][0]["rgb_map"], outs["graph"][1]["rgb_map"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_sr_frame_end_to_end(dev, oracle_mod, precision):
+    """RADNeRFTorsowithSR.render with the super-resolution stage on (the configuration of the released May checkpoint): sr_rgb_map
+    [1,3,512,512] vs the oracle chain (NeRF frame oracle -> oracle/sr_oracle.py), noise_mode 'const' for determinism."""
+    from oracle import sr_oracle
+    case = frame_case("may_torso_sr", 256)
+    ref = oracle_render(oracle_mod, case)
+    sr_sd = __import__("genefaceplusplus_amd.synthetic", fromlist=["x"]).synthetic_sr_state()
+    ref_rgb = np.transpose(ref["rgb_map"].reshape(1, 256, 256, 3), (0, 3, 1, 2)).astype(np.float32)
+    ref_sr = np.clip(sr_oracle.superresolution(ref_rgb, sr_sd, noise_mode="const"), 0.0, 1.0)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    case2 = dict(case)
+    case2["hp"] = dict(case["hp"], sr_noise_mode="const")
+    res = product_render(model, case2, dev, "oracle", oracle_mod)
+    assert "sr_rgb_map" in res and tuple(res["sr_rgb_map"].shape) == (1, 3, 512, 512)
+    got = res["sr_rgb_map"].float().cpu().numpy()
+    err = np.abs(got - ref_sr)
+    psnr = 10 * np.log10(1.0 / float(np.mean((got - ref_sr) ** 2)))
+    print("sr frame", precision, "max", float(err.max()), "mean", float(err.mean()), "psnr", psnr)
+    assert psnr >= (55.0 if precision == "fp32" else 42.0), psnr
+    assert (err.max(axis=1) > (2e-2 if precision == "fp32" else 8e-2)).mean() <= 1e-3

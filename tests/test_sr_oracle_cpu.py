@@ -1,0 +1,52 @@
+"""Super-resolution stage: the oracle restatement (oracle/sr_oracle.py) against golden vectors produced by the
+reference's own Superresolution module (tests/golden/make_golden_sr.py), and the product's state-dict layout against the reference's."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from genefaceplusplus_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "sr_golden.npz"))
+
+
+def _inputs():
+    rng = np.random.default_rng(11)
+    a = rng.random((1, 3, 256, 256)).astype(np.float32)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 256, dtype=np.float32), np.linspace(0, 1, 256, dtype=np.float32), indexing="ij")
+    b = np.stack([0.5 + 0.5 * np.sin(9 * xx + 3 * yy), yy * xx, 0.25 + 0.5 * (np.cos(17 * yy) > 0)], 0)[None].astype(np.float32)
+    return {"noise": a, "smooth": b}
+
+
+@pytest.mark.parametrize("name", ["noise", "smooth"])
+@pytest.mark.parametrize("mode", ["const", "none"])
+def test_sr_oracle_reproduces_reference(golden, name, mode):
+    from oracle import sr_oracle
+    sd = syn.synthetic_sr_state(prefix="sr_net.")
+    y = sr_oracle.superresolution(_inputs()[name], sd, noise_mode=mode)
+    assert y.shape == (1, 3, 512, 512) and y.dtype == np.float32
+    crops = np.stack([y[0, :, r:r + 32, c:c + 32] for r, c in golden["crops"]])
+    np.testing.assert_allclose(crops, golden[f"{name}.{mode}.crops"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y.astype(np.float64).sum(axis=(0, 2, 3)), golden[f"{name}.{mode}.sum"], rtol=1e-5, atol=0.5)
+    np.testing.assert_allclose(np.abs(y).astype(np.float64).sum(axis=(0, 2, 3)), golden[f"{name}.{mode}.abs_sum"], rtol=1e-5)
+
+
+def test_sr_state_layout_matches_reference():
+    """sr_net.* keys / shapes / dtypes of the product's SR models == the reference's Superresolution(channels=3).state_dict()."""
+    import torch
+    from genefaceplusplus_amd import radnerfs
+    from genefaceplusplus_amd.configs import may_hparams
+    manifest = json.load(open(os.path.join(HERE, "golden", "sr_state_manifest.json")))
+    for cls, variant in ((radnerfs.RADNeRFTorsowithSR, "may_torso_sr"),):
+        model = cls(may_hparams(variant))
+        mine = {k[len("sr_net."):]: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items() if k.startswith("sr_net.")}
+        assert mine == manifest
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synthetic_sr_state().items()}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all(not k.startswith("sr_net.") for k in missing)
