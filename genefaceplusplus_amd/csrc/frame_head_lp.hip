@@ -333,7 +333,22 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
     n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t rays_per_tile = (uint32_t)kLpSlots / n_step < (uint32_t)kLpRays ? (uint32_t)kLpSlots / n_step : (uint32_t)kLpRays;
+    // Rays per wavefront tile: at most 64 (128 sample slots).  A wavefront works through its tiles' 32-sample blocks one after the other,
+    // so the launch lasts (tiles per wavefront) x (blocks per tile) block times: take the largest tile that minimises that product --
+    // few large tiles would leave most wavefronts idle behind a 4-block critical path (small frames, late trips), many small ones only
+    // add per-tile overhead.
+    const uint32_t waves_total = gridDim.x * kLpWaves;
+    uint32_t rays_per_tile = (uint32_t)kLpSlots / n_step < (uint32_t)kLpRays ? (uint32_t)kLpSlots / n_step : (uint32_t)kLpRays;
+    {
+        uint32_t best = 0xFFFFFFFFu, best_rpt = rays_per_tile;
+        for (uint32_t rpt = rays_per_tile; rpt * n_step >= 32u || rpt == rays_per_tile; rpt >>= 1) {
+            const uint32_t tiles = (n_alive + rpt - 1) / rpt;
+            const uint32_t crit = ((tiles + waves_total - 1) / waves_total) * ((rpt * n_step + 31u) / 32u);
+            if (crit < best) { best = crit; best_rpt = rpt; }
+            if (rpt == 1u) break;
+        }
+        rays_per_tile = best_rpt;
+    }
     const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
     if ((uint32_t)blockIdx.x * kLpWaves >= n_tiles) return;   // no tile for any wavefront of this workgroup
 

@@ -118,7 +118,9 @@ class _TorsoBase(RADNeRF):
         return {"image": image.clamp(0, 1), "depth": depth, "torso_alpha": torso_alpha, "torso_bg": torso_bg, "deform": deform}
 
     def _render_common(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                       eye_area_percent, use_head_for_torso):
+                       eye_area_percent, use_head_for_torso, post=None, post_key=()):
+        """`post(out)`: extra device work on the pipeline's result dict (the SR stage), issued inside the frame so that it is part of the
+        captured graph; `post_key` distinguishes graphs captured with different post work."""
         self._require_inference()
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -130,20 +132,27 @@ class _TorsoBase(RADNeRF):
                 def cond_feat():                                                        # runs on the pipeline's side stream
                     with torch.no_grad():
                         return self.cal_cond_feat(cond, eye_area_percent=eye)
-                return self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
-                                                         max_steps, T_thresh, bg_color, use_head_for_torso)
+                o = self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
+                                                      max_steps, T_thresh, bg_color, use_head_for_torso)
+                if post is not None:
+                    post(o)
+                return o
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_coords": bg_coords, "poses": poses,
                       "lm68": lm68, "bg_color": bg_color}
             if self.use_graph and not torch.is_grad_enabled():
-                out = self.pipeline().graphed(("torso", float(dt_gamma), int(max_steps), float(T_thresh), bool(use_head_for_torso)), frame, inputs)
+                out = self.pipeline().graphed(("torso", float(dt_gamma), int(max_steps), float(T_thresh), bool(use_head_for_torso)) + tuple(post_key),
+                                              frame, inputs)
             else:
                 out = frame(**inputs)
             if self.return_deform:
                 # the reference returns dx of the masked pixels only ([P,2]); compacting needs a host sync, hence opt-in
                 out["deform"] = out["deform_dense"][out["torso_mask"].bool()]
             return out
-        return self._render_staged(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                                   eye_area_percent, use_head_for_torso)
+        out = self._render_staged(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                                  eye_area_percent, use_head_for_torso)
+        if post is not None:
+            post(out)
+        return out
 
 
 class RADNeRFTorso(_TorsoBase):
@@ -204,19 +213,26 @@ class RADNeRFTorsowithSR(_TorsoBase):
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, upscale_torso=False, lm68=None, eye_area_percent=None, **kwargs):
         sr_noise = kwargs.get("sr_noise_mode", "random")     # the reference always renders with the layers' default, 'random'
-        out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                                  eye_area_percent, True)
         side = self.sr_net.input_resolution          # 256: the reference hard-codes [1,256,256,3] (radnerf_torso_sr.py:219,229)
+
+        def superresolve(o):
+            if self.sr_net.ready:
+                o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
+                if upscale_torso:
+                    o["sr_torso_rgb"] = self.sr_net(o["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
+
+        out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
+                                  eye_area_percent, True, post=superresolve, post_key=("sr", sr_noise, bool(upscale_torso)))
         rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         torso_bg = out["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": torso_bg, "depth_map": out["depth"].view(*rays_o.shape[:-1]),
                "rgb_map": rgb}
         if out["deform"] is not None:
             res["deform"] = out["deform"]
-        if self.sr_net.ready:
-            res["sr_rgb_map"] = self.sr_net(rgb, noise_mode=sr_noise).clamp(0, 1)
-            if upscale_torso:
-                res["sr_torso_rgb_map"] = self.sr_net(torso_bg, noise_mode=sr_noise).clamp(0, 1)
+        if "sr_rgb" in out:
+            res["sr_rgb_map"] = out["sr_rgb"]
+        if "sr_torso_rgb" in out:
+            res["sr_torso_rgb_map"] = out["sr_torso_rgb"]
         return res
 
 
