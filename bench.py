@@ -260,6 +260,47 @@ def main():
             dt = time.perf_counter() - t1
             modes[prec] = {"value": round(n_m / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_m, 4), "steps": n_m}
         model.precision = args.precision
+        if args.variant == "may_torso" and HW == 512:
+            # the released May checkpoint's shape: 256^2 rays, landmark-conditioned head-aware torso, StyleGAN2 super-resolution to 512^2
+            try:
+                hp_sr = may_hparams("may_torso_sr")
+                sd_sr = dict(syn.synthetic_state_dict(hp_sr, "may_torso_sr"))
+                sd_sr.update(syn.synthetic_sr_state())
+                m_sr = getattr(radnerfs, CLASSES["may_torso_sr"])(hp_sr)
+                m_sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_sr.items()}, strict=True)
+                m_sr = m_sr.to(dev).eval()
+                m_sr.precision, m_sr.use_graph = args.precision, model.use_graph
+                bgc = camera.get_bg_coords(256, 256, dev)
+                bg256 = torch.full((1, 256 * 256, 3), 0.5, device=dev)
+                ins = []
+                for fidx in range(4):
+                    pose = torch.from_numpy(syn.synthetic_pose(fidx)).to(dev)[None]
+                    rays = camera.get_rays(pose, syn.intrinsics_for(256, 256), 256, 256)
+                    fi = syn.synthetic_frame_inputs(hp_sr, fidx)
+                    ins.append((rays["rays_o"], rays["rays_d"], torch.from_numpy(fi["cond"]).to(dev), camera.convert_poses(pose),
+                                torch.from_numpy(fi["lm68"]).to(dev), torch.from_numpy(fi["eye_area_percent"]).to(dev)))
+                u8 = torch.empty(512, 512, 3, dtype=torch.uint8, device=dev)
+
+                def render_sr(i):
+                    ro, rd, cond, poses6, lm, eye = ins[i % 4]
+                    with torch.no_grad():
+                        r = m_sr.render(ro, rd, cond, bgc, poses6, index=i, staged=False, bg_color=bg256, lm68=lm, perturb=False, force_all_rays=False,
+                                        T_thresh=0.01, eye_area_percent=eye, **hp_sr)
+                    frames.to_uint8_hwc(r["sr_rgb_map"].permute(0, 2, 3, 1).reshape(512, 512, 3), u8)
+                for i in range(4):
+                    render_sr(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(20):
+                    render_sr(i)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                modes["may_torso_sr"] = {"value": round(20 / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / 20, 4), "steps": 20,
+                                         "precision": args.precision,
+                                         "workload": "256x256 rays + landmark-conditioned head-aware torso + StyleGAN2 super-resolution -> 512x512 frame"}
+                del m_sr
+            except Exception as exc:
+                modes["may_torso_sr"] = {"value": None, "error": str(exc)}
         result["modes"] = modes
 
     # ---- HBM-side traffic of the trip launches: from the committed rocprofv3 --pmc pass of this same workload ---------------------------

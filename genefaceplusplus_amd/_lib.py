@@ -29,6 +29,15 @@ _SIGNATURES = {
     "gfpp_grid_encode_forward": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_u32, c_i, c_u32, c_i, c_p],
     "gfpp_sh_encode_forward": [c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p],
     "gfpp_freq_encode_forward": [c_p, c_u32, c_u32, c_u32, c_u32, c_p, c_p],
+    "gfpp_march_rays_train": [c_p, c_p, c_p, c_f, c_f, c_u32, c_u32, c_u32, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gfpp_march_rays_train_backward": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_p, c_p, c_p],
+    "gfpp_composite_rays_train_forward": [c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_f, c_p, c_p, c_p, c_p, c_p],
+    "gfpp_composite_rays_train_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_f, c_p, c_p, c_p, c_p],
+    "gfpp_morton3D_dilation": [c_p, c_u32, c_u32, c_p, c_p],
+    "gfpp_sph_from_ray": [c_p, c_p, c_f, c_u32, c_p, c_p],
+    "gfpp_grid_encode_dydx": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_u32, c_p],
+    "gfpp_grid_encode_backward": [c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
+    "gfpp_grad_total_variation": [c_p, c_p, c_p, c_p, c_f, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_p],
     "gfpp_get_rays": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_p],
     "gfpp_rgb_to_u8": [c_p, ctypes.c_uint64, c_p, c_p],
 }

@@ -61,6 +61,46 @@ def _training_only(name):
     return fn
 
 
+def sph_from_ray(rays_o, rays_d, radius, N, coords):                                             # raymarching.h:8
+    call("gfpp_sph_from_ray", _p(rays_o), _p(rays_d), float(radius), int(N), _p(coords), _st())
+
+
+def morton3D_dilation(grid, C, H, grid_dilation):                                                # raymarching.h:11
+    call("gfpp_morton3D_dilation", _p(grid), int(C), int(H), _p(grid_dilation), _st())
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):   # raymarching.h:12
+    call("gfpp_march_rays_train", _p(rays_o), _p(rays_d), _p(grid), float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H), int(M),
+         _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter), _p(noises), _st())
+
+
+def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):   # raymarching.h:13
+    call("gfpp_march_rays_train_backward", _p(grad_xyzs), _p(grad_dirs), _p(rays), _p(deltas), int(N), int(M), _p(grad_rays_o), _p(grad_rays_d), _st())
+
+
+def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):   # raymarching.h:14
+    call("gfpp_composite_rays_train_forward", _p(sigmas), _p(rgbs), _p(ambient), _p(deltas), _p(rays), int(M), int(N), float(T_thresh), _p(weights_sum),
+         _p(ambient_sum), _p(depth), _p(image), _st())
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image, M, N,
+                                  T_thresh, grad_sigmas, grad_rgbs, grad_ambient):               # raymarching.h:15
+    call("gfpp_composite_rays_train_backward", _p(grad_weights_sum), _p(grad_ambient_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(ambient), _p(deltas),
+         _p(rays), _p(weights_sum), _p(ambient_sum), _p(image), int(M), int(N), float(T_thresh), _p(grad_sigmas), _p(grad_rgbs), _p(grad_ambient), _st())
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):   # gridencoder.h:13
+    if embeddings.dtype != torch.float32:
+        raise NotImplementedError("grid_encode_backward: fp32 tables only (train without autocast)")
+    call("gfpp_grid_encode_backward", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), int(B), int(D), int(C), int(L), float(S), int(H),
+         _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st())
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):   # gridencoder.h:15
+    call("gfpp_grad_total_variation", _p(inputs), _p(embeddings), _p(grad), _p(offsets), float(weight), int(B), int(D), int(C), int(L), float(S), int(H),
+         int(gridtype), int(bool(align_corners)), _st())
+
+
 # ---- _gridencoder / _shencoder / _freqencoder ------------------------------------------------------------------------
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
     dtype = {torch.float32: 0, torch.float16: 1}[embeddings.dtype]
@@ -84,14 +124,12 @@ def _module(name, fns):
 
 def install():
     rm = dict(near_far_from_aabb=near_far_from_aabb, morton3D=morton3D, morton3D_invert=morton3D_invert, packbits=packbits,
-              march_rays=march_rays, composite_rays=composite_rays)
-    for n in ("sph_from_ray", "morton3D_dilation", "march_rays_train", "march_rays_train_backward", "composite_rays_train_forward",
-              "composite_rays_train_backward"):
-        rm[n] = _training_only(n)
+              march_rays=march_rays, composite_rays=composite_rays, sph_from_ray=sph_from_ray, morton3D_dilation=morton3D_dilation,
+              march_rays_train=march_rays_train, march_rays_train_backward=march_rays_train_backward,
+              composite_rays_train_forward=composite_rays_train_forward, composite_rays_train_backward=composite_rays_train_backward)
     sys.modules["_raymarching_face"] = _module("_raymarching_face", rm)
-    sys.modules["_gridencoder"] = _module("_gridencoder", dict(grid_encode_forward=grid_encode_forward,
-                                                                 grid_encode_backward=_training_only("grid_encode_backward"),
-                                                                 grad_total_variation=_training_only("grad_total_variation")))
+    sys.modules["_gridencoder"] = _module("_gridencoder", dict(grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward,
+                                                                 grad_total_variation=grad_total_variation))
     sys.modules["_shencoder"] = _module("_shencoder", dict(sh_encode_forward=sh_encode_forward, sh_encode_backward=_training_only("sh_encode_backward")))
     sys.modules["_freqencoder"] = _module("_freqencoder", dict(freq_encode_forward=freq_encode_forward,
                                                                  freq_encode_backward=_training_only("freq_encode_backward")))

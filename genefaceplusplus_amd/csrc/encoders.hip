@@ -96,7 +96,11 @@ GFPP_API int gfpp_grid_encode_forward(const float *inputs, const void *embedding
                                       int align_corners, uint32_t interp, int dtype, gfpp_stream_t stream) {
     if (B == 0 || L == 0) return 0;
     if (!inputs || !embeddings || !offsets || !outputs) { set_error("gfpp_grid_encode_forward: null pointer"); return GFPP_EINVAL; }
-    if (dy_dx) { set_error("gfpp_grid_encode_forward: dy_dx (input gradients) is a training feature, not built"); return GFPP_EUNSUPPORTED; }
+    if (dy_dx) {   // the optional second output of the reference's grid_encode_forward (gridencoder.cu:198-243)
+        if (dtype != GFPP_F32) { set_error("gfpp_grid_encode_forward: dy_dx is available for fp32 tables only"); return GFPP_EUNSUPPORTED; }
+        const int rc = gfpp_grid_encode_dydx(inputs, (const float *)embeddings, offsets, (float *)dy_dx, B, D, C, L, S, H, gridtype, align_corners, interp, stream);
+        if (rc) return rc;
+    }
     if (L > kMaxLevels || gridtype > 1 || interp > 1) { set_error("gfpp_grid_encode_forward: L<=32, gridtype in {0,1}, interp in {0,1}"); return GFPP_EINVAL; }
     LevelScales ls;
     for (uint32_t l = 0; l < L; ++l) {

@@ -1,0 +1,463 @@
+// train.hip -- training-side kernels behind the reference's `_raymarching_face` and `_gridencoder` extension APIs:
+//   march_rays_train (+ backward), composite_rays_train forward / backward, morton3D_dilation, sph_from_ray        raymarching.cu:162-820
+//   grid_encode dy_dx, grid_encode_backward (table gradient + input gradient), grad_total_variation                 gridencoder.cu:198-368, 505-609
+// One thread per ray / per (point, level); 256-thread workgroups.  Arithmetic follows the reference expression by expression with the
+// same explicit-fmaf policy as the inference kernels, so the CPU restatement used by the tests agrees bit for bit wherever no
+// atomic summation order is involved (table gradients are sums of atomics: equal up to fp32 reassociation).
+#include <hip/hip_runtime.h>
+
+#include "grid_device.h"
+#include "march_device.h"
+
+namespace gfpp {
+
+constexpr int kTrBlock = 256;
+
+// ---- march_rays_train: two passes per ray (count, then write), ranges handed out with atomics -----------------------------------
+__global__ __launch_bounds__(kTrBlock) void k_march_rays_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                              const uint8_t *__restrict__ bitfield, MarchParams mp, uint32_t max_steps, uint32_t N,
+                                                              uint32_t M, const float *__restrict__ nears, const float *__restrict__ fars,
+                                                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                              int32_t *__restrict__ rays, int32_t *__restrict__ counter,
+                                                              const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= N) return;
+    const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;
+    const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+    const float far = fars[n];
+    float t0 = nears[n];
+    t0 = fmaf(clampf(t0 * mp.dt_gamma, mp.dt_min, mp.dt_max), noises[n], t0);
+    float t = t0;
+    const uint32_t num_steps = march_one_ray(ox, oy, oz, dx, dy, dz, t, far, max_steps, bitfield, mp, [](uint32_t, const Sample &) {});
+    const uint32_t point_index = (uint32_t)atomicAdd(&counter[0], (int)num_steps);
+    const uint32_t ray_index = (uint32_t)atomicAdd(&counter[1], 1);
+    rays[3ull * ray_index] = (int32_t)n;
+    rays[3ull * ray_index + 1] = (int32_t)point_index;
+    rays[3ull * ray_index + 2] = (int32_t)num_steps;
+    if (num_steps == 0 || point_index + num_steps > M) return;
+    float *px = xyzs + 3ull * point_index, *pd = dirs + 3ull * point_index, *pt = deltas + 2ull * point_index;
+    t = t0;
+    march_one_ray(ox, oy, oz, dx, dy, dz, t, far, num_steps, bitfield, mp, [&](uint32_t s, const Sample &smp) {
+        px[3 * s] = smp.x; px[3 * s + 1] = smp.y; px[3 * s + 2] = smp.z;
+        pd[3 * s] = dx; pd[3 * s + 1] = dy; pd[3 * s + 2] = dz;
+        pt[2 * s] = smp.dt; pt[2 * s + 1] = smp.t_end;
+    });
+}
+
+__global__ __launch_bounds__(kTrBlock) void k_march_rays_train_backward(const float *__restrict__ grad_xyzs, const float *__restrict__ grad_dirs,
+                                                                       const int32_t *__restrict__ rays, const float *__restrict__ deltas, uint32_t N,
+                                                                       uint32_t M, float *__restrict__ grad_rays_o, float *__restrict__ grad_rays_d) {
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    float go[3], gd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { go[k] = grad_rays_o[3ull * n + k]; gd[k] = grad_rays_d[3ull * n + k]; }
+    for (uint32_t s = 0; s < num_steps; ++s) {
+        const float *gx = grad_xyzs + 3ull * (offset + s), *gdir = grad_dirs + 3ull * (offset + s);
+        const float tend = deltas[2ull * (offset + s) + 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            go[k] += gx[k];
+            gd[k] += fmaf(gx[k], tend, gdir[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { grad_rays_o[3ull * n + k] = go[k]; grad_rays_d[3ull * n + k] = gd[k]; }
+}
+
+// ---- composite_rays_train ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTrBlock) void k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                                 const float *__restrict__ ambient, const float *__restrict__ deltas,
+                                                                 const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh,
+                                                                 float *__restrict__ weights_sum, float *__restrict__ ambient_sum,
+                                                                 float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f, ws = 0.0f, d = 0.0f, amb = 0.0f;
+    if (!(num_steps == 0 || offset + num_steps > M)) {
+        for (uint32_t s = 0; s < num_steps; ++s) {
+            const size_t k = offset + s;
+            const float alpha = 1.0f - __expf(-sigmas[k] * deltas[2 * k]);
+            const float weight = alpha * T;
+            r = fmaf(weight, rgbs[3 * k], r);
+            g = fmaf(weight, rgbs[3 * k + 1], g);
+            b = fmaf(weight, rgbs[3 * k + 2], b);
+            d = fmaf(weight, deltas[2 * k + 1], d);
+            ws += weight;
+            amb += ambient[k];
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[index] = ws;
+    ambient_sum[index] = amb;
+    depth[index] = d;
+    image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
+}
+
+__global__ __launch_bounds__(kTrBlock) void k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_ambient_sum,
+                                                                 const float *__restrict__ grad_image, const float *__restrict__ sigmas,
+                                                                 const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                                 const int32_t *__restrict__ rays, const float *__restrict__ weights_sum,
+                                                                 const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+                                                                 float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs,
+                                                                 float *__restrict__ grad_ambient) {
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index], gamb = grad_ambient_sum[index];
+    const float gi0 = grad_image[3ull * index], gi1 = grad_image[3ull * index + 1], gi2 = grad_image[3ull * index + 2];
+    const float r_final = image[3ull * index], g_final = image[3ull * index + 1], b_final = image[3ull * index + 2], ws_final = weights_sum[index];
+    float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t s = 0; s < num_steps; ++s) {
+        const size_t k = offset + s;
+        const float c0 = rgbs[3 * k], c1 = rgbs[3 * k + 1], c2 = rgbs[3 * k + 2], dt = deltas[2 * k];
+        const float alpha = 1.0f - __expf(-sigmas[k] * dt);
+        const float weight = alpha * T;
+        r = fmaf(weight, c0, r);
+        g = fmaf(weight, c1, g);
+        b = fmaf(weight, c2, b);
+        T *= 1.0f - alpha;
+        grad_rgbs[3 * k] = gi0 * weight; grad_rgbs[3 * k + 1] = gi1 * weight; grad_rgbs[3 * k + 2] = gi2 * weight;
+        grad_ambient[k] = gamb;
+        float acc = gi0 * fmaf(T, c0, -(r_final - r));
+        acc = fmaf(gi1, fmaf(T, c1, -(g_final - g)), acc);
+        acc = fmaf(gi2, fmaf(T, c2, -(b_final - b)), acc);
+        acc = fmaf(gws, 1.0f - ws_final, acc);
+        grad_sigmas[k] = dt * acc;
+        if (T < T_thresh) break;
+    }
+}
+
+// ---- density-grid upkeep ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTrBlock) void k_morton_dilation(const float *__restrict__ grid, uint32_t C, uint32_t H, float *__restrict__ out) {
+    const uint32_t H3 = H * H * H;
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= C * H3) return;
+    const uint32_t c = n / H3, ind = n - c * H3;
+    const uint32_t x = compact3(ind), y = compact3(ind >> 1), z = compact3(ind >> 2);
+    const float *g = grid + (size_t)c * H3;
+    float res = grid[n];
+    if (x + 1 < H) res = fmaxf(res, g[morton3(x + 1, y, z)]);
+    if (x > 0) res = fmaxf(res, g[morton3(x - 1, y, z)]);
+    if (y + 1 < H) res = fmaxf(res, g[morton3(x, y + 1, z)]);
+    if (y > 0) res = fmaxf(res, g[morton3(x, y - 1, z)]);
+    if (z + 1 < H) res = fmaxf(res, g[morton3(x, y, z + 1)]);
+    if (z > 0) res = fmaxf(res, g[morton3(x, y, z - 1)]);
+    out[n] = res;
+}
+
+__global__ __launch_bounds__(kTrBlock) void k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius, uint32_t N,
+                                                          float *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
+    if (n >= N) return;
+    constexpr float RPI = 0.3183098861837907f;
+    const float ox = rays_o[3ull * n], oy = rays_o[3ull * n + 1], oz = rays_o[3ull * n + 2];
+    const float dx = rays_d[3ull * n], dy = rays_d[3ull * n + 1], dz = rays_d[3ull * n + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float Cc = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+    const float t = (-B + sqrtf(fmaf(B, B, -(A * Cc)))) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+    const float phi = atan2f(z, x);
+    coords[2ull * n] = fmaf(2.0f * theta, RPI, -1.0f);
+    coords[2ull * n + 1] = phi * RPI;
+}
+
+// ---- grid encoder: per-(point, level) fractional position shared by dy_dx / backward / TV ---------------------------------------------
+struct TrLevels {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+template <int D>
+__device__ __forceinline__ bool tr_locate(const float *__restrict__ in, float scale, bool align_corners, uint32_t interp, float (&pos)[D],
+                                          float (&deriv)[D], uint32_t (&pg)[D]) {
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) inside = inside && !(in[d] < 0.0f || in[d] > 1.0f);
+    if (!inside) return false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float p = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)fl;
+        p -= (float)pg[d];
+        if (interp == 1) { deriv[d] = 6.0f * p * (1.0f - p); p = p * p * fmaf(-2.0f, p, 3.0f); }
+        else deriv[d] = 1.0f;
+        pos[d] = p;
+    }
+    return true;
+}
+
+// dy_dx [B, L, D, C] (gridencoder.cu:198-243)
+template <int D, int C>
+__global__ __launch_bounds__(kTrBlock) void k_grid_dydx(const float *__restrict__ inputs, const float *__restrict__ table, const int32_t *__restrict__ offsets,
+                                                       float *__restrict__ dy_dx, uint32_t B, uint32_t L, TrLevels lv, uint32_t gridtype,
+                                                       bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    float *out = dy_dx + ((size_t)b * L + level) * D * C;
+    float pos[D], deriv[D];
+    uint32_t pg[D];
+    const float scale = lv.scale[level];
+    if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) {
+#pragma unroll
+        for (int i = 0; i < D * C; ++i) out[i] = 0.0f;
+        return;
+    }
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    const float *grid = table + (size_t)off * C;
+#pragma unroll
+    for (int gd = 0; gd < D; ++gd) {
+        float rg[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) rg[c] = 0.0f;
+#pragma unroll
+        for (int idx = 0; idx < (1 << (D - 1)); ++idx) {
+            float w = scale;
+            uint32_t pl[D];
+#pragma unroll
+            for (int nd = 0; nd < D - 1; ++nd) {
+                const int d = (nd >= gd) ? nd + 1 : nd;
+                if ((idx & (1 << nd)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+            }
+            pl[gd] = pg[gd];
+            const uint32_t il = grid_row<D>(pl, gridtype, align_corners, size, res);
+            pl[gd] = pg[gd] + 1u;
+            const uint32_t ir = grid_row<D>(pl, gridtype, align_corners, size, res);
+#pragma unroll
+            for (int c = 0; c < C; ++c) rg[c] = fmaf(w * (grid[(size_t)ir * C + c] - grid[(size_t)il * C + c]), deriv[gd], rg[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[gd * C + c] = rg[c];
+    }
+}
+
+// table gradient: grad [L, B, C] scattered into grad_table with atomics (gridencoder.cu:247-340)
+template <int D, int C>
+__global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                           const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
+                                                           TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    float pos[D], deriv[D];
+    uint32_t pg[D];
+    if (!tr_locate<D>(inputs + (size_t)b * D, lv.scale[level], align_corners, interp, pos, deriv, pg)) return;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    float *gg = grad_table + (size_t)off * C;
+    float gc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gc[c] = grad[((size_t)level * B + b) * C + c];
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); ++idx) {
+        float w = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if ((idx & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+        }
+        const uint32_t row = grid_row<D>(pl, gridtype, align_corners, size, res);
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(&gg[(size_t)row * C + c], w * gc[c]);
+    }
+}
+
+// input gradient from dy_dx (gridencoder.cu:342-368)
+__global__ __launch_bounds__(kTrBlock) void k_grid_input_backward(const float *__restrict__ grad, const float *__restrict__ dy_dx, float *__restrict__ grad_inputs,
+                                                                 uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    const uint32_t t = blockIdx.x * kTrBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float *dd = dy_dx + (size_t)b * L * D * C;
+    float r = 0.0f;
+    for (uint32_t l = 0; l < L; ++l)
+        for (uint32_t c = 0; c < C; ++c) r = fmaf(grad[((size_t)l * B + b) * C + c], dd[(l * D + d) * C + c], r);
+    grad_inputs[t] = r;
+}
+
+// total-variation gradient (gridencoder.cu:505-597)
+template <int D, int C>
+__global__ __launch_bounds__(kTrBlock) void k_grad_tv(const float *__restrict__ inputs, const float *__restrict__ table, float *__restrict__ grad,
+                                                     const int32_t *__restrict__ offsets, float weight, uint32_t B, uint32_t L, TrLevels lv,
+                                                     uint32_t gridtype, bool align_corners) {
+    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const float *in = inputs + (size_t)b * D;
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) inside = inside && !(in[d] < 0.0f || in[d] > 1.0f);
+    if (!inside) return;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    const float *grid = table + (size_t)off * C;
+    float *gg = grad + (size_t)off * C;
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) pg[d] = (uint32_t)floorf(fmaf(in[d], lv.scale[level], align_corners ? 0.0f : 0.5f));
+    float results[C], idelta[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { results[c] = 0.0f; idelta[c] = 0.0f; }
+    const uint32_t row = grid_row<D>(pg, gridtype, align_corners, size, res);
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const uint32_t cur = pg[d];
+        if (cur < res) {
+            pg[d] = cur + 1u;
+            const uint32_t rr = grid_row<D>(pg, gridtype, align_corners, size, res);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float gv = grid[(size_t)row * C + c] - grid[(size_t)rr * C + c];
+                results[c] += gv;
+                idelta[c] = fmaf(gv, gv, idelta[c]);
+            }
+        }
+        if (cur > 0) {
+            pg[d] = cur - 1u;
+            const uint32_t rl = grid_row<D>(pg, gridtype, align_corners, size, res);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float gv = grid[(size_t)row * C + c] - grid[(size_t)rl * C + c];
+                results[c] += gv;
+                idelta[c] = fmaf(gv, gv, idelta[c]);
+            }
+        }
+        pg[d] = cur;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) atomicAdd(&gg[(size_t)row * C + c], w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f)));
+}
+
+static int tr_levels(TrLevels &lv, uint32_t L, float S, uint32_t H) {
+    if (L == 0 || L > (uint32_t)kMaxLevels) return GFPP_EINVAL;
+    GridLevels g;
+    fill_level_scales(g, L, S, H);
+    for (uint32_t l = 0; l < L; ++l) { lv.scale[l] = g.scale[l]; lv.resolution[l] = g.resolution[l]; }
+    return 0;
+}
+
+}  // namespace gfpp
+
+using namespace gfpp;
+
+GFPP_API int gfpp_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
+                                   uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
+                                   float *deltas, int32_t *rays, int32_t *counter, const float *noises, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !counter || !noises) { set_error("gfpp_march_rays_train: null pointer"); return GFPP_EINVAL; }
+    if (C < 1 || C > 8 || max_steps == 0) { set_error("gfpp_march_rays_train: cascade must be 1..8, max_steps > 0"); return GFPP_EINVAL; }
+    const MarchParams mp = make_march_params(bound, dt_gamma, max_steps, C, H);
+    hipLaunchKernelGGL(k_march_rays_train, dim3(div_up(N, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, rays_o, rays_d, grid, mp, max_steps, N, M, nears,
+                       fars, xyzs, dirs, deltas, rays, counter, noises);
+    return check_launch("gfpp_march_rays_train");
+}
+
+GFPP_API int gfpp_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays, const float *deltas, uint32_t N, uint32_t M,
+                                            float *grad_rays_o, float *grad_rays_d, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    if (!grad_xyzs || !grad_dirs || !rays || !deltas || !grad_rays_o || !grad_rays_d) { set_error("gfpp_march_rays_train_backward: null pointer"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_march_rays_train_backward, dim3(div_up(N, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, grad_xyzs, grad_dirs, rays, deltas, N, M,
+                       grad_rays_o, grad_rays_d);
+    return check_launch("gfpp_march_rays_train_backward");
+}
+
+GFPP_API int gfpp_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, uint32_t M,
+                                               uint32_t N, float T_thresh, float *weights_sum, float *ambient_sum, float *depth, float *image,
+                                               gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    if (!sigmas || !rgbs || !ambient || !deltas || !rays || !weights_sum || !ambient_sum || !depth || !image) { set_error("gfpp_composite_rays_train_forward: null pointer"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up(N, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh,
+                       weights_sum, ambient_sum, depth, image);
+    return check_launch("gfpp_composite_rays_train_forward");
+}
+
+GFPP_API int gfpp_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_ambient_sum, const float *grad_image, const float *sigmas,
+                                                const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, const float *weights_sum,
+                                                const float *ambient_sum, const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                                float *grad_rgbs, float *grad_ambient, gfpp_stream_t stream) {
+    (void)ambient; (void)ambient_sum;
+    if (N == 0) return 0;
+    if (!grad_weights_sum || !grad_ambient_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs || !grad_ambient) {
+        set_error("gfpp_composite_rays_train_backward: null pointer");
+        return GFPP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up(N, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, grad_weights_sum, grad_ambient_sum, grad_image, sigmas,
+                       rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_ambient);
+    return check_launch("gfpp_composite_rays_train_backward");
+}
+
+GFPP_API int gfpp_morton3D_dilation(const float *grid, uint32_t C, uint32_t H, float *grid_dilation, gfpp_stream_t stream) {
+    if (!grid || !grid_dilation || C == 0 || H == 0 || H > 1024) { set_error("gfpp_morton3D_dilation: bad arguments"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_morton_dilation, dim3(div_up(C * H * H * H, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, grid, C, H, grid_dilation);
+    return check_launch("gfpp_morton3D_dilation");
+}
+
+GFPP_API int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, gfpp_stream_t stream) {
+    if (N == 0) return 0;
+    if (!rays_o || !rays_d || !coords) { set_error("gfpp_sph_from_ray: null pointer"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(div_up(N, kTrBlock)), dim3(kTrBlock), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
+    return check_launch("gfpp_sph_from_ray");
+}
+
+#define GFPP_DISPATCH_DC(KERNEL, ...)                                                                                                  \
+    do {                                                                                                                                \
+        const dim3 grid_(div_up(B, kTrBlock), L), block_(kTrBlock);                                                                     \
+        if (D == 2 && C == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid_, block_, 0, st, __VA_ARGS__);                                    \
+        else if (D == 3 && C == 2) hipLaunchKernelGGL((KERNEL<3, 2>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else if (D == 2 && C == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else if (D == 3 && C == 1) hipLaunchKernelGGL((KERNEL<3, 1>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else if (D == 2 && C == 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else if (D == 3 && C == 4) hipLaunchKernelGGL((KERNEL<3, 4>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2 or 4 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; } \
+    } while (0)
+
+GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings, const int32_t *offsets, float *dy_dx, uint32_t B, uint32_t D, uint32_t C,
+                                   uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+    if (B == 0) return 0;
+    if (!inputs || !embeddings || !offsets || !dy_dx || gridtype > 1 || interp > 1) { set_error("gfpp_grid_encode_dydx: bad arguments"); return GFPP_EINVAL; }
+    TrLevels lv;
+    if (tr_levels(lv, L, S, H)) { set_error("gfpp_grid_encode_dydx: 1 <= L <= 32"); return GFPP_EINVAL; }
+    const hipStream_t st = (hipStream_t)stream;
+    GFPP_DISPATCH_DC(k_grid_dydx, inputs, embeddings, offsets, dy_dx, B, L, lv, gridtype, align_corners != 0, interp);
+    return check_launch("gfpp_grid_encode_dydx");
+}
+
+GFPP_API int gfpp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, float *grad_embeddings, uint32_t B,
+                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                                       int align_corners, uint32_t interp, gfpp_stream_t stream) {
+    (void)embeddings;
+    if (B == 0) return 0;
+    if (!grad || !inputs || !offsets || !grad_embeddings || gridtype > 1 || interp > 1 || ((dy_dx == nullptr) != (grad_inputs == nullptr))) {
+        set_error("gfpp_grid_encode_backward: bad arguments (dy_dx and grad_inputs go together)");
+        return GFPP_EINVAL;
+    }
+    TrLevels lv;
+    if (tr_levels(lv, L, S, H)) { set_error("gfpp_grid_encode_backward: 1 <= L <= 32"); return GFPP_EINVAL; }
+    const hipStream_t st = (hipStream_t)stream;
+    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp);
+    int rc = check_launch("gfpp_grid_encode_backward(table)");
+    if (rc || !dy_dx) return rc;
+    hipLaunchKernelGGL(k_grid_input_backward, dim3(div_up(B * D, kTrBlock)), dim3(kTrBlock), 0, st, grad, dy_dx, grad_inputs, B, D, C, L);
+    return check_launch("gfpp_grid_encode_backward(inputs)");
+}
+
+GFPP_API int gfpp_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t D,
+                                       uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, gfpp_stream_t stream) {
+    if (B == 0) return 0;
+    if (!inputs || !embeddings || !grad || !offsets || gridtype > 1) { set_error("gfpp_grad_total_variation: bad arguments"); return GFPP_EINVAL; }
+    TrLevels lv;
+    if (tr_levels(lv, L, S, H)) { set_error("gfpp_grad_total_variation: 1 <= L <= 32"); return GFPP_EINVAL; }
+    const hipStream_t st = (hipStream_t)stream;
+    GFPP_DISPATCH_DC(k_grad_tv, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, align_corners != 0);
+    return check_launch("gfpp_grad_total_variation");
+}

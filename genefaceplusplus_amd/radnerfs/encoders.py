@@ -3,7 +3,8 @@
 Same constructor arguments, attributes, parameter/buffer names (``embeddings``, ``offsets``) and output layouts as the
 reference's encoders/gridencoder/grid.py:96-164, encoders/shencoder/sphere_harmonics.py:61-87,
 encoders/freqencoder/freq.py:54-78 and the factory encoders/encoding.py:6-35 -- so reference checkpoints load
-unchanged -- but forward() runs our HIP kernels through the C ABI.  Forward only (no autograd).
+unchanged -- but forward() runs our HIP kernels through the C ABI.  The grid encoder is differentiable (table and input gradients,
+total-variation gradient); SH and frequency encodings are forward only (their inputs never require grad on the radnerfs paths).
 """
 import numpy as np
 import torch
@@ -38,6 +39,37 @@ def grid_encode_raw(inputs01, embeddings, offsets, per_level_scale, base_resolut
     call("gfpp_grid_encode_forward", inputs01.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S,
          int(base_resolution), None, int(gridtype_id), int(bool(align_corners)), int(interp_id), dtype, _stream())
     return out
+
+
+class _GridEncodeFn(torch.autograd.Function):
+    """Differentiable lookup (reference: _grid_encode, grid.py:24-94): gradients w.r.t. the table always, w.r.t. the inputs when they
+    require grad (then the forward also produces dy_dx).  fp32 tables (the reference casts to half under autocast; training here is fp32)."""
+
+    @staticmethod
+    def forward(ctx, inputs01, embeddings, offsets, per_level_scale, base_resolution, gridtype_id, align_corners, interp_id):
+        inputs01 = inputs01.float().contiguous()
+        emb = embeddings.float().contiguous()
+        B, D = inputs01.shape
+        L, C = offsets.shape[0] - 1, emb.shape[1]
+        S = float(np.log2(per_level_scale))
+        out = torch.empty(L, B, C, device=inputs01.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * C, device=inputs01.device, dtype=torch.float32) if inputs01.requires_grad else None
+        call("gfpp_grid_encode_forward", inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S, int(base_resolution),
+             dy_dx.data_ptr() if dy_dx is not None else None, int(gridtype_id), int(bool(align_corners)), int(interp_id), 0, _stream())
+        ctx.save_for_backward(inputs01, emb, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, int(base_resolution), int(gridtype_id), int(bool(align_corners)), int(interp_id))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs01, emb, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, ac, interp = ctx.dims
+        grad = grad.float().contiguous()
+        grad_emb = torch.zeros_like(emb)
+        grad_inputs = torch.zeros_like(inputs01) if dy_dx is not None else None
+        call("gfpp_grid_encode_backward", grad.data_ptr(), inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), grad_emb.data_ptr(), B, D, C, L, S, H,
+             dy_dx.data_ptr() if dy_dx is not None else None, grad_inputs.data_ptr() if grad_inputs is not None else None, gridtype, ac, interp, _stream())
+        return grad_inputs, grad_emb, None, None, None, None, None, None
 
 
 class GridEncoder(nn.Module):
@@ -90,10 +122,30 @@ class GridEncoder(nn.Module):
         inputs = (inputs + bound) / (2 * bound)
         prefix = list(inputs.shape[:-1])
         flat = inputs.reshape(-1, self.input_dim)
-        out = grid_encode_raw(flat, self.table(), self.offsets, self.per_level_scale, self.base_resolution, self.gridtype_id,
-                              self.align_corners, self.interp_id)
+        if torch.is_grad_enabled() and (self.embeddings.requires_grad or flat.requires_grad):
+            out = _GridEncodeFn.apply(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, self.gridtype_id,
+                                      self.align_corners, self.interp_id)
+        else:
+            out = grid_encode_raw(flat, self.table(), self.offsets, self.per_level_scale, self.base_resolution, self.gridtype_id,
+                                  self.align_corners, self.interp_id)
         B = flat.shape[0]
         return out.permute(1, 0, 2).reshape(B, self.output_dim).view(prefix + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """Adds the total-variation gradient of the cells visited by `inputs` (or B random points) to embeddings.grad (grid.py:166-189)."""
+        D, C, L = self.input_dim, self.embeddings.shape[1], self.offsets.shape[0] - 1
+        if inputs is None:
+            inputs = torch.rand(B, D, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).reshape(-1, D)
+        inputs = inputs.float().contiguous()
+        if self.embeddings.grad is None:
+            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
+        emb = self.embeddings.detach().float().contiguous()
+        call("gfpp_grad_total_variation", inputs.data_ptr(), emb.data_ptr(), self.embeddings.grad.data_ptr(), self.offsets.data_ptr(), float(weight),
+             inputs.shape[0], D, C, L, float(np.log2(self.per_level_scale)), int(self.base_resolution), self.gridtype_id, int(bool(self.align_corners)),
+             _stream())
 
 
 class SHEncoder(nn.Module):

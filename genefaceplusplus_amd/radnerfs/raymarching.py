@@ -105,3 +105,104 @@ def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, we
     call("gfpp_composite_rays", n_alive, n_step, float(T_thresh), rays_alive.data_ptr(), rays_t.data_ptr(), sigmas.data_ptr(),
          rgbs.data_ptr(), deltas.data_ptr(), weights_sum.data_ptr(), depth.data_ptr(), image.data_ptr(), _stream())
     return tuple()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training side (reference: raymarching.py:186-345; kernels raymarching.cu:162-820) -- same argument lists and return values
+# ---------------------------------------------------------------------------------------------------------------------
+def morton3D_dilation(grid):
+    """grid [C, H^3] f32 in Morton order -> 6-neighbour max pool (raymarching.py:131-152)."""
+    grid = _f32(grid, "grid")
+    C, H3 = grid.shape
+    H = int(round(H3 ** (1.0 / 3.0)))
+    out = torch.empty_like(grid)
+    call("gfpp_morton3D_dilation", grid.data_ptr(), C, H, out.data_ptr(), _stream())
+    return out
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    """-> coords [N,2] in [-1,1] (raymarching.py:50-78)."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    coords = torch.empty(rays_o.shape[0], 2, dtype=torch.float32, device=rays_o.device)
+    call("gfpp_sph_from_ray", rays_o.data_ptr(), rays_d.data_ptr(), float(radius), rays_o.shape[0], coords.data_ptr(), _stream())
+    return coords
+
+
+class _MarchRaysTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
+                align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+        rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+        _req(density_bitfield, torch.uint8, "density_bitfield")
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = mean_count
+        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        _req(step_counter, torch.int32, "step_counter")
+        noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else torch.zeros(N, dtype=torch.float32, device=dev)
+        call("gfpp_march_rays_train", rays_o.data_ptr(), rays_d.data_ptr(), density_bitfield.data_ptr(), float(bound), float(dt_gamma), int(max_steps),
+             N, int(C), int(H), M, _f32(nears, "nears").data_ptr(), _f32(fars, "fars").data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(),
+             rays.data_ptr(), step_counter.data_ptr(), noises.data_ptr(), _stream())
+        if force_all_rays or mean_count <= 0:
+            m = int(step_counter[0].item())          # D2H copy, as in the reference (raymarching.py:248)
+            if align > 0:
+                m += align - m % align
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        ctx.save_for_backward(rays, deltas)
+        return xyzs, dirs, deltas, rays
+
+    @staticmethod
+    def backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays):
+        rays, deltas = ctx.saved_tensors
+        N, M = rays.shape[0], grad_xyzs.shape[0]
+        grad_rays_o = torch.zeros(N, 3, device=rays.device)
+        grad_rays_d = torch.zeros(N, 3, device=rays.device)
+        call("gfpp_march_rays_train_backward", _f32(grad_xyzs, "grad_xyzs").data_ptr(), _f32(grad_dirs, "grad_dirs").data_ptr(), rays.data_ptr(),
+             deltas.contiguous().data_ptr(), N, M, grad_rays_o.data_ptr(), grad_rays_d.data_ptr(), _stream())
+        return (grad_rays_o, grad_rays_d) + (None,) * 13
+
+
+march_rays_train = _MarchRaysTrain.apply
+
+
+class _CompositeRaysTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, ambient, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs, ambient, deltas = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(ambient, "ambient"), _f32(deltas, "deltas")
+        _req(rays, torch.int32, "rays")
+        M, N = sigmas.shape[0], rays.shape[0]
+        dev = sigmas.device
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        ambient_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        call("gfpp_composite_rays_train_forward", sigmas.data_ptr(), rgbs.data_ptr(), ambient.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N,
+             float(T_thresh), weights_sum.data_ptr(), ambient_sum.data_ptr(), depth.data_ptr(), image.data_ptr(), _stream())
+        ctx.save_for_backward(sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image)
+        ctx.dims = (M, N, float(T_thresh))
+        return weights_sum, ambient_sum, depth, image
+
+    @staticmethod
+    def backward(ctx, grad_weights_sum, grad_ambient_sum, grad_depth, grad_image):
+        sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        gw, ga, gi = _f32(grad_weights_sum, "grad_weights_sum"), _f32(grad_ambient_sum, "grad_ambient_sum"), _f32(grad_image, "grad_image")
+        grad_sigmas, grad_rgbs, grad_ambient = torch.zeros_like(sigmas), torch.zeros_like(rgbs), torch.zeros_like(ambient)
+        call("gfpp_composite_rays_train_backward", gw.data_ptr(), ga.data_ptr(), gi.data_ptr(), sigmas.data_ptr(), rgbs.data_ptr(), ambient.data_ptr(),
+             deltas.data_ptr(), rays.data_ptr(), weights_sum.data_ptr(), ambient_sum.data_ptr(), image.data_ptr(), M, N, T_thresh, grad_sigmas.data_ptr(),
+             grad_rgbs.data_ptr(), grad_ambient.data_ptr(), _stream())
+        return grad_sigmas, grad_rgbs, grad_ambient, None, None, None
+
+
+composite_rays_train = _CompositeRaysTrain.apply

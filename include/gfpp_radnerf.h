@@ -378,6 +378,52 @@ int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, 
                         float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Section A.3 -- training-side entry points of _raymarching_face and _gridencoder.  Same conventions as Section A:
+ * caller-allocated outputs, written in place; fp32.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* replaces march_rays_train (raymarching.h:12; kernel raymarching.cu:352-518): per ray, count the occupied samples (<= max_steps), reserve
+ * a range with atomicAdd(counter[0], count) / a row with atomicAdd(counter[1], 1), write rays [N,3] = (ray, first point, count) and, if the
+ * range fits below M, the samples xyzs/dirs [M,3], deltas [M,2] = (dt, t + dt).  noises [N]: perturbation of the start, 0 = none. */
+int gfpp_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
+                          uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
+                          float *deltas, int32_t *rays, int32_t *counter, const float *noises, gfpp_stream_t stream);
+
+/* replaces march_rays_train_backward (raymarching.h:13; raymarching.cu:535-583): grad_rays_o/d [N,3] += sums over each ray's samples. */
+int gfpp_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays, const float *deltas, uint32_t N, uint32_t M,
+                                   float *grad_rays_o, float *grad_rays_d, gfpp_stream_t stream);
+
+/* replaces composite_rays_train_forward (raymarching.h:14; raymarching.cu:603-688): T *= 1 - alpha, stop when T < T_thresh AFTER the update. */
+int gfpp_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, uint32_t M,
+                                      uint32_t N, float T_thresh, float *weights_sum, float *ambient_sum, float *depth, float *image, gfpp_stream_t stream);
+
+/* replaces composite_rays_train_backward (raymarching.h:15; raymarching.cu:711-810). */
+int gfpp_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_ambient_sum, const float *grad_image, const float *sigmas,
+                                       const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, const float *weights_sum,
+                                       const float *ambient_sum, const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                       float *grad_rgbs, float *grad_ambient, gfpp_stream_t stream);
+
+/* replaces morton3D_dilation (raymarching.h:11; raymarching.cu:304-335): 6-neighbour max pool of a Morton-ordered [C, H^3] grid. */
+int gfpp_morton3D_dilation(const float *grid, uint32_t C, uint32_t H, float *grid_dilation, gfpp_stream_t stream);
+
+/* replaces sph_from_ray (raymarching.h:8; raymarching.cu:162-199): far intersection with a sphere -> (theta, phi) in [-1,1]^2, coords [N,2]. */
+int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, gfpp_stream_t stream);
+
+/* the dy_dx half of grid_encode_forward (gridencoder.h:12; gridencoder.cu:198-243): d features / d inputs, [B, L, D, C]; D in {2,3}, C in {1,2,4}. */
+int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings, const int32_t *offsets, float *dy_dx, uint32_t B, uint32_t D, uint32_t C,
+                          uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
+
+/* replaces grid_encode_backward (gridencoder.h:13; gridencoder.cu:247-368): grad [L,B,C] -> grad_embeddings (+=, atomics) and, when dy_dx and
+ * grad_inputs are given (both or neither), grad_inputs [B,D]. */
+int gfpp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, float *grad_embeddings, uint32_t B,
+                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                              int align_corners, uint32_t interp, gfpp_stream_t stream);
+
+/* replaces grad_total_variation (gridencoder.h:15; gridencoder.cu:505-609): TV gradient of the cells visited by `inputs`, grad (+=, atomics). */
+int gfpp_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t D,
+                              uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, gfpp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Super-resolution stage of the *_sr models: replaces Superresolution.forward (modules/radnerfs/radnerf_sr.py:30-43 =
  * SynthesisBlockNoUp superresolution.py:159-258 + SynthesisBlock networks_stylegan2.py:375-478, layers :286-371, modulated_conv2d
  * :37-94, conv2d_resample.py:47-147, upfirdn2d.py:330-355, bias_act.py:95-125).  ws = ones there, so the styles are constants: the

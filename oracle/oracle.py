@@ -645,3 +645,124 @@ def render_torso(rays_o, rays_d, cond, bg_coords, poses, params, hp, bg_color=No
     image_out, depth_out = _finish(image, weights_sum, depth, nears, fars, torso_bg, prefix)
     return {"rgb_map": image_out, "depth_map": depth_out, "torso_alpha_map": torso_alpha, "torso_rgb_map": torso_bg,
             "deform": deform, "weights_sum": weights_sum, "head_image": image, "mask": mask}
+
+
+# ---------------------------------------------------------------------------------------------
+# training-side kernels (radnerf_oracle.c, second half; reference raymarching.cu:162-820, gridencoder.cu:198-368, 505-609)
+# ---------------------------------------------------------------------------------------------
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, M=None, noises=None, dt_gamma=0.0, max_steps=1024):
+    """-> xyzs [M,3], dirs [M,3], deltas [M,2], rays [N,3] i32, counter [2] i32 (rays visited in index order)."""
+    rays_o, rays_d = _c(rays_o, f32).reshape(-1, 3), _c(rays_d, f32).reshape(-1, 3)
+    N = rays_o.shape[0]
+    M = N * max_steps if M is None else int(M)
+    xyzs, dirs, deltas = np.zeros((M, 3), f32), np.zeros((M, 3), f32), np.zeros((M, 2), f32)
+    rays = np.zeros((N, 3), np.int32)
+    counter = np.zeros(2, np.int32)
+    noises = np.zeros(N, f32) if noises is None else _c(noises, f32)
+    nears, fars, grid = _c(nears, f32), _c(fars, f32), _c(density_bitfield, np.uint8)
+    lib().orc_march_rays_train(_p(rays_o, _FP), _p(rays_d, _FP), _p(grid, _UP), ctypes.c_float(bound), ctypes.c_float(dt_gamma), ctypes.c_uint32(max_steps),
+                               ctypes.c_uint32(N), ctypes.c_uint32(C), ctypes.c_uint32(H), ctypes.c_uint32(M), _p(nears, _FP), _p(fars, _FP), _p(xyzs, _FP),
+                               _p(dirs, _FP), _p(deltas, _FP), _p(rays, _IP), _p(counter, _IP), _p(noises, _FP))
+    return xyzs, dirs, deltas, rays, counter
+
+
+def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas):
+    grad_xyzs, grad_dirs, deltas, rays = _c(grad_xyzs, f32), _c(grad_dirs, f32), _c(deltas, f32), _c(rays, np.int32)
+    N, M = rays.shape[0], grad_xyzs.shape[0]
+    go, gd = np.zeros((N, 3), f32), np.zeros((N, 3), f32)
+    lib().orc_march_rays_train_backward(_p(grad_xyzs, _FP), _p(grad_dirs, _FP), _p(rays, _IP), _p(deltas, _FP), ctypes.c_uint32(N), ctypes.c_uint32(M),
+                                        _p(go, _FP), _p(gd, _FP))
+    return go, gd
+
+
+def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, T_thresh=1e-4):
+    sigmas, rgbs, ambient, deltas, rays = _c(sigmas, f32), _c(rgbs, f32), _c(ambient, f32), _c(deltas, f32), _c(rays, np.int32)
+    M, N = sigmas.shape[0], rays.shape[0]
+    ws, amb, depth, image = np.zeros(N, f32), np.zeros(N, f32), np.zeros(N, f32), np.zeros((N, 3), f32)
+    lib().orc_composite_rays_train_forward(_p(sigmas, _FP), _p(rgbs, _FP), _p(ambient, _FP), _p(deltas, _FP), _p(rays, _IP), ctypes.c_uint32(M), ctypes.c_uint32(N),
+                                           ctypes.c_float(T_thresh), _p(ws, _FP), _p(amb, _FP), _p(depth, _FP), _p(image, _FP))
+    return ws, amb, depth, image
+
+
+def composite_rays_train_backward(grad_ws, grad_amb, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image, T_thresh=1e-4):
+    a = [_c(v, f32) for v in (grad_ws, grad_amb, grad_image, sigmas, rgbs, ambient, deltas)]
+    rays = _c(rays, np.int32)
+    weights_sum, ambient_sum, image = _c(weights_sum, f32), _c(ambient_sum, f32), _c(image, f32)
+    M, N = a[3].shape[0], rays.shape[0]
+    gs, gr, ga = np.zeros(M, f32), np.zeros((M, 3), f32), np.zeros(M, f32)
+    lib().orc_composite_rays_train_backward(_p(a[0], _FP), _p(a[1], _FP), _p(a[2], _FP), _p(a[3], _FP), _p(a[4], _FP), _p(a[5], _FP), _p(a[6], _FP), _p(rays, _IP),
+                                            _p(weights_sum, _FP), _p(ambient_sum, _FP), _p(image, _FP), ctypes.c_uint32(M), ctypes.c_uint32(N),
+                                            ctypes.c_float(T_thresh), _p(gs, _FP), _p(gr, _FP), _p(ga, _FP))
+    return gs, gr, ga
+
+
+def morton3D_dilation(grid, C, H):
+    grid = _c(grid, f32).reshape(C, H ** 3)
+    out = np.zeros_like(grid)
+    lib().orc_morton3D_dilation(_p(grid, _FP), ctypes.c_uint32(C), ctypes.c_uint32(H), _p(out, _FP))
+    return out
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    rays_o, rays_d = _c(rays_o, f32).reshape(-1, 3), _c(rays_d, f32).reshape(-1, 3)
+    out = np.zeros((rays_o.shape[0], 2), f32)
+    lib().orc_sph_from_ray(_p(rays_o, _FP), _p(rays_d, _FP), ctypes.c_float(radius), ctypes.c_uint32(rays_o.shape[0]), _p(out, _FP))
+    return out
+
+
+def _grid_args(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation):
+    x01, embeddings, offsets = _c(x01, f32), _c(embeddings, f32), _c(offsets, np.int32)
+    B, D = x01.shape
+    C, L = embeddings.shape[1], offsets.shape[0] - 1
+    S = f32(np.log2(per_level_scale))
+    gt = {"hash": 0, "tiled": 1}[gridtype]
+    it = {"linear": 0, "smoothstep": 1}[interpolation]
+    return x01, embeddings, offsets, B, D, C, L, S, gt, it
+
+
+def grid_encode_dydx(x01, embeddings, offsets, per_level_scale, base_resolution=16, gridtype="tiled", align_corners=False, interpolation="linear"):
+    """x01 in [0,1] -> dy_dx [B, L, D, C]."""
+    x01, embeddings, offsets, B, D, C, L, S, gt, it = _grid_args(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation)
+    out = np.zeros((B, L, D, C), f32)
+    rc = lib().orc_grid_encode_dydx(_p(x01, _FP), _p(embeddings, _FP), _p(offsets, _IP), _p(out, _FP), ctypes.c_uint32(B), ctypes.c_uint32(D), ctypes.c_uint32(C),
+                                    ctypes.c_uint32(L), ctypes.c_float(S), ctypes.c_uint32(base_resolution), ctypes.c_uint32(gt), ctypes.c_int(int(align_corners)),
+                                    ctypes.c_uint32(it))
+    assert rc == 0
+    return out
+
+
+def grid_encode_backward(grad, x01, embeddings, offsets, per_level_scale, base_resolution=16, gridtype="tiled", align_corners=False, interpolation="linear",
+                         dy_dx=None):
+    """grad [L,B,C] -> grad_embeddings [rows, C] (and grad_inputs [B,D] when dy_dx is given)."""
+    x01, embeddings, offsets, B, D, C, L, S, gt, it = _grid_args(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation)
+    grad = _c(grad, f32)
+    ge = np.zeros_like(embeddings)
+    rc = lib().orc_grid_encode_backward(_p(grad, _FP), _p(x01, _FP), _p(offsets, _IP), _p(ge, _FP), ctypes.c_uint32(B), ctypes.c_uint32(D), ctypes.c_uint32(C),
+                                        ctypes.c_uint32(L), ctypes.c_float(S), ctypes.c_uint32(base_resolution), ctypes.c_uint32(gt), ctypes.c_int(int(align_corners)),
+                                        ctypes.c_uint32(it))
+    assert rc == 0
+    gi = None
+    if dy_dx is not None:
+        dy_dx = _c(dy_dx, f32)
+        gi = np.zeros((B, D), f32)
+        lib().orc_grid_input_backward(_p(grad, _FP), _p(dy_dx, _FP), _p(gi, _FP), ctypes.c_uint32(B), ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L))
+    return ge, gi
+
+
+def grad_total_variation(x01, embeddings, grad, offsets, weight, per_level_scale, base_resolution=16, gridtype="tiled", align_corners=False):
+    x01, embeddings, offsets, B, D, C, L, S, gt, _ = _grid_args(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, "linear")
+    grad = _c(grad, f32).copy()
+    rc = lib().orc_grad_total_variation(_p(x01, _FP), _p(embeddings, _FP), _p(grad, _FP), _p(offsets, _IP), ctypes.c_float(weight), ctypes.c_uint32(B),
+                                        ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(S), ctypes.c_uint32(base_resolution),
+                                        ctypes.c_uint32(gt), ctypes.c_int(int(align_corners)))
+    assert rc == 0
+    return grad
+
+
+def grid_encode_levels(x01, embeddings, offsets, per_level_scale, base_resolution=16, gridtype="tiled", align_corners=False, interpolation="linear"):
+    """Level-major forward [L,B,C] for inputs already in [0,1] (the layout the backward kernels' `grad` uses)."""
+    return grid_encode_raw(x01, embeddings, offsets, np.log2(per_level_scale), base_resolution, GRIDTYPE[gridtype], align_corners, INTERP[interpolation])

@@ -391,3 +391,369 @@ ORC_API void orc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D
         }
     }
 }
+
+/* ==========================================================================================
+ * TRAINING-SIDE KERNELS
+ * ========================================================================================== */
+
+/* one step of the marcher shared by the two passes of kernel_march_rays_train (raymarching.cu:400-441 and :461-515, which repeat
+ * the code of kernel_march_rays).  Returns 1 if the cell at t is occupied (then *x,y,z,dt are the sample), else advances *t past
+ * the empty voxel and returns 0. */
+static inline int orc_train_probe(float ox, float oy, float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz,
+                                  float bound, float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H, const uint8_t *grid,
+                                  float *t, float *x_, float *y_, float *z_, float *dt_) {
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    const float x = orc_clampf(fmaf(*t, dx, ox), -bound, bound);
+    const float y = orc_clampf(fmaf(*t, dy, oy), -bound, bound);
+    const float z = orc_clampf(fmaf(*t, dz, oz), -bound, bound);
+    const float dt = orc_clampf(*t * dt_gamma, dt_min, dt_max);
+    const int lvl_p = orc_mip_from_pos(x, y, z, (float)C);
+    const int lvl_d = orc_mip_from_dt(dt, (float)H, (float)C);
+    const int level = lvl_p > lvl_d ? lvl_p : lvl_d;
+    const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = (int)orc_clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const int ny = (int)orc_clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const int nz = (int)orc_clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const uint32_t gidx = (uint32_t)fmaf((float)level, H3, (float)orc_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    if (grid[gidx / 8] & (1 << (gidx % 8))) {
+        *x_ = x; *y_ = y; *z_ = z; *dt_ = dt;
+        return 1;
+    }
+    const float tx = fmaf(fmaf(((float)nx + 0.5f + 0.5f * orc_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
+    const float ty = fmaf(fmaf(((float)ny + 0.5f + 0.5f * orc_signf(dy)) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
+    const float tz = fmaf(fmaf(((float)nz + 0.5f + 0.5f * orc_signf(dz)) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
+    const float tt = *t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        *t += orc_clampf(*t * dt_gamma, dt_min, dt_max);
+    } while (*t < tt);
+    return 0;
+}
+
+/* kernel_march_rays_train -- raymarching.cu:352-518.  rays [N,3] i32 = (ray id, first point, point count); counter[0] = points,
+ * counter[1] = rays.  The reference hands out point ranges with atomicAdd in whatever order the hardware schedules the rays; this
+ * restatement visits the rays in index order, i.e. ONE of the valid outcomes (compare per ray, not per slot). */
+ORC_API void orc_march_rays_train(const float *rays_o_, const float *rays_d_, const uint8_t *grid, float bound, float dt_gamma,
+                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                                  const float *fars, float *xyzs_, float *dirs_, float *deltas_, int32_t *rays, int32_t *counter,
+                                  const float *noises) {
+    const float dt_max = 2 * ORC_SQRT3 * (float)(1 << (C - 1)) / (float)H;
+    const float dt_min = fminf(dt_max, 2 * ORC_SQRT3 / (float)max_steps);
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o_[3 * n], oy = rays_o_[3 * n + 1], oz = rays_o_[3 * n + 2];
+        const float dx = rays_d_[3 * n], dy = rays_d_[3 * n + 1], dz = rays_d_[3 * n + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        const float far = fars[n];
+        float t0 = nears[n];
+        t0 = fmaf(orc_clampf(t0 * dt_gamma, dt_min, dt_max), noises[n], t0);                       /* :392 */
+        float t = t0, x, y, z, dt;
+        uint32_t num_steps = 0;
+        while (t < far && num_steps < max_steps) {                                                   /* first pass :400-441 */
+            if (orc_train_probe(ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, bound, dt_gamma, dt_min, dt_max, C, H, grid, &t, &x, &y, &z, &dt)) {
+                num_steps++;
+                t += dt;
+            }
+        }
+        const uint32_t point_index = (uint32_t)counter[0];                                           /* :446-447 (atomicAdd) */
+        counter[0] += (int32_t)num_steps;
+        const uint32_t ray_index = (uint32_t)counter[1];
+        counter[1] += 1;
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+        if (num_steps == 0) continue;
+        if (point_index + num_steps > M) continue;
+        float *xyzs = xyzs_ + (size_t)point_index * 3, *dirs = dirs_ + (size_t)point_index * 3, *deltas = deltas_ + (size_t)point_index * 2;
+        t = t0;
+        uint32_t step = 0;
+        while (t < far && step < num_steps) {                                                        /* second pass :461-515 */
+            if (orc_train_probe(ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, bound, dt_gamma, dt_min, dt_max, C, H, grid, &t, &x, &y, &z, &dt)) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+                t += dt;
+                deltas[0] = dt;
+                deltas[1] = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+                step++;
+            }
+        }
+    }
+}
+
+/* kernel_march_rays_train_backward -- raymarching.cu:535-583.  grad_rays_o/d are ACCUMULATED into (the caller zero-fills). */
+ORC_API void orc_march_rays_train_backward(const float *grad_xyzs_, const float *grad_dirs_, const int32_t *rays, const float *deltas_,
+                                           uint32_t N, uint32_t M, float *grad_rays_o_, float *grad_rays_d_) {
+    for (uint32_t n = 0; n < N; n++) {
+        float *go = grad_rays_o_ + 3 * (size_t)n, *gd = grad_rays_d_ + 3 * (size_t)n;      /* indexed by n, NOT by rays[n*3] (as the reference) */
+        const uint32_t offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float *gx = grad_xyzs_ + (size_t)offset * 3, *gdir = grad_dirs_ + (size_t)offset * 3, *deltas = deltas_ + (size_t)offset * 2;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            for (int k = 0; k < 3; k++) {
+                go[k] += gx[k];
+                gd[k] += fmaf(gx[k], deltas[1], gdir[k]);
+            }
+            gx += 3; gdir += 3; deltas += 2;
+        }
+    }
+}
+
+/* kernel_composite_rays_train_forward -- raymarching.cu:603-688 (T *= 1 - alpha, post-update threshold test: NOT the inference rule) */
+ORC_API void orc_composite_rays_train_forward(const float *sigmas_, const float *rgbs_, const float *ambient_, const float *deltas_,
+                                              const int32_t *rays, uint32_t M, uint32_t N, float T_thresh, float *weights_sum,
+                                              float *ambient_sum, float *depth, float *image) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) {
+            weights_sum[index] = 0; ambient_sum[index] = 0; depth[index] = 0;
+            image[index * 3] = image[index * 3 + 1] = image[index * 3 + 2] = 0;
+            continue;
+        }
+        const float *sigmas = sigmas_ + offset, *rgbs = rgbs_ + (size_t)offset * 3, *ambient = ambient_ + offset, *deltas = deltas_ + (size_t)offset * 2;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0, amb = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-sigmas[0] * deltas[0]);          /* __expf in the reference (fast intrinsic) */
+            const float weight = alpha * T;
+            r = fmaf(weight, rgbs[0], r);
+            g = fmaf(weight, rgbs[1], g);
+            b = fmaf(weight, rgbs[2], b);
+            d = fmaf(weight, deltas[1], d);
+            ws += weight;
+            amb += ambient[0];
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+            sigmas++; rgbs += 3; ambient++; deltas += 2;
+        }
+        weights_sum[index] = ws; ambient_sum[index] = amb; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+/* kernel_composite_rays_train_backward -- raymarching.cu:711-810 */
+ORC_API void orc_composite_rays_train_backward(const float *grad_weights_sum_, const float *grad_ambient_sum_, const float *grad_image_,
+                                               const float *sigmas_, const float *rgbs_, const float *ambient_, const float *deltas_,
+                                               const int32_t *rays, const float *weights_sum_, const float *ambient_sum_, const float *image_,
+                                               uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas_, float *grad_rgbs_,
+                                               float *grad_ambient_) {
+    (void)ambient_; (void)ambient_sum_;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float gws = grad_weights_sum_[index], gamb = grad_ambient_sum_[index];
+        const float *gi = grad_image_ + (size_t)index * 3;
+        const float r_final = image_[index * 3], g_final = image_[index * 3 + 1], b_final = image_[index * 3 + 2], ws_final = weights_sum_[index];
+        const float *sigmas = sigmas_ + offset, *rgbs = rgbs_ + (size_t)offset * 3, *deltas = deltas_ + (size_t)offset * 2;
+        float *gs = grad_sigmas_ + offset, *gr = grad_rgbs_ + (size_t)offset * 3, *ga = grad_ambient_ + offset;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-sigmas[0] * deltas[0]);
+            const float weight = alpha * T;
+            r = fmaf(weight, rgbs[0], r);
+            g = fmaf(weight, rgbs[1], g);
+            b = fmaf(weight, rgbs[2], b);
+            ws += weight;
+            T *= 1.0f - alpha;
+            gr[0] = gi[0] * weight; gr[1] = gi[1] * weight; gr[2] = gi[2] * weight;
+            ga[0] = gamb;
+            float acc = gi[0] * fmaf(T, rgbs[0], -(r_final - r));
+            acc = fmaf(gi[1], fmaf(T, rgbs[1], -(g_final - g)), acc);
+            acc = fmaf(gi[2], fmaf(T, rgbs[2], -(b_final - b)), acc);
+            acc = fmaf(gws, 1 - ws_final, acc);
+            gs[0] = deltas[0] * acc;
+            if (T < T_thresh) break;
+            sigmas++; rgbs += 3; deltas += 2; gs++; gr += 3; ga++;
+        }
+    }
+}
+
+/* kernel_morton3D_dilation -- raymarching.cu:304-335: 6-neighbour max pool of a Morton-ordered [C, H^3] grid */
+ORC_API void orc_morton3D_dilation(const float *grid, uint32_t C, uint32_t H, float *out) {
+    const uint32_t H3 = H * H * H;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)C * H3; n++) {
+        const uint32_t c = (uint32_t)(n / H3), ind = (uint32_t)(n - (int64_t)c * H3);
+        const uint32_t x = orc_morton3D_invert(ind), y = orc_morton3D_invert(ind >> 1), z = orc_morton3D_invert(ind >> 2);
+        const float *g = grid + (size_t)c * H3;
+        float res = grid[n];
+        if (x + 1 < H) res = fmaxf(res, g[orc_morton3D(x + 1, y, z)]);
+        if (x > 0) res = fmaxf(res, g[orc_morton3D(x - 1, y, z)]);
+        if (y + 1 < H) res = fmaxf(res, g[orc_morton3D(x, y + 1, z)]);
+        if (y > 0) res = fmaxf(res, g[orc_morton3D(x, y - 1, z)]);
+        if (z + 1 < H) res = fmaxf(res, g[orc_morton3D(x, y, z + 1)]);
+        if (z > 0) res = fmaxf(res, g[orc_morton3D(x, y, z - 1)]);
+        out[n] = res;
+    }
+}
+
+/* kernel_sph_from_ray -- raymarching.cu:162-199 */
+ORC_API void orc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords) {
+    const float RPI = 0.3183098861837907f;
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+        const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+        const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+        const float Cc = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+        const float t = (-B + sqrtf(fmaf(B, B, -(A * Cc)))) / A;
+        const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+        const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+        const float phi = atan2f(z, x);
+        coords[2 * n] = fmaf(2 * theta, RPI, -1.0f);
+        coords[2 * n + 1] = phi * RPI;
+    }
+}
+
+/* grid encoder: dy_dx of the forward (gridencoder.cu:198-243), layout [B, L, D, C] */
+ORC_API int orc_grid_encode_dydx(const float *inputs_, const float *embeddings, const int32_t *offsets, float *dy_dx_, uint32_t B, uint32_t D,
+                                 uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp) {
+    if (D < 1 || D > 7 || C < 1 || C > 8) return -1;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t level = 0; level < (int64_t)L; level++) {
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+            const float *inputs = inputs_ + (size_t)b * D;
+            float *dy_dx = dy_dx_ + (size_t)b * D * L * C + (size_t)level * D * C;
+            int flag_oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (inputs[d] < 0 || inputs[d] > 1) flag_oob = 1;
+            if (flag_oob) {                                              /* :119-133: zeros */
+                for (uint32_t i = 0; i < D * C; i++) dy_dx[i] = 0;
+                continue;
+            }
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            float scale; uint32_t resolution;
+            orc_grid_level_params((uint32_t)level, S, H, &scale, &resolution);
+            float pos[7], pos_deriv[7]; uint32_t pos_grid[7];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) { pos_deriv[d] = 6 * pos[d] * (1 - pos[d]); pos[d] = pos[d] * pos[d] * fmaf(-2.0f, pos[d], 3.0f); }  /* :155-160 */
+                else pos_deriv[d] = 1.0f;
+            }
+            for (uint32_t gd = 0; gd < D; gd++) {
+                float results_grad[8] = {0};
+                for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                    float w = scale;
+                    uint32_t pgl[7];
+                    for (uint32_t nd = 0; nd < D - 1; nd++) {
+                        const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                        if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                        else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                    }
+                    pgl[gd] = pos_grid[gd];
+                    const uint32_t il = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                    pgl[gd] = pos_grid[gd] + 1;
+                    const uint32_t ir = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                    for (uint32_t ch = 0; ch < C; ch++) results_grad[ch] = fmaf(w * (grid[ir + ch] - grid[il + ch]), pos_deriv[gd], results_grad[ch]);
+                }
+                for (uint32_t ch = 0; ch < C; ch++) dy_dx[gd * C + ch] = results_grad[ch];
+            }
+        }
+    }
+    return 0;
+}
+
+/* kernel_grid_backward -- gridencoder.cu:247-340: grad [L,B,C] -> grad_embeddings (+=).  Serial over points (atomicAdd order in the
+ * reference is unspecified; fp32 sums may differ in the last bits). */
+ORC_API int orc_grid_encode_backward(const float *grad_, const float *inputs_, const int32_t *offsets, float *grad_embeddings, uint32_t B,
+                                     uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                     uint32_t interp) {
+    if (D < 1 || D > 7 || C < 1 || C > 8) return -1;
+    for (uint32_t level = 0; level < L; level++) {
+        float *grad_grid = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *inputs = inputs_ + (size_t)b * D;
+            const float *grad = grad_ + (size_t)level * B * C + (size_t)b * C;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (inputs[d] < 0 || inputs[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[7]; uint32_t pos_grid[7];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * fmaf(-2.0f, pos[d], 3.0f);
+            }
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pgl[7];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                for (uint32_t c = 0; c < C; c++) grad_grid[index + c] += w * grad[c];
+            }
+        }
+    }
+    return 0;
+}
+
+/* kernel_input_backward -- gridencoder.cu:342-368: grad_inputs[b][d] = sum_l sum_ch grad[l][b][ch] * dy_dx[b][l][d][ch] */
+ORC_API void orc_grid_input_backward(const float *grad, const float *dy_dx_, float *grad_inputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    for (uint32_t t = 0; t < B * D; t++) {
+        const uint32_t b = t / D, d = t - b * D;
+        const float *dy_dx = dy_dx_ + (size_t)b * L * D * C;
+        float result = 0;
+        for (uint32_t l = 0; l < L; l++)
+            for (uint32_t ch = 0; ch < C; ch++) result = fmaf(grad[(size_t)l * B * C + (size_t)b * C + ch], dy_dx[l * D * C + d * C + ch], result);
+        grad_inputs[t] = result;
+    }
+}
+
+/* kernel_grad_tv -- gridencoder.cu:505-597: total-variation gradient at the cells visited by `inputs`, accumulated into grad */
+ORC_API int orc_grad_total_variation(const float *inputs_, const float *embeddings, float *grad_, const int32_t *offsets, float weight,
+                                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners) {
+    if (D < 1 || D > 7 || C < 1 || C > 8) return -1;
+    for (uint32_t level = 0; level < L; level++) {
+        const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+        float *grad = grad_ + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *inputs = inputs_ + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (inputs[d] < 0 || inputs[d] > 1) oob = 1;
+            if (oob) continue;
+            uint32_t pos_grid[7];
+            for (uint32_t d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f));
+            float results[8] = {0}, idelta[8] = {0};
+            const uint32_t index = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pos_grid);
+            const float w = weight / (float)(2 * D);
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t cur_d = pos_grid[d];
+                if (cur_d < resolution) {
+                    pos_grid[d] = cur_d + 1;
+                    const uint32_t ir = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float gv = grid[index + ch] - grid[ir + ch];
+                        results[ch] += gv;
+                        idelta[ch] = fmaf(gv, gv, idelta[ch]);
+                    }
+                }
+                if (cur_d > 0) {
+                    pos_grid[d] = cur_d - 1;
+                    const uint32_t il = orc_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float gv = grid[index + ch] - grid[il + ch];
+                        results[ch] += gv;
+                        idelta[ch] = fmaf(gv, gv, idelta[ch]);
+                    }
+                }
+                pos_grid[d] = cur_d;
+            }
+            for (uint32_t ch = 0; ch < C; ch++) grad[index + ch] += w * results[ch] * (1.0f / sqrtf(idelta[ch] + 1e-9f));
+        }
+    }
+    return 0;
+}
