@@ -9,14 +9,16 @@ the "unfused" baseline for measurements.
 """
 import copy
 import math
+import random
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import raymarching
 from .cond_nets import AudioNet, AudioAttNet, MLP
 from .encoders import get_encoder
-from .camera import trunc_exp
+from .camera import trunc_exp, get_audio_features
 
 _COND_DIMS = {"esperanto": 44, "deepspeech": 29}
 _KEYPOINT_DIMS = {"lm68": 68 * 3, "lm131": 131 * 3, "lm468": 468 * 3}
@@ -86,10 +88,96 @@ class NeRFRenderer(nn.Module):
             return None
         return self.individual_embeddings[index if self.training else 0]
 
-    def _require_inference(self):
-        if self.training:
-            raise NotImplementedError("training-time rendering (march_rays_train / composite_rays_train) is not built yet "
-                                      "(SURVEY.md 8f-2); call .eval() first")
+    # -- occupancy grid upkeep (training side) ------------------------------------------------------------------
+    def _cell_block(self, lo, hi):
+        """Integer cell coordinates [n,3] of the sub-cube lo..hi (per axis) and their Morton codes."""
+        dev = self.density_bitfield.device
+        axes = [torch.arange(a, b, dtype=torch.int32, device=dev) for a, b in zip(lo, hi)]
+        coords = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3)
+        return coords, raymarching.morton3D(coords).long()
+
+    def _cell_blocks(self, S):
+        G = self.grid_size
+        for x in range(0, G, S):
+            for y in range(0, G, S):
+                for z in range(0, G, S):
+                    yield self._cell_block((x, y, z), (min(x + S, G), min(y + S, G), min(z + S, G)))
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """Cells no training camera sees get density -1 and are never marched (renderer.py:131-199).
+        poses [B,4,4] camera-to-world, intrinsic (fx, fy, cx, cy)."""
+        if not self.cuda_ray:
+            return
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        fx, fy, cx, cy = intrinsic
+        dev = self.density_grid.device
+        poses = poses.to(dev)
+        seen = torch.zeros_like(self.density_grid)
+        for coords, cell in self._cell_blocks(S):
+            unit = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)              # [1,n,3] in [-1,1]
+            for cas in range(self.cascade):
+                bound = min(2 ** cas, self.bound)
+                half_cell = bound / self.grid_size
+                world = unit * (bound - half_cell)
+                for head in range(0, poses.shape[0], S):
+                    cam = poses[head:head + S]
+                    # world -> camera: (p - t) R  (R is camera-to-world, so right-multiplying applies its transpose)
+                    p = (world - cam[:, :3, 3].unsqueeze(1)) @ cam[:, :3, :3]
+                    inside = (p[..., 2] > 0) \
+                        & (p[..., 0].abs() < cx / fx * p[..., 2] + half_cell * 2) \
+                        & (p[..., 1].abs() < cy / fy * p[..., 2] + half_cell * 2)
+                    seen[cas, cell] += inside.sum(0).to(seen.dtype)
+        self.density_grid[seen == 0] = -1
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """Refresh the occupancy grid from the current density field, then re-pack the bitfield the marcher reads
+        (renderer.py:201-284).  ``self.conds`` ([T, t_win, C], set by the training task) supplies a random conditioning
+        window; densities are probed at one jittered point per cell, dilated, and blended in with a decaying maximum."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        pick = random.randint(0, self.conds.shape[0] - 1)
+        hp = getattr(self, "hparams", None)           # the reference reads the global hparams here; the model's own copy is the same dict
+        window = get_audio_features(self.conds, 2, pick, smo_win_size=hp["smo_win_size"] if hp else None)
+        cond_feat = self.cal_cond_feat(window.to(dev))
+        probe = torch.zeros_like(self.density_grid)
+        for coords, cell in self._cell_blocks(S):
+            unit = 2 * coords.float() / (self.grid_size - 1) - 1
+            for cas in range(self.cascade):
+                bound = min(2 ** cas, self.bound)
+                half_cell = bound / self.grid_size
+                pts = unit * (bound - half_cell)
+                pts += (torch.rand_like(pts) * 2 - 1) * half_cell
+                sigma = self.density(pts, cond_feat)["sigma"].reshape(-1).detach().to(probe.dtype)
+                probe[cas, cell] = sigma * self.density_scale
+        probe = raymarching.morton3D_dilation(probe)
+        both = (self.density_grid >= 0) & (probe >= 0)
+        self.density_grid[both] = torch.maximum(self.density_grid[both] * decay, probe[both])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
+        seen_steps = min(16, self.local_step)
+        if seen_steps > 0:
+            self.mean_count = int(self.step_counter[:seen_steps, 0].sum().item() / seen_steps)
+        self.local_step = 0
+
+    def _march_eval_composite_train(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, max_steps, perturb,
+                                    force_all_rays):
+        """Training-time pass (renderer.py:319-340): one packed sample list for the whole batch of rays, evaluated by the
+        autograd-visible networks, composited by the differentiable kernel pair."""
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                force_all_rays, dt_gamma, max_steps)
+        sigmas, rgbs, ambient = self(xyzs, dirs, cond_feat, ind_code)
+        sigmas = self.density_scale * sigmas
+        weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient.abs().sum(-1), deltas, rays)
+        return weights_sum, ambient_sum, depth, image, xyzs
 
     def pipeline(self):
         """Lazily build the fused frame pipeline (packs weights for the HIP kernels; rebuilt if parameters move)."""
@@ -142,11 +230,20 @@ class NeRFRenderer(nn.Module):
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False,
                force_all_rays=False, max_steps=1024, T_thresh=1e-4, cond_mask=None, eye_area_percent=None, **kwargs):
         """Head-only frame: rays [B,N,3] (B == 1) -> {'rgb_map' [B,N,3], 'depth_map' [B,N]} (renderer.py:286-399)."""
-        self._require_inference()
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         ind_code = self._individual_code(index)
+        if self.training:
+            cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+            weights_sum, ambient_sum, depth, image, xyzs = self._march_eval_composite_train(
+                rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, max_steps, perturb, force_all_rays)
+            if bg_color is None:
+                bg_color = 1
+            image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3).clamp(0, 1)
+            depth = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+            return {"weights_sum": weights_sum, "ambient": ambient_sum, "position": xyzs, "depth_map": depth, "rgb_map": image}
         if self.executor == "fused" and cond_mask is None and not perturb and max_steps <= 63:
             def frame(rays_o, rays_d, cond, eye, bg_color):
                 cond_feat = lambda: self.cal_cond_feat(cond, eye_area_percent=eye)     # runs on the pipeline's side stream

@@ -16,6 +16,7 @@ from . import raymarching
 from .cond_nets import MLP
 from .encoders import get_encoder
 from .head import RADNeRF
+from .camera import convert_poses
 
 _CHIN_LANDMARKS = [5, 6, 7, 8, 9, 10, 11]   # the 7 of 68 landmarks the SR variant conditions on (radnerf_torso_sr.py:86)
 
@@ -83,6 +84,34 @@ class _TorsoBase(RADNeRF):
             return None
         return self.torso_individual_codes[index if self.training else 0]
 
+    def _probe_pose_and_landmarks(self, pick):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """Torso stage: only the 2-D torso occupancy grid is refreshed, the head grid stays frozen (radnerf_torso.py:201-244).
+        One jittered probe per pixel cell under a random training pose, 5x5 max-dilated, blended with a decaying maximum."""
+        G = self.grid_size
+        dev = self.density_grid_torso.device
+        pick = random.randint(0, self.poses.shape[0] - 1)
+        pose, lm68 = self._probe_pose_and_landmarks(pick)
+        code = self.torso_individual_codes[[pick]] if self.torso_individual_embedding_dim > 0 else None
+        probe = torch.zeros_like(self.density_grid_torso)
+        half_cell = 1 / G
+        for x0 in range(0, G, S):
+            for y0 in range(0, G, S):
+                xs = torch.arange(x0, min(x0 + S, G), dtype=torch.int32, device=dev)
+                ys = torch.arange(y0, min(y0 + S, G), dtype=torch.int32, device=dev)
+                coords = torch.stack(torch.meshgrid(xs, ys, indexing="ij"), dim=-1).reshape(-1, 2)
+                cell = (coords[:, 1] * G + coords[:, 0]).long()          # row-major in (y, x): the grid is sampled as an image
+                pts = (2 * coords.float() / (G - 1) - 1) * (1 - half_cell)
+                pts += (torch.rand_like(pts) * 2 - 1) * half_cell
+                alpha, _, _ = self._forward_torso(pts, pose, code, None, None, lm68)
+                probe[cell] = alpha.squeeze(1).float()
+        probe = F.max_pool2d(probe.view(1, 1, G, G), kernel_size=5, stride=1, padding=2).view(-1)
+        self.density_grid_torso = torch.maximum(self.density_grid_torso * decay, probe)
+        self.mean_density_torso = torch.mean(self.density_grid_torso).item()
+
     def _torso_mask(self, bg_coords):
         thresh = min(self.density_thresh_torso, self.mean_density_torso)
         occ = F.grid_sample(self.density_grid_torso.view(1, 1, self.grid_size, self.grid_size), bg_coords.view(1, -1, 1, 2),
@@ -90,14 +119,20 @@ class _TorsoBase(RADNeRF):
         return occ > thresh
 
     def _render_staged(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                       eye_area_percent, use_head_for_torso):
+                       eye_area_percent, use_head_for_torso, force_all_rays=False):
         N = rays_o.shape[0]
         dev = rays_o.device
-        with torch.no_grad():
-            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        extra = {}
+        with torch.no_grad():       # the head field is frozen while the torso trains (radnerf_torso.py:93)
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
             cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
-            weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, self._individual_code(index),
-                                                                          dt_gamma, max_steps, T_thresh, perturb)
+            if self.training:
+                weights_sum, ambient_sum, depth, image, _ = self._march_eval_composite_train(
+                    rays_o, rays_d, nears, fars, cond_feat, self._individual_code(index), dt_gamma, max_steps, perturb, force_all_rays)
+                extra = {"weights_sum": weights_sum, "ambient": ambient_sum}
+            else:
+                weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, self._individual_code(index),
+                                                                              dt_gamma, max_steps, T_thresh, perturb)
         if bg_color is None:
             bg_color = 1
         code = self._torso_code(index)
@@ -115,17 +150,16 @@ class _TorsoBase(RADNeRF):
         torso_bg = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
         image = (image + (1 - weights_sum).unsqueeze(-1) * torso_bg)
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        return {"image": image.clamp(0, 1), "depth": depth, "torso_alpha": torso_alpha, "torso_bg": torso_bg, "deform": deform}
+        return {"image": image.clamp(0, 1), "depth": depth, "torso_alpha": torso_alpha, "torso_bg": torso_bg, "deform": deform, **extra}
 
     def _render_common(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                       eye_area_percent, use_head_for_torso, post=None, post_key=()):
+                       eye_area_percent, use_head_for_torso, post=None, post_key=(), force_all_rays=False):
         """`post(out)`: extra device work on the pipeline's result dict (the SR stage), issued inside the frame so that it is part of the
         captured graph; `post_key` distinguishes graphs captured with different post work."""
-        self._require_inference()
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
-        if self.executor == "fused" and not perturb and max_steps <= 63:
+        if self.executor == "fused" and not self.training and not perturb and max_steps <= 63:
             ind_code, torso_code = self._individual_code(index), self._torso_code(index)
 
             def frame(rays_o, rays_d, cond, eye, bg_coords, poses, lm68, bg_color):
@@ -149,7 +183,7 @@ class _TorsoBase(RADNeRF):
                 out["deform"] = out["deform_dense"][out["torso_mask"].bool()]
             return out
         out = self._render_staged(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                                  eye_area_percent, use_head_for_torso)
+                                  eye_area_percent, use_head_for_torso, force_all_rays)
         if post is not None:
             post(out)
         return out
@@ -172,6 +206,9 @@ class RADNeRFTorso(_TorsoBase):
         """x [P,2] in [-1,1], poses [1,6] -> alpha [P,1], color [P,3], dx [P,2] (radnerf_torso.py:51-84)."""
         return self._forward_torso(x, poses, c, image, weights_sum, None)
 
+    def _probe_pose_and_landmarks(self, pick):
+        return convert_poses(self.poses[[pick]]).to(self.density_grid_torso.device), None
+
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, **kwargs):
         prefix = rays_o.shape[:-1]
@@ -179,11 +216,14 @@ class RADNeRFTorso(_TorsoBase):
         use_head = random.random() < 0.5 if self.hparams["torso_head_aware"] else False
         # NB: this variant calls cal_cond_feat(cond) without eye_area_percent (radnerf_torso.py:106)
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, None,
-                                  None, use_head)
+                                  None, use_head, force_all_rays=force_all_rays)
         res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"], "depth_map": out["depth"].view(*prefix),
                "rgb_map": out["image"].view(*prefix, 3)}
         if out["deform"] is not None:
             res["deform"] = out["deform"]
+        for k in ("weights_sum", "ambient"):        # training only (radnerf_torso.py:126-128)
+            if k in out:
+                res[k] = out[k]
         return res
 
 
@@ -210,25 +250,36 @@ class RADNeRFTorsowithSR(_TorsoBase):
         """(radnerf_torso_sr.py:75-114)."""
         return self._forward_torso(x, poses, c, image, weights_sum, lm68)
 
+    def _probe_pose_and_landmarks(self, pick):
+        dev = self.density_grid_torso.device         # radnerf_torso_sr.py:253-255
+        return convert_poses(self.poses[[pick]]).to(dev), self.lm68s[[pick]].to(dev).reshape(1, 68 * 2)
+
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, upscale_torso=False, lm68=None, eye_area_percent=None, **kwargs):
         sr_noise = kwargs.get("sr_noise_mode", "random")     # the reference always renders with the layers' default, 'random'
         side = self.sr_net.input_resolution          # 256: the reference hard-codes [1,256,256,3] (radnerf_torso_sr.py:219,229)
 
         def superresolve(o):
+            if self.sr_net.ready and self.training and torch.is_grad_enabled():
+                raise NotImplementedError("the super-resolution stage is inference-only so far (folded-weight HIP kernels, no backward); "
+                                          "train with sr_net left uninitialised or under torch.no_grad()")
             if self.sr_net.ready:
                 o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
                 if upscale_torso:
                     o["sr_torso_rgb"] = self.sr_net(o["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
 
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                                  eye_area_percent, True, post=superresolve, post_key=("sr", sr_noise, bool(upscale_torso)))
+                                  eye_area_percent, True, post=superresolve, post_key=("sr", sr_noise, bool(upscale_torso)),
+                                  force_all_rays=force_all_rays)
         rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         torso_bg = out["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": torso_bg, "depth_map": out["depth"].view(*rays_o.shape[:-1]),
                "rgb_map": rgb}
         if out["deform"] is not None:
             res["deform"] = out["deform"]
+        for k in ("weights_sum", "ambient"):
+            if k in out:
+                res[k] = out[k]
         if "sr_rgb" in out:
             res["sr_rgb_map"] = out["sr_rgb"]
         if "sr_torso_rgb" in out:
@@ -254,5 +305,7 @@ class RADNeRFwithSR(RADNeRF):
         rgb = res["rgb_map"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         res["rgb_map"] = rgb
         if self.sr_net.ready:
+            if self.training and torch.is_grad_enabled():
+                raise NotImplementedError("the super-resolution stage is inference-only so far (no backward kernels)")
             res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
         return res
