@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying the per-frame hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-stage", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=5, help="multi-GPU: all_gather the finished uint8 frames every this many frames, "
+                                                                "overlapped with the rendering of the next chunk")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (control-flow checks of the N>1 path on one GPU)")
     return ap.parse_args()
 
 
@@ -97,11 +100,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()          # (== local_rank on a real node; lets the gloo check share one GPU)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from genefaceplusplus_amd import synthetic as syn
     from genefaceplusplus_amd.configs import may_hparams
@@ -131,22 +138,34 @@ def main():
     intr = syn.intrinsics_for(HW, HW)
     bg_coords = camera.get_bg_coords(HW, HW, dev)
     bg_color = torch.full((1, N, 3), 0.5, device=dev)
-    inputs = []
-    for fidx in my_frames:
-        pose = torch.from_numpy(syn.synthetic_pose(fidx)).to(dev)[None]
-        rays = camera.get_rays(pose, intr, HW, HW)
-        fi = syn.synthetic_frame_inputs(hp, fidx)
-        inputs.append({"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose),
-                       "cond": torch.from_numpy(fi["cond"]).to(dev), "lm68": torch.from_numpy(fi["lm68"]).to(dev),
-                       "eye": torch.from_numpy(fi["eye_area_percent"]).to(dev)})
-    HWO = 512 if args.variant == "may_torso_sr" else HW          # the *_sr models render 256^2 rays and super-resolve to 512^2
+    fi_all = [syn.synthetic_frame_inputs(hp, fidx) for fidx in my_frames]
+    batch = {"ngp_poses": np.stack([syn.synthetic_pose(fidx) for fidx in my_frames]).astype(np.float32),
+             "cond_wins": np.stack([f["cond"] for f in fi_all]), "lm68": np.stack([f["lm68"] for f in fi_all]),
+             "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_all])}
+    # the clip renderer = the caller's frame loop (genefacepp_infer.py:246-269, 460-469): pose -> rays on the device -> model.render() -> uint8 HWC
+    # on the device, one hipGraph per frame.  The driving signals of all frames are resident in HBM before the timed region starts.
+    from genefaceplusplus_amd.clip import ClipRenderer
+    cr = ClipRenderer(model, HW, HW, intr, bg_img=bg_color, T_thresh=0.01, use_graph=model.use_graph)
+    clip = cr.prepare(batch, dev)
+    HWO = cr.out_hw[0]                                          # the *_sr models render 256^2 rays and super-resolve to 512^2
     out_u8 = torch.empty(K, HWO, HWO, 3, dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(out_u8) for _ in range(world)] if world > 1 else None
+    # multi-GPU: finished frames are all_gathered in chunks while the next chunk renders (RCCL runs on its own stream)
+    chunk = max(1, min(K, args.gather_every))
+    bounds = [(c, min(c + chunk, K)) for c in range(0, K, chunk)]
+    gathered = [torch.empty(world * (e - b), HWO, HWO, 3, dtype=torch.uint8, device=dev) for b, e in bounds] if world > 1 else None
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    # reference-shaped per-frame API with pre-materialised rays (what genefacepp_infer.py calls today): used by `modes` below
+    inputs = []
+    for j in range(min(len(my_frames), W + 4)):
+        pose = torch.from_numpy(batch["ngp_poses"][j]).to(dev)[None]
+        rays = camera.get_rays(pose, intr, HW, HW)
+        inputs.append({"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose),
+                       "cond": torch.from_numpy(fi_all[j]["cond"]).to(dev), "lm68": torch.from_numpy(fi_all[j]["lm68"]).to(dev),
+                       "eye": torch.from_numpy(fi_all[j]["eye_area_percent"]).to(dev)})
+    scratch_u8 = torch.empty(HWO, HWO, 3, dtype=torch.uint8, device=dev)
 
     def render(i, slot=None, timed=False):
-        x = inputs[i]
+        x = inputs[i % len(inputs)]
         with torch.no_grad():
             res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=i, staged=False, bg_color=bg_color,
                                lm68=x["lm68"], perturb=False, force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
@@ -154,20 +173,25 @@ def main():
         if args.variant == "may_torso_sr":
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1)              # [1,3,512,512] view of NHWC memory
         if slot is not None:
-            frames.to_uint8_hwc(rgb.reshape(HWO, HWO, 3), out_u8[slot])
+            frames.to_uint8_hwc(rgb.reshape(HWO, HWO, 3), scratch_u8)
         return res
 
-    for i in range(W):
-        render(i)
+    # warm-up: W frames, and one collective of the timed size so that RCCL's lazy channel set-up is not inside the timed region
+    cr.render_to_device(clip, range(W), out=out_u8[:W] if W <= K else None)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered[0], out_u8[bounds[0][0]:bounds[0][1]])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(K):
-        render(W + k, slot=k)
-    if world > 1:
-        dist.all_gather(gathered, out_u8)
+    pending = []
+    for (b, e), g in zip(bounds, gathered or [None] * len(bounds)):
+        cr.render_to_device(clip, range(W + b, W + e), out=out_u8[b:e])
+        if world > 1:
+            pending.append(dist.all_gather_into_tensor(g, out_u8[b:e], async_op=True))
+    for work in pending:
+        work.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -189,7 +213,8 @@ def main():
                                          + (" + StyleGAN2 super-resolution to 512x512 (random noise inputs, like the reference)" if args.variant == "may_torso_sr" else "")
                                          + ", max_steps 16, T_thresh 0.01, "
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
-                             "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (" + RCCL all_gather of uint8 frames" if world > 1 else ""),
+                             "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (f" + RCCL all_gather of uint8 frames every {chunk} frames, overlapped with rendering" if world > 1 else ""),
+                             "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: pose -> rays on device -> model.render() -> uint8 HWC on device",
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 
@@ -249,17 +274,51 @@ def main():
             if prec == args.precision:
                 continue
             model.precision = prec
-            for i in range(3):
-                render(i)
+            n_m = min(10, K)
+            cr.render_to_device(clip, range(3), out=out_u8[:3] if K >= 3 else None)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n_m = 10
-            for k in range(n_m):
-                render(W + (k % K), slot=k % K)
+            cr.render_to_device(clip, range(W, W + n_m), out=out_u8[:n_m])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             modes[prec] = {"value": round(n_m / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_m, 4), "steps": n_m}
         model.precision = args.precision
+        # the reference-shaped call sequence as genefacepp_infer.py issues it today: rays pre-materialised per frame (6.3 MB each), one
+        # model.render() per frame, uint8 conversion as a separate launch
+        for i in range(3):
+            render(i, slot=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(20):
+            render(W + k, slot=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        modes["per_frame_api"] = {"value": round(20 / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / 20, 4), "steps": 20,
+                                  "precision": args.precision, "workload": "model.render(rays_o, rays_d, ...) per frame with pre-materialised rays"}
+        # the caller's whole loop (genefacepp_infer.py:246-269, 460-469) through genefaceplusplus_amd.clip: rays generated on the device from the
+        # pose, uint8 conversion on the device, every frame delivered to HOST memory through the pinned ring -- the PCIe-inclusive rate
+        try:
+            n_c = 64
+            fi_c = [syn.synthetic_frame_inputs(hp, i) for i in range(n_c)]
+            batch_c = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(n_c)]).astype(np.float32),
+                       "cond_wins": np.stack([f["cond"] for f in fi_c]), "lm68": np.stack([f["lm68"] for f in fi_c]),
+                       "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_c])}
+            clip_c = cr.prepare(batch_c, dev)
+            sunk = [0]
+
+            def sink(i, frame):
+                sunk[0] += int(frame[0, 0, 0]) * 0 + 1
+            cr.render_to_host(clip_c, sink=sink, frame_indices=range(4))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cr.render_to_host(clip_c, sink=sink)
+            dt = time.perf_counter() - t1
+            modes["clip_to_host"] = {"value": round(n_c / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_c, 4), "steps": n_c,
+                                     "precision": args.precision, "frames_delivered": sunk[0] - 4,
+                                     "workload": "the headline frame loop + every frame delivered to host memory through the pinned ring (async D2H): "
+                                                 "the PCIe-inclusive rate"}
+        except Exception as exc:
+            modes["clip_to_host"] = {"value": None, "error": str(exc)}
         if args.variant == "may_torso" and HW == 512:
             # the released May checkpoint's shape: 256^2 rays, landmark-conditioned head-aware torso, StyleGAN2 super-resolution to 512^2
             try:

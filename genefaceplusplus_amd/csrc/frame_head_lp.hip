@@ -27,7 +27,10 @@
 
 namespace gfpp {
 
-constexpr int kLpThreads = 512;
+#ifndef GFPP_LP_THREADS
+#define GFPP_LP_THREADS 512
+#endif
+constexpr int kLpThreads = GFPP_LP_THREADS;
 constexpr int kLpWaves = kLpThreads / 64;
 constexpr int kLpSlots = 128;   // sample slots of one wavefront tile
 constexpr int kLpRays = 64;     // rays of one wavefront tile (at most)
@@ -299,6 +302,9 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         u3[0] = (wt.px[slot] + a.mp.bound) / b2;
         u3[1] = (wt.py[slot] + a.mp.bound) / b2;
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
+#ifdef GFPP_EXP_CONST_POS
+        for (int d = 0; d < 3; ++d) u3[d] = u3[d] * 1e-9f + 0.4f;
+#endif
         encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
     }
     lap(0);
@@ -307,7 +313,11 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
         lap(1);
 #pragma unroll
+#ifdef GFPP_EXP_CONST_AMB
+        for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) * 1e-9f + 1.0f) / 2.0f;
+#else
         for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
+#endif
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
     lap(2);
@@ -316,7 +326,7 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
 }
 
 template <int AMB_D, typename H, bool SLOW>
-__global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
+__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(LpTripArgs a) {
     __shared__ LpShared sh;
     // ---- loop state, recomputed from the per-trip counters (renderer.py:354-384) ----------------------------------
     uint32_t step_before = 0;
@@ -364,9 +374,9 @@ __global__ __launch_bounds__(kLpThreads, 2) void k_head_trip_lp(LpTripArgs a) {
     // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
     for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
     for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
-    if (tid < 256) sh.bias[tid] = a.frame_consts[tid];
-    else if (tid < 512) {   // 2 x 16 descriptors x 8 dwords
-        const int k = tid - 256, which = k >> 7, w = k & 127;
+    for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
+    for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
+        const int which = k >> 7, w = k & 127;
         reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
     }
     __syncthreads();

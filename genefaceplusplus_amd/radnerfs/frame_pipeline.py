@@ -244,9 +244,10 @@ class GraphedFrame:
     which is how the reference's caller uses them (it moves every frame to the host right away, genefacepp_infer.py:465-469).
     Host cost per frame: a handful of small device-to-device copies + one graph launch instead of ~25 launches and their Python."""
 
-    def __init__(self, fn, inputs):
+    def __init__(self, fn, inputs, copy_inputs=True):
+        """copy_inputs=False: `inputs` already ARE the static buffers (the caller refreshes them itself before `graph.replay()`)."""
         self.fn = fn
-        self.static = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+        self.static = {k: (v.detach().clone() if torch.is_tensor(v) and copy_inputs else v) for k, v in inputs.items()}
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream), torch.no_grad():

@@ -1,0 +1,78 @@
+"""Clip renderer (genefaceplusplus_amd/clip.py): device-side ray generation + uint8 conversion + pinned async hand-off
+must deliver, frame for frame, the bytes that the reference-shaped per-frame call sequence delivers."""
+import numpy as np
+import pytest
+import torch
+
+from genefaceplusplus_amd import synthetic as syn
+from helpers import frame_case, build_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _clip_batch(hp, F):
+    fi = [syn.synthetic_frame_inputs(hp, i) for i in range(F)]
+    return {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(F)]).astype(np.float32),
+            "cond_wins": np.stack([f["cond"] for f in fi]), "lm68": np.stack([f["lm68"] for f in fi]),
+            "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi])}
+
+
+def _reference_shaped_loop(model, case, batch, dev, HW, sr):
+    """The caller's loop of inference/genefacepp_infer.py:246-269, 460-469 on the same model object."""
+    from genefaceplusplus_amd.radnerfs import camera
+    hp = case["hp"]
+    out = []
+    bg = torch.from_numpy(case["bg_color"]).to(dev)
+    for i in range(batch["ngp_poses"].shape[0]):
+        pose = torch.from_numpy(batch["ngp_poses"][i:i + 1]).to(dev)
+        rays = camera.get_rays(pose, case["intr"], HW, HW)
+        with torch.no_grad():
+            res = model.render(rays["rays_o"], rays["rays_d"], torch.from_numpy(batch["cond_wins"][i]).to(dev), camera.get_bg_coords(HW, HW, dev),
+                               camera.convert_poses(pose), index=i, staged=False, bg_color=bg, lm68=torch.from_numpy(batch["lm68"][i]).to(dev),
+                               perturb=False, force_all_rays=False, T_thresh=case["T_thresh"],
+                               eye_area_percent=torch.from_numpy(batch["eye_area_percent"][i]).to(dev), sr_noise_mode="const", **hp)
+        if sr:
+            rgb = res["sr_rgb_map"][0].cpu()
+            img = (rgb.permute(1, 2, 0) * 255.).int().numpy().astype(np.uint8)
+        else:
+            img = (res["rgb_map"][0].reshape(HW, HW, 3).cpu() * 255.).int().numpy().astype(np.uint8)
+        out.append(img)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("variant,HW,precision,graph", [("may_torso", 128, "fp32", True), ("may_torso", 128, "fp16", True),
+                                                        ("may_head", 96, "fp32", False), ("may_torso_sr", 256, "fp16", True)])
+def test_clip_bytes_equal_per_frame_calls(dev, variant, HW, precision, graph):
+    from genefaceplusplus_amd.clip import ClipRenderer
+    case = frame_case(variant, HW)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    F = 7
+    batch = _clip_batch(case["hp"], F)
+    sr = variant.endswith("_sr")
+    want = _reference_shaped_loop(model, case, batch, dev, HW, sr)
+    kw = dict(case["hp"])
+    if sr:
+        kw["sr_noise_mode"] = "const"            # the reference's default ('random') draws fresh noise per frame: not comparable
+    r = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], ring=3, use_graph=graph,
+                     render_kwargs=kw)
+    clip = r.prepare(batch, dev)
+    got = r.render_to_host(clip)
+    assert got.shape == want.shape and got.dtype == np.uint8
+    assert want.std() > 10, "degenerate frames"
+    np.testing.assert_array_equal(got, want)
+    # streaming hand-off: in order, one call per frame, and a sub-range works
+    seen = []
+    r.render_to_host(clip, sink=lambda i, a: seen.append((i, a.copy())), frame_indices=[5, 2, 6])
+    assert [i for i, _ in seen] == [5, 2, 6]
+    for i, a in seen:
+        np.testing.assert_array_equal(a, want[i])
+    # device-resident stack (what the multi-GPU gather consumes)
+    stack = r.render_to_device(clip, [1, 3])
+    np.testing.assert_array_equal(stack.cpu().numpy(), want[[1, 3]])
