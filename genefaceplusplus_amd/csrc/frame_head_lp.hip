@@ -18,6 +18,8 @@
 //   * Wavefronts are autonomous: a wavefront marches 64 / 32 / 16 rays (<= 128 sample slots), compacts, evaluates 32 samples
 //     per pass, composites and appends its survivors -- no workgroup barrier after the weight copy, so one wavefront's
 //     gathers overlap another's MFMAs on the same SIMD.
+#include <cstdlib>
+
 #include "head_eval_device.h"
 #include "lp_mfma_device.h"
 
@@ -78,12 +80,12 @@ struct LpTripArgs {
     uint32_t *consumed;           // [N]: how many the previous trips used up (the role of rays_t)
     uint32_t sample_stride;
     float *weights_sum, *depth, *image;
-    const int32_t *alive_in;
-    int32_t *alive_out;
+    int32_t *alive[2];            // ping-pong survivor lists: trip k reads alive[k & 1], writes alive[(k + 1) & 1]
     int32_t *counters;
+    int32_t *sync;                // barrier word of multi-trip launches (counters[127], zeroed by k_frame_begin)
     const float *frame_consts;
     float T_thresh, density_scale;
-    uint32_t N, trip, max_steps;
+    uint32_t N, trip, trip_end, max_steps;   // this launch runs the trips [trip, trip_end)
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
 
@@ -325,44 +327,80 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
     lap(3);
 }
 
+// Counters are written by other workgroups (atomics at the device's coherence point) while this kernel runs when it covers several
+// trips: read them there, not through the per-XCD caches.
+__device__ __forceinline__ uint32_t counter_load(const int32_t *p) {
+    return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Device-wide barrier between two trips of one launch.  Every workgroup of the launch is resident (one per CU, the launch never has
+// more workgroups than the device has CUs), so spinning cannot starve a workgroup that has not started; kernels of other streams only
+// delay it.  Release/acquire at agent scope write back and invalidate the per-XCD L2s, which is what makes one trip's ray state and
+// survivor list visible to whichever workgroup picks the ray up in the next trip.  The spin is bounded: on a timeout the barrier word
+// is poisoned (negative, so later barriers fall through and the host can see it, FramePipeline.trip_counters) instead of hanging the GPU.
+__device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (counter_load(bar) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) { __hip_atomic_store(bar, (int32_t)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// One launch runs the trips [a.trip, a.trip_end) (renderer.py:352-384: one loop iteration each).  The host issues the first few trips as
+// separate launches (no barrier needed: the stream orders them) and the rest -- which most frames never reach -- as ONE launch that
+// finds its first counter at zero and returns, instead of ten empty launches.
 template <int AMB_D, typename H, bool SLOW>
 __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(LpTripArgs a) {
     __shared__ LpShared sh;
-    // ---- loop state, recomputed from the per-trip counters (renderer.py:354-384) ----------------------------------
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t waves_total = gridDim.x * kLpWaves;
+    const bool prof = a.phase_cycles != nullptr;
+    bool weights_resident = false;
+    uint32_t barriers = 0;
+    // ---- loop state up to the first trip of this launch (renderer.py:354-384) ------------------------------------------------------
     uint32_t step_before = 0;
     for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = (uint32_t)a.counters[k];
+        const uint32_t na = counter_load(a.counters + k);
         if (na == 0) return;
         uint32_t ns = a.N / na;
         ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
         step_before += ns;
     }
-    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
-    if (n_alive == 0 || step_before >= a.max_steps) return;
+  for (uint32_t trip = a.trip; trip < a.trip_end; ++trip) {
+    const uint32_t n_alive = counter_load(a.counters + trip);
+    if (n_alive == 0 || step_before >= a.max_steps) return;   // the same decision in every workgroup
     uint32_t n_step = a.N / n_alive;
     n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+    step_before += n_step;
+    const int32_t *alive_in = a.alive[trip & 1];
+    int32_t *alive_out = a.alive[(trip + 1) & 1];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Rays per wavefront tile: at most 64 (128 sample slots).  A wavefront works through its tiles' 32-sample blocks one after the other,
-    // so the launch lasts (tiles per wavefront) x (blocks per tile) block times: take the largest tile that minimises that product --
+    // so the launch lasts (tiles per wavefront) x (blocks per tile + per-tile overhead) block times: take the largest tile that minimises that --
     // few large tiles would leave most wavefronts idle behind a 4-block critical path (small frames, late trips), many small ones only
     // add per-tile overhead.
-    const uint32_t waves_total = gridDim.x * kLpWaves;
     uint32_t rays_per_tile = (uint32_t)kLpSlots / n_step < (uint32_t)kLpRays ? (uint32_t)kLpSlots / n_step : (uint32_t)kLpRays;
     {
         uint32_t best = 0xFFFFFFFFu, best_rpt = rays_per_tile;
         for (uint32_t rpt = rays_per_tile; rpt * n_step >= 32u || rpt == rays_per_tile; rpt >>= 1) {
             const uint32_t tiles = (n_alive + rpt - 1) / rpt;
-            const uint32_t crit = ((tiles + waves_total - 1) / waves_total) * ((rpt * n_step + 31u) / 32u);
+            // cost in fifths of a block time: every tile also pays for fetching its rays' state and compositing (~0.6 block, measured)
+            const uint32_t crit = ((tiles + waves_total - 1) / waves_total) * (5u * ((rpt * n_step + 31u) / 32u) + 3u);
             if (crit < best) { best = crit; best_rpt = rpt; }
             if (rpt == 1u) break;
         }
         rays_per_tile = best_rpt;
     }
     const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
-    if ((uint32_t)blockIdx.x * kLpWaves >= n_tiles) return;   // no tile for any wavefront of this workgroup
+   if ((uint32_t)blockIdx.x * kLpWaves < n_tiles) {   // else: no tile for any wavefront of this workgroup in this trip
 
-    const bool prof = a.phase_cycles != nullptr;
     unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull, cyc[4] = {0ull, 0ull, 0ull, 0ull};
     auto lap = [&](int phase) {
         if (prof) {
@@ -372,14 +410,17 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         }
     };
     // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
-    for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
-    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
-    for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
-    for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
-        const int which = k >> 7, w = k & 127;
-        reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
+    if (!weights_resident) {
+        for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
+        for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
+        for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
+        for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
+            const int which = k >> 7, w = k & 127;
+            reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
+        }
+        __syncthreads();
+        weights_resident = true;
     }
-    __syncthreads();
     lap(0);
 
     LpWaveTile &wt = sh.tile[wave];
@@ -392,8 +433,8 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         const bool has_ray = (uint32_t)lane < rays_per_tile && n < n_alive;
         uint32_t ray = 0, cnt = 0, used = 0;
         if (has_ray) {
-            ray = a.trip == 0 ? n : (uint32_t)a.alive_in[n];
-            used = a.trip == 0 ? 0u : a.consumed[ray];
+            ray = trip == 0 ? n : (uint32_t)alive_in[n];
+            used = trip == 0 ? 0u : a.consumed[ray];
             const uint32_t avail = a.sample_cnt[ray] - used;
             cnt = avail < n_step ? avail : n_step;
             wt.ray[lane] = ray;
@@ -450,18 +491,21 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         const unsigned long long ballot = __ballot(survives);
         const uint32_t total = (uint32_t)__popcll(ballot);
         uint32_t out_base = 0;
-        if (lane == 0 && total) out_base = (uint32_t)atomicAdd(&a.counters[a.trip + 1], (int)total);
+        if (lane == 0 && total) out_base = (uint32_t)atomicAdd(&a.counters[trip + 1], (int)total);
         out_base = (uint32_t)__shfl((int)out_base, 0);
-        if (survives) a.alive_out[out_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (int32_t)ray;
+        if (survives) alive_out[out_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (int32_t)ray;
         wave_sync();
         lap(3);
     }
     if (prof && lane == 0)
         for (int ph = 0; ph < 4; ++ph) {
-            atomicAdd(&a.phase_cycles[8 * a.trip + ph], cyc[ph]);
-            atomicAdd(&a.phase_cycles[8 * a.trip + 4 + ph], sub[ph]);
+            atomicAdd(&a.phase_cycles[8 * trip + ph], cyc[ph]);
+            atomicAdd(&a.phase_cycles[8 * trip + 4 + ph], sub[ph]);
         }
-    if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + a.trip], (int)evaluated);   // evaluated samples of this trip
+    if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + trip], (int)evaluated);   // evaluated samples of this trip
+   }
+    if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
+  }
 }
 
 // The sample positions of a ray do not depend on the radiance field (only on the occupancy bitfield), and the reference's marcher
@@ -495,6 +539,17 @@ static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
 
 static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {
     return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
+}
+
+// How many trips get a launch of their own before the multi-trip launch takes over (GFPP_LP_SEPARATE_TRIPS overrides, for experiments).
+static uint32_t lp_separate_trips() {
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("GFPP_LP_SEPARATE_TRIPS");
+        n = e ? atoi(e) : 6;
+        if (n < 0) n = 0;
+    }
+    return (uint32_t)n;
 }
 
 static int lp_cu_count() {
@@ -580,10 +635,13 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     void (*launch)(uint32_t, hipStream_t, const LpTripArgs &) =
         amb3 ? (bf ? (slow ? launch_lp<3, __bf16, true> : launch_lp<3, __bf16, false>) : (slow ? launch_lp<3, _Float16, true> : launch_lp<3, _Float16, false>))
              : (bf ? (slow ? launch_lp<2, __bf16, true> : launch_lp<2, __bf16, false>) : (slow ? launch_lp<2, _Float16, true> : launch_lp<2, _Float16, false>));
-    for (uint32_t trip = 0; trip < max_steps; ++trip) {
+    a.alive[0] = ws->alive[0]; a.alive[1] = ws->alive[1];
+    a.sync = ws->counters + 127;
+    // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
+    const uint32_t separate = lp_separate_trips() < max_steps ? lp_separate_trips() : max_steps;
+    for (uint32_t trip = 0; trip <= separate && trip < max_steps; ++trip) {
         a.trip = trip;
-        a.alive_in = ws->alive[trip & 1];
-        a.alive_out = ws->alive[(trip + 1) & 1];
+        a.trip_end = trip < separate ? trip + 1 : max_steps;
         launch(grid, st, a);
         const int rc = check_launch("gfpp_head_frame_trips_lp");
         if (rc) return rc;

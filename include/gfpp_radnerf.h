@@ -263,7 +263,8 @@ typedef struct gfpp_frame_ws {
     float *depth;        /* [N] */
     float *image;        /* [N,3] premultiplied head colour */
     int32_t *alive[2];   /* [N] each: ping-pong lists of alive ray ids */
-    int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated */
+    int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated;
+                          * counters[127] = barrier word of the 16-bit kernel's multi-trip launch (negative = a barrier timed out) */
     float *frame_consts; /* [256] f32: folded biases of ambient_net.0 and color_net.0 in fragment order */
     float *sample_t;        /* 16-bit kernel only: [N, sample_stride] f32, t of every occupied sample of each ray in march order */
     uint32_t *sample_cnt;   /* 16-bit kernel only: [N] u32 */
