@@ -367,7 +367,12 @@ def main():
         tfile = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.precision}.json")
         if os.path.exists(tfile):
             try:
-                result["roofline"]["traffic"] = json.load(open(tfile))
+                detail = json.load(open(tfile))
+                # per launch, like `achieved`: fabric-side bytes (FETCH_SIZE x 2 as the guide prescribes for 16-B-per-lane reads, + WRITE_SIZE)
+                result["roofline"]["traffic"] = detail.get("bytes_per_launch")
+                result["roofline"]["algorithmic_bytes_per_launch"] = int(result["roofline"]["samples_per_frame"] * GATHER_BYTES_PER_SAMPLE
+                                                                         / max(result["roofline"]["nonempty_trips_per_frame"], 1))
+                result["roofline"]["traffic_detail"] = detail
             except Exception:
                 pass
 

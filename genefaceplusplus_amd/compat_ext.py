@@ -65,26 +65,26 @@ def sph_from_ray(rays_o, rays_d, radius, N, coords):                            
     call("gfpp_sph_from_ray", _p(rays_o), _p(rays_d), float(radius), int(N), _p(coords), _st())
 
 
-def morton3D_dilation(grid, C, H, grid_dilation):                                                # raymarching.h:11
+def morton3D_dilation(grid, C, H, grid_dilation):                                                # raymarching.h:12
     call("gfpp_morton3D_dilation", _p(grid), int(C), int(H), _p(grid_dilation), _st())
 
 
-def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):   # raymarching.h:12
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):   # raymarching.h:14
     call("gfpp_march_rays_train", _p(rays_o), _p(rays_d), _p(grid), float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H), int(M),
          _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter), _p(noises), _st())
 
 
-def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):   # raymarching.h:13
+def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):   # raymarching.h:15
     call("gfpp_march_rays_train_backward", _p(grad_xyzs), _p(grad_dirs), _p(rays), _p(deltas), int(N), int(M), _p(grad_rays_o), _p(grad_rays_d), _st())
 
 
-def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):   # raymarching.h:14
+def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):   # raymarching.h:16
     call("gfpp_composite_rays_train_forward", _p(sigmas), _p(rgbs), _p(ambient), _p(deltas), _p(rays), int(M), int(N), float(T_thresh), _p(weights_sum),
          _p(ambient_sum), _p(depth), _p(image), _st())
 
 
 def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image, M, N,
-                                  T_thresh, grad_sigmas, grad_rgbs, grad_ambient):               # raymarching.h:15
+                                  T_thresh, grad_sigmas, grad_rgbs, grad_ambient):               # raymarching.h:17
     call("gfpp_composite_rays_train_backward", _p(grad_weights_sum), _p(grad_ambient_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(ambient), _p(deltas),
          _p(rays), _p(weights_sum), _p(ambient_sum), _p(image), int(M), int(N), float(T_thresh), _p(grad_sigmas), _p(grad_rgbs), _p(grad_ambient), _st())
 

@@ -65,3 +65,42 @@ def gather_clip(local_frames, n_frames, interleaved=False, group=None):
         if idx:
             clip[torch.tensor(idx, device=clip.device)] = parts[r][:len(idx)]
     return clip
+
+
+# ---- several identities on one node (BASELINE config 5: 4 person-specific models on 8 GPUs, 2 GPUs each) --------
+
+def identity_groups(world, n_identities):
+    """Contiguous rank blocks, one per identity: identity i owns ranks[i].  Contiguous so that the ranks of one identity are xGMI
+    neighbours on one node and its frame gather stays inside the block.  world must be a multiple of n_identities."""
+    if n_identities < 1 or world % n_identities:
+        raise ValueError(f"{world} ranks cannot be split evenly over {n_identities} identities")
+    per = world // n_identities
+    return [list(range(i * per, (i + 1) * per)) for i in range(n_identities)]
+
+
+def make_identity_groups(n_identities):
+    """Create one sub-communicator per identity (every rank must call this: `new_group` is collective).
+    Returns (my_identity, my_group, all_rank_lists)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ranks = identity_groups(world, n_identities)
+    mine, my_group = None, None
+    for i, block in enumerate(ranks):
+        g = dist.new_group(ranks=block)
+        if rank in block:
+            mine, my_group = i, g
+    return mine, my_group, ranks
+
+
+def share_driving_signals(tensors, src=0):
+    """The upstream audio2motion result (expression / landmark windows, blink values: tens of KB) is computed once on `src` and broadcast to every
+    rank of the job, instead of once per identity (the reference runs it per inference call, genefacepp_infer.py:298-431).
+    `tensors`: dict name -> tensor, same shapes on every rank (allocate empties on the receivers)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for name in sorted(tensors):
+            dist.broadcast(tensors[name], src=src)
+    return tensors
+
+
+def gather_identity_clip(local_frames, n_frames, my_group, interleaved=False):
+    """Frame gather inside one identity's rank block (the only collective of the multi-identity job besides the one broadcast)."""
+    return gather_clip(local_frames, n_frames, interleaved, group=my_group)

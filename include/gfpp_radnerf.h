@@ -14,7 +14,7 @@
  *   - nothing here allocates, frees or synchronises, so every call is hipGraph-capturable.
  *
  * Section A mirrors, one to one, the reference's native extension API (the functions its Python shims call):
- *     _raymarching_face : modules/radnerfs/raymarching/src/raymarching.h:7-19, bindings.cpp:7-20
+ *     _raymarching_face : modules/radnerfs/raymarching/src/raymarching.h:7-20, bindings.cpp:7-20
  *     _gridencoder      : modules/radnerfs/encoders/gridencoder/src/gridencoder.h:12-15
  *     _shencoder        : modules/radnerfs/encoders/shencoder/src/shencoder.h
  *     _freqencoder      : modules/radnerfs/encoders/freqencoder/src/freqencoder.h
@@ -66,7 +66,7 @@ int gfpp_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, gf
  * grid [N*8] f32 -> bitfield [N] u8, bit i of byte n <=> grid[8n+i] > density_thresh. */
 int gfpp_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, gfpp_stream_t stream);
 
-/* replaces march_rays (raymarching.h:18; kernel raymarching.cu:827-929), argument order of the C++ binding.
+/* replaces march_rays (raymarching.h:19; kernel raymarching.cu:827-929), argument order of the C++ binding.
  * rays_alive [n_alive] i32; rays_t, nears, fars [N] f32; rays_o, rays_d [N,3]; grid = density bitfield [C*H^3/8] u8;
  * xyzs, dirs [M,3], deltas [M,2] f32 with M >= n_alive*n_step, ZERO-INITIALISED by the caller (raymarching.py:384-386);
  * noises [n_alive] f32.  Slot layout n*n_step + s. */
@@ -75,7 +75,7 @@ int gfpp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive
                     const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                     const float *noises, gfpp_stream_t stream);
 
-/* replaces composite_rays (raymarching.h:19; kernel raymarching.cu:942-1029).
+/* replaces composite_rays (raymarching.h:20; kernel raymarching.cu:942-1029).
  * sigmas [M], rgbs [M,3], deltas [M,2] f32; in/out: rays_alive [n_alive] (set to -1 when the ray terminates),
  * rays_t, weights_sum, depth [N], image [N,3]. */
 int gfpp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
@@ -383,28 +383,28 @@ int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, 
  * caller-allocated outputs, written in place; fp32.
  * ---------------------------------------------------------------------------------------------------------- */
 
-/* replaces march_rays_train (raymarching.h:12; kernel raymarching.cu:352-518): per ray, count the occupied samples (<= max_steps), reserve
+/* replaces march_rays_train (raymarching.h:14; kernel raymarching.cu:352-518): per ray, count the occupied samples (<= max_steps), reserve
  * a range with atomicAdd(counter[0], count) / a row with atomicAdd(counter[1], 1), write rays [N,3] = (ray, first point, count) and, if the
  * range fits below M, the samples xyzs/dirs [M,3], deltas [M,2] = (dt, t + dt).  noises [N]: perturbation of the start, 0 = none. */
 int gfpp_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
                           uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
                           float *deltas, int32_t *rays, int32_t *counter, const float *noises, gfpp_stream_t stream);
 
-/* replaces march_rays_train_backward (raymarching.h:13; raymarching.cu:535-583): grad_rays_o/d [N,3] += sums over each ray's samples. */
+/* replaces march_rays_train_backward (raymarching.h:15; raymarching.cu:535-583): grad_rays_o/d [N,3] += sums over each ray's samples. */
 int gfpp_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays, const float *deltas, uint32_t N, uint32_t M,
                                    float *grad_rays_o, float *grad_rays_d, gfpp_stream_t stream);
 
-/* replaces composite_rays_train_forward (raymarching.h:14; raymarching.cu:603-688): T *= 1 - alpha, stop when T < T_thresh AFTER the update. */
+/* replaces composite_rays_train_forward (raymarching.h:16; raymarching.cu:603-688): T *= 1 - alpha, stop when T < T_thresh AFTER the update. */
 int gfpp_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, uint32_t M,
                                       uint32_t N, float T_thresh, float *weights_sum, float *ambient_sum, float *depth, float *image, gfpp_stream_t stream);
 
-/* replaces composite_rays_train_backward (raymarching.h:15; raymarching.cu:711-810). */
+/* replaces composite_rays_train_backward (raymarching.h:17; raymarching.cu:711-810). */
 int gfpp_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_ambient_sum, const float *grad_image, const float *sigmas,
                                        const float *rgbs, const float *ambient, const float *deltas, const int32_t *rays, const float *weights_sum,
                                        const float *ambient_sum, const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                        float *grad_rgbs, float *grad_ambient, gfpp_stream_t stream);
 
-/* replaces morton3D_dilation (raymarching.h:11; raymarching.cu:304-335): 6-neighbour max pool of a Morton-ordered [C, H^3] grid. */
+/* replaces morton3D_dilation (raymarching.h:12; raymarching.cu:304-335): 6-neighbour max pool of a Morton-ordered [C, H^3] grid. */
 int gfpp_morton3D_dilation(const float *grid, uint32_t C, uint32_t H, float *grid_dilation, gfpp_stream_t stream);
 
 /* replaces sph_from_ray (raymarching.h:8; raymarching.cu:162-199): far intersection with a sphere -> (theta, phi) in [-1,1]^2, coords [N,2]. */

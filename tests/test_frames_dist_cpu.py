@@ -69,3 +69,49 @@ def test_gather_clip_world2_gloo(n_frames, inter):
         assert p.exitcode == 0
     assert sorted(r for r, _, _ in results) == [0, 1]
     assert all(ok for _, ok, _ in results) and all(t == 2.0 for _, _, t in results)
+
+
+def test_identity_groups_partition():
+    assert frames.identity_groups(8, 4) == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert frames.identity_groups(2, 2) == [[0], [1]]
+    assert frames.identity_groups(4, 1) == [[0, 1, 2, 3]]
+    with pytest.raises(ValueError):
+        frames.identity_groups(8, 3)
+
+
+def _identity_worker(rank, world, port, n_ident, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ident, group, blocks = frames.make_identity_groups(n_ident)
+    # shared upstream result: computed on rank 0 only, then identical everywhere
+    sig = {"cond": torch.arange(12, dtype=torch.float32).reshape(3, 4) if rank == 0 else torch.zeros(3, 4),
+           "eye": torch.full((3, 1), 0.25) if rank == 0 else torch.zeros(3, 1)}
+    frames.share_driving_signals(sig, src=0)
+    shared_ok = bool(torch.equal(sig["cond"], torch.arange(12, dtype=torch.float32).reshape(3, 4)) and float(sig["eye"].sum()) == 0.75)
+    # every identity renders the whole clip, frame-parallel inside its block; a frame's pixels encode (identity, frame)
+    local_rank, local_world = blocks[ident].index(rank), len(blocks[ident])
+    mine = frames.shard_frames(n_frames, local_rank, local_world)
+    local = torch.stack([torch.full((2, 2, 3), 16 * ident + i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 2, 2, 3, dtype=torch.uint8)
+    clip = frames.gather_identity_clip(local, n_frames, group)
+    clip_ok = clip.shape[0] == n_frames and all(int(clip[i, 0, 0, 0]) == 16 * ident + i for i in range(n_frames))
+    q.put((rank, ident, shared_ok, bool(clip_ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_ident", [(2, 2), (4, 2)])
+def test_multi_identity_groups_gloo(world, n_ident):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_identity_worker, args=(r, world, port, n_ident, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per = world // n_ident
+    for rank, ident, shared_ok, clip_ok in results:
+        assert ident == rank // per and shared_ok and clip_ok

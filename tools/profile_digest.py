@@ -28,14 +28,15 @@ def demangle(name):
     return name
 
 
-def main(tag, precision):
+def main(tag, precision, bench_args=None):
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     rows = list(csv.DictReader(open(os.path.join(src, f"{tag}_stats", "bench_kernel_stats.csv"))))
     bench_line = [l for l in open(os.path.join(src, f"{tag}_bench.log")) if l.startswith('{"metric')][-1].strip()
     out = [f"# rocprofv3 --kernel-trace --stats -- {tag}",
            "",
-           f"Command (1x MI355X via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --precision {precision} --no-cpu-baseline --no-modes`",
+           f"Command (1x MI355X via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
+           + (bench_args or f"--steps 20 --warmup 3 --precision {precision} --no-cpu-baseline --no-modes") + "`",
            "",
            "bench line of the profiled run (profiling costs a few % of wall time):", "", "```", bench_line, "```", "",
            "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
@@ -48,12 +49,17 @@ def main(tag, precision):
     rf = d.get("roofline", {})
     trip = [r for r in rows if "k_head_trip" in r["Name"]]
     if trip:
-        frames = 20 + 3 + 5          # timed + warm-up + the roofline section's repetitions
+        calls = sum(int(r["Calls"]) for r in trip)
+        per_frame = 16 if precision == "fp32" else 7      # launches per frame: fp32 = one per trip (max_steps); 16-bit = 6 single trips + 1 multi-trip
+        frames = calls / per_frame
         tot_ms = sum(int(r["TotalDurationNs"]) for r in trip) / 1e6
-        out += ["", f"Trip launches in this trace: {sum(int(r['Calls']) for r in trip)} dispatches, {tot_ms:.3f} ms in total = {tot_ms / frames:.4f} ms per frame over "
-                    f"{frames} frames (20 timed + 3 warm-up + 5 in the roofline section); bench.py's HIP-event measurement of the same launches: "
-                    f"{rf.get('ms_per_frame_all_trips')} ms per frame, {rf.get('avg_launch_ms')} ms per non-empty launch."]
+        out += ["", f"Trip launches in this trace: {calls} dispatches = {frames:.0f} frames x {per_frame} launches (timed + warm-up + graph warm-up + the roofline section's "
+                    f"repetitions), {tot_ms:.3f} ms in total = {tot_ms / frames:.4f} ms per frame; bench.py's HIP-event measurement of the same launches: "
+                    f"{rf.get('ms_per_frame_all_trips')} ms per frame, {rf.get('avg_launch_ms')} ms per non-empty launch "
+                    f"({rf.get('nonempty_trips_per_frame')} non-empty launches per frame -> {tot_ms / frames / max(rf.get('nonempty_trips_per_frame') or 1, 1):.4f} ms each from this trace)."]
     open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w").write("\n".join(out) + "\n")
+    if not os.path.exists(os.path.join(src, f"{tag}_pmc.txt")):
+        return
 
     pmc = open(os.path.join(src, f"{tag}_pmc.txt")).read()
     pmc = "\n".join(demangle(w) if w.startswith("_Z") else w for w in re.split(r"(\s+)", pmc)) if False else pmc
@@ -63,7 +69,9 @@ def main(tag, precision):
         lines.append((demangle(m.group(1)).split("(")[0] + m.group(2)) if m else line)
     head = [f"# rocprofv3 --pmc passes -- {tag}", "",
             f"Each counter group in its own run (`rocprofv3 --pmc <group> --kernel-trace -- python tools/profile_frame.py may_torso 512 3 {precision}`), summed per kernel over the",
-            "dispatches of the LAST rendered frame (16 trip launches, 6 of them non-empty); `per trip` lists the first 8 trip launches.",
+            ("dispatches of the LAST rendered frame (16 trip launches, 6 of them non-empty);" if precision == "fp32" else
+             "dispatches of the LAST rendered frame (trip launches: one per trip for the first six trips, then one multi-trip launch that finds nothing left);"),
+            "`per trip` lists those launches in order.",
             "Units as rocprofv3 reports them: FETCH_SIZE / WRITE_SIZE in KiB of fabric-side (L2 <-> Infinity Cache / HBM) traffic -- on gfx950 a wide coalesced read",
             "is under-reported by 2x and other access shapes are uncalibrated (MI355X_MICROARCH.md, HBM section), so read them as lower bounds and compare runs, not absolutes;",
             "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles summed over wavefronts; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; GRBM_GUI_ACTIVE in cycles summed over XCDs.", "",
@@ -75,14 +83,25 @@ def main(tag, precision):
         return float(m.group(1)) if m else None
     fetch, write = grab("FETCH_SIZE"), grab("WRITE_SIZE")
     hit, miss = grab("TCC_HIT_sum"), grab("TCC_MISS_sum")
-    traffic = {"source": f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, one frame = 16 trip launches)",
-               "fetch_MB_per_frame": round(fetch * 1024 / 1e6, 1) if fetch else None, "write_MB_per_frame": round(write * 1024 / 1e6, 1) if write else None,
+    m = re.search(r"per trip FETCH_SIZE \[([^\]]*)\]", pmc)
+    per_trip = [float(v) for v in m.group(1).split(",")] if m else []
+    nonempty = max(1, sum(1 for v in per_trip if v > 1000.0))
+    # MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B fabric request for 16-B-per-lane reads -> double it.
+    # WRITE_SIZE is uncalibrated and taken as reported.  KiB -> bytes.
+    fetch_b = 2.0 * fetch * 1024 if fetch else None
+    write_b = write * 1024 if write else None
+    traffic = {"source": f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, summed over the trip launches of one frame)",
+               "bytes_per_launch": int((fetch_b + write_b) / nonempty) if fetch_b and write_b else None,
+               "nonempty_launches_per_frame": nonempty,
+               "fetch_MB_per_frame": round(fetch_b / 1e6, 1) if fetch_b else None, "write_MB_per_frame": round(write_b / 1e6, 1) if write_b else None,
+               "fetch_MB_per_frame_uncorrected": round(fetch * 1024 / 1e6, 1) if fetch else None,
                "l2_hit_rate": round(hit / (hit + miss), 4) if hit and miss else None,
-               "note": "fabric-side (L2 <-> Infinity Cache / HBM) KiB as rocprofv3 reports them; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 and is "
-                       "uncalibrated for 16-byte gathers, so this is a lower bound.  Algorithmic gather bytes per frame = samples x 2060 B (~1.9 GB): the tables live in L2 / Infinity Cache"}
+               "note": "fabric-side (L2 <-> Infinity Cache / HBM) traffic; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950 (calibrated there on "
+                       "coalesced streams; the 16-byte gathers here are the same instruction width), Infinity-Cache hits are counted, not excluded.  Algorithmic gather bytes per "
+                       "frame = samples x 2060 B (~1.9 GB): the tables are L2 / Infinity-Cache resident, so fabric traffic is a fraction of the algorithmic stream"}
     json.dump(traffic, open(os.path.join(dst, f"r01_pmc_traffic_{precision}.json"), "w"), indent=1)
     print(json.dumps(traffic))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
