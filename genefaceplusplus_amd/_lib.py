@@ -29,6 +29,8 @@ _SIGNATURES = {
     "gfpp_grid_encode_forward": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_u32, c_i, c_u32, c_i, c_p],
     "gfpp_sh_encode_forward": [c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p],
     "gfpp_freq_encode_forward": [c_p, c_u32, c_u32, c_u32, c_u32, c_p, c_p],
+    "gfpp_sh_encode_backward": [c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p, c_p],
+    "gfpp_freq_encode_backward": [c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_p, c_p],
     "gfpp_march_rays_train": [c_p, c_p, c_p, c_f, c_f, c_u32, c_u32, c_u32, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "gfpp_march_rays_train_backward": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_p, c_p, c_p],
     "gfpp_composite_rays_train_forward": [c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_f, c_p, c_p, c_p, c_p, c_p],

@@ -55,12 +55,6 @@ def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, 
          _p(weights_sum), _p(depth), _p(image), _st())
 
 
-def _training_only(name):
-    def fn(*a, **k):
-        raise NotImplementedError(f"{name}: training kernels are not built yet (SURVEY.md 8f-2)")
-    return fn
-
-
 def sph_from_ray(rays_o, rays_d, radius, N, coords):                                             # raymarching.h:8
     call("gfpp_sph_from_ray", _p(rays_o), _p(rays_d), float(radius), int(N), _p(coords), _st())
 
@@ -112,8 +106,16 @@ def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
     call("gfpp_sh_encode_forward", _p(inputs), _p(outputs), int(B), int(D), int(C), _p(dy_dx), _st())
 
 
+def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):                                # shencoder.h:10
+    call("gfpp_sh_encode_backward", _p(grad), _p(inputs), int(B), int(D), int(C), _p(dy_dx), _p(grad_inputs), _st())
+
+
 def freq_encode_forward(inputs, B, D, deg, C, outputs):
     call("gfpp_freq_encode_forward", _p(inputs), int(B), int(D), int(deg), int(C), _p(outputs), _st())
+
+
+def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):                              # freqencoder.h:10
+    call("gfpp_freq_encode_backward", _p(grad), _p(outputs), int(B), int(D), int(deg), int(C), _p(grad_inputs), _st())
 
 
 def _module(name, fns):
@@ -130,6 +132,5 @@ def install():
     sys.modules["_raymarching_face"] = _module("_raymarching_face", rm)
     sys.modules["_gridencoder"] = _module("_gridencoder", dict(grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward,
                                                                  grad_total_variation=grad_total_variation))
-    sys.modules["_shencoder"] = _module("_shencoder", dict(sh_encode_forward=sh_encode_forward, sh_encode_backward=_training_only("sh_encode_backward")))
-    sys.modules["_freqencoder"] = _module("_freqencoder", dict(freq_encode_forward=freq_encode_forward,
-                                                                 freq_encode_backward=_training_only("freq_encode_backward")))
+    sys.modules["_shencoder"] = _module("_shencoder", dict(sh_encode_forward=sh_encode_forward, sh_encode_backward=sh_encode_backward))
+    sys.modules["_freqencoder"] = _module("_freqencoder", dict(freq_encode_forward=freq_encode_forward, freq_encode_backward=freq_encode_backward))

@@ -64,6 +64,45 @@ __global__ __launch_bounds__(kEncBlock) void k_sh_encode(const float *__restrict
     for (uint32_t i = 0; i < n; ++i) o[i] = sh[i];
 }
 
+// dy_dx [B, 3, degree^2]: rows d/dx, d/dy, d/dz of the features (shencoder.cu:125-352)
+__global__ __launch_bounds__(kEncBlock) void k_sh_dydx(const float *__restrict__ inputs, float *__restrict__ dy_dx, uint32_t B, uint32_t degree) {
+    const uint32_t b = blockIdx.x * kEncBlock + threadIdx.x;
+    if (b >= B) return;
+    float dx[16], dy[16], dz[16];
+    sh_basis4_grad(inputs[3ull * b], inputs[3ull * b + 1], inputs[3ull * b + 2], dx, dy, dz);
+    const uint32_t n = degree * degree;
+    float *o = dy_dx + (size_t)b * 3 * n;
+    for (uint32_t i = 0; i < n; ++i) { o[i] = dx[i]; o[n + i] = dy[i]; o[2 * n + i] = dz[i]; }
+}
+
+// grad_inputs[b, d] += sum_c grad[b, c] * dy_dx[b, d, c]   (kernel_sh_backward, shencoder.cu:359-382)
+__global__ __launch_bounds__(kEncBlock) void k_sh_backward(const float *__restrict__ grad, const float *__restrict__ dy_dx, uint32_t B, uint32_t n,
+                                                           float *__restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * kEncBlock + threadIdx.x;
+    if (t >= B * 3u) return;
+    const uint32_t b = t / 3u;
+    const float *g = grad + (size_t)b * n, *j = dy_dx + (size_t)t * n;
+    float acc = grad_inputs[t];
+    for (uint32_t c = 0; c < n; ++c) acc = fmaf(g[c], j[c], acc);
+    grad_inputs[t] = acc;
+}
+
+// grad_inputs[b, d] = grad[b, d] + sum_f 2^f (grad_sin * cos - grad_cos * sin), with sin / cos read back from the forward outputs
+// (kernel_freq_backward, freqencoder.cu:63-93)
+__global__ __launch_bounds__(kEncBlock) void k_freq_backward(const float *__restrict__ grad, const float *__restrict__ outputs, uint32_t B, uint32_t D,
+                                                             uint32_t deg, uint32_t C, float *__restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * kEncBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float *g = grad + (size_t)b * C, *o = outputs + (size_t)b * C;
+    float acc = g[d];
+    for (uint32_t f = 0; f < deg; ++f) {
+        const uint32_t s = D + 2u * D * f + d, c = s + D;
+        acc += scalbnf(1.0f, (int)f) * (g[s] * o[c] - g[c] * o[s]);
+    }
+    grad_inputs[t] = acc;
+}
+
 // One thread per output element (coalesced stores of the [B,C] row-major output).
 __global__ __launch_bounds__(kEncBlock) void k_freq_encode(const float *__restrict__ inputs, uint32_t B, uint32_t D, uint32_t C, float *__restrict__ outputs) {
     const size_t t = (size_t)blockIdx.x * kEncBlock + threadIdx.x;
@@ -128,9 +167,20 @@ GFPP_API int gfpp_sh_encode_forward(const float *inputs, float *outputs, uint32_
                                     gfpp_stream_t stream) {
     if (B == 0) return 0;
     if (!inputs || !outputs) { set_error("gfpp_sh_encode_forward: null pointer"); return GFPP_EINVAL; }
-    if (D != 3 || degree < 1 || degree > 4 || dy_dx) { set_error("gfpp_sh_encode_forward: needs D=3, 1<=degree<=4, dy_dx=NULL"); return GFPP_EUNSUPPORTED; }
+    if (D != 3 || degree < 1 || degree > 4) { set_error("gfpp_sh_encode_forward: needs D=3, 1<=degree<=4"); return GFPP_EUNSUPPORTED; }
     hipLaunchKernelGGL(k_sh_encode, dim3(div_up(B, kEncBlock)), dim3(kEncBlock), 0, (hipStream_t)stream, inputs, outputs, B, degree);
+    if (dy_dx) hipLaunchKernelGGL(k_sh_dydx, dim3(div_up(B, kEncBlock)), dim3(kEncBlock), 0, (hipStream_t)stream, inputs, dy_dx, B, degree);
     return check_launch("gfpp_sh_encode_forward");
+}
+
+GFPP_API int gfpp_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t degree, const float *dy_dx,
+                                     float *grad_inputs, gfpp_stream_t stream) {
+    (void)inputs;
+    if (B == 0) return 0;
+    if (!grad || !dy_dx || !grad_inputs) { set_error("gfpp_sh_encode_backward: null pointer"); return GFPP_EINVAL; }
+    if (D != 3 || degree < 1 || degree > 4) { set_error("gfpp_sh_encode_backward: needs D=3, 1<=degree<=4"); return GFPP_EUNSUPPORTED; }
+    hipLaunchKernelGGL(k_sh_backward, dim3(div_up(B * 3u, kEncBlock)), dim3(kEncBlock), 0, (hipStream_t)stream, grad, dy_dx, B, degree * degree, grad_inputs);
+    return check_launch("gfpp_sh_encode_backward");
 }
 
 GFPP_API int gfpp_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs,
@@ -141,4 +191,13 @@ GFPP_API int gfpp_freq_encode_forward(const float *inputs, uint32_t B, uint32_t 
     const size_t total = (size_t)B * C;
     hipLaunchKernelGGL(k_freq_encode, dim3((uint32_t)((total + kEncBlock - 1) / kEncBlock)), dim3(kEncBlock), 0, (hipStream_t)stream, inputs, B, D, C, outputs);
     return check_launch("gfpp_freq_encode_forward");
+}
+
+GFPP_API int gfpp_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *grad_inputs,
+                                       gfpp_stream_t stream) {
+    if (B == 0) return 0;
+    if (!grad || !outputs || !grad_inputs) { set_error("gfpp_freq_encode_backward: null pointer"); return GFPP_EINVAL; }
+    if (C != D + 2 * D * deg || D == 0) { set_error("gfpp_freq_encode_backward: C must equal D + 2*D*deg"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_freq_backward, dim3(div_up(B * D, kEncBlock)), dim3(kEncBlock), 0, (hipStream_t)stream, grad, outputs, B, D, deg, C, grad_inputs);
+    return check_launch("gfpp_freq_encode_backward");
 }

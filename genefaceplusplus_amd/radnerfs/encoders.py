@@ -148,6 +148,52 @@ class GridEncoder(nn.Module):
              _stream())
 
 
+class _SHEncodeFn(torch.autograd.Function):
+    """sphere_harmonics.py:14-58: forward keeps dy_dx [B, 3 * degree^2] when the directions need a gradient."""
+
+    @staticmethod
+    def forward(ctx, flat, degree):
+        B = flat.shape[0]
+        out = torch.empty(B, degree ** 2, dtype=torch.float32, device=flat.device)
+        dy_dx = torch.empty(B, 3 * degree ** 2, dtype=torch.float32, device=flat.device) if flat.requires_grad else None
+        call("gfpp_sh_encode_forward", flat.data_ptr(), out.data_ptr(), B, 3, degree, dy_dx.data_ptr() if dy_dx is not None else None, _stream())
+        ctx.save_for_backward(flat, dy_dx)
+        ctx.degree = degree
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        flat, dy_dx = ctx.saved_tensors
+        if dy_dx is None:
+            return None, None
+        grad = grad.float().contiguous()
+        grad_inputs = torch.zeros_like(flat)
+        call("gfpp_sh_encode_backward", grad.data_ptr(), flat.data_ptr(), flat.shape[0], 3, ctx.degree, dy_dx.data_ptr(), grad_inputs.data_ptr(), _stream())
+        return grad_inputs, None
+
+
+class _FreqEncodeFn(torch.autograd.Function):
+    """freq.py:14-53: the backward reads sin / cos back from the forward outputs."""
+
+    @staticmethod
+    def forward(ctx, flat, degree, output_dim):
+        B, D = flat.shape
+        out = torch.empty(B, output_dim, dtype=torch.float32, device=flat.device)
+        call("gfpp_freq_encode_forward", flat.data_ptr(), B, D, degree, output_dim, out.data_ptr(), _stream())
+        ctx.save_for_backward(out)
+        ctx.dims = (B, D, degree, output_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (out,) = ctx.saved_tensors
+        B, D, degree, C = ctx.dims
+        grad = grad.float().contiguous()
+        grad_inputs = torch.empty(B, D, dtype=torch.float32, device=grad.device)
+        call("gfpp_freq_encode_backward", grad.data_ptr(), out.data_ptr(), B, D, degree, C, grad_inputs.data_ptr(), _stream())
+        return grad_inputs, None, None
+
+
 class SHEncoder(nn.Module):
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
@@ -165,8 +211,11 @@ class SHEncoder(nn.Module):
         flat = inputs.reshape(-1, 3).float().contiguous()
         if not flat.is_cuda:
             raise GfppError("sh_encode: inputs must be on the GPU (no CPU path)")
-        out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
-        call("gfpp_sh_encode_forward", flat.data_ptr(), out.data_ptr(), flat.shape[0], 3, self.degree, None, _stream())
+        if torch.is_grad_enabled() and flat.requires_grad:
+            out = _SHEncodeFn.apply(flat, self.degree)
+        else:
+            out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
+            call("gfpp_sh_encode_forward", flat.data_ptr(), out.data_ptr(), flat.shape[0], 3, self.degree, None, _stream())
         return out.view(prefix + [self.output_dim])
 
 
@@ -182,9 +231,12 @@ class FreqEncoder(nn.Module):
         flat = inputs.reshape(-1, self.input_dim).float().contiguous()
         if not flat.is_cuda:
             raise GfppError("freq_encode: inputs must be on the GPU (no CPU path)")
-        out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
-        call("gfpp_freq_encode_forward", flat.data_ptr(), flat.shape[0], self.input_dim, self.degree, self.output_dim,
-             out.data_ptr(), _stream())
+        if torch.is_grad_enabled() and flat.requires_grad:
+            out = _FreqEncodeFn.apply(flat, self.degree, self.output_dim)
+        else:
+            out = torch.empty(flat.shape[0], self.output_dim, dtype=torch.float32, device=flat.device)
+            call("gfpp_freq_encode_forward", flat.data_ptr(), flat.shape[0], self.input_dim, self.degree, self.output_dim,
+                 out.data_ptr(), _stream())
         return out.view(prefix + [self.output_dim])
 
 

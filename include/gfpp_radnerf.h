@@ -94,15 +94,25 @@ int gfpp_grid_encode_forward(const float *inputs, const void *embeddings, const 
                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype,
                              int align_corners, uint32_t interp, int dtype, gfpp_stream_t stream);
 
-/* replaces sh_encode_forward (shencoder.h; kernel shencoder.cu:28-68, degree <= 4 part).
- * inputs [B,3] f32, outputs [B,degree^2] f32; dy_dx must be NULL. */
+/* replaces sh_encode_forward (shencoder.h:9; kernel shencoder.cu:28-352, degree <= 4 part).
+ * inputs [B,3] f32, outputs [B,degree^2] f32; dy_dx NULL or [B,3,degree^2] f32 (rows d/dx, d/dy, d/dz of the features). */
 int gfpp_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t degree, float *dy_dx,
                            gfpp_stream_t stream);
+
+/* replaces sh_encode_backward (shencoder.h:10; kernel shencoder.cu:359-382): grad [B,degree^2], dy_dx from the forward,
+ * grad_inputs [B,3] += grad . dy_dx (the caller zero-initialises, sphere_harmonics.py:47-49). `inputs` is unused, as in the reference. */
+int gfpp_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t degree, const float *dy_dx,
+                            float *grad_inputs, gfpp_stream_t stream);
 
 /* replaces freq_encode_forward (freqencoder.h; kernel freqencoder.cu:30-58).
  * inputs [B,D] f32, outputs [B,C] f32, C = D + 2*D*deg; layout [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]. */
 int gfpp_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs,
                              gfpp_stream_t stream);
+
+/* replaces freq_encode_backward (freqencoder.h:10; kernel freqencoder.cu:63-93): grad, outputs [B,C] (outputs = the forward result,
+ * its sin / cos columns are the derivative factors), grad_inputs [B,D] = grad_x + sum_f 2^f (grad_sin cos - grad_cos sin). */
+int gfpp_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                              float *grad_inputs, gfpp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section A.3 -- ray generation (modules/radnerfs/utils.py:283-364 get_rays with N = -1; pure PyTorch in the

@@ -766,3 +766,54 @@ def grad_total_variation(x01, embeddings, grad, offsets, weight, per_level_scale
 def grid_encode_levels(x01, embeddings, offsets, per_level_scale, base_resolution=16, gridtype="tiled", align_corners=False, interpolation="linear"):
     """Level-major forward [L,B,C] for inputs already in [0,1] (the layout the backward kernels' `grad` uses)."""
     return grid_encode_raw(x01, embeddings, offsets, np.log2(per_level_scale), base_resolution, GRIDTYPE[gridtype], align_corners, INTERP[interpolation])
+
+
+# ---------------------------------------------------------------------------------------------
+# SH / frequency encoder gradients (shencoder.cu:125-382, freqencoder.cu:63-93) -- numpy restatements
+# ---------------------------------------------------------------------------------------------
+def _sh4_monomials():
+    """Component k of the degree-<=4 real SH basis as {(i, j, l): coeff} over x^i y^j z^l (the polynomials of kernel_sh,
+    shencoder.cu:44-68).  Derivatives are then taken symbolically, so the table below is the only hand-written input."""
+    a, b, e = 0.48860251190291987, 1.0925484305920792, 0.54627421529603959
+    f, g, h = 0.59004358992664352, 2.8906114426405538, 0.45704579946446572
+    k, m = 0.3731763325901154, 1.4453057213202769
+    return [
+        {(0, 0, 0): 0.28209479177387814},
+        {(0, 1, 0): -a}, {(0, 0, 1): a}, {(1, 0, 0): -a},
+        {(1, 1, 0): b}, {(0, 1, 1): -b}, {(0, 0, 2): 0.94617469575755997, (0, 0, 0): -0.31539156525251999}, {(1, 0, 1): -b},
+        {(2, 0, 0): e, (0, 2, 0): -e},
+        {(0, 3, 0): f, (2, 1, 0): -3 * f}, {(1, 1, 1): g}, {(0, 1, 0): h, (0, 1, 2): -5 * h}, {(0, 0, 3): 5 * k, (0, 0, 1): -3 * k},
+        {(1, 0, 0): h, (1, 0, 2): -5 * h}, {(2, 0, 1): m, (0, 2, 1): -m}, {(1, 2, 0): 3 * f, (3, 0, 0): -f},
+    ]
+
+
+def sh_encode_dydx(dirs, degree=4):
+    """-> [B, 3, degree^2]: d feature / d(x, y, z), coordinates treated as independent (shencoder.cu:125-352)."""
+    d = np.asarray(dirs, np.float64).reshape(-1, 3)
+    n = degree * degree
+    out = np.zeros((d.shape[0], 3, n), np.float64)
+    for c, poly in enumerate(_sh4_monomials()[:n]):
+        for powers, coeff in poly.items():
+            for axis in range(3):
+                if powers[axis] == 0:
+                    continue
+                p = list(powers)
+                p[axis] -= 1
+                out[:, axis, c] += coeff * powers[axis] * d[:, 0] ** p[0] * d[:, 1] ** p[1] * d[:, 2] ** p[2]
+    return out.astype(f32)
+
+
+def sh_encode_backward(grad, dirs, degree=4):
+    """kernel_sh_backward (shencoder.cu:359-382): grad [B, degree^2] -> grad_inputs [B, 3]."""
+    return np.einsum("bc,bdc->bd", np.asarray(grad, np.float64), sh_encode_dydx(dirs, degree).astype(np.float64)).astype(f32)
+
+
+def freq_encode_backward(grad, outputs, D, degree):
+    """kernel_freq_backward (freqencoder.cu:63-93): grad, outputs [B, C], C = D + 2 D degree -> grad_inputs [B, D]."""
+    g = np.asarray(grad, f32).reshape(-1, D + 2 * D * degree)
+    o = np.asarray(outputs, f32).reshape(g.shape)
+    res = g[:, :D].copy()
+    for k in range(degree):
+        s = D + 2 * D * k
+        res = res + f32(2.0 ** k) * (g[:, s:s + D] * o[:, s + D:s + 2 * D] - g[:, s + D:s + 2 * D] * o[:, s:s + D])
+    return res.astype(f32)

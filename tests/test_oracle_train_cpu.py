@@ -165,3 +165,30 @@ def test_dilation_tv_sph(orc):
     E = np.ones((int(off[-1]), 2), f32)
     g = orc.grad_total_variation(rng.random((50, 2)).astype(f32), E, np.zeros_like(E), off, 1.0, pls, 16, "tiled", False)
     assert np.abs(g).max() == 0
+
+
+def test_sh_and_freq_gradients_match_finite_differences(orc=None):
+    import oracle.oracle as orc
+    rng = np.random.default_rng(11)
+    d = rng.standard_normal((40, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for degree in (1, 2, 3, 4):
+        jac = orc.sh_encode_dydx(d, degree)
+        eps = 1e-3
+        for axis in range(3):
+            step = np.zeros(3)
+            step[axis] = eps
+            num = (orc.sh_encode((d + step).astype(f32), degree).astype(np.float64) - orc.sh_encode((d - step).astype(f32), degree)) / (2 * eps)
+            np.testing.assert_allclose(jac[:, axis], num, atol=2e-3)
+        g = rng.standard_normal((40, degree * degree)).astype(f32)
+        np.testing.assert_allclose(orc.sh_encode_backward(g, d, degree), np.einsum("bc,bdc->bd", g, jac), rtol=1e-5, atol=1e-5)
+    # frequency encoding: d/dx [x, sin(2^k x), cos(2^k x)] = [1, 2^k cos, -2^k sin]
+    x = rng.uniform(-1, 1, (30, 2)).astype(f32)
+    for deg in (1, 4, 10):
+        out = orc.freq_encode(x, deg)
+        g = rng.standard_normal(out.shape).astype(f32)
+        want = g[:, :2].astype(np.float64).copy()
+        for k in range(deg):
+            s = 2 + 4 * k
+            want += 2.0 ** k * (g[:, s:s + 2] * np.cos(2.0 ** k * x.astype(np.float64)) - g[:, s + 2:s + 4] * np.sin(2.0 ** k * x.astype(np.float64)))
+        np.testing.assert_allclose(orc.freq_encode_backward(g, out, 2, deg), want, rtol=2e-4, atol=2e-3 * 2.0 ** deg / 1024 + 1e-4)
