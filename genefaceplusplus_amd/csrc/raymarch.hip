@@ -120,6 +120,24 @@ __global__ __launch_bounds__(kBlock) void k_get_rays(const float *__restrict__ p
     }
 }
 
+// the same for a list of pixel indices (training: random / patch / rect sampling, utils.py:310-343); inds are h * W + w, int64 like torch.randint's
+__global__ __launch_bounds__(kBlock) void k_get_rays_at(const float *__restrict__ pose, float fx, float fy, float cx, float cy, uint32_t W,
+                                                       const long long *__restrict__ inds, uint32_t n_rays, float *__restrict__ rays_o,
+                                                       float *__restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_rays) return;
+    const uint32_t pix = (uint32_t)inds[n];
+    const uint32_t h = pix / W, w = pix - h * W;
+    const float xs = ((float)w + 0.5f - cx) / fx;
+    const float ys = ((float)h + 0.5f - cy) / fy;
+    const float norm = sqrtf(fmaf(xs, xs, fmaf(ys, ys, 1.0f)));
+    const float ux = xs / norm, uy = ys / norm, uz = 1.0f / norm;
+    for (int r = 0; r < 3; ++r) {
+        rays_d[3ull * n + r] = fmaf(pose[4 * r + 2], uz, fmaf(pose[4 * r + 1], uy, pose[4 * r] * ux));
+        rays_o[3ull * n + r] = pose[4 * r + 3];
+    }
+}
+
 // float -> uint8 with truncation (x * 255 then int cast), 4 values per thread
 __global__ __launch_bounds__(kBlock) void k_rgb_to_u8(const float *__restrict__ rgb, size_t n, uint8_t *__restrict__ out) {
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -210,6 +228,15 @@ GFPP_API int gfpp_get_rays(const float *pose, float fx, float fy, float cx, floa
     GFPP_REQUIRE(pose && rays_o && rays_d, "gfpp_get_rays");
     hipLaunchKernelGGL(k_get_rays, dim3(div_up(H * W, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, H, W, rays_o, rays_d);
     return check_launch("gfpp_get_rays");
+}
+
+GFPP_API int gfpp_get_rays_at(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,
+                              uint32_t n_rays, float *rays_o, float *rays_d, gfpp_stream_t stream) {
+    if (n_rays == 0) return 0;
+    GFPP_REQUIRE(pose && inds && rays_o && rays_d && H && W, "gfpp_get_rays_at");
+    hipLaunchKernelGGL(k_get_rays_at, dim3(div_up(n_rays, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, W,
+                       (const long long *)inds, n_rays, rays_o, rays_d);
+    return check_launch("gfpp_get_rays_at");
 }
 
 GFPP_API int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_stream_t stream) {

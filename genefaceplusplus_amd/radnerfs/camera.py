@@ -78,31 +78,52 @@ def get_audio_features(features, att_mode, index, smo_win_size=None):
 
 
 def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
-    """All-pixel ray generation (utils.py:283-364 with N=-1, or ``rect`` = (xmin,xmax,ymin,ymax) row/col window).
+    """Ray generation (utils.py:283-364): every pixel (N = -1, the inference case), N random pixels, random patch_size^2 patches
+    (N // patch_size^2 of them), or the pixels of ``rect`` = (xmin, xmax, ymin, ymax) row/col window.
 
-    poses [B,4,4] cam2world on the GPU; returns rays_o/rays_d [B,n,3], inds [B,n], i/j pixel centres.
-    Random / patch sampling (N>0) is training-only and not built.
+    poses [B,4,4] cam2world on the GPU; returns rays_o/rays_d [B,n,3], inds [B,n], i/j pixel centres.  Random indices are drawn with
+    the same torch.randint calls, in the same order, as the reference (so a seeded generator gives the reference's pixels); the rays
+    of the selected pixels come from one HIP launch per pose instead of a full-frame meshgrid + gather.
     """
-    if N > 0 and rect is None:
-        raise NotImplementedError("get_rays: random ray sampling (N>0) is a training feature (SURVEY 8f-2)")
     if not poses.is_cuda:
         raise GfppError("get_rays: poses must be on the GPU (no CPU path)")
     fx, fy, cx, cy = [float(v) for v in intrinsics]
     B = poses.shape[0]
     dev = poses.device
     poses = poses.float().contiguous()
-    rays_o = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
-    rays_d = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    for b in range(B):
-        call("gfpp_get_rays", poses[b].data_ptr(), fx, fy, cx, cy, H, W, rays_o[b].data_ptr(), rays_d[b].data_ptr(), st)
-    inds = torch.arange(H * W, device=dev).expand(B, H * W)
     if rect is not None:
         xmin, xmax, ymin, ymax = rect
-        mask = torch.zeros(H, W, dtype=torch.bool, device=dev)
-        mask[xmin:xmax, ymin:ymax] = True
-        sel = torch.where(mask.view(-1))[0]
-        rays_o, rays_d, inds = rays_o[:, sel], rays_d[:, sel], sel.unsqueeze(0)
+        N = (xmax - xmin) * (ymax - ymin)
+    if N > 0:
+        N = min(N, H * W)
+        if patch_size > 1:
+            num_patch = N // (patch_size ** 2)
+            top = torch.randint(0, H - patch_size, size=[num_patch], device=dev)
+            left = torch.randint(0, W - patch_size, size=[num_patch], device=dev)
+            corner = torch.stack([top, left], dim=-1)                                                   # [np, 2]
+            pi, pj = torch.meshgrid(torch.arange(patch_size, device=dev), torch.arange(patch_size, device=dev), indexing="ij")
+            cells = (corner.unsqueeze(1) + torch.stack([pi.reshape(-1), pj.reshape(-1)], dim=-1).unsqueeze(0)).view(-1, 2)
+            sel = cells[:, 0] * W + cells[:, 1]
+        elif rect is not None:
+            mask = torch.zeros(H, W, dtype=torch.bool, device=dev)
+            mask[xmin:xmax, ymin:ymax] = True
+            sel = torch.where(mask.view(-1))[0]
+        else:
+            sel = torch.randint(0, H * W, size=[N], device=dev)                                        # may repeat, like the reference
+        sel = sel.to(torch.int64).contiguous()
+        n = sel.shape[0]
+        rays_o = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
+        rays_d = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
+        for b in range(B):
+            call("gfpp_get_rays_at", poses[b].data_ptr(), fx, fy, cx, cy, H, W, sel.data_ptr(), n, rays_o[b].data_ptr(), rays_d[b].data_ptr(), st)
+        inds = sel.unsqueeze(0).expand(B, n) if rect is None else sel.unsqueeze(0)
+    else:
+        rays_o = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
+        rays_d = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
+        for b in range(B):
+            call("gfpp_get_rays", poses[b].data_ptr(), fx, fy, cx, cy, H, W, rays_o[b].data_ptr(), rays_d[b].data_ptr(), st)
+        inds = torch.arange(H * W, device=dev).expand(B, H * W)
     i = (inds % W).float() + 0.5
     j = torch.div(inds, W, rounding_mode="floor").float() + 0.5
     return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds, "i": i, "j": j}

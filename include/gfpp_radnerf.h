@@ -125,6 +125,11 @@ int gfpp_freq_encode_backward(const float *grad, const float *outputs, uint32_t 
 int gfpp_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
                   float *rays_d, gfpp_stream_t stream);
 
+/* replaces get_rays with N > 0 or rect (modules/radnerfs/utils.py:310-343 pick the pixel indices, :352-363 the directions): the rays of the
+ * listed pixels only.  inds [n_rays] i64 (= h*W + w, what torch.randint / torch.where produce), rays_o, rays_d [n_rays,3] f32. */
+int gfpp_get_rays_at(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,
+                     uint32_t n_rays, float *rays_o, float *rays_d, gfpp_stream_t stream);
+
 /* replaces the per-frame `(pred_rgb * 255.).int() ... astype(np.uint8)` host conversion of the caller
  * (inference/genefacepp_infer.py:468): rgb [n_values] f32 in [0,1] -> out [n_values] u8, truncating. rgb 16-byte aligned. */
 int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_stream_t stream);

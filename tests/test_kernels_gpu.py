@@ -233,6 +233,24 @@ def test_get_rays(dev, oracle_mod):
     # the reference computes bg_coords with the very same torch expression on its GPU
     np.testing.assert_allclose(get_bg_coords(H, W, dev).cpu().numpy(), oracle_mod.get_bg_coords(H, W), atol=1.5e-7)
     np.testing.assert_allclose(convert_poses(t(pose, dev)[None]).cpu().numpy(), oracle_mod.convert_poses(pose[None]), atol=1e-6)
+    # sampled variants (training, utils.py:310-343): the selected rays are bit-identical to the same pixels of the full frame, the index draw
+    # follows the reference's torch.randint call sequence, patches are patch_size^2 contiguous pixels, rect selects a row/col window
+    full_o, full_d = got["rays_o"][0], got["rays_d"][0]
+    torch.manual_seed(5)
+    r = get_rays(t(pose, dev)[None], intr, H, W, N=300)
+    torch.manual_seed(5)
+    want = torch.randint(0, H * W, size=[300], device=dev)
+    assert torch.equal(r["inds"][0], want) and r["rays_d"].shape == (1, 300, 3)
+    assert torch.equal(r["rays_d"][0], full_d[want]) and torch.equal(r["rays_o"][0], full_o[want])
+    assert torch.equal(r["i"][0], (want % W).float() + 0.5) and torch.equal(r["j"][0], (want // W).float() + 0.5)
+    r = get_rays(t(pose, dev)[None], intr, H, W, N=4 * 64, patch_size=8)
+    idx = r["inds"][0].view(4, 8, 8)
+    assert torch.equal(idx, idx[:, :1, :1] + (torch.arange(8, device=dev).view(1, 8, 1) * W + torch.arange(8, device=dev).view(1, 1, 8)))
+    assert int(idx.max()) < H * W and torch.equal(r["rays_d"][0], full_d[r["inds"][0]])
+    r = get_rays(t(pose, dev)[None], intr, H, W, rect=(5, 9, 10, 30))
+    rows, cols = torch.meshgrid(torch.arange(5, 9, device=dev), torch.arange(10, 30, device=dev), indexing="ij")
+    assert torch.equal(r["inds"][0], (rows * W + cols).reshape(-1)) and torch.equal(r["rays_d"][0], full_d[r["inds"][0]])
+    assert get_rays(t(pose, dev)[None], intr, H, W, N=10 ** 9)["rays_d"].shape == (1, H * W, 3)       # N is clipped to H*W
 
 
 @pytest.mark.parametrize("variant", ["may_head", "may_torso_sr"])
