@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- rendered 512x512 head+torso frames/s of the GeneFace++ motion2video NeRF path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 4
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one frame (one pass of the hot path over one frame of synthetic driving input) per rank.  Frames are
@@ -47,8 +47,8 @@ PEAK_HBM_GBPS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--hw", type=int, default=512, help="frame side (rays = hw*hw)")
     ap.add_argument("--variant", default="may_torso", choices=["may_head", "may_torso", "may_torso_sr"])
     ap.add_argument("--executor", default="fused", choices=["fused", "staged"])
@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-grid-stage", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5, help="multi-GPU: all_gather the finished uint8 frames every this many frames, "
                                                                 "overlapped with the rendering of the next chunk")
+    ap.add_argument("--lanes", type=int, default=2, help="frames in flight per GPU: consecutive frames alternate between this many streams, each with "
+                                                         "its own workspace and hipGraph (weights / tables shared), so one frame's small prologue launches and "
+                                                         "sparse late trips overlap the other's full-width launches; 1 = strictly one frame at a time")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (control-flow checks of the N>1 path on one GPU)")
     return ap.parse_args()
 
@@ -145,12 +148,12 @@ def main():
     # the clip renderer = the caller's frame loop (genefacepp_infer.py:246-269, 460-469): pose -> rays on the device -> model.render() -> uint8 HWC
     # on the device, one hipGraph per frame.  The driving signals of all frames are resident in HBM before the timed region starts.
     from genefaceplusplus_amd.clip import ClipRenderer
-    cr = ClipRenderer(model, HW, HW, intr, bg_img=bg_color, T_thresh=0.01, use_graph=model.use_graph)
+    cr = ClipRenderer(model, HW, HW, intr, bg_img=bg_color, T_thresh=0.01, use_graph=model.use_graph, lanes=args.lanes)
     clip = cr.prepare(batch, dev)
     HWO = cr.out_hw[0]                                          # the *_sr models render 256^2 rays and super-resolve to 512^2
     out_u8 = torch.empty(K, HWO, HWO, 3, dtype=torch.uint8, device=dev)
     # multi-GPU: finished frames are all_gathered in chunks while the next chunk renders (RCCL runs on its own stream)
-    chunk = max(1, min(K, args.gather_every))
+    chunk = max(1, min(K, args.gather_every)) if world > 1 else K
     bounds = [(c, min(c + chunk, K)) for c in range(0, K, chunk)]
     gathered = [torch.empty(world * (e - b), HWO, HWO, 3, dtype=torch.uint8, device=dev) for b, e in bounds] if world > 1 else None
 
@@ -186,8 +189,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pending = []
-    for (b, e), g in zip(bounds, gathered or [None] * len(bounds)):
-        cr.render_to_device(clip, range(W + b, W + e), out=out_u8[b:e])
+    for c, ((b, e), g) in enumerate(zip(bounds, gathered or [None] * len(bounds))):
+        cr.render_to_device(clip, range(W + b, W + e), out=out_u8[b:e], after_caller_stream=(c == 0))
         if world > 1:
             pending.append(dist.all_gather_into_tensor(g, out_u8[b:e], async_op=True))
     for work in pending:
@@ -215,6 +218,7 @@ def main():
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + (f" + RCCL all_gather of uint8 frames every {chunk} frames, overlapped with rendering" if world > 1 else ""),
                              "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: pose -> rays on device -> model.render() -> uint8 HWC on device",
+                             "frames_in_flight": cr.lanes,
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 
@@ -329,35 +333,29 @@ def main():
                 m_sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_sr.items()}, strict=True)
                 m_sr = m_sr.to(dev).eval()
                 m_sr.precision, m_sr.use_graph = args.precision, model.use_graph
-                bgc = camera.get_bg_coords(256, 256, dev)
-                bg256 = torch.full((1, 256 * 256, 3), 0.5, device=dev)
-                ins = []
-                for fidx in range(4):
-                    pose = torch.from_numpy(syn.synthetic_pose(fidx)).to(dev)[None]
-                    rays = camera.get_rays(pose, syn.intrinsics_for(256, 256), 256, 256)
-                    fi = syn.synthetic_frame_inputs(hp_sr, fidx)
-                    ins.append((rays["rays_o"], rays["rays_d"], torch.from_numpy(fi["cond"]).to(dev), camera.convert_poses(pose),
-                                torch.from_numpy(fi["lm68"]).to(dev), torch.from_numpy(fi["eye_area_percent"]).to(dev)))
-                u8 = torch.empty(512, 512, 3, dtype=torch.uint8, device=dev)
-
-                def render_sr(i):
-                    ro, rd, cond, poses6, lm, eye = ins[i % 4]
-                    with torch.no_grad():
-                        r = m_sr.render(ro, rd, cond, bgc, poses6, index=i, staged=False, bg_color=bg256, lm68=lm, perturb=False, force_all_rays=False,
-                                        T_thresh=0.01, eye_area_percent=eye, **hp_sr)
-                    frames.to_uint8_hwc(r["sr_rgb_map"].permute(0, 2, 3, 1).reshape(512, 512, 3), u8)
-                for i in range(4):
-                    render_sr(i)
+                n_s = 40
+                fi_s = [syn.synthetic_frame_inputs(hp_sr, i) for i in range(n_s)]
+                batch_s = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(n_s)]).astype(np.float32),
+                           "cond_wins": np.stack([f["cond"] for f in fi_s]), "lm68": np.stack([f["lm68"] for f in fi_s]),
+                           "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_s])}
+                cr_sr = ClipRenderer(m_sr, 256, 256, syn.intrinsics_for(256, 256), bg_img=torch.full((1, 256 * 256, 3), 0.5, device=dev), T_thresh=0.01,
+                                     use_graph=model.use_graph, lanes=args.lanes)
+                clip_s = cr_sr.prepare(batch_s, dev)
+                stack = torch.empty(n_s, 512, 512, 3, dtype=torch.uint8, device=dev)
+                cr_sr.render_to_device(clip_s, range(4), out=stack[:4])
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(20):
-                    render_sr(i)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                modes["may_torso_sr"] = {"value": round(20 / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / 20, 4), "steps": 20,
+                dt = None
+                for _ in range(2):          # the first pass also pages the second model's tables into the caches
+                    t1 = time.perf_counter()
+                    cr_sr.render_to_device(clip_s, out=stack)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    if os.environ.get("GFPP_BENCH_DEBUG"):
+                        print("sr mode pass", n_s / dt, file=sys.stderr)
+                modes["may_torso_sr"] = {"value": round(n_s / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_s, 4), "steps": n_s,
                                          "precision": args.precision,
                                          "workload": "256x256 rays + landmark-conditioned head-aware torso + StyleGAN2 super-resolution -> 512x512 frame"}
-                del m_sr
+                del cr_sr, m_sr
             except Exception as exc:
                 modes["may_torso_sr"] = {"value": None, "error": str(exc)}
         result["modes"] = modes

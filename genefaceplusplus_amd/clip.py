@@ -28,7 +28,10 @@ class ClipRenderer:
     bg_img [1, H*W, 3] float in [0,1] or None (white), as `sample['bg_img']` in the reference.
     """
 
-    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None):
+    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=2):
+        """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
+        workspace and graph; weights and tables are shared), so one frame's prologue (slab test, pre-march, conditioning nets: small
+        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
@@ -46,52 +49,93 @@ class ClipRenderer:
         self.out_hw = (H * scale, W * scale)
         self.bg_coords = camera.get_bg_coords(H, W, dev)
         self.bg_img = None if bg_img is None else bg_img.to(dev).float().reshape(1, H * W, 3).contiguous()
-        self.rays_o = torch.empty(1, H * W, 3, dtype=torch.float32, device=dev)
-        self.rays_d = torch.empty(1, H * W, 3, dtype=torch.float32, device=dev)
-        self.frame_u8 = torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev)
-        self.ring = max(2, int(ring))
-        self._dev_ring = [torch.empty_like(self.frame_u8) for _ in range(self.ring)]
+        fused = getattr(model, "executor", "fused") == "fused"
+        self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
+        self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
+                       "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
+                       "u8": torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev),
+                       "stream": torch.cuda.Stream(device=dev) if self.lanes > 1 else None,
+                       "graph": None, "key": None, "static_in": None} for _ in range(self.lanes)]
+        self.ring = max(2, int(ring), self.lanes)
+        self._dev_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev) for _ in range(self.ring)]
         self._host_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8).pin_memory() for _ in range(self.ring)]
         self._ready = [torch.cuda.Event() for _ in range(self.ring)]
         self._done = [torch.cuda.Event() for _ in range(self.ring)]
         self._copy_stream = torch.cuda.Stream(device=dev)
-        self._graph = None
 
     # -- one frame of device work --------------------------------------------------------------------------------------------
-    def _frame(self, pose, pose6, cond, lm68, eye):
+    def _enter_lane(self, lane):
+        """Point the model's per-frame mutable state (pipeline workspace, side stream, SR activations) at this lane."""
+        if getattr(self.model, "executor", "fused") == "fused":
+            pipe = self.model.pipeline()
+            pipe.lane, pipe.frames_in_flight = lane, self.lanes
+        if self.with_sr:
+            self.model.sr_net.lane = lane
+
+    def _leave_lane(self):
+        if getattr(self.model, "executor", "fused") == "fused":
+            pipe = self.model.pipeline()
+            pipe.lane, pipe.frames_in_flight = 0, 1
+        if self.with_sr:
+            self.model.sr_net.lane = 0
+
+    def _frame(self, lane, pose, pose6, cond, lm68, eye):
+        L = self._lane[lane]
         fx, fy, cx, cy = self.intrinsics
-        call("gfpp_get_rays", pose.data_ptr(), fx, fy, cx, cy, self.H, self.W, self.rays_o.data_ptr(), self.rays_d.data_ptr(),
+        call("gfpp_get_rays", pose.data_ptr(), fx, fy, cx, cy, self.H, self.W, L["rays_o"].data_ptr(), L["rays_d"].data_ptr(),
              torch.cuda.current_stream().cuda_stream)
         kw = dict(self.render_kwargs)
         kw.update(index=0, staged=False, bg_color=self.bg_img, lm68=lm68, perturb=False, force_all_rays=False, T_thresh=self.T_thresh,
                   eye_area_percent=eye)
-        res = self.model.render(self.rays_o, self.rays_d, cond, self.bg_coords, pose6, **kw)
+        res = self.model.render(L["rays_o"], L["rays_d"], cond, self.bg_coords, pose6, **kw)
         if self.with_sr:
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1)        # [1,3,h,w] view of NHWC memory
         else:
             rgb = res["rgb_map"]
-        frames.to_uint8_hwc(rgb.reshape(*self.out_hw, 3), self.frame_u8)
-        return {"u8": self.frame_u8}
+        frames.to_uint8_hwc(rgb.reshape(*self.out_hw, 3), L["u8"])
+        return {"u8": L["u8"]}
 
-    def _launch(self, clip, i):
-        """Run frame i of a prepared clip; returns the static uint8 frame buffer (overwritten by the next launch)."""
-        if not self.use_graph:
-            with torch.no_grad():
-                return self._frame(**self._views(clip["packed"][i], clip["layout"]))["u8"]
-        key = (clip["layout"], self.model.resolved_precision())
-        if self._graph is None or self._graph_key != key:
-            # all driving signals of a frame travel as ONE small row (a few KB): one device-to-device copy per frame feeds the graph
-            self._static_in = clip["packed"][i].clone()
-            views = self._views(self._static_in, clip["layout"])
-            inner, self.model.use_graph = self.model.use_graph, False       # this graph already contains the model's launches
-            try:
-                self._graph = GraphedFrame(self._frame, views, copy_inputs=False)
-            finally:
-                self.model.use_graph = inner
-            self._graph_key = key
-        self._static_in.copy_(clip["packed"][i], non_blocking=True)
-        self._graph.graph.replay()
-        return self.frame_u8
+    def _launch(self, clip, i, lane=0):
+        """Issue frame i of a prepared clip on the CURRENT stream with lane `lane`'s buffers; returns that lane's static uint8 frame
+        buffer (overwritten by the lane's next launch)."""
+        L = self._lane[lane]
+        inner, self.model.use_graph = self.model.use_graph, False           # a frame here is one graph of its own (or plain launches)
+        self._enter_lane(lane)
+        try:
+            if not self.use_graph:
+                with torch.no_grad():
+                    return self._frame(lane, **self._views(clip["packed"][i], clip["layout"]))["u8"]
+            key = (clip["layout"], self.model.resolved_precision())
+            if L["graph"] is None or L["key"] != key:
+                # all driving signals of a frame travel as ONE small row (a few KB): one device-to-device copy per frame feeds the graph
+                L["static_in"] = clip["packed"][i].clone()
+                views = self._views(L["static_in"], clip["layout"])
+                L["graph"] = GraphedFrame(lambda **v: self._frame(lane, **v), views, copy_inputs=False)
+                L["graph"].fn = None     # only needed for the capture; keeping it would tie the renderer into a reference cycle, and a cycle
+                L["key"] = key           # is freed by the garbage collector at a random time -- destroying a hipGraph during someone's capture fails
+            L["static_in"].copy_(clip["packed"][i], non_blocking=True)
+            L["graph"].graph.replay()
+            return L["u8"]
+        finally:
+            self._leave_lane()
+            self.model.use_graph = inner
+
+    def _fork(self):
+        """Lane streams start after everything queued on the caller's stream."""
+        main = torch.cuda.current_stream()
+        for L in self._lane:
+            if L["stream"] is not None:
+                L["stream"].wait_stream(main)
+        return main
+
+    def _join(self, main):
+        for L in self._lane:
+            if L["stream"] is not None:
+                main.wait_stream(L["stream"])
+
+    def _on_lane(self, lane):
+        st = self._lane[lane]["stream"]
+        return torch.cuda.stream(st) if st is not None else _NullContext()
 
     @staticmethod
     def _views(row, layout):
@@ -127,14 +171,20 @@ class ClipRenderer:
         return {"packed": packed, "layout": tuple((n, s) for n, s, _ in layout), "strides": tuple(w for _, _, w in layout), "frames": F}
 
     # -- public API -----------------------------------------------------------------------------------------------------------
-    def render_to_device(self, clip, frame_indices=None, out=None):
+    def render_to_device(self, clip, frame_indices=None, out=None, after_caller_stream=True):
         """Render frames (all, or the given indices) into a uint8 stack [F,h,w,3] that stays on the GPU (the multi-GPU path
-        gathers these with frames.gather_clip).  No host synchronisation."""
+        gathers these with frames.gather_clip).  No host synchronisation; the stack is complete in the caller's stream order.
+        after_caller_stream=False: the frames do not wait for work queued on the caller's stream (use it for the second and later chunks
+        of a clip rendered chunk by chunk, so that frames keep overlapping across chunk boundaries; `clip` and `out` must already exist)."""
         idx = list(range(clip["frames"])) if frame_indices is None else list(frame_indices)
         if out is None:
             out = torch.empty(len(idx), *self.out_hw, 3, dtype=torch.uint8, device=self.device)
+        main = self._fork() if after_caller_stream else torch.cuda.current_stream()
         for k, i in enumerate(idx):
-            out[k].copy_(self._launch(clip, i), non_blocking=True)
+            lane = k % self.lanes
+            with self._on_lane(lane):
+                out[k].copy_(self._launch(clip, i, lane), non_blocking=True)
+        self._join(main)
         return out
 
     def render_to_host(self, clip, sink=None, frame_indices=None):
@@ -149,27 +199,38 @@ class ClipRenderer:
             def sink(k, arr, _pos=[0]):
                 collected[_pos[0]] = arr
                 _pos[0] += 1
-        main = torch.cuda.current_stream()
 
         def retire(k):
             slot = k % self.ring
             self._done[slot].synchronize()
             sink(idx[k], self._host_ring[slot].numpy())
 
+        main = self._fork()
         for k, i in enumerate(idx):
-            slot = k % self.ring
+            slot, lane = k % self.ring, k % self.lanes
             if k >= self.ring:
                 retire(k - self.ring)
-            u8 = self._launch(clip, i)
-            self._dev_ring[slot].copy_(u8, non_blocking=True)
-            self._ready[slot].record(main)
+            with self._on_lane(lane):
+                st = torch.cuda.current_stream()
+                st.wait_event(self._done[slot])             # the slot's previous device->host copy has drained (no-op the first time round)
+                self._dev_ring[slot].copy_(self._launch(clip, i, lane), non_blocking=True)
+                self._ready[slot].record(st)
             self._copy_stream.wait_event(self._ready[slot])
             with torch.cuda.stream(self._copy_stream):
                 self._host_ring[slot].copy_(self._dev_ring[slot], non_blocking=True)
                 self._done[slot].record(self._copy_stream)
         for k in range(max(0, len(idx) - self.ring), len(idx)):
             retire(k)
+        self._join(main)
         return collected
+
+
+class _NullContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 def render_clip_distributed(renderer, clip, n_frames=None, interleaved=False, group=None):

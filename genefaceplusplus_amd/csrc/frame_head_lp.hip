@@ -638,7 +638,8 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     a.alive[0] = ws->alive[0]; a.alive[1] = ws->alive[1];
     a.sync = ws->counters + 127;
     // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
-    const uint32_t separate = lp_separate_trips() < max_steps ? lp_separate_trips() : max_steps;
+    const uint32_t want_separate = ws->separate_trips ? ws->separate_trips : lp_separate_trips();
+    const uint32_t separate = want_separate < max_steps ? want_separate : max_steps;
     for (uint32_t trip = 0; trip <= separate && trip < max_steps; ++trip) {
         a.trip = trip;
         a.trip_end = trip < separate ? trip + 1 : max_steps;

@@ -41,7 +41,7 @@ class HeadModel(ctypes.Structure):
 class FrameWs(ctypes.Structure):
     _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("rays_t", c_p), ("weights_sum", c_p), ("depth", c_p), ("image", c_p),
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
-                ("sample_stride", c_u32), ("phase_cycles", c_p)]
+                ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32)]
 
 
 class CondModel(ctypes.Structure):
@@ -291,7 +291,10 @@ class FramePipeline:
         self._lp_images = {}
         self.precision = "fp32"
         self._graphs = {}
-        self._side_stream = None
+        self._side_stream = {}
+        #: which of several independent workspaces (and side streams) the next frame uses: frames of different lanes may be in flight at
+        #: the same time on different streams (clip.ClipRenderer(lanes=2)); weights and tables are shared
+        self.lane = 0
         self._versions = self._fingerprint(model)
         self.head = self._build_head(model)
         self.torso = self._build_torso(model) if hasattr(model, "torso_deform_net") else None
@@ -500,7 +503,7 @@ class FramePipeline:
 
     # -- per-resolution workspace ------------------------------------------------------------------------------------
     def workspace(self, N):
-        ent = self._ws.get(N)
+        ent = self._ws.get((N, self.lane))
         if ent is None:
             dev = self.device
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -516,9 +519,15 @@ class FramePipeline:
             ws.alive[0], ws.alive[1] = t["alive0"].data_ptr(), t["alive1"].data_ptr()
             ws.phase_cycles = None
             ws.sample_t, ws.sample_cnt, ws.sample_stride = None, None, 0
+            # lanes other than 0 only exist when several frames are in flight: no multi-trip launches then (see gfpp_frame_ws.separate_trips)
+            ws.separate_trips = 0
             ent = (ws, t)
-            self._ws[N] = ent
+            self._ws[(N, self.lane)] = ent
+        ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else 0
         return ent
+
+    #: set > 1 by a caller that keeps frames of several lanes in flight at once (ClipRenderer)
+    frames_in_flight = 1
 
     # -- frames ------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -557,9 +566,9 @@ class FramePipeline:
 
         side = None
         if callable(cond_feat):
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            side = self._side_stream
+            side = self._side_stream.get(self.lane)
+            if side is None:
+                side = self._side_stream[self.lane] = torch.cuda.Stream(device=self.device)
             side.wait_stream(main)                      # fork: everything the caller queued so far (input copies) is visible
             with torch.cuda.stream(side):
                 t["cond_feat"] = fold(cond_feat(), side.cuda_stream)

@@ -184,8 +184,6 @@ class Superresolution(nn.Module):
             "bias": [l.bias.detach().float().contiguous() for l in (b0.conv0, b0.conv1, b1.conv0, b1.conv1)],
             "rgb0_w": b0.torgb.effective_weight().float().contiguous(), "rgb0_b": b0.torgb.bias.detach().float().contiguous(),
             "rgb1_w": b1.torgb.effective_weight().float().contiguous(), "rgb1_b": b1.torgb.bias.detach().float().contiguous(),
-            "x0": torch.empty(256, 256, 128, dtype=torch.float16, device=dev), "x1": torch.empty(256, 256, 128, dtype=torch.float16, device=dev),
-            "x2": torch.empty(512, 512, 64, dtype=torch.float16, device=dev), "img256": torch.empty(256, 256, 3, dtype=torch.float32, device=dev),
         }
         m = SrModel()
         for k in ("w_first", "w_b0c1", "w_up", "w_b1c1", "rgb0_w", "rgb0_b", "rgb1_w", "rgb1_b"):
@@ -200,11 +198,23 @@ class Superresolution(nn.Module):
         for i in range(4):
             m.fir[i] = float(f1[i] * 2.0)                 # gain up^2 = 4 -> 2 per axis
         m.conv_clamp = float(self.conv_clamp)
-        ws = SrWs()
-        for k in ("x0", "x1", "x2", "img256"):
-            setattr(ws, k, keep[k].data_ptr())
-        self._packed = {"fp": fp, "keep": keep, "model": m, "ws": ws}
+        self._packed = {"fp": fp, "keep": keep, "model": m, "ws": {}}
         return self._packed
+
+    #: which activation workspace forward() uses; frames of different lanes may be in flight on different streams (clip.ClipRenderer)
+    lane = 0
+
+    def _workspace(self, P):
+        ent = P["ws"].get(self.lane)
+        if ent is None:
+            dev = self.resample_filter.device
+            bufs = {"x0": torch.empty(256, 256, 128, dtype=torch.float16, device=dev), "x1": torch.empty(256, 256, 128, dtype=torch.float16, device=dev),
+                    "x2": torch.empty(512, 512, 64, dtype=torch.float16, device=dev), "img256": torch.empty(256, 256, 3, dtype=torch.float32, device=dev)}
+            ws = SrWs()
+            for k, v in bufs.items():
+                setattr(ws, k, v.data_ptr())
+            ent = P["ws"][self.lane] = (ws, bufs)
+        return ent[0]
 
     # -- forward ------------------------------------------------------------------------------------------------------------------
     def forward(self, rgb, noise_mode="random", **block_kwargs):
@@ -231,6 +241,6 @@ class Superresolution(nn.Module):
             noises = None
         arr = (c_p * 4)(*[n.data_ptr() for n in noises]) if noises is not None else None
         out = torch.empty(512, 512, 3, dtype=torch.float32, device=x.device)
-        call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(P["ws"]), x.data_ptr(), arr, out.data_ptr(),
+        call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(self._workspace(P)), x.data_ptr(), arr, out.data_ptr(),
              torch.cuda.current_stream().cuda_stream)
         return out.permute(2, 0, 1).unsqueeze(0)                                # [1,3,512,512] view

@@ -287,6 +287,10 @@ typedef struct gfpp_frame_ws {
     uint64_t *phase_cycles; /* optional (NULL = off), [64][8] u64, caller-zeroed: gfpp_head_frame_march_lp adds, per trip, the shader
                              * cycles its wavefronts spent in {weight copy, sample fetch, evaluate, composite} and, splitting evaluate,
                              * {position encode, ambient MLP, ambient encode, sigma + colour MLP} -- a profiling aid */
+    uint32_t separate_trips; /* 16-bit kernel: how many trips get a launch of their own before ONE multi-trip launch (device-wide barrier
+                              * between its trips) takes the rest; 0 = default (6).  Set it >= max_steps when frames are in flight on
+                              * several streams at once (one workspace each): two multi-trip launches spinning at their barriers could
+                              * keep each other's workgroups from ever becoming resident. */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

@@ -46,9 +46,10 @@ def _reference_shaped_loop(model, case, batch, dev, HW, sr):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("variant,HW,precision,graph", [("may_torso", 128, "fp32", True), ("may_torso", 128, "fp16", True),
-                                                        ("may_head", 96, "fp32", False), ("may_torso_sr", 256, "fp16", True)])
-def test_clip_bytes_equal_per_frame_calls(dev, variant, HW, precision, graph):
+@pytest.mark.parametrize("variant,HW,precision,graph,lanes", [("may_torso", 128, "fp32", True, 2), ("may_torso", 128, "fp16", True, 2),
+                                                              ("may_torso", 128, "fp16", True, 1), ("may_torso", 128, "fp16", True, 3),
+                                                              ("may_head", 96, "fp32", False, 2), ("may_torso_sr", 256, "fp16", True, 2)])
+def test_clip_bytes_equal_per_frame_calls(dev, variant, HW, precision, graph, lanes):
     from genefaceplusplus_amd.clip import ClipRenderer
     case = frame_case(variant, HW)
     model = build_model(case, dev, "fused")
@@ -61,7 +62,8 @@ def test_clip_bytes_equal_per_frame_calls(dev, variant, HW, precision, graph):
     if sr:
         kw["sr_noise_mode"] = "const"            # the reference's default ('random') draws fresh noise per frame: not comparable
     r = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], ring=3, use_graph=graph,
-                     render_kwargs=kw)
+                     render_kwargs=kw, lanes=lanes)
+    assert r.lanes == lanes
     clip = r.prepare(batch, dev)
     got = r.render_to_host(clip)
     assert got.shape == want.shape and got.dtype == np.uint8

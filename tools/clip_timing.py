@@ -25,9 +25,10 @@ hp = case["hp"]
 fi = [syn.synthetic_frame_inputs(hp, i) for i in range(F)]
 batch = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(F)]).astype(np.float32), "cond_wins": np.stack([f["cond"] for f in fi]),
          "lm68": np.stack([f["lm68"] for f in fi]), "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi])}
-for graph in (True, False):
-    for ring in (2, 4, 8):
-        r = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=0.01, ring=ring, use_graph=graph)
+lanes_list = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2]
+for graph, ring, lanes in [(g, r, l) for g in (True, False) for l in lanes_list for r in ((4, 8) if g else (4,))]:
+    if True:
+        r = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=0.01, ring=ring, use_graph=graph, lanes=lanes)
         clip = r.prepare(batch, dev)
         r.render_to_device(clip, range(4))
         torch.cuda.synchronize()
@@ -40,5 +41,6 @@ for graph in (True, False):
         t = time.perf_counter()
         r.render_to_host(clip, sink=lambda i, a: n.__setitem__(0, n[0] + 1))
         t_host = time.perf_counter() - t
-        print(f"graph={graph} ring={ring}: device-resident {F / t_dev:8.1f} fps (host launch loop alone {1e3 * t_launch / F:.3f} ms/frame), "
+        del clip
+        print(f"graph={graph} lanes={lanes} ring={ring}: device-resident {F / t_dev:8.1f} fps (host launch loop alone {1e3 * t_launch / F:.3f} ms/frame), "
               f"to pinned host {F / t_host:8.1f} fps")
