@@ -523,8 +523,11 @@ class FramePipeline:
             ws.separate_trips = 0
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
-        ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else 0
+        ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else (self.separate_trips or 0)
         return ent
+
+    #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
+    separate_trips = None
 
     #: set > 1 by a caller that keeps frames of several lanes in flight at once (ClipRenderer)
     frames_in_flight = 1

@@ -136,3 +136,74 @@ def test_sr_frame_end_to_end(dev, oracle_mod, precision):
     print("sr frame", precision, "max", float(err.max()), "mean", float(err.mean()), "psnr", psnr)
     assert psnr >= (55.0 if precision == "fp32" else 42.0), psnr
     assert (err.max(axis=1) > (2e-2 if precision == "fp32" else 8e-2)).mean() <= 1e-3
+
+
+def _rgb(res):
+    return res["rgb_map"].float().cpu().numpy().reshape(-1, 3)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_long_loop_scene_and_launch_splits(dev, oracle_mod, precision):
+    """A field that never terminates a ray (sigma ~ 1: alpha 0.03 per step) runs the loop to its step budget: 7 trips instead of 6.  In the 16-bit
+    modes the trips past the sixth then do real work inside the multi-trip launch (device-wide barrier between trips); every split of the trips
+    over launches must give the same bits, and the frame must match the oracle."""
+    case = frame_case("may_torso", 96, sigma_gain=0.05)
+    trace = []
+    ref = oracle_render(oracle_mod, case, trace=trace)
+    assert len(trace) >= 7, trace
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    res = product_render(model, case, dev, "oracle", oracle_mod)
+    alive, samples = model.pipeline().trip_counters(96 * 96)
+    assert int((samples[:16] > 0).sum()) == len(trace)
+    if precision == "fp32":
+        assert [int(a) for a in alive[:len(trace)]] == [n for n, _ in trace]            # identical trip schedule
+        compare_frames(res, ref, "may_torso", 96)
+        return
+    err = np.abs(_rgb(res) - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
+    assert (err > 2e-2).mean() <= 5e-4 and _psnr(_rgb(res), ref["rgb_map"].reshape(-1, 3)) >= 45.0
+    pipe = model.pipeline()
+    assert int(pipe.workspace(96 * 96)[1]["counters"][127]) > 0, "the multi-trip launch must have passed at least one barrier"
+    base = _rgb(res).copy()
+    for split in (1, 3, 64):                     # 1: trips 1..15 in one launch; 64: every trip its own launch
+        pipe.separate_trips = split
+        again = product_render(model, case, dev, "oracle", oracle_mod)
+        np.testing.assert_array_equal(_rgb(again), base)
+        assert int(pipe.workspace(96 * 96)[1]["counters"][127]) >= 0, "barrier timed out"
+    pipe.separate_trips = None
+
+
+@pytest.mark.parametrize("variant,HW,precision", [("may_head", 37, "fp32"), ("may_torso", 37, "fp16"), ("may_torso", 2, "fp16"), ("may_head", 1, "fp32")])
+def test_ragged_and_tiny_frames(dev, oracle_mod, variant, HW, precision):
+    """Ray counts that are no multiple of the tile (1369), of the wavefront (4) or a single ray (the torso needs >= 2x2: its pixel grid is linspace(-1, 1, H))."""
+    case = frame_case(variant, HW)
+    ref = oracle_render(oracle_mod, case)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    res = product_render(model, case, dev, "oracle", oracle_mod)
+    tol = 2e-4 if precision == "fp32" else 2e-2
+    err = np.abs(_rgb(res) - ref["rgb_map"].reshape(-1, 3))
+    assert (err.max(axis=1) > tol).mean() <= (5e-4 if HW > 8 else 0.0), float(err.max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_empty_and_full_occupancy(dev, oracle_mod, precision):
+    """All-zero bitfield: no sample anywhere, every ray dies in trip 0 and the frame is the torso / background composite.
+    All-ones bitfield: every ray marches the whole slab, the sample lists are at their maximum length."""
+    for fill in (0, 255):
+        case = frame_case("may_torso", 48)
+        case["sd"] = dict(case["sd"])
+        case["sd"]["density_bitfield"] = np.full_like(case["sd"]["density_bitfield"], fill)
+        trace = []
+        ref = oracle_render(oracle_mod, case, trace=trace)
+        model = build_model(case, dev, "fused")
+        model.precision = precision
+        res = product_render(model, case, dev, "oracle", oracle_mod)
+        alive, samples = model.pipeline().trip_counters(48 * 48)
+        if fill == 0:
+            assert int(samples.sum()) == 0 and int(alive[1]) == 0
+            np.testing.assert_allclose(_rgb(res), ref["rgb_map"].reshape(-1, 3), atol=2e-2 if precision != "fp32" else 2e-4)
+        else:
+            assert int(samples[0]) == 48 * 48
+            err = np.abs(_rgb(res) - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
+            assert (err > (2e-4 if precision == "fp32" else 2e-2)).mean() <= 5e-4, float(err.max())
