@@ -210,7 +210,9 @@ def main():
         fps = world * K / elapsed
         result = {"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
                   "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-                  "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16 operands / f32 accumulate", "bf16": "bf16 operands / f32 accumulate"}[args.precision],
+                  "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision],
+                  "dtype_note": "MLP layers on MFMA: f32 = exact-fp32 MFMA; f16 / bf16 = 16-bit operands with fp32 accumulation; marcher, grid interpolation, "
+                                "activations' transcendental parts and compositing are fp32 in every mode",
                   "data": "synthetic",
                   "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame"
                                          + (" + StyleGAN2 super-resolution to 512x512 (random noise inputs, like the reference)" if args.variant == "may_torso_sr" else "")

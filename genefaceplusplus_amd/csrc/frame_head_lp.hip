@@ -29,10 +29,9 @@
 
 namespace gfpp {
 
-#ifndef GFPP_LP_THREADS
-#define GFPP_LP_THREADS 512
-#endif
-constexpr int kLpThreads = GFPP_LP_THREADS;
+// 512 threads = 2 wavefronts per SIMD with up to 256 registers each.  Measured alternatives: 256 threads (1 per SIMD, no spills) is 1.49x
+// slower; 768 threads (3 per SIMD, 168 registers) spills ~140 registers and is 1.8x slower.
+constexpr int kLpThreads = 512;
 constexpr int kLpWaves = kLpThreads / 64;
 constexpr int kLpSlots = 128;   // sample slots of one wavefront tile
 constexpr int kLpRays = 64;     // rays of one wavefront tile (at most)
@@ -304,9 +303,6 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         u3[0] = (wt.px[slot] + a.mp.bound) / b2;
         u3[1] = (wt.py[slot] + a.mp.bound) / b2;
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
-#ifdef GFPP_EXP_CONST_POS
-        for (int d = 0; d < 3; ++d) u3[d] = u3[d] * 1e-9f + 0.4f;
-#endif
         encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
     }
     lap(0);
@@ -315,11 +311,7 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
         lap(1);
 #pragma unroll
-#ifdef GFPP_EXP_CONST_AMB
-        for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) * 1e-9f + 1.0f) / 2.0f;
-#else
         for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
-#endif
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
     lap(2);
