@@ -403,7 +403,12 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
     };
     // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
     if (!weights_resident) {
-        for (int i = tid; i < kLpWeightChunks; i += kLpThreads) sh.w[i] = a.w16[i];
+        // 124 KB of fragments: direct global -> LDS transfers (no register round trip, all 16 requests of a thread in flight at once); the
+        // LDS address of such a load is wave-uniform base + lane x 16, which is exactly the fragment layout
+        static_assert(kLpWeightChunks % 64 == 0, "whole wavefront rows");
+        for (int i = tid; i < kLpWeightChunks; i += kLpThreads)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w16 + i),
+                                             (__attribute__((address_space(3))) void *)(&sh.w[i - lane]), 16, 0, 0);
         for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
         for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
         for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
