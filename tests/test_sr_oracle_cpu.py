@@ -50,3 +50,36 @@ def test_sr_state_layout_matches_reference():
         sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synthetic_sr_state().items()}
         missing, unexpected = model.load_state_dict(sd, strict=False)
         assert not unexpected and all(not k.startswith("sr_net.") for k in missing)
+
+
+def test_host_side_weight_folding_matches_the_oracle_layers():
+    """The product never runs modulation / demodulation / transposed convolution / FIR filtering on the device: they are folded into plain 3x3
+    weights on the host (superres.py::effective_weight, _compose_up_weights).  Plain torch convolutions with the folded weights must
+    reproduce the oracle's modulated_conv2d, for the plain layers and for the x2 layer (4 phases x 64 channels, depth-to-space)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import sr_oracle
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution, _compose_up_weights
+    sd = syn.synthetic_sr_state(prefix="")
+    sr = Superresolution(channels=3)
+    sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    rng = np.random.default_rng(2)
+    filt = torch.from_numpy(sd["resample_filter"]).float()
+    for name, layer in (("block0.conv1", sr.block0.conv1), ("block1.conv0", sr.block1.conv0), ("block1.conv1", sr.block1.conv1)):
+        x = torch.from_numpy(rng.standard_normal((1, layer.in_channels, 10, 12)).astype(np.float32))
+        styles = sr_oracle.styles_from_ones(sd[name + ".affine.weight"], sd[name + ".affine.bias"])
+        ref = sr_oracle.modulated_conv2d(x, sd[name + ".weight"], styles, None, layer.up, 1, filt, True)
+        w = layer.effective_weight()
+        if layer.up == 1:
+            got = F.conv2d(x.double(), w, padding=1)
+        else:
+            wc = _compose_up_weights(w, filt)                                             # [4 * Cout, Cin, 3, 3], channel = Cout * (2 py + px) + o
+            y = F.conv2d(x.double(), wc, padding=1).reshape(1, 2, 2, layer.out_channels, 10, 12)
+            got = y.permute(0, 3, 4, 1, 5, 2).reshape(1, layer.out_channels, 20, 24)      # (2 y + py, 2 x + px)
+        np.testing.assert_allclose(got.numpy(), ref.double().numpy(), rtol=2e-4, atol=2e-4)
+    # ToRGB: modulation only, 1x1
+    x = torch.from_numpy(rng.standard_normal((1, 64, 6, 6)).astype(np.float32))
+    styles = sr_oracle.styles_from_ones(sd["block1.torgb.affine.weight"], sd["block1.torgb.affine.bias"]) * (1.0 / np.sqrt(64))
+    ref = sr_oracle.modulated_conv2d(x, sd["block1.torgb.weight"], styles, None, 1, 0, filt, False)
+    got = F.conv2d(x.double(), sr.block1.torgb.effective_weight().double().t().reshape(3, 64, 1, 1))   # stored [in, out]
+    np.testing.assert_allclose(got.numpy(), ref.double().numpy(), rtol=2e-4, atol=2e-4)
