@@ -53,6 +53,10 @@ class _Affine(nn.Module):
     def styles_for_ones(self):
         return (self.weight.detach().double() * self.weight_gain).sum(dim=1) + self.bias.detach().double()
 
+    def styles_autograd(self):
+        """the same, as part of the autograd graph (training)"""
+        return (self.weight * self.weight_gain).sum(dim=1) + self.bias
+
 
 class _SynthesisLayer(nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, resolution, up=1):
@@ -72,6 +76,25 @@ class _SynthesisLayer(nn.Module):
         return w * d.reshape(-1, 1, 1, 1)
 
 
+    def forward_autograd(self, x, noise, conv_clamp):
+        """SynthesisLayer.forward (networks_stylegan2.py:321-344) in plain differentiable torch ops: modulate / demodulate the weight
+        (:60-70), correlate -- for up = 2 a stride-2 transposed convolution followed by the 4x4 FIR filter with gain 4
+        (conv2d_resample.py:117-133) --, add noise, bias, leaky ReLU(0.2) x sqrt(2), clamp."""
+        w = self.weight * self.affine.styles_autograd().reshape(1, -1, 1, 1)
+        w = w * (w.square().sum(dim=[1, 2, 3]) + 1e-8).rsqrt().reshape(-1, 1, 1, 1)
+        if self.up == 1:
+            x = F.conv2d(x, w, padding=1)
+        else:
+            f = self.resample_filter.to(x.dtype)
+            x = F.conv_transpose2d(x, w.transpose(0, 1), stride=2)                     # [H, W] -> [2H + 1, 2W + 1]
+            x = F.pad(x, [1, 1, 1, 1])
+            x = F.conv2d(x, (f * 4.0).flip([0, 1])[None, None].repeat(x.shape[1], 1, 1, 1), groups=x.shape[1])   # -> [2H, 2W]
+        if noise is not None:
+            x = x + noise * self.noise_strength
+        x = F.leaky_relu(x + self.bias.reshape(1, -1, 1, 1), 0.2) * float(np.sqrt(2.0))
+        return x.clamp(-conv_clamp, conv_clamp)
+
+
 class _ToRGB(nn.Module):
     def __init__(self, in_channels, out_channels, w_dim):
         super().__init__()
@@ -84,6 +107,12 @@ class _ToRGB(nn.Module):
         """modulated, NOT demodulated (networks_stylegan2.py:363-366) -> [in, out] float64."""
         s = self.affine.styles_for_ones() * self.weight_gain
         return (self.weight.detach().double()[:, :, 0, 0] * s.reshape(1, -1)).t().contiguous()
+
+
+    def forward_autograd(self, x, conv_clamp):
+        """ToRGBLayer.forward (networks_stylegan2.py:363-368): modulated 1x1, no demodulation, linear, clamp."""
+        w = self.weight * (self.affine.styles_autograd() * self.weight_gain).reshape(1, -1, 1, 1)
+        return (F.conv2d(x, w) + self.bias.reshape(1, -1, 1, 1)).clamp(-conv_clamp, conv_clamp)
 
 
 class _Block(nn.Module):
@@ -216,6 +245,32 @@ class Superresolution(nn.Module):
             ent = P["ws"][self.lane] = (ws, bufs)
         return ent[0]
 
+    # -- training: the same network in autograd-visible torch ops (the convolutions go to MIOpen) ----------------------------------------
+    def _forward_autograd(self, rgb, noise_mode):
+        """radnerf_sr.py:30-43 over superresolution.py:219-245 (block0, no up-sampling) and networks_stylegan2.py:446-472 (block1, x2),
+        architecture 'skip', ws = ones.  Used in training mode only; inference runs the folded-weight HIP kernels."""
+        layers = (self.block0.conv0, self.block0.conv1, self.block1.conv0, self.block1.conv1)
+        if noise_mode == "const":
+            noises = [l.noise_const for l in layers]
+        elif noise_mode == "random":
+            noises = [torch.randn(l.resolution, l.resolution, device=rgb.device) for l in layers]
+        else:
+            noises = [None] * 4
+        c = self.conv_clamp
+        x = self.block0.conv0.forward_autograd(rgb, noises[0], c)
+        x = self.block0.conv1.forward_autograd(x, noises[1], c)
+        img = rgb + self.block0.torgb.forward_autograd(x, c)
+        x = self.block1.conv0.forward_autograd(x, noises[2], c)
+        x = self.block1.conv1.forward_autograd(x, noises[3], c)
+        # upfirdn2d.upsample2d of the running image (upfirdn2d.py:330-355): zero-stuff x2, pad (2, 1), 4x4 FIR with gain 4
+        f = self.resample_filter.to(img.dtype)
+        B, C, H, W = img.shape
+        up = torch.zeros(B, C, H, 2, W, 2, dtype=img.dtype, device=img.device)
+        up[:, :, :, 0, :, 0] = img
+        up = F.pad(up.reshape(B, C, 2 * H, 2 * W), [2, 1, 2, 1])
+        up = F.conv2d(up, (f * 4.0).flip([0, 1])[None, None].repeat(C, 1, 1, 1), groups=C)
+        return up + self.block1.torgb.forward_autograd(x, c)
+
     # -- forward ------------------------------------------------------------------------------------------------------------------
     def forward(self, rgb, noise_mode="random", **block_kwargs):
         """rgb [1,3,256,256] in [0,1] -> [1,3,512,512] fp32 (radnerf_sr.py:30-43).  noise_mode: 'random' (the reference's default: a fresh
@@ -230,6 +285,8 @@ class Superresolution(nn.Module):
                                 antialias=self.sr_antialias)
         if rgb.shape[-1] != self.input_resolution or rgb.shape[-2] != self.input_resolution:
             raise GfppError("Superresolution: input must be 256x256 (or smaller, then it is interpolated up like in the reference)")
+        if torch.is_grad_enabled() and (rgb.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            return self._forward_autograd(rgb.float(), noise_mode)
         P = self._pack()
         x = rgb.detach().float().permute(0, 2, 3, 1).contiguous()               # NHWC view of the NeRF image: no copy when it came from render()
         layers = (self.block0.conv0, self.block0.conv1, self.block1.conv0, self.block1.conv1)

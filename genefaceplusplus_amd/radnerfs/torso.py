@@ -260,9 +260,6 @@ class RADNeRFTorsowithSR(_TorsoBase):
         side = self.sr_net.input_resolution          # 256: the reference hard-codes [1,256,256,3] (radnerf_torso_sr.py:219,229)
 
         def superresolve(o):
-            if self.sr_net.ready and self.training and torch.is_grad_enabled():
-                raise NotImplementedError("the super-resolution stage is inference-only so far (folded-weight HIP kernels, no backward); "
-                                          "train with sr_net left uninitialised or under torch.no_grad()")
             if self.sr_net.ready:
                 o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
                 if upscale_torso:
@@ -305,7 +302,5 @@ class RADNeRFwithSR(RADNeRF):
         rgb = res["rgb_map"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         res["rgb_map"] = rgb
         if self.sr_net.ready:
-            if self.training and torch.is_grad_enabled():
-                raise NotImplementedError("the super-resolution stage is inference-only so far (no backward kernels)")
             res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
         return res

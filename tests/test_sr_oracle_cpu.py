@@ -83,3 +83,35 @@ def test_host_side_weight_folding_matches_the_oracle_layers():
     ref = sr_oracle.modulated_conv2d(x, sd["block1.torgb.weight"], styles, None, 1, 0, filt, False)
     got = F.conv2d(x.double(), sr.block1.torgb.effective_weight().double().t().reshape(3, 64, 1, 1))   # stored [in, out]
     np.testing.assert_allclose(got.numpy(), ref.double().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_training_path_of_the_sr_stage_matches_oracle_and_differentiates():
+    """Superresolution._forward_autograd (plain torch ops, what training mode runs) == the oracle (itself pinned on the reference's golden
+    vectors), and its gradients agree with central differences."""
+    import torch
+    from oracle import sr_oracle
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    sr = Superresolution(channels=3)
+    sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    x = _inputs()["smooth"]
+    for mode in ("const", "none"):
+        with torch.no_grad():
+            got = sr._forward_autograd(torch.from_numpy(x), mode).numpy()
+        ref = sr_oracle.superresolution(x, syn.synthetic_sr_state(prefix="sr_net."), noise_mode=mode)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-4)
+    # gradients (float64, small image, no noise): d loss / d (input, one conv weight, one affine bias) vs central differences
+    sr = sr.double()
+    torch.manual_seed(0)
+    xs = torch.rand(1, 3, 8, 8, dtype=torch.float64, requires_grad=True)
+    target = torch.rand(1, 3, 16, 16, dtype=torch.float64)
+    loss_fn = lambda: ((sr._forward_autograd(xs, "none") - target) ** 2).mean()
+    loss_fn().backward()
+    for t in (xs, sr.block1.conv0.weight, sr.block0.conv1.affine.bias, sr.block1.torgb.weight):
+        g = t.grad.clone()
+        assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+        d = g / g.norm()
+        eps = 1e-5
+        with torch.no_grad():
+            t.add_(eps * d); up = float(loss_fn()); t.sub_(2 * eps * d); down = float(loss_fn()); t.add_(eps * d)
+        assert abs((up - down) / (2 * eps) - float((g * d).sum())) <= 1e-5 * max(1.0, float(g.norm()))

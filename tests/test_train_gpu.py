@@ -383,3 +383,32 @@ def test_sh_and_freq_encoder_backward(dev, oracle_mod):
         # no gradient requested -> plain forward, nothing saved
         with torch.no_grad():
             assert not enc(_t(x2, dev)).requires_grad
+
+
+def test_sr_model_trains_end_to_end(dev, oracle_mod):
+    """RADNeRFTorsowithSR in training mode: the torso field and the SR net receive gradients (head frozen), and the autograd-visible SR path agrees
+    with the folded-weight HIP kernels that inference runs."""
+    from helpers import frame_case, build_model
+    from genefaceplusplus_amd.radnerfs import camera
+    case = frame_case("may_torso_sr", 256)
+    model = build_model(case, dev, "fused")
+    x = torch.rand(1, 3, 256, 256, device=dev)
+    with torch.no_grad():
+        fast = model.sr_net(x, noise_mode="const")                                       # HIP kernels (eval)
+        slow = model.sr_net._forward_autograd(x, "const")                                 # torch ops
+    assert float((fast - slow).abs().max()) <= 1e-2, float((fast - slow).abs().max())
+    model.train()
+    pose = torch.from_numpy(case["pose"]).to(dev)
+    r = camera.get_rays(pose, case["intr"], 256, 256)
+    out = model.render(r["rays_o"], r["rays_d"], torch.from_numpy(case["cond"]).to(dev), camera.get_bg_coords(256, 256, dev), camera.convert_poses(pose),
+                       index=0, bg_color=torch.full((1, 256 * 256, 3), 0.5, device=dev), lm68=torch.from_numpy(case["lm68"]).to(dev),
+                       eye_area_percent=torch.from_numpy(case["eye_area_percent"]).to(dev), force_all_rays=True, dt_gamma=case["hp"]["dt_gamma"],
+                       max_steps=case["hp"]["max_steps"], sr_noise_mode="const")
+    assert out["sr_rgb_map"].shape == (1, 3, 512, 512) and out["sr_rgb_map"].requires_grad
+    (out["sr_rgb_map"].mean() + out["rgb_map"].mean()).backward()
+    named = dict(model.named_parameters())
+    for name in ("sr_net.block0.conv0.weight", "sr_net.block1.conv0.affine.weight", "sr_net.block1.torgb.bias", "torso_embedder.embeddings",
+                 "torso_deform_net.net.0.weight"):
+        g = named[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+    assert named["sigma_net.net.0.weight"].grad is None                                   # head frozen (radnerf_torso_sr.py:123)
