@@ -255,7 +255,9 @@ class GraphedFrame:
                 fn(**self.static)
         torch.cuda.current_stream().wait_stream(stream)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: other threads of the process (RCCL's watchdog in multi-GPU runs, a video writer) may keep calling into HIP while this
+        # thread captures; only this thread's calls have to be capturable
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.out = fn(**self.static)
 
     def matches(self, inputs):
@@ -663,4 +665,4 @@ class FramePipeline:
     def trip_counters(self, N):
         """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises."""
         c = self.workspace(N)[1]["counters"].cpu().numpy()
-        return c[:64], c[64:]
+        return c[:64], c[64:127]
