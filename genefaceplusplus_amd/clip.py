@@ -28,10 +28,11 @@ class ClipRenderer:
     bg_img [1, H*W, 3] float in [0,1] or None (white), as `sample['bg_img']` in the reference.
     """
 
-    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=2):
+    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None):
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
         workspace and graph; weights and tables are shared), so one frame's prologue (slab test, pre-march, conditioning nets: small
-        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches."""
+        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches.  None = 2 for
+        512x512 rays, 3 for the 256x256 frames of the super-resolution models (measured: a third lane adds 12 % there, nothing at 512^2)."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
@@ -50,6 +51,8 @@ class ClipRenderer:
         self.bg_coords = camera.get_bg_coords(H, W, dev)
         self.bg_img = None if bg_img is None else bg_img.to(dev).float().reshape(1, H * W, 3).contiguous()
         fused = getattr(model, "executor", "fused") == "fused"
+        if lanes is None:
+            lanes = 3 if H * W <= 256 * 256 else 2
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
