@@ -399,6 +399,21 @@ def main():
             return {"kernel": "k_grid_encode<3,2,float>", "bound": "hbm", "points": int(u.shape[0]), "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4), "ms": round(t * 1e3, 4), "input": label, "bytes_per_point": GRID_BYTES_PER_POINT}
 
+        # measured streaming ceiling of this GPU (SURVEY 8d asks for it next to the nominal 8 TB/s): 1 GiB device-to-device copy, read + write
+        src_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_buf = torch.empty_like(src_buf)
+        for _ in range(2):
+            dst_buf.copy_(src_buf)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst_buf.copy_(src_buf)
+        c1.record()
+        torch.cuda.synchronize()
+        t_copy = c0.elapsed_time(c1) * 1e-3 / 5
+        result["hbm_stream_copy"] = {"achieved": round(2 * src_buf.numel() * 4 / t_copy / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBPS,
+                                     "what": "1 GiB device-to-device copy (read + write bytes / time): the measured streaming ceiling"}
+        del src_buf, dst_buf
         result["grid_stage"] = grid_entry(torch.rand(1 << 22, 3, device=dev), "2^22 points uniform in [0,1]^3 (cache-hostile)")
         # (ii) the marcher's real sample stream: every occupied sample of the first 8 steps of one frame
         x = inputs[W]
