@@ -68,7 +68,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(variant, hw_sample=256, hw_full=512):
+def cpu_baseline(variant, hw_sample=512, hw_full=512):
     """Oracle (CPU restatement of the reference path) on one hw_sample^2 frame, scaled to frames/s at hw_full^2."""
     threads = min(os.cpu_count() or 1, 64)
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
@@ -429,7 +429,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(args.variant if args.variant != "may_torso_sr" else "may_torso_sr",
-                                                  hw_sample=256, hw_full=HW)
+                                                  hw_sample=HW, hw_full=HW)
         except Exception as exc:  # the oracle is optional equipment for the bench, never for the product
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
 
