@@ -8,7 +8,7 @@ frame) over RCCL / xGMI -- backend "nccl" on ROCm; the same code runs on "gloo" 
 import torch
 import torch.distributed as dist
 
-from ._lib import call
+from ._lib import GfppError, call
 
 
 def shard_frames(n_frames, rank, world, interleaved=False):
@@ -36,10 +36,9 @@ def to_uint8_hwc(rgb, out=None):
     rgb = rgb.contiguous()
     if out is None:
         out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
-    if rgb.is_cuda:
-        call("gfpp_rgb_to_u8", rgb.data_ptr(), rgb.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    else:  # host-side convenience for the gloo tests only (no kernel involved)
-        out.copy_((rgb * 255.0).to(torch.int32).clamp_(0, 255).to(torch.uint8))
+    if not rgb.is_cuda:
+        raise GfppError("to_uint8_hwc: the frame must be on the GPU (there is no CPU path)")
+    call("gfpp_rgb_to_u8", rgb.data_ptr(), rgb.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     return out
 
 

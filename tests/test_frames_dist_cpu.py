@@ -25,9 +25,10 @@ def test_shard_frames_partitions():
         frames.shard_frames(4, 2, 2)
 
 
-def test_to_uint8_truncates():
-    x = torch.tensor([[0.0, 0.5, 1.0], [0.999, 0.0039, 0.00392157]])
-    assert frames.to_uint8_hwc(x).tolist() == [[0, 127, 255], [254, 0, 1]]
+def test_to_uint8_has_no_cpu_path():
+    from genefaceplusplus_amd._lib import GfppError
+    with pytest.raises(GfppError):
+        frames.to_uint8_hwc(torch.tensor([[0.0, 0.5, 1.0]]))
 
 
 def _free_port():

@@ -293,3 +293,15 @@ def test_superresolution_matches_oracle(dev, noise_mode):
     psnr = 10 * np.log10(span ** 2 / float(np.mean((got - ref) ** 2)))
     print("sr", noise_mode, "max", float(err.max()), "mean", float(err.mean()), "psnr", psnr, "range", float(ref.min()), float(ref.max()))
     assert psnr >= 50.0 and err.max() <= 4e-2, (psnr, float(err.max()))
+
+
+def test_rgb_to_uint8_truncates_like_the_caller(dev):
+    """gfpp_rgb_to_u8 == `(pred_rgb * 255.).int() ... astype(np.uint8)` of inference/genefacepp_infer.py:468 (truncation, values in [0,1])."""
+    from genefaceplusplus_amd import frames
+    x = torch.tensor([[0.0, 0.5, 1.0], [0.999, 0.0039, 0.00392157]], device=dev)
+    assert frames.to_uint8_hwc(x).cpu().tolist() == [[0, 127, 255], [254, 0, 1]]
+    rng = np.random.default_rng(4)
+    for n in (1, 3, 4, 5, 4099):                                    # tails that are not a multiple of the 4-value vector width
+        v = rng.random((n, 3)).astype(np.float32)
+        got = frames.to_uint8_hwc(t(v, dev)).cpu().numpy()
+        np.testing.assert_array_equal(got, (v * np.float32(255.0)).astype(np.int32).astype(np.uint8))
