@@ -116,3 +116,39 @@ def test_multi_identity_groups_gloo(world, n_ident):
     per = world // n_ident
     for rank, ident, shared_ok, clip_ok in results:
         assert ident == rank // per and shared_ok and clip_ok
+
+
+class _FakeRenderer:
+    """Stands in for clip.ClipRenderer in the CPU test of the distributed clip path: a 'frame' is a tiny image holding its index."""
+
+    def render_to_device(self, clip, frame_indices=None, out=None):
+        idx = list(range(clip["frames"])) if frame_indices is None else list(frame_indices)
+        return torch.stack([torch.full((2, 3, 3), i, dtype=torch.uint8) for i in idx]) if idx else torch.zeros(0, 2, 3, 3, dtype=torch.uint8)
+
+
+def _clip_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genefaceplusplus_amd.clip import render_clip_distributed
+    out = render_clip_distributed(_FakeRenderer(), {"frames": n_frames})
+    ok = out.shape == (n_frames, 2, 3, 3) and all(int(out[i, 0, 0, 0]) == i for i in range(n_frames))
+    inter = render_clip_distributed(_FakeRenderer(), {"frames": n_frames}, interleaved=True)
+    ok = ok and all(int(inter[i, 1, 2, 2]) == i for i in range(n_frames))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_render_clip_distributed_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clip_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)
