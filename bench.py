@@ -242,11 +242,11 @@ def main():
             ind = model.individual_embeddings[0].detach().float().contiguous()
             cf = cond_feat.detach().float().contiguous()
             call("gfpp_head_frame_begin", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), cf.data_ptr(), ind.data_ptr(), st)
-            if args.precision != "fp32":   # the once-per-frame bitfield walk is its own kernel; the roofline is about the trip launches
-                call("gfpp_head_frame_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
-                     int(hp["max_steps"]), st)
+            # the once-per-frame bitfield walk is its own kernel; the roofline is about the trip launches
+            call("gfpp_head_frame_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
+                 int(hp["max_steps"]), st)
             e0.record()
-            call("gfpp_head_frame_march" if args.precision == "fp32" else "gfpp_head_frame_trips_lp", ctypes.byref(pipe.head), ctypes.byref(ws),
+            call("gfpp_head_frame_trips" if args.precision == "fp32" else "gfpp_head_frame_trips_lp", ctypes.byref(pipe.head), ctypes.byref(ws),
                  ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), int(hp["max_steps"]), 0.01, st)
             e1.record()
             torch.cuda.synchronize()
@@ -259,7 +259,7 @@ def main():
                   "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
         if args.precision == "fp32":
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
-            result["roofline"] = {"kernel": "k_head_trip<3> (fused march + grid encode + fp32 MFMA MLP + composite)", "bound": "mfma",
+            result["roofline"] = {"kernel": "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)", "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         else:

@@ -36,6 +36,10 @@ struct TripArgs {
     const float *frame_consts;  // [0,128): ambient bias frag, [128,256): colour bias frag
     float T_thresh, density_scale;
     uint32_t N, trip, max_steps;
+    // wave-autonomous kernel only (k_head_trip_w): the frame's pre-marched sample lists (k_premarch in frame_head_lp.hip)
+    const float *sample_t;
+    const uint32_t *sample_cnt;
+    uint32_t sample_stride;
 };
 
 __device__ __forceinline__ v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -82,8 +86,8 @@ struct TileShared {
 };
 
 // Evaluate RADNeRF.forward for the 32 occupied samples [first, first+32) of the tile.
-template <int AMB_D>
-__device__ __forceinline__ void evaluate_block(const TripArgs &a, TileShared &sh, uint32_t first, uint32_t n_step, int lane_in) {
+template <int AMB_D, typename Tile>
+__device__ __forceinline__ void evaluate_block(const TripArgs &a, Tile &sh, uint32_t first, uint32_t n_step, int lane_in) {
     int lane = lane_in;
     // launder the lane id: keeps the (tile-loop-invariant) per-lane weight addresses from being hoisted out of the
     // tile loop and spilled
@@ -263,6 +267,122 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
     }
 }
 
+// ---- the same trip with autonomous wavefronts -------------------------------------------------------------------------------------
+// k_head_trip above synchronises its four wavefronts around every phase of a 128-slot tile (one 32-sample block each between barriers)
+// and walks the occupancy bitfield inside the trip.  This variant takes the structure of the 16-bit kernel (frame_head_lp.hip): samples
+// come from the frame's pre-marched lists, a wavefront owns a tile of up to 64 rays / 128 slots from fetch to survivor append, and there
+// is no workgroup barrier at all -- one wavefront's grid gathers and compositing overlap the other wavefronts' MFMA chains.  The per-sample
+// arithmetic is evaluate_block, unchanged, so every sample gets the same bits as in k_head_trip.
+constexpr int kWSlots = 128, kWRays = 64;
+struct WaveTile {
+    float px[kWSlots], py[kWSlots], pz[kWSlots], dt[kWSlots], tend[kWSlots];   // by slot = ray_local * n_step + s
+    float sigma[kWSlots], cr[kWSlots], cg[kWSlots], cb[kWSlots];               // by slot
+    float dx[kWRays], dy[kWRays], dz[kWRays];                                  // by ray_local
+    uint32_t order[kWSlots];                                                   // compact index -> slot
+    uint32_t n_valid;
+};
+
+template <int AMB_D>
+__global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
+    __shared__ WaveTile tiles[kThreads / 64];
+    uint32_t step_before = 0;
+    for (uint32_t k = 0; k < a.trip; ++k) {
+        const uint32_t na = (uint32_t)a.counters[k];
+        if (na == 0) return;
+        uint32_t ns = a.N / na;
+        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
+        step_before += ns;
+    }
+    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
+    if (n_alive == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N / n_alive;
+    n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr uint32_t kWaves = kThreads / 64;
+    const uint32_t waves_total = gridDim.x * kWaves;
+    // tile size by cost: (tiles per wavefront) x (blocks per tile + per-tile overhead); see k_head_trip_lp
+    uint32_t rays_per_tile = (uint32_t)kWSlots / n_step < (uint32_t)kWRays ? (uint32_t)kWSlots / n_step : (uint32_t)kWRays;
+    {
+        uint32_t best = 0xFFFFFFFFu, best_rpt = rays_per_tile;
+        for (uint32_t rpt = rays_per_tile; rpt * n_step >= 32u || rpt == rays_per_tile; rpt >>= 1) {
+            const uint32_t tiles_n = (n_alive + rpt - 1) / rpt;
+            const uint32_t crit = ((tiles_n + waves_total - 1) / waves_total) * (10u * ((rpt * n_step + 31u) / 32u) + 1u);
+            if (crit < best) { best = crit; best_rpt = rpt; }
+            if (rpt == 1u) break;
+        }
+        rays_per_tile = best_rpt;
+    }
+    const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
+    WaveTile &wt = tiles[wave];
+    const uint32_t gw = blockIdx.x * kWaves + wave;
+    uint32_t evaluated = 0;
+    // every ray that is still alive took the full n_step samples in each earlier trip (a shorter take declares it dead), so its cursor into
+    // the pre-marched list is the loop's cumulative step count
+    const uint32_t used = step_before;
+    for (uint32_t tile = gw; tile < n_tiles; tile += waves_total) {
+        // ---- phase 1: this trip's samples of every ray (one lane per ray) --------------------------------------------------------------
+        const uint32_t n = tile * rays_per_tile + lane;
+        const bool has_ray = (uint32_t)lane < rays_per_tile && n < n_alive;
+        uint32_t ray = 0, cnt = 0;
+        if (has_ray) {
+            ray = a.trip == 0 ? n : (uint32_t)a.alive_in[n];
+            const uint32_t avail = a.sample_cnt[ray] - used;
+            cnt = avail < n_step ? avail : n_step;
+            const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+            const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+            wt.dx[lane] = dx; wt.dy[lane] = dy; wt.dz[lane] = dz;
+            const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
+            const uint32_t base = lane * n_step;
+            for (uint32_t s = 0; s < cnt; ++s) {
+                // the same expressions as march_one_ray (raymarching.cu:873-882, 905-913) evaluated at the stored t
+                const float t0 = ts[s];
+                const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);
+                wt.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                wt.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                wt.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                wt.dt[base + s] = dt;
+                wt.tend[base + s] = t0 + dt;
+            }
+        }
+        const uint32_t incl = wave_inclusive_scan(cnt, lane);
+        const uint32_t n_valid = (uint32_t)__shfl((int)incl, 63);
+        {
+            const uint32_t pos = incl - cnt;
+            for (uint32_t s = 0; s < cnt; ++s) wt.order[pos + s] = lane * n_step + s;
+            if (lane == 0) wt.n_valid = n_valid;
+        }
+        wave_sync();
+        // ---- phase 2: evaluate, 32 samples per pass ---------------------------------------------------------------------------------------
+        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block<AMB_D>(a, wt, first, n_step, lane);
+        evaluated += n_valid;
+        wave_sync();
+        // ---- phase 3: composite, survivor compaction ------------------------------------------------------------------------------------------
+        bool survives = false;
+        if (has_ray) {
+            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            const uint32_t base = lane * n_step;
+            uint32_t s = 0;
+            for (; s < cnt; ++s) {
+                const uint32_t k = base + s;
+                if (composite_sample(acc, wt.sigma[k], wt.dt[k], wt.tend[k], wt.cr[k], wt.cg[k], wt.cb[k], a.T_thresh)) break;
+            }
+            survives = (s == n_step);
+            a.weights_sum[ray] = acc.wsum;
+            a.depth[ray] = acc.depth;
+            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+        }
+        const unsigned long long ballot = __ballot(survives);
+        const uint32_t total = (uint32_t)__popcll(ballot);
+        uint32_t out_base = 0;
+        if (lane == 0 && total) out_base = (uint32_t)atomicAdd(&a.counters[a.trip + 1], (int)total);
+        out_base = (uint32_t)__shfl((int)out_base, 0);
+        if (survives) a.alive_out[out_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (int32_t)ray;
+        wave_sync();
+    }
+    if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + a.trip], (int)evaluated);
+}
+
 // ---- frame begin: slab test + state reset + constant folding ------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, uint32_t N,
                                                          float min_near, float ax0, float ay0, float az0, float ax1, float ay1, float az1,
@@ -420,6 +540,52 @@ GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_fram
         if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip<3>, dim3(grid), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL(k_head_trip<2>, dim3(grid), dim3(kThreads), 0, st, a);
         const int rc = check_launch("gfpp_head_frame_march");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                   float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_trips: null argument"); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > (uint32_t)kMaxTrips) { set_error("gfpp_head_frame_trips: max_steps must be in 1..%d", kMaxTrips); return GFPP_EUNSUPPORTED; }
+    if (!grid_ok(model->pos_grid, 3) || !(grid_ok(model->amb_grid, 2) || grid_ok(model->amb_grid, 3))) {
+        set_error("gfpp_head_frame_trips: grids must be 16-level fp32, position D=3, ambient D in {2,3}");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (!ws->alive[0] || !ws->alive[1] || !ws->sample_t || !ws->sample_cnt || ws->sample_stride < max_steps + 7u) {
+        set_error("gfpp_head_frame_trips: the workspace needs alive[2], sample_t [N, sample_stride >= max_steps + 7] and sample_cnt [N] (gfpp_head_frame_premarch)");
+        return GFPP_EINVAL;
+    }
+    TripArgs a;
+    a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
+    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
+                      (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
+    a.bitfield = model->density_bitfield;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
+    a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.counters = ws->counters;
+    a.frame_consts = ws->frame_consts;
+    a.T_thresh = T_thresh; a.density_scale = model->density_scale;
+    a.N = ws->N; a.max_steps = max_steps;
+    a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const uint32_t grid = 2u * (uint32_t)cus;   // two resident workgroups per CU (register-bound), tiles are taken wave-stride
+    const hipStream_t st = (hipStream_t)stream;
+    for (uint32_t trip = 0; trip < max_steps; ++trip) {
+        a.trip = trip;
+        a.alive_in = ws->alive[trip & 1];
+        a.alive_out = ws->alive[(trip + 1) & 1];
+        if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(grid), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(grid), dim3(kThreads), 0, st, a);
+        const int rc = check_launch("gfpp_head_frame_trips");
         if (rc) return rc;
     }
     return 0;

@@ -88,13 +88,6 @@ struct LpTripArgs {
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
 
-// LDS traffic of one wavefront is executed in program order; this only stops the compiler from moving accesses across.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
     mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);

@@ -86,6 +86,13 @@ __device__ __forceinline__ void encode_half(const float (&u)[D], const GridDev &
     }
 }
 
+// LDS traffic of one wavefront is executed in program order; this only stops the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {

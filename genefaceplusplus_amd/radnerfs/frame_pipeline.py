@@ -72,6 +72,7 @@ _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTE
 _lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_fold", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
+_lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
@@ -528,6 +529,10 @@ class FramePipeline:
         ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else (self.separate_trips or 0)
         return ent
 
+    #: exact-fp32 mode: 'wave' = autonomous wavefronts over pre-marched samples (gfpp_head_frame_trips), 'tile' = the workgroup-synchronous
+    #: kernel that marches inside the trip (gfpp_head_frame_march); same bits per sample
+    fp32_kernel = "wave"
+
     #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
     separate_trips = None
 
@@ -556,7 +561,8 @@ class FramePipeline:
         main = torch.cuda.current_stream()
         st = main.cuda_stream
         lp = self.precision != "fp32"
-        if lp and ws.sample_stride < int(max_steps) + 7:
+        premarched = lp or self.fp32_kernel == "wave"
+        if premarched and ws.sample_stride < int(max_steps) + 7:
             stride = (int(max_steps) + 7 + 7) // 8 * 8
             t["sample_t"] = torch.empty(N, stride, dtype=torch.float32, device=self.device)
             t["sample_cnt"] = torch.empty(N, dtype=torch.int32, device=self.device)
@@ -580,12 +586,12 @@ class FramePipeline:
         call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), None, None, st)
         if side is None:
             fold(cond_feat, st)
-        if lp:
+        if premarched:
             call("gfpp_head_frame_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
                  int(max_steps), st)
         if side is not None:
             main.wait_stream(side)                      # join
-        call("gfpp_head_frame_trips_lp" if lp else "gfpp_head_frame_march", ctypes.byref(self.head), ctypes.byref(ws),
+        call("gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march"), ctypes.byref(self.head), ctypes.byref(ws),
              rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
         return ws, t
 

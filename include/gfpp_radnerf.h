@@ -313,6 +313,12 @@ int gfpp_head_frame_fold(const gfpp_head_model *model, const gfpp_frame_ws *ws, 
 int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                           float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
 
+/* The trip launches of the exact-fp32 mode over the frame's pre-marched sample lists (renderer.py:354-384 loop; per-sample arithmetic
+ * radnerf.py:108-141 on exact-fp32 MFMA, compositing raymarching.cu:942-1029): call gfpp_head_frame_begin, gfpp_head_frame_premarch,
+ * then this.  Same results as gfpp_head_frame_march sample for sample; wavefronts own their tiles (no workgroup barriers). */
+int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                          float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
 /* Same loop as gfpp_head_frame_march (renderer.py:354-384, raymarching.cu:827-929, :942-1029, radnerf.py:108-141) with the five
  * wide layers on 16-bit MFMA operands (model->lp_weights), fp32 accumulation -- the precision class of the reference's own
  * inference path (inference/genefacepp_infer.py:433-486 renders under torch.autocast: nn.Linear in fp16).  March, grid interpolation, tanh / exp / sigmoid, SH and compositing are fp32 and
