@@ -305,3 +305,25 @@ def test_rgb_to_uint8_truncates_like_the_caller(dev):
         v = rng.random((n, 3)).astype(np.float32)
         got = frames.to_uint8_hwc(t(v, dev)).cpu().numpy()
         np.testing.assert_array_equal(got, (v * np.float32(255.0)).astype(np.int32).astype(np.uint8))
+
+
+def test_empty_inputs_are_no_ops(dev):
+    """Zero rays / points / samples: every wrapper returns correctly shaped empties and launches nothing (the reference's shims get here when
+    a frame has no alive ray or a batch has no masked pixel)."""
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    from genefaceplusplus_amd.radnerfs.encoders import GridEncoder, SHEncoder, FreqEncoder
+    z3 = torch.zeros(0, 3, device=dev)
+    aabb = torch.tensor([-1, -0.5, -1, 1, 0.5, 1], dtype=torch.float32, device=dev)
+    nears, fars = rm.near_far_from_aabb(z3, z3, aabb, 0.05)
+    assert nears.shape == (0,) and fars.shape == (0,)
+    assert rm.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
+    assert rm.morton3D_invert(torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 3)
+    bitfield = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=dev)
+    xyzs, dirs, deltas = rm.march_rays(0, 4, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, device=dev), z3, z3, 1.0, bitfield, 1, 128,
+                                       nears, fars, 128, False, 0.0, 16)
+    assert xyzs.shape[1] == 3 and float(xyzs.abs().sum()) == 0.0 and float(deltas.abs().sum()) == 0.0
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048, gridtype="tiled").to(dev)
+    assert enc(z3, bound=1).shape == (0, 32)
+    assert SHEncoder(degree=4)(z3).shape == (0, 16)
+    assert FreqEncoder(input_dim=2, degree=10)(torch.zeros(0, 2, device=dev)).shape == (0, 42)
+    torch.cuda.synchronize()
