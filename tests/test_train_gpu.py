@@ -412,3 +412,34 @@ def test_sr_model_trains_end_to_end(dev, oracle_mod):
         g = named[name].grad
         assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
     assert named["sigma_net.net.0.weight"].grad is None                                   # head frozen (radnerf_torso_sr.py:123)
+
+
+def test_march_rays_train_budget_overflow(dev, oracle_mod, scene):
+    """mean_count smaller than the frame needs (and force_all_rays off): the point budget M is mean_count rounded up to `align`; the counter keeps
+    counting, rays whose range would pass M write nothing (raymarching.cu:452-456), the others are untouched."""
+    from genefaceplusplus_amd.radnerfs import raymarching as rm
+    hp, sd, o, d = scene
+    aabb = np.array([-1, -0.5, -1, 1, 0.5, 1], f32)
+    nears, fars = oracle_mod.near_far_from_aabb(o, d, aabb, 0.05)
+    full = oracle_mod.march_rays_train(o, d, 1.0, sd["density_bitfield"], 1, 128, nears, fars, dt_gamma=hp["dt_gamma"], max_steps=32)
+    total = int(full[4][0])
+    mean_count = total // 2
+    M = mean_count + (128 - mean_count % 128)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(_t(o, dev), _t(d, dev), 1.0, _t(sd["density_bitfield"], dev), 1, 128, _t(nears, dev), _t(fars, dev), counter,
+                                                   mean_count, False, 128, False, hp["dt_gamma"], 32)
+    assert xyzs.shape[0] == M and int(counter[0]) == total and int(counter[1]) == o.shape[0]
+    r = rays.cpu().numpy()
+    X, T = xyzs.cpu().numpy(), deltas.cpu().numpy()
+    cnt_ref = {int(a): int(k) for a, _, k in full[3]}
+    written = np.zeros(M, bool)
+    n_fit = 0
+    for ray, off, cnt in r:
+        assert cnt == cnt_ref[int(ray)]                               # counts are reported even for the rays that did not fit
+        if off + cnt <= M:
+            n_fit += 1
+            written[off:off + cnt] = True
+            off_r = int(full[3][int(ray)][1])
+            np.testing.assert_array_equal(X[off:off + cnt], full[0][off_r:off_r + cnt])
+    assert 0 < n_fit < o.shape[0]
+    assert float(np.abs(X[~written]).sum()) == 0.0 and float(np.abs(T[~written]).sum()) == 0.0     # nothing else was touched
