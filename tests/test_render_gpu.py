@@ -207,3 +207,20 @@ def test_empty_and_full_occupancy(dev, oracle_mod, precision):
             assert int(samples[0]) == 48 * 48
             err = np.abs(_rgb(res) - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
             assert (err > (2e-4 if precision == "fp32" else 2e-2)).mean() <= 5e-4, float(err.max())
+
+
+def test_full_size_frame_matches_oracle(dev, oracle_mod):
+    """BASELINE.json's full size: 512 x 512 = 262 144 rays, head + torso, every precision mode against one oracle render."""
+    case = frame_case("may_torso", 512)
+    ref = oracle_render(oracle_mod, case)
+    rref = ref["rgb_map"].reshape(-1, 3)
+    model = build_model(case, dev, "fused")
+    for precision, tol in (("fp32", 2e-4), ("fp16", 2e-2), ("bf16", 5e-2)):
+        model.precision = precision
+        res = product_render(model, case, dev, "oracle", oracle_mod)
+        err = np.abs(_rgb(res) - rref).max(axis=1)
+        assert (err > tol).mean() <= 5e-4, (precision, float(err.max()))
+        if precision == "fp32":
+            compare_frames(res, ref, "may_torso", 512)
+        else:
+            assert _psnr(_rgb(res), rref) >= 45.0
