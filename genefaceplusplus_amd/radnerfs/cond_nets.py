@@ -8,7 +8,6 @@ These nets see a [smo_win, 1, 204] window once per frame (~0.1 MFLOP): they stay
 per-sample MLPs (ambient / sigma / colour / torso) are evaluated by the fused HIP kernels, which read the weights out of
 the MLP containers below; ``MLP.forward`` (plain torch GEMMs) is kept for the stand-alone ``forward()/density()`` API.
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 

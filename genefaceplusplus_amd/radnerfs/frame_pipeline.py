@@ -6,7 +6,6 @@ grid tables, fills the C descriptor structs, and owns the per-resolution device 
 frame of a resolution), no host synchronisation, hence capturable in a hipGraph (see ``GraphedFrame``).
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
