@@ -17,6 +17,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <typename H>
 struct LpTraits;
@@ -27,14 +28,20 @@ struct LpTraits<_Float16> {
     typedef _Float16 pair __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+    static __device__ __forceinline__ vec relu(vec t) { return __builtin_elementwise_max(t, (vec)(_Float16)0.0f); }   // v_pk_max_f16
 };
 template <>
 struct LpTraits<__bf16> {
     typedef bf16x8 vec;
-    static constexpr bool kPackedMax = false;
+    static constexpr bool kPackedMax = true;
     typedef __bf16 pair __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+    // there is no packed bf16 max, but a bf16 is negative exactly when its bit pattern is a negative int16: clamp the patterns at zero
+    // (v_pk_max_i16; -0.0 and negative NaNs become +0.0)
+    static __device__ __forceinline__ vec relu(vec t) {
+        return __builtin_bit_cast(vec, __builtin_elementwise_max(__builtin_bit_cast(s16x8, t), (s16x8)(short)0));
+    }
 };
 
 // acc[t] += W[32 t.., 16 s..] * b[s] for NS steps; A operands come from the LDS-resident weight image, kAhead steps ahead of
@@ -73,11 +80,11 @@ __device__ __forceinline__ void act_pack(const v16f (&acc)[T], typename LpTraits
 #pragma unroll
     for (int s = 0; s < 2 * T; ++s) {
         if constexpr (ACT == 1 && LpTraits<H>::kPackedMax) {
-            // round first, clamp the packed pairs afterwards (v_pk_max_f16): relu(round(x)) == round(relu(x))
+            // round first, clamp the packed pairs afterwards: relu(round(x)) == round(relu(x))
             typename LpTraits<H>::vec t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (H)acc[s >> 1][8 * (s & 1) + e];
-            b[s] = __builtin_elementwise_max(t, (typename LpTraits<H>::vec)(H)0.0f);
+            b[s] = LpTraits<H>::relu(t);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
