@@ -81,9 +81,17 @@ __device__ __forceinline__ void act_pack(const v16f (&acc)[T], typename LpTraits
     for (int s = 0; s < 2 * T; ++s) {
         if constexpr (ACT == 1 && LpTraits<H>::kPackedMax) {
             // round first, clamp the packed pairs afterwards: relu(round(x)) == round(relu(x))
+            // two values per conversion instruction (v_cvt_pk_*): spelled as 2-vectors, the compiler does not pair scalar bf16 conversions
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef typename LpTraits<H>::pair pair;
             typename LpTraits<H>::vec t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (H)acc[s >> 1][8 * (s & 1) + e];
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {acc[s >> 1][8 * (s & 1) + e], acc[s >> 1][8 * (s & 1) + e + 1]};
+                const pair p = __builtin_convertvector(v, pair);
+                t[e] = p[0];
+                t[e + 1] = p[1];
+            }
             b[s] = LpTraits<H>::relu(t);
         } else {
 #pragma unroll
