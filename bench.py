@@ -289,7 +289,7 @@ def main():
             if prec == args.precision:
                 continue
             model.precision = prec
-            n_m = min(10, K)
+            n_m = min(40, K)                          # long enough for the two frames in flight to reach their steady state
             cr.render_to_device(clip, range(3), out=out_u8[:3] if K >= 3 else None)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
