@@ -47,7 +47,8 @@ def install(hparams=None):
     _alias("modules.radnerfs.utils", get_rays=camera.get_rays, get_bg_coords=camera.get_bg_coords, convert_poses=camera.convert_poses,
            nerf_matrix_to_ngp=camera.nerf_matrix_to_ngp, get_audio_features=camera.get_audio_features, trunc_exp=camera.trunc_exp)
     _alias("modules.radnerfs.raymarching", **{k: getattr(raymarching, k) for k in
-                                               ("near_far_from_aabb", "morton3D", "morton3D_invert", "packbits", "march_rays", "composite_rays")})
+                                               ("near_far_from_aabb", "morton3D", "morton3D_invert", "packbits", "march_rays", "composite_rays",
+                                                "morton3D_dilation", "sph_from_ray", "march_rays_train", "composite_rays_train")})
     _alias("modules.radnerfs.encoders.encoding", get_encoder=encoders.get_encoder)
     _alias("modules.radnerfs.encoders.gridencoder", GridEncoder=encoders.GridEncoder)
     _alias("modules.radnerfs.encoders.shencoder", SHEncoder=encoders.SHEncoder)

@@ -84,3 +84,34 @@ def test_host_interface_matches_reference():
     bad = dict(hp, cond_type="nope")
     with pytest.raises(NotImplementedError):
         RADNeRF(bad)
+
+
+def test_compat_install_resolves_the_callers_imports():
+    """genefacepp_infer.py:39-43 and the training tasks import the renderer by its reference paths; compat.install() must make exactly those
+    imports work (in a child interpreter: the shim edits sys.modules)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import genefaceplusplus_amd.compat as compat
+names = compat.install({"smo_win_size": 5})
+from modules.radnerfs.radnerf import RADNeRF
+from modules.radnerfs.radnerf_sr import RADNeRFwithSR
+from modules.radnerfs.radnerf_torso import RADNeRFTorso
+from modules.radnerfs.radnerf_torso_sr import RADNeRFTorsowithSR
+from modules.radnerfs.utils import get_rays, get_bg_coords, convert_poses, nerf_matrix_to_ngp, get_audio_features
+from modules.radnerfs.renderer import NeRFRenderer
+from modules.radnerfs.cond_encoder import AudioNet, AudioAttNet, MLP
+from modules.radnerfs.encoders.encoding import get_encoder
+import modules.radnerfs.raymarching as rm
+for n in ("near_far_from_aabb", "march_rays", "composite_rays", "march_rays_train", "composite_rays_train", "packbits", "morton3D", "morton3D_dilation"):
+    assert callable(getattr(rm, n)), n
+assert issubclass(RADNeRFTorso, RADNeRF) and issubclass(RADNeRF, NeRFRenderer)
+import torch
+win = get_audio_features(torch.zeros(9, 1, 4), 2, 0)            # smo_win_size comes from the seeded runtime hparams
+assert win.shape == (5, 1, 4)
+print("ok", len(names))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
