@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY.  The reference's Python shims (modules/radnerfs/raymarching/raymarching.py,
 encoders/gridencoder/grid.py, encoders/shencoder/sphere_harmonics.py, encoders/freqencoder/freq.py) do
 ``import _raymarching_face as _backend`` etc.  ``install()`` registers modules of those names in ``sys.modules`` whose
-functions have the pybind signatures of raymarching.h:7-19 / gridencoder.h:12-15 / shencoder.h / freqencoder.h but run
+functions have the pybind signatures of raymarching.h:7-20 / gridencoder.h:12-15 / shencoder.h / freqencoder.h but run
 radnerf_oracle.c on CPU torch tensors (in place, like the CUDA originals).  tests/golden/make_golden.py uses this to
 execute the reference's own Python control flow without CUDA.
 """
@@ -71,14 +71,58 @@ def morton3D_invert(indices, N, coords):
     orc.lib().orc_morton3D_invert_batch(_ip(indices), _u32(N), _ip(coords))
 
 
+def morton3D_dilation(grid, C, H, grid_dilation):
+    orc.lib().orc_morton3D_dilation(_fp(grid), _u32(C), _u32(H), _fp(grid_dilation))
+
+
+def sph_from_ray(rays_o, rays_d, radius, N, coords):
+    orc.lib().orc_sph_from_ray(_fp(rays_o), _fp(rays_d), ctypes.c_float(radius), _u32(N), _fp(coords))
+
+
+# training side (raymarching.h:14-17)
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):
+    orc.lib().orc_march_rays_train(_fp(rays_o), _fp(rays_d), _up(grid), ctypes.c_float(bound), ctypes.c_float(dt_gamma), _u32(max_steps), _u32(N), _u32(C),
+                                   _u32(H), _u32(M), _fp(nears), _fp(fars), _fp(xyzs), _fp(dirs), _fp(deltas), _ip(rays), _ip(counter), _fp(noises))
+
+
+def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):
+    orc.lib().orc_march_rays_train_backward(_fp(grad_xyzs.contiguous()), _fp(grad_dirs.contiguous()), _ip(rays), _fp(deltas.contiguous()), _u32(N), _u32(M),
+                                            _fp(grad_rays_o), _fp(grad_rays_d))
+
+
+def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):
+    orc.lib().orc_composite_rays_train_forward(_fp(sigmas), _fp(rgbs), _fp(ambient), _fp(deltas.contiguous()), _ip(rays), _u32(M), _u32(N),
+                                               ctypes.c_float(T_thresh), _fp(weights_sum), _fp(ambient_sum), _fp(depth), _fp(image))
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image,
+                                  M, N, T_thresh, grad_sigmas, grad_rgbs, grad_ambient):
+    orc.lib().orc_composite_rays_train_backward(_fp(grad_weights_sum), _fp(grad_ambient_sum), _fp(grad_image), _fp(sigmas), _fp(rgbs), _fp(ambient),
+                                                _fp(deltas.contiguous()), _ip(rays), _fp(weights_sum), _fp(ambient_sum), _fp(image), _u32(M), _u32(N),
+                                                ctypes.c_float(T_thresh), _fp(grad_sigmas), _fp(grad_rgbs), _fp(grad_ambient))
+
+
 # ---- _gridencoder / _shencoder / _freqencoder ------------------------------------------------------------
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
-    assert dy_dx is None, "oracle restates the inference path only"
+    if dy_dx is not None:          # [B, L * D * C], the layout of gridencoder.cu:125,202 (B, L, D, C)
+        rc = orc.lib().orc_grid_encode_dydx(_fp(inputs), _fp(embeddings), _ip(offsets), _fp(dy_dx), _u32(B), _u32(D), _u32(C), _u32(L), ctypes.c_float(S),
+                                            _u32(H), _u32(gridtype), ctypes.c_int(int(align_corners)), _u32(interp))
+        if rc != 0:
+            raise RuntimeError("GridEncoding: unsupported D/C")
     rc = orc.lib().orc_grid_encode_forward(_fp(inputs), _fp(embeddings), _ip(offsets), _fp(outputs), _u32(B), _u32(D), _u32(C),
                                            _u32(L), ctypes.c_float(S), _u32(H), _u32(gridtype), ctypes.c_int(int(align_corners)),
                                            _u32(interp))
     if rc != 0:
         raise RuntimeError("GridEncoding: unsupported D/C")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
+    rc = orc.lib().orc_grid_encode_backward(_fp(grad), _fp(inputs), _ip(offsets), _fp(grad_embeddings), _u32(B), _u32(D), _u32(C), _u32(L), ctypes.c_float(S),
+                                            _u32(H), _u32(gridtype), ctypes.c_int(int(align_corners)), _u32(interp))
+    if rc != 0:
+        raise RuntimeError("GridEncoding: unsupported D/C")
+    if dy_dx is not None:
+        orc.lib().orc_grid_input_backward(_fp(grad), _fp(dy_dx), _fp(grad_inputs), _u32(B), _u32(D), _u32(C), _u32(L))
 
 
 def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
@@ -103,7 +147,10 @@ def install():
     """Register the four backend modules (idempotent)."""
     sys.modules["_raymarching_face"] = _module("_raymarching_face", near_far_from_aabb=near_far_from_aabb, march_rays=march_rays,
                                                composite_rays=composite_rays, packbits=packbits, morton3D=morton3D,
-                                               morton3D_invert=morton3D_invert)
-    sys.modules["_gridencoder"] = _module("_gridencoder", grid_encode_forward=grid_encode_forward)
+                                               morton3D_invert=morton3D_invert, morton3D_dilation=morton3D_dilation, sph_from_ray=sph_from_ray,
+                                               march_rays_train=march_rays_train, march_rays_train_backward=march_rays_train_backward,
+                                               composite_rays_train_forward=composite_rays_train_forward,
+                                               composite_rays_train_backward=composite_rays_train_backward)
+    sys.modules["_gridencoder"] = _module("_gridencoder", grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward)
     sys.modules["_shencoder"] = _module("_shencoder", sh_encode_forward=sh_encode_forward)
     sys.modules["_freqencoder"] = _module("_freqencoder", freq_encode_forward=freq_encode_forward)

@@ -192,3 +192,49 @@ def test_sh_and_freq_gradients_match_finite_differences(orc=None):
             s = 2 + 4 * k
             want += 2.0 ** k * (g[:, s:s + 2] * np.cos(2.0 ** k * x.astype(np.float64)) - g[:, s + 2:s + 4] * np.sin(2.0 ** k * x.astype(np.float64)))
         np.testing.assert_allclose(orc.freq_encode_backward(g, out, 2, deg), want, rtol=2e-4, atol=2e-3 * 2.0 ** deg / 1024 + 1e-4)
+
+
+def test_training_render_composition_matches_reference_python(orc=None):
+    """tests/golden/ref_python_train_golden.npz comes from the reference's own NeRFRenderer.render (training branch) and autograd shims run on
+    CPU over the oracle kernels (tests/golden/make_golden_train.py).  The oracle-side composition that the GPU tests compare the product with
+    must reproduce its forward results, and mark_untrained_grid's visibility rule its mask."""
+    import os
+    import oracle.oracle as orc
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.configs import may_hparams
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python_train_golden.npz"))
+    HW = 24
+    hp = may_hparams("may_head")
+    sd = syn.synthetic_state_dict(hp, "may_head")
+    pose = syn.synthetic_pose(0)[None]
+    r = orc.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+    o, d = r["rays_o"].reshape(-1, 3), r["rays_d"].reshape(-1, 3)
+    fi = syn.synthetic_frame_inputs(hp, 0)
+    nears, fars = orc.near_far_from_aabb(o, d, sd["aabb_train"], hp["min_near"])
+    xyzs, dirs, deltas, rays, counter = orc.march_rays_train(o, d, hp["bound"], sd["density_bitfield"], 1, hp["grid_size"], nears, fars,
+                                                             dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"])
+    M = int(counter[0])
+    assert int(g["fwd.step_counter"][0, 0]) == M and int(g["fwd.step_counter"][0, 1]) == HW * HW and int(g["fwd.local_step"][0]) == 1
+    cond_feat = orc.cal_cond_feat(fi["cond"], sd, hp, eye_area_percent=fi["eye_area_percent"])
+    sig, rgb, amb = orc.head_forward(xyzs[:M], dirs[:M], cond_feat, sd["individual_embeddings"][0], sd, hp)
+    ws, amb_sum, depth, image = orc.composite_rays_train_forward(sig, rgb, np.abs(amb).sum(-1), deltas[:M], rays)
+    img, dep = orc._finish(image, ws, depth, nears, fars, np.full((HW * HW, 3), 0.5, f32), (1, HW * HW))
+    np.testing.assert_allclose(ws, g["fwd.weights_sum"], atol=2e-5)
+    np.testing.assert_allclose(amb_sum, g["fwd.ambient"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(img, g["fwd.rgb_map"], atol=2e-5)
+    ok = np.isfinite(g["fwd.depth_map"])
+    np.testing.assert_allclose(dep[ok], g["fwd.depth_map"][ok], atol=1e-4)
+    # mark_untrained_grid: a cell is trained iff some camera sees it (renderer.py:171-190)
+    G = hp["grid_size"]
+    fx, fy, cx, cy = syn.intrinsics_for(HW, HW)
+    untrained = np.unpackbits(g["mark.untrained"])[:G ** 3].astype(bool)
+    rng = np.random.default_rng(1)
+    pick = rng.integers(0, G, (3000, 3))
+    code = np.array([orc.morton3D(*c) for c in pick], np.int64)
+    half = 1.0 / G
+    world = (2 * pick.astype(f32) / (G - 1) - 1) * f32(1 - half)
+    seen = np.zeros(len(pick), bool)
+    for P in g["mark.poses"]:
+        cam = (world - P[:3, 3]) @ P[:3, :3]
+        seen |= (cam[:, 2] > 0) & (np.abs(cam[:, 0]) < cx / fx * cam[:, 2] + half * 2) & (np.abs(cam[:, 1]) < cy / fy * cam[:, 2] + half * 2)
+    np.testing.assert_array_equal(untrained[code], ~seen)

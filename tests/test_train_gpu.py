@@ -443,3 +443,50 @@ def test_march_rays_train_budget_overflow(dev, oracle_mod, scene):
             np.testing.assert_array_equal(X[off:off + cnt], full[0][off_r:off_r + cnt])
     assert 0 < n_fit < o.shape[0]
     assert float(np.abs(X[~written]).sum()) == 0.0 and float(np.abs(T[~written]).sum()) == 0.0     # nothing else was touched
+
+
+def test_training_step_matches_reference_python_golden(dev):
+    """One training render + backward of the product against tests/golden/ref_python_train_golden.npz: the reference's own NeRFRenderer.render
+    (training branch), RADNeRF.forward and autograd shims executed on CPU over the oracle kernels (tests/golden/make_golden_train.py).  Same
+    model, rays, conditioning, target and loss; results and parameter gradients must agree (fp32 summation order and the GPU's atomic
+    accumulation differ, hence norm-relative bounds)."""
+    import os
+    from helpers import frame_case, build_model
+    from genefaceplusplus_amd.radnerfs import camera
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python_train_golden.npz"))
+    HW = 24
+    case = frame_case("may_head", HW)
+    model = build_model(case, dev, "fused")
+    model.train()
+    pose = torch.from_numpy(case["pose"]).to(dev)
+    r = camera.get_rays(pose, case["intr"], HW, HW)
+    res = model.render(r["rays_o"], r["rays_d"], torch.from_numpy(case["cond"]).to(dev), camera.get_bg_coords(HW, HW, dev), camera.convert_poses(pose),
+                       index=0, dt_gamma=case["hp"]["dt_gamma"], bg_color=torch.full((1, HW * HW, 3), 0.5, device=dev), perturb=False,
+                       force_all_rays=True, max_steps=case["hp"]["max_steps"], eye_area_percent=torch.from_numpy(case["eye_area_percent"]).to(dev))
+    assert int(model.step_counter[0, 0]) == int(g["fwd.step_counter"][0, 0]) and model.local_step == 1
+    np.testing.assert_allclose(res["weights_sum"].detach().cpu().numpy(), g["fwd.weights_sum"], atol=2e-4)
+    np.testing.assert_allclose(res["ambient"].detach().cpu().numpy(), g["fwd.ambient"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(res["rgb_map"].detach().cpu().numpy(), g["fwd.rgb_map"], atol=2e-4)
+    target = torch.from_numpy(g["target"]).to(dev)
+    loss = ((res["rgb_map"] - target) ** 2).mean() + 1e-3 * res["ambient"].mean() + 1e-2 * res["weights_sum"].mean()
+    assert abs(float(loss.detach()) - float(g["loss"][0])) <= 2e-5
+    loss.backward()
+    named = dict(model.named_parameters())
+
+    def rel(a, b):
+        return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+    for key in g.files:
+        if key.startswith("grad."):
+            name = key[5:]
+            got = named[name].grad.detach().cpu().numpy()
+            want = g[key]
+            if name == "individual_embeddings":
+                got = got[:4]
+            assert rel(got, want) <= 2e-3, (name, rel(got, want))
+        elif key.startswith("gradsum."):
+            name = key[8:]
+            got = named[name].grad.detach().cpu().numpy()
+            assert abs(float(np.abs(got).astype(np.float64).sum()) - g[key][1]) <= 2e-3 * g[key][1], name
+            rows = g["gradrows." + name]
+            assert rel(got[rows], g["gradvals." + name]) <= 2e-3, (name, rel(got[rows], g["gradvals." + name]))
