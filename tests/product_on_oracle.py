@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Test helper (run in a child interpreter by tests/test_oracle_train_cpu.py; not shipped): run the PRODUCT's Python training path on CPU tensors with its C-ABI calls redirected to the CPU oracle,
+and compare one training step with tests/golden/ref_python_train_golden.npz.  Separates wiring differences (visible here) from kernel /
+numerics differences (only visible on the GPU).  Usage: python tests/product_on_oracle.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import oracle.oracle as orc  # noqa: E402
+
+F, I, U = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8)
+fp = lambda p: ctypes.cast(p, F)
+ip = lambda p: ctypes.cast(p, I)
+up = lambda p: ctypes.cast(p, U)
+u32 = lambda v: ctypes.c_uint32(int(v))
+cf = lambda v: ctypes.c_float(float(v))
+
+
+def dispatch(name, *a):
+    L = orc.lib()
+    if name == "gfpp_near_far_from_aabb":
+        L.orc_near_far_from_aabb(fp(a[0]), fp(a[1]), fp(a[2]), u32(a[3]), cf(a[4]), fp(a[5]), fp(a[6]))
+    elif name == "gfpp_march_rays_train":
+        L.orc_march_rays_train(fp(a[0]), fp(a[1]), up(a[2]), cf(a[3]), cf(a[4]), u32(a[5]), u32(a[6]), u32(a[7]), u32(a[8]), u32(a[9]), fp(a[10]), fp(a[11]),
+                               fp(a[12]), fp(a[13]), fp(a[14]), ip(a[15]), ip(a[16]), fp(a[17]))
+    elif name == "gfpp_composite_rays_train_forward":
+        L.orc_composite_rays_train_forward(fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), ip(a[4]), u32(a[5]), u32(a[6]), cf(a[7]), fp(a[8]), fp(a[9]), fp(a[10]), fp(a[11]))
+    elif name == "gfpp_composite_rays_train_backward":
+        L.orc_composite_rays_train_backward(fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]), fp(a[5]), fp(a[6]), ip(a[7]), fp(a[8]), fp(a[9]), fp(a[10]),
+                                            u32(a[11]), u32(a[12]), cf(a[13]), fp(a[14]), fp(a[15]), fp(a[16]))
+    elif name == "gfpp_grid_encode_forward":
+        inputs, emb, offsets, out, B, D, C, Lv, S, H, dy_dx, gridtype, ac, interp, dtype = a[:15]
+        assert dtype == 0
+        if dy_dx:
+            assert L.orc_grid_encode_dydx(fp(inputs), fp(emb), ip(offsets), fp(dy_dx), u32(B), u32(D), u32(C), u32(Lv), cf(S), u32(H), u32(gridtype),
+                                          ctypes.c_int(ac), u32(interp)) == 0
+        assert L.orc_grid_encode_forward(fp(inputs), fp(emb), ip(offsets), fp(out), u32(B), u32(D), u32(C), u32(Lv), cf(S), u32(H), u32(gridtype),
+                                         ctypes.c_int(ac), u32(interp)) == 0
+    elif name == "gfpp_grid_encode_backward":
+        grad, inputs, emb, offsets, grad_emb, B, D, C, Lv, S, H, dy_dx, grad_inputs, gridtype, ac, interp = a[:16]
+        assert L.orc_grid_encode_backward(fp(grad), fp(inputs), ip(offsets), fp(grad_emb), u32(B), u32(D), u32(C), u32(Lv), cf(S), u32(H), u32(gridtype),
+                                          ctypes.c_int(ac), u32(interp)) == 0
+        if dy_dx:
+            L.orc_grid_input_backward(fp(grad), fp(dy_dx), fp(grad_inputs), u32(B), u32(D), u32(C), u32(Lv))
+    elif name == "gfpp_sh_encode_forward":
+        assert not a[5]
+        assert L.orc_sh_encode_forward(fp(a[0]), fp(a[1]), u32(a[2]), u32(a[4])) == 0
+    elif name == "gfpp_get_rays":
+        raise RuntimeError("use the oracle's get_rays for the inputs")
+    else:
+        raise NotImplementedError(name)
+    return 0
+
+
+def main():
+    from genefaceplusplus_amd import synthetic as syn, radnerfs
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import raymarching, encoders, camera
+    for mod in (raymarching, encoders, camera):
+        mod.call = dispatch
+    raymarching._stream = encoders._stream = lambda: None
+    torch.Tensor.is_cuda = property(lambda self: True)          # the product refuses CPU tensors; this harness is the one exception
+    g = np.load(os.path.join(HERE, "golden", "ref_python_train_golden.npz"))
+    HW = 24
+    hp = may_hparams("may_head")
+    sd = syn.synthetic_state_dict(hp, "may_head")
+    model = radnerfs.RADNeRF(hp)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model.train()
+    pose = syn.synthetic_pose(0)[None]
+    r = orc.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+    fi = syn.synthetic_frame_inputs(hp, 0)
+    res = model.render(torch.from_numpy(r["rays_o"]), torch.from_numpy(r["rays_d"]), torch.from_numpy(fi["cond"]),
+                       torch.from_numpy(orc.get_bg_coords(HW, HW)), torch.from_numpy(orc.convert_poses(pose)), index=0, dt_gamma=hp["dt_gamma"],
+                       bg_color=torch.full((1, HW * HW, 3), 0.5), perturb=False, force_all_rays=True, max_steps=hp["max_steps"],
+                       eye_area_percent=torch.from_numpy(fi["eye_area_percent"]))
+    worst = 0.0
+    for k in ("weights_sum", "ambient", "rgb_map"):
+        err = float(np.abs(res[k].detach().numpy() - g["fwd." + k]).max())
+        worst = max(worst, err)
+        print("fwd", k, err)
+    target = torch.from_numpy(g["target"])
+    loss = ((res["rgb_map"] - target) ** 2).mean() + 1e-3 * res["ambient"].mean() + 1e-2 * res["weights_sum"].mean()
+    print("loss", float(loss.detach()), float(g["loss"][0]))
+    loss.backward()
+    named = dict(model.named_parameters())
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+    for key in g.files:
+        if key.startswith("grad."):
+            name = key[5:]
+            got = named[name].grad.detach().numpy()
+            got = got[:4] if name == "individual_embeddings" else got
+            worst = max(worst, rel(got, g[key]))
+            print(f"{name:45s} rel err {rel(got, g[key]):.3e}   |ref| {np.linalg.norm(g[key]):.3e}")
+        elif key.startswith("gradsum."):
+            name = key[8:]
+            got = named[name].grad.detach().numpy()
+            worst = max(worst, rel(got[g['gradrows.' + name]], g['gradvals.' + name]))
+            print(f"{name:45s} abs-sum {np.abs(got).astype(np.float64).sum():.6e} vs {g[key][1]:.6e}   rows rel err {rel(got[g['gradrows.' + name]], g['gradvals.' + name]):.3e}")
+    print("worst", worst)
+    return worst
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() <= 1e-6 else 1)

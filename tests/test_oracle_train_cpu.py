@@ -238,3 +238,17 @@ def test_training_render_composition_matches_reference_python(orc=None):
         cam = (world - P[:3, 3]) @ P[:3, :3]
         seen |= (cam[:, 2] > 0) & (np.abs(cam[:, 0]) < cx / fx * cam[:, 2] + half * 2) & (np.abs(cam[:, 1]) < cy / fy * cam[:, 2] + half * 2)
     np.testing.assert_array_equal(untrained[code], ~seen)
+
+
+def test_product_training_wiring_equals_reference_python():
+    """The product's own training-mode Python (NeRFRenderer.render, RADNeRF.forward, the autograd wrappers of raymarching.py / encoders.py) run
+    on CPU tensors with its C-ABI calls redirected to the oracle reproduces the reference's golden step -- forward results and every recorded
+    gradient -- to the last bit: the two Python layers are wired identically around the kernels.  (Child interpreter: the helper patches
+    Tensor.is_cuda, the one place where the product's refusal of CPU tensors is overridden.)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "product_on_oracle.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "worst 0.0" in out.stdout, out.stdout[-2000:]
