@@ -112,3 +112,17 @@ def test_render_matches_reference_python(golden, oracle_mod, variant, HW):
         assert np.abs(ta[sel] - golden[f"{variant}.render.torso_alpha"]).max() < 2e-4
         np.testing.assert_allclose(ta.astype(np.float64).sum(), golden[f"{variant}.render.torso_alpha_sum"][0], rtol=2e-5)
         np.testing.assert_allclose(np.abs(res["deform"]).astype(np.float64).sum(), golden[f"{variant}.render.deform_abs_sum"][0], rtol=2e-5)
+
+
+def test_product_inference_wiring_equals_reference_python():
+    """The product's reference-shaped executor (model.executor = 'staged': near/far, march, RADNeRF.forward, composite, loop control, torso pass,
+    compositing) run on CPU tensors with its C-ABI calls redirected to the oracle reproduces the reference's own renders of
+    ref_python_golden.npz -- head, torso, torso-SR -- exactly: both Python layers are wired identically around the kernels.  What then
+    remains between the product and the reference is the kernels, which the -m gpu tests compare with the oracle one by one, and the fused
+    executor, which they compare with the oracle frame by frame.  (Child interpreter: the helper overrides Tensor.is_cuda.)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "product_on_oracle.py"), "--infer"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
