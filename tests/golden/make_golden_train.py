@@ -79,6 +79,24 @@ def main():
     model.mark_untrained_grid(poses, intr)
     out["mark.poses"] = poses
     out["mark.untrained"] = np.packbits(model.density_grid.numpy() < 0)
+    # update_extra_state: occupancy-grid refresh from the density field (renderer.py:201-284).  It draws random.randint once and
+    # torch.rand_like once per cascade; with both generators seeded the whole refresh is reproducible on CPU.
+    import random
+    model.load_state_dict(to_t(sd), strict=True)               # back to the initial grid / bitfield
+    model.mean_density = model.iter_density = 0
+    rng = np.random.default_rng(5)
+    conds = np.clip(rng.standard_normal((40, 1, 204)), -1.5, 1.5).astype(np.float32)
+    model.conds = torch.from_numpy(conds)
+    out["upd.conds"] = conds
+    random.seed(3)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        model.update_extra_state(decay=0.95)
+    grid = model.density_grid.numpy()
+    out["upd.grid_sample"] = grid[0, ::997].copy()
+    out["upd.grid_sum"] = np.array([grid.astype(np.float64).sum(), float((grid > 0).sum())])
+    out["upd.bitfield"] = model.density_bitfield.numpy().copy()
+    out["upd.scalars"] = np.array([model.mean_density, model.iter_density, model.mean_count, model.local_step], np.float64)
     np.savez_compressed(os.path.join(HERE, "ref_python_train_golden.npz"), **out)
     print({k: (v.shape, float(np.abs(v).sum())) for k, v in out.items() if k.startswith(("fwd", "loss"))})
 

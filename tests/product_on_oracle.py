@@ -51,6 +51,12 @@ def dispatch(name, *a):
     elif name == "gfpp_sh_encode_forward":
         assert not a[5]
         assert L.orc_sh_encode_forward(fp(a[0]), fp(a[1]), u32(a[2]), u32(a[4])) == 0
+    elif name == "gfpp_morton3D":
+        L.orc_morton3D_batch(ip(a[0]), u32(a[1]), ip(a[2]))
+    elif name == "gfpp_morton3D_dilation":
+        L.orc_morton3D_dilation(fp(a[0]), u32(a[1]), u32(a[2]), fp(a[3]))
+    elif name == "gfpp_packbits":
+        L.orc_packbits(fp(a[0]), u32(a[1]), cf(a[2]), up(a[3]))
     elif name == "gfpp_march_rays":
         L.orc_march_rays(u32(a[0]), u32(a[1]), ip(a[2]), fp(a[3]), fp(a[4]), fp(a[5]), cf(a[6]), cf(a[7]), u32(a[8]), u32(a[9]), u32(a[10]), up(a[11]),
                          fp(a[12]), fp(a[13]), fp(a[14]), fp(a[15]), fp(a[16]), fp(a[17]))
@@ -162,6 +168,27 @@ def main():
             got = named[name].grad.detach().numpy()
             worst = max(worst, rel(got[g['gradrows.' + name]], g['gradvals.' + name]))
             print(f"{name:45s} abs-sum {np.abs(got).astype(np.float64).sum():.6e} vs {g[key][1]:.6e}   rows rel err {rel(got[g['gradrows.' + name]], g['gradvals.' + name]):.3e}")
+    # occupancy-grid upkeep, same call sequence as tests/golden/make_golden_train.py
+    import random
+    model.density_grid.zero_()
+    model.mark_untrained_grid(g["mark.poses"], syn.intrinsics_for(HW, HW))
+    same = np.array_equal(np.packbits(model.density_grid.numpy() < 0), g["mark.untrained"])
+    print("mark_untrained_grid identical", same)
+    worst = max(worst, 0.0 if same else 1.0)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model.mean_density = model.iter_density = 0
+    model.conds = torch.from_numpy(g["upd.conds"])
+    random.seed(3)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        model.update_extra_state(decay=0.95)
+    grid = model.density_grid.numpy()
+    errs = {"grid_sample": float(np.abs(grid[0, ::997] - g["upd.grid_sample"]).max()),
+            "grid_sum": abs(float(grid.astype(np.float64).sum()) - g["upd.grid_sum"][0]), "occupied": abs(float((grid > 0).sum()) - g["upd.grid_sum"][1]),
+            "bitfield": float((model.density_bitfield.numpy() != g["upd.bitfield"]).sum()),
+            "scalars": float(np.abs(np.array([model.mean_density, model.iter_density, model.mean_count, model.local_step], np.float64) - g["upd.scalars"]).max())}
+    print("update_extra_state", errs)
+    worst = max(worst, *errs.values())
     print("worst", worst)
     return worst
 
