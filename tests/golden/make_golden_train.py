@@ -97,6 +97,40 @@ def main():
     out["upd.grid_sum"] = np.array([grid.astype(np.float64).sum(), float((grid > 0).sum())])
     out["upd.bitfield"] = model.density_bitfield.numpy().copy()
     out["upd.scalars"] = np.array([model.mean_density, model.iter_density, model.mean_count, model.local_step], np.float64)
+    # ------------------------------------------------------------------ torso model: training step (head frozen) + 2-D grid refresh
+    from modules.radnerfs.radnerf_torso import RADNeRFTorso
+    ref_hp_t = set_hparams(config=VARIANT_YAML["may_torso"], exp_name="", print_hparams=False, global_hparams=True)
+    hp_t = may_hparams("may_torso")
+    sd_t = syn.synthetic_state_dict(hp_t, "may_torso")
+    torso = RADNeRFTorso(ref_hp_t)
+    torso.load_state_dict(to_t(sd_t), strict=True)
+    torso.train()
+    fi_t = syn.synthetic_frame_inputs(hp_t, 0)
+    random.seed(11)
+    res = torso.render(rays["rays_o"], rays["rays_d"], torch.from_numpy(fi_t["cond"]), ref_utils.get_bg_coords(HW, HW, "cpu"), ref_utils.convert_poses(pose),
+                       index=0, dt_gamma=hp_t["dt_gamma"], bg_color=bg, perturb=False, force_all_rays=True, max_steps=hp_t["max_steps"])
+    for k in ("weights_sum", "ambient", "rgb_map", "depth_map", "torso_alpha_map", "torso_rgb_map"):
+        out["torso.fwd." + k] = res[k].detach().numpy().copy()
+    out["torso.fwd.deform"] = res["deform"].detach().numpy().copy()
+    loss = ((res["rgb_map"] - target) ** 2).mean() + 1e-2 * res["torso_alpha_map"].mean() + 1e-3 * res["deform"].abs().mean()
+    out["torso.loss"] = np.array([float(loss.detach())])
+    loss.backward()
+    named = dict(torso.named_parameters())
+    for name in ("torso_deform_net.net.0.weight", "torso_deform_net.net.2.weight", "torso_canonicial_net.net.0.weight", "torso_canonicial_net.net.2.weight"):
+        out["torso.grad." + name] = named[name].grad.numpy().copy()
+    gte = named["torso_embedder.embeddings"].grad.numpy()
+    out["torso.gradsum.torso_embedder.embeddings"] = np.array([gte.astype(np.float64).sum(), np.abs(gte).astype(np.float64).sum()])
+    out["torso.grad.torso_individual_codes"] = named["torso_individual_codes"].grad[:4].numpy().copy()
+    out["torso.head_has_grad"] = np.array([int(named["sigma_net.net.0.weight"].grad is not None)])
+    poses_t = np.stack([syn.synthetic_pose(i) for i in range(6)]).astype(np.float32)
+    torso.poses = torch.from_numpy(poses_t)
+    out["torso.upd.poses"] = poses_t
+    random.seed(4)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        torso.update_extra_state(decay=0.95)
+    out["torso.upd.grid"] = torso.density_grid_torso.numpy().copy()
+    out["torso.upd.mean"] = np.array([torso.mean_density_torso], np.float64)
     np.savez_compressed(os.path.join(HERE, "ref_python_train_golden.npz"), **out)
     print({k: (v.shape, float(np.abs(v).sum())) for k, v in out.items() if k.startswith(("fwd", "loss"))})
 

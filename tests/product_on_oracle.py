@@ -189,6 +189,45 @@ def main():
             "scalars": float(np.abs(np.array([model.mean_density, model.iter_density, model.mean_count, model.local_step], np.float64) - g["upd.scalars"]).max())}
     print("update_extra_state", errs)
     worst = max(worst, *errs.values())
+    # ---- torso model: one training step with the head frozen, then the 2-D grid refresh (radnerf_torso.py:86-244)
+    hp_t = may_hparams("may_torso")
+    sd_t = syn.synthetic_state_dict(hp_t, "may_torso")
+    torso = radnerfs.RADNeRFTorso(hp_t)
+    torso.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_t.items()}, strict=True)
+    torso.train()
+    torso.return_deform = True
+    fi_t = syn.synthetic_frame_inputs(hp_t, 0)
+    random.seed(11)
+    res = torso.render(torch.from_numpy(r["rays_o"]), torch.from_numpy(r["rays_d"]), torch.from_numpy(fi_t["cond"]), torch.from_numpy(orc.get_bg_coords(HW, HW)),
+                       torch.from_numpy(orc.convert_poses(pose)), index=0, dt_gamma=hp_t["dt_gamma"], bg_color=torch.full((1, HW * HW, 3), 0.5), perturb=False,
+                       force_all_rays=True, max_steps=hp_t["max_steps"])
+    errs = {}
+    for k in ("weights_sum", "ambient", "rgb_map", "depth_map", "torso_alpha_map", "torso_rgb_map", "deform"):
+        a, b = res[k].detach().numpy(), g["torso.fwd." + k]
+        ok = np.isfinite(b)
+        errs[k] = float(np.abs(a.reshape(b.shape)[ok] - b[ok]).max())
+    loss = ((res["rgb_map"] - target) ** 2).mean() + 1e-2 * res["torso_alpha_map"].mean() + 1e-3 * res["deform"].abs().mean()
+    errs["loss"] = abs(float(loss.detach()) - float(g["torso.loss"][0]))
+    loss.backward()
+    named = dict(torso.named_parameters())
+    for key in g.files:
+        if key.startswith("torso.grad."):
+            name = key[len("torso.grad."):]
+            got = named[name].grad.detach().numpy()
+            got = got[:4] if name == "torso_individual_codes" else got
+            errs["grad " + name] = rel(got, g[key])
+    gte = named["torso_embedder.embeddings"].grad.numpy()
+    errs["grad torso_embedder abs-sum"] = abs(float(np.abs(gte).astype(np.float64).sum()) - g["torso.gradsum.torso_embedder.embeddings"][1])
+    errs["head frozen"] = float(int(named["sigma_net.net.0.weight"].grad is not None) != int(g["torso.head_has_grad"][0]))
+    torso.poses = torch.from_numpy(g["torso.upd.poses"])
+    random.seed(4)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        torso.update_extra_state(decay=0.95)
+    errs["torso grid"] = float(np.abs(torso.density_grid_torso.numpy() - g["torso.upd.grid"]).max())
+    errs["torso mean density"] = abs(torso.mean_density_torso - float(g["torso.upd.mean"][0]))
+    print("torso", errs)
+    worst = max(worst, *errs.values())
     print("worst", worst)
     return worst
 
