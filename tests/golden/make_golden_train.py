@@ -131,6 +131,16 @@ def main():
         torso.update_extra_state(decay=0.95)
     out["torso.upd.grid"] = torso.density_grid_torso.numpy().copy()
     out["torso.upd.mean"] = np.array([torso.mean_density_torso], np.float64)
+    # ------------------------------------------------------------------ training-time ray sampling (utils.py:283-364 with N > 0 / patch / rect)
+    H2 = W2 = 40
+    intr2 = syn.intrinsics_for(H2, W2)
+    for tag, kw in (("rand", dict(N=300)), ("patch", dict(N=4 * 64, patch_size=8)), ("rect", dict(rect=(5, 9, 10, 30))), ("clip", dict(N=10 ** 9))):
+        torch.manual_seed(21)
+        rr = ref_utils.get_rays(pose, intr2, H2, W2, **kw)
+        out[f"rays.{tag}.inds"] = rr["inds"].numpy().astype(np.int64)
+        out[f"rays.{tag}.rays_d"] = rr["rays_d"].numpy().copy()
+        out[f"rays.{tag}.rays_o"] = rr["rays_o"].numpy().copy()
+        out[f"rays.{tag}.ij"] = np.stack([rr["i"].numpy(), rr["j"].numpy()])
     np.savez_compressed(os.path.join(HERE, "ref_python_train_golden.npz"), **out)
     print({k: (v.shape, float(np.abs(v).sum())) for k, v in out.items() if k.startswith(("fwd", "loss"))})
 

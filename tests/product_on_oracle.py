@@ -64,8 +64,19 @@ def dispatch(name, *a):
         L.orc_composite_rays(u32(a[0]), u32(a[1]), cf(a[2]), ip(a[3]), fp(a[4]), fp(a[5]), fp(a[6]), fp(a[7]), fp(a[8]), fp(a[9]), fp(a[10]))
     elif name == "gfpp_freq_encode_forward":
         L.orc_freq_encode_forward(fp(a[0]), u32(a[1]), u32(a[2]), u32(a[3]), u32(a[4]), fp(a[5]))
-    elif name == "gfpp_get_rays":
-        raise RuntimeError("use the oracle's get_rays for the inputs")
+    elif name in ("gfpp_get_rays", "gfpp_get_rays_at"):
+        # the oracle restates ray generation in numpy (oracle.get_rays, utils.py:352-363); pick the listed pixels
+        pose = np.ctypeslib.as_array(fp(a[0]), shape=(16,)).reshape(4, 4).copy()
+        H, W = int(a[5]), int(a[6])
+        full = orc.get_rays(pose[None], (a[1], a[2], a[3], a[4]), H, W)
+        if name == "gfpp_get_rays":
+            sel, ro_p, rd_p = np.arange(H * W), a[7], a[8]
+        else:
+            n = int(a[8])
+            sel = np.ctypeslib.as_array(ctypes.cast(a[7], ctypes.POINTER(ctypes.c_int64)), shape=(n,)).copy()
+            ro_p, rd_p = a[9], a[10]
+        np.ctypeslib.as_array(fp(ro_p), shape=(len(sel), 3))[:] = full["rays_o"][0][sel]
+        np.ctypeslib.as_array(fp(rd_p), shape=(len(sel), 3))[:] = full["rays_d"][0][sel]
     else:
         raise NotImplementedError(name)
     return 0
@@ -76,6 +87,8 @@ def patch():
     for mod in (raymarching, encoders, camera):
         mod.call = dispatch
     raymarching._stream = encoders._stream = lambda: None
+    import types
+    torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=None)
     torch.Tensor.is_cuda = property(lambda self: True)          # the product refuses CPU tensors; this harness is the one exception
 
 
@@ -130,6 +143,7 @@ def infer():
 def main():
     from genefaceplusplus_amd import synthetic as syn, radnerfs
     from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import camera
     patch()
     g = np.load(os.path.join(HERE, "golden", "ref_python_train_golden.npz"))
     HW = 24
@@ -228,6 +242,19 @@ def main():
     errs["torso mean density"] = abs(torso.mean_density_torso - float(g["torso.upd.mean"][0]))
     print("torso", errs)
     worst = max(worst, *errs.values())
+    # ---- training-time ray sampling: same torch.randint call sequence as the reference, so a seeded generator gives the same pixels
+    H2 = W2 = 40
+    pose_t = torch.from_numpy(pose)
+    errs = {}
+    for tag, kw in (("rand", dict(N=300)), ("patch", dict(N=4 * 64, patch_size=8)), ("rect", dict(rect=(5, 9, 10, 30))), ("clip", dict(N=10 ** 9))):
+        torch.manual_seed(21)
+        rr = camera.get_rays(pose_t, syn.intrinsics_for(H2, W2), H2, W2, **kw)
+        errs[tag + " inds"] = float((rr["inds"].numpy().astype(np.int64) != g[f"rays.{tag}.inds"]).sum()) if rr["inds"].shape == g[f"rays.{tag}.inds"].shape else 1.0
+        errs[tag + " rays_d"] = float(np.abs(rr["rays_d"].numpy() - g[f"rays.{tag}.rays_d"]).max())
+        errs[tag + " rays_o"] = float(np.abs(rr["rays_o"].numpy() - g[f"rays.{tag}.rays_o"]).max())
+        errs[tag + " ij"] = float(np.abs(np.stack([rr["i"].numpy(), rr["j"].numpy()]) - g[f"rays.{tag}.ij"]).max())
+    print("get_rays", errs)
+    worst = max(worst, *[0.0 if v <= 3e-7 else v for v in errs.values()])        # directions: numpy vs torch division order, 1-2 ulp
     print("worst", worst)
     return worst
 
