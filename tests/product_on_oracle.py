@@ -115,6 +115,19 @@ def infer():
             model.executor = "staged"
             model.return_deform = True
             fi = syn.synthetic_frame_inputs(hp, 0)
+            # conditioning nets (plain torch in both code bases) and the per-sample API
+            cf = model.cal_cond_feat(torch.from_numpy(fi["cond"]), eye_area_percent=torch.from_numpy(fi["eye_area_percent"]))
+            worst = max(worst, float(np.abs(cf.numpy() - g[f"{variant}.cond_feat"]).max()))
+            if variant == "may_head":
+                P, Dn = torch.from_numpy(g["fwd.position"]), torch.from_numpy(g["fwd.direction"])
+                sigma, color, amb = model(P, Dn, cf, model.individual_embeddings[0])
+                dens = model.density(P, cf)
+                api = {"sigma": float(np.abs(sigma.numpy() - g["fwd.sigma"]).max()), "color": float(np.abs(color.numpy() - g["fwd.color"]).max()),
+                       "ambient": float(np.abs(amb.numpy() - g["fwd.ambient"]).max()),
+                       "density": float(np.abs(dens["sigma"].numpy() - g["fwd.density_sigma"]).max()),
+                       "geo_feat": float(np.abs(dens["geo_feat"].numpy().sum(axis=1) - g["fwd.geo_feat_sum"]).max())}
+                print("forward()/density()", api)
+                worst = max(worst, *api.values())
             HW = 256 if variant == "may_torso_sr" else 64
             pose = syn.synthetic_pose(0)[None]
             r = orc.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
