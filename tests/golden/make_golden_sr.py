@@ -61,6 +61,31 @@ def main():
                 out[f"{name}.{mode}.sum"] = y.astype(np.float64).sum(axis=(0, 2, 3))
                 out[f"{name}.{mode}.abs_sum"] = np.abs(y).astype(np.float64).sum(axis=(0, 2, 3))
                 print(name, mode, "mean", y.mean(axis=(0, 2, 3)), "range", y.min(), y.max())
+    # one TRAINING step of the reference module (noise_mode 'random' from a seeded generator: four randn draws, one per layer, in
+    # execution order): output, and gradients of a photometric loss w.r.t. the input and a handful of parameters
+    model.train()
+    x = torch.from_numpy(sr_inputs()["smooth"]).clone().requires_grad_(True)
+    torch.manual_seed(13)
+    # Superresolution.forward (radnerf_sr.py:30-43) spelled out with two separate clones for `x` and `rgb`: on CPU the blocks run in fp32, so
+    # `x.to(dtype)` is the input itself and the block's in-place `img.add_(y)` would overwrite a tensor autograd still needs (on the GPU the
+    # fp16 cast makes the copy).  The blocks themselves are the reference's, unmodified.
+    ws = torch.ones([1, 14, model.w_dim])[:, -1:, :].repeat(1, 3, 1)
+    feat, img = model.block0(x.clone(), x.clone(), ws, noise_mode="random")
+    feat, y = model.block1(feat, img, ws, noise_mode="random")
+    torch.manual_seed(14)
+    target = torch.rand(1, 3, 512, 512)
+    loss = ((y - target) ** 2).mean()
+    loss.backward()
+    yn = y.detach().numpy()
+    out["train.crops"] = np.stack([yn[0, :, r:r + 32, c:c + 32] for r, c in CROPS])
+    out["train.sum"] = yn.astype(np.float64).sum(axis=(0, 2, 3))
+    out["train.loss"] = np.array([float(loss.detach())])
+    out["train.grad_input_crop"] = x.grad.numpy()[0, :, 100:132, 60:92].copy()
+    out["train.grad_input_abs_sum"] = np.array([np.abs(x.grad.numpy()).astype(np.float64).sum()])
+    named = dict(model.named_parameters())
+    for name in ("block0.conv0.weight", "block0.conv1.affine.bias", "block0.conv1.noise_strength", "block0.torgb.weight", "block1.conv0.weight",
+                 "block1.conv0.affine.weight", "block1.conv1.bias", "block1.torgb.bias"):
+        out["train.grad." + name] = named[name].grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, "sr_golden.npz"), **out)
     print("wrote", len(out), "arrays")
 

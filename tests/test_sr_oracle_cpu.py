@@ -115,3 +115,35 @@ def test_training_path_of_the_sr_stage_matches_oracle_and_differentiates():
         with torch.no_grad():
             t.add_(eps * d); up = float(loss_fn()); t.sub_(2 * eps * d); down = float(loss_fn()); t.add_(eps * d)
         assert abs((up - down) / (2 * eps) - float((g * d).sum())) <= 1e-5 * max(1.0, float(g.norm()))
+
+
+def test_training_path_of_the_sr_stage_matches_the_reference_module(golden):
+    """One training step of the reference's own Superresolution blocks (tests/golden/make_golden_sr.py: noise_mode 'random' from a seeded
+    generator, photometric loss, backward) against the product's training path: output, input gradient, parameter gradients.  The noise fields
+    are drawn with the same four torch.randn calls, so the seeded generator yields the same noise."""
+    import torch
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    sr = Superresolution(channels=3)
+    sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    sr.train()
+    x = torch.from_numpy(_inputs()["smooth"]).clone().requires_grad_(True)
+    torch.manual_seed(13)
+    y = sr._forward_autograd(x, "random")
+    torch.manual_seed(14)
+    target = torch.rand(1, 3, 512, 512)
+    loss = ((y - target) ** 2).mean()
+    loss.backward()
+    yn = y.detach().numpy()
+    crops = np.stack([yn[0, :, r:r + 32, c:c + 32] for r, c in golden["crops"]])
+    np.testing.assert_allclose(crops, golden["train.crops"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(yn.astype(np.float64).sum(axis=(0, 2, 3)), golden["train.sum"], rtol=1e-5, atol=0.5)
+    assert abs(float(loss.detach()) - float(golden["train.loss"][0])) <= 1e-5
+    np.testing.assert_allclose(x.grad.numpy()[0, :, 100:132, 60:92], golden["train.grad_input_crop"], rtol=2e-3, atol=2e-9)
+    assert abs(float(np.abs(x.grad.numpy()).astype(np.float64).sum()) - float(golden["train.grad_input_abs_sum"][0])) <= 1e-3 * float(golden["train.grad_input_abs_sum"][0])
+    named = dict(sr.named_parameters())
+    for key in golden.files:
+        if key.startswith("train.grad."):
+            name = key[len("train.grad."):]
+            got, want = named[name].grad.numpy().astype(np.float64), golden[key].astype(np.float64)
+            assert np.linalg.norm(got - want) <= 1e-3 * np.linalg.norm(want) + 1e-9, (name, np.linalg.norm(got - want), np.linalg.norm(want))
