@@ -8,7 +8,8 @@ encoders/freqencoder/freq.py) run on MI355X without touching them:
 Function names, argument order and in-place output convention are those of the pybind modules
 (raymarching/src/bindings.cpp:7-20, gridencoder/src/bindings.cpp, shencoder/src/bindings.cpp, freqencoder/src/bindings.cpp);
 arguments are torch CUDA(=HIP) tensors, converted to raw pointers for the C ABI.  Kernels run on torch's current stream.
-Inference entry points only; the training-only functions raise NotImplementedError.
+Inference and training entry points; half tables (the reference's autocast) are served through fp32 up-casts where the
+ABI is fp32-only.
 """
 import sys
 import types
@@ -85,18 +86,42 @@ def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):   # gridencoder.h:13
     if embeddings.dtype != torch.float32:
-        raise NotImplementedError("grid_encode_backward: fp32 tables only (train without autocast)")
+        # Under autocast the reference's grid.py:43-44 hands half tables / half grad / half dy_dx to the extension
+        # (egs_bases/radnerf/base.yaml:50 `amp: true`).  The C ABI accumulates table gradients in fp32 only: up-cast, run, and cast the
+        # results into the caller's tensors (more accurate than the reference's __half2 atomics, same interface).
+        ge32 = torch.zeros(grad_embeddings.shape, dtype=torch.float32, device=grad_embeddings.device)
+        gi32 = torch.zeros(grad_inputs.shape, dtype=torch.float32, device=grad_inputs.device) if grad_inputs is not None else None
+        grid_encode_backward(grad.float(), inputs, embeddings.float(), offsets, ge32, B, D, C, L, S, H, dy_dx.float() if dy_dx is not None else None, gi32,
+                             gridtype, align_corners, interp)
+        grad_embeddings.add_(ge32.to(grad_embeddings.dtype))
+        if grad_inputs is not None:
+            grad_inputs.add_(gi32.to(grad_inputs.dtype))
+        return
     call("gfpp_grid_encode_backward", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), int(B), int(D), int(C), int(L), float(S), int(H),
          _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st())
 
 
 def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):   # gridencoder.h:15
+    if embeddings.dtype != torch.float32:
+        g32 = torch.zeros(grad.shape, dtype=torch.float32, device=grad.device)
+        grad_total_variation(inputs, embeddings.float(), g32, offsets, weight, B, D, C, L, S, H, gridtype, align_corners)
+        grad.add_(g32.to(grad.dtype))
+        return
     call("gfpp_grad_total_variation", _p(inputs), _p(embeddings), _p(grad), _p(offsets), float(weight), int(B), int(D), int(C), int(L), float(S), int(H),
          int(gridtype), int(bool(align_corners)), _st())
 
 
 # ---- _gridencoder / _shencoder / _freqencoder ------------------------------------------------------------------------
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
+    if dy_dx is not None and embeddings.dtype != torch.float32:
+        # training under autocast (grid.py:43-52 with calc_grad_inputs): the ABI produces dy_dx in fp32 only -- compute on an fp32 view of
+        # the half tables and round once into the caller's half outputs
+        o32 = torch.empty(outputs.shape, dtype=torch.float32, device=outputs.device)
+        d32 = torch.empty(dy_dx.shape, dtype=torch.float32, device=dy_dx.device)
+        grid_encode_forward(inputs, embeddings.float(), offsets, o32, B, D, C, L, S, H, d32, gridtype, align_corners, interp)
+        outputs.copy_(o32)
+        dy_dx.copy_(d32)
+        return
     dtype = {torch.float32: 0, torch.float16: 1}[embeddings.dtype]
     call("gfpp_grid_encode_forward", _p(inputs), _p(embeddings), _p(offsets), _p(outputs), int(B), int(D), int(C), int(L), float(S), int(H),
          _p(dy_dx), int(gridtype), int(bool(align_corners)), int(interp), dtype, _st())

@@ -40,6 +40,8 @@ struct TripArgs {
     const float *sample_t;
     const uint32_t *sample_cnt;
     uint32_t sample_stride;
+    // per-sample evaluation entry only (k_head_eval): tanh(ambient_net) of sample c goes to dbg_ambient[c * AMB_D ...]
+    float *dbg_ambient;
 };
 
 __device__ __forceinline__ v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -86,7 +88,7 @@ struct TileShared {
 };
 
 // Evaluate RADNeRF.forward for the 32 occupied samples [first, first+32) of the tile.
-template <int AMB_D, typename Tile>
+template <int AMB_D, typename Tile, bool DBG = false>
 __device__ __forceinline__ void evaluate_block(const TripArgs &a, Tile &sh, uint32_t first, uint32_t n_step, int lane_in) {
     int lane = lane_in;
     // launder the lane id: keeps the (tile-loop-invariant) per-lane weight addresses from being hoisted out of the
@@ -121,7 +123,11 @@ __device__ __forceinline__ void evaluate_block(const TripArgs &a, Tile &sh, uint
     valu_rows<AMB_D>(a.w.amb_w2, bs, hi, amb);
     float ua[AMB_D];
 #pragma unroll
-    for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
+    for (int d = 0; d < AMB_D; ++d) {
+        const float th = tanhf(amb[d]);
+        if constexpr (DBG) { if (a.dbg_ambient && valid && hi == 0) a.dbg_ambient[(size_t)c * AMB_D + d] = th; }
+        ua[d] = (th + 1.0f) / 2.0f;
+    }
     float famb[16];
     encode_half<AMB_D>(ua, a.amb, hi, valid, famb);
 
@@ -384,6 +390,49 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
 }
 
 // ---- frame begin: slab test + state reset + constant folding ------------------------------------------------------
+// ---- per-sample evaluation (RADNeRF.forward, radnerf.py:108-141) with the trip kernels' own arithmetic ---------------------------------
+// A wavefront takes 32 caller-supplied (position, direction) pairs, lays them out as a one-sample-per-ray tile and runs evaluate_block --
+// the very function the trips run -- so a per-sample parity test of this entry pins the MFMA layer wiring of the frame path.
+struct EvalArgs {
+    TripArgs t;
+    const float *positions, *directions;
+    float *sigma, *color, *ambient;
+    uint32_t M;
+};
+
+template <int AMB_D>
+__global__ __launch_bounds__(kThreads, 2) void k_head_eval(EvalArgs e) {
+    __shared__ WaveTile tiles[kThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31;
+    WaveTile &wt = tiles[wave];
+    for (uint32_t base = (blockIdx.x * (kThreads / 64) + wave) * 32u; base < e.M; base += gridDim.x * (kThreads / 64) * 32u) {
+        const uint32_t idx = base + (uint32_t)j;
+        const bool ok = idx < e.M;
+        if (lane < 32) {
+            wt.px[j] = ok ? e.positions[3ull * idx] : 0.0f;
+            wt.py[j] = ok ? e.positions[3ull * idx + 1] : 0.0f;
+            wt.pz[j] = ok ? e.positions[3ull * idx + 2] : 0.0f;
+            wt.dx[j] = ok ? e.directions[3ull * idx] : 0.0f;
+            wt.dy[j] = ok ? e.directions[3ull * idx + 1] : 0.0f;
+            wt.dz[j] = ok ? e.directions[3ull * idx + 2] : 1.0f;
+            wt.order[j] = (uint32_t)j;
+        }
+        if (lane == 0) wt.n_valid = e.M - base < 32u ? e.M - base : 32u;
+        wave_sync();
+        TripArgs a = e.t;
+        a.dbg_ambient = e.ambient ? e.ambient + (size_t)base * AMB_D : nullptr;
+        evaluate_block<AMB_D, WaveTile, true>(a, wt, 0, 1, lane);
+        wave_sync();
+        if (lane < 32 && ok) {
+            e.sigma[idx] = wt.sigma[j];
+            e.color[3ull * idx] = wt.cr[j];
+            e.color[3ull * idx + 1] = wt.cg[j];
+            e.color[3ull * idx + 2] = wt.cb[j];
+        }
+        wave_sync();
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, uint32_t N,
                                                          float min_near, float ax0, float ay0, float az0, float ax1, float ay1, float az1,
                                                          float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ rays_t,
@@ -529,6 +578,7 @@ GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_fram
     a.frame_consts = ws->frame_consts;
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
+    a.dbg_ambient = nullptr;
     // enough workgroups for the worst trip (ceil(N / floor(128/n_step)) tiles), capped: tiles are taken grid-stride
     uint32_t grid = div_up(ws->N, 120);
     if (grid > 4096u) grid = 4096u;
@@ -571,6 +621,7 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
+    a.dbg_ambient = nullptr;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
@@ -589,6 +640,31 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
         if (rc) return rc;
     }
     return 0;
+}
+
+GFPP_API int gfpp_head_eval_samples(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *positions, const float *directions, uint32_t M,
+                                    float *sigma, float *color, float *ambient, gfpp_stream_t stream) {
+    if (M == 0) return 0;
+    if (!model || !ws || !positions || !directions || !sigma || !color || !ws->frame_consts) { set_error("gfpp_head_eval_samples: null argument"); return GFPP_EINVAL; }
+    if (!grid_ok(model->pos_grid, 3) || !(grid_ok(model->amb_grid, 2) || grid_ok(model->amb_grid, 3))) {
+        set_error("gfpp_head_eval_samples: grids must be 16-level fp32, position D=3, ambient D in {2,3}");
+        return GFPP_EUNSUPPORTED;
+    }
+    EvalArgs e{};
+    TripArgs &a = e.t;
+    a.mp = make_march_params(model->bound, 0.0f, 16, model->cascade, model->grid_size);
+    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
+    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
+                      (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
+    a.frame_consts = ws->frame_consts;
+    a.density_scale = model->density_scale;
+    e.positions = positions; e.directions = directions; e.sigma = sigma; e.color = color; e.ambient = ambient; e.M = M;
+    uint32_t grid = div_up(M, 32u * (kThreads / 64));
+    if (grid > 1024u) grid = 1024u;
+    if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_eval<3>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, e);
+    else hipLaunchKernelGGL(k_head_eval<2>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, e);
+    return check_launch("gfpp_head_eval_samples");
 }
 
 GFPP_API int gfpp_head_frame_finish(const gfpp_frame_ws *ws, const float *bg_color, float bg_scalar, float *out_image, float *out_depth,

@@ -418,7 +418,9 @@ GFPP_API int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float r
         else if (D == 3 && C == 1) hipLaunchKernelGGL((KERNEL<3, 1>), grid_, block_, 0, st, __VA_ARGS__);                               \
         else if (D == 2 && C == 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid_, block_, 0, st, __VA_ARGS__);                               \
         else if (D == 3 && C == 4) hipLaunchKernelGGL((KERNEL<3, 4>), grid_, block_, 0, st, __VA_ARGS__);                               \
-        else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2 or 4 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; } \
+        else if (D == 2 && C == 8) hipLaunchKernelGGL((KERNEL<2, 8>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else if (D == 3 && C == 8) hipLaunchKernelGGL((KERNEL<3, 8>), grid_, block_, 0, st, __VA_ARGS__);                               \
+        else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2, 4 or 8 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; } \
     } while (0)
 
 GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings, const int32_t *offsets, float *dy_dx, uint32_t B, uint32_t D, uint32_t C,

@@ -3,11 +3,11 @@
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
 ``cpu_baseline`` leg, never by the product package ``genefaceplusplus_amd``.
 
-PARITY STATUS: the reference has no tests or golden vectors and its CUDA kernels cannot run here, so
-the *kernel-level* semantics (radnerf_oracle.c) are pinned only by SURVEY.md section 8c invariants:
-"kernel-level parity unpinned".  The *host-level* logic in this file (MLP wiring, render loop,
-torso pass, ray generation, conditioning nets) IS pinned: tests/golden/make_golden.py imports the
-reference's own Python modules from /root/reference, plugs radnerf_oracle.c under their native
+PARITY STATUS: pinned.  Kernel level: radnerf_oracle.c reproduces the outputs of the reference's own native
+extensions, compiled unmodified for gfx950 (oracle/build_ref.py -> oracle/_ref/) and run on an MI355X
+(tests/golden/ref_kernel_golden.npz, tests/test_oracle_ref_kernels_cpu.py; live: tests/test_ref_kernels_gpu.py).
+Host level (MLP wiring, render loop, torso pass, ray generation, conditioning nets): tests/golden/make_golden.py
+imports the reference's own Python modules from /root/reference, plugs radnerf_oracle.c under their native
 extension names, runs them on CPU and commits the outputs as fixtures that this file must reproduce.
 
 All arrays are numpy float32 unless noted; parameters use the reference's state_dict key names.

@@ -126,10 +126,29 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
 
 
 def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
-    assert dy_dx is None and D == 3
+    assert D == 3
     rc = orc.lib().orc_sh_encode_forward(_fp(inputs), _fp(outputs), _u32(B), _u32(C))
     if rc != 0:
         raise RuntimeError("SH encoding: degree must be in 1..4 in the oracle")
+    if dy_dx is not None:          # [B, D * C^2] = (B, D, C^2), shencoder.cu:125-130
+        dy_dx.copy_(torch.from_numpy(orc.sh_encode_dydx(inputs.numpy(), C)).reshape(B, -1))
+
+
+def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+    # kernel_sh_backward (shencoder.cu:359-382): grad_inputs[b, d] += sum_c grad[b, c] * dy_dx[b, d, c]
+    g = np.einsum("bc,bdc->bd", grad.numpy().astype(np.float64), dy_dx.numpy().reshape(B, D, C * C).astype(np.float64))
+    grad_inputs.add_(torch.from_numpy(g.astype(np.float32)))
+
+
+def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):
+    grad_inputs.copy_(torch.from_numpy(orc.freq_encode_backward(grad.numpy(), outputs.numpy(), D, deg)))
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+    rc = orc.lib().orc_grad_total_variation(_fp(inputs), _fp(embeddings), _fp(grad), _ip(offsets), ctypes.c_float(weight), _u32(B), _u32(D), _u32(C), _u32(L),
+                                            ctypes.c_float(S), _u32(H), _u32(gridtype), ctypes.c_int(int(align_corners)))
+    if rc != 0:
+        raise RuntimeError("GridEncoding: unsupported D/C")
 
 
 def freq_encode_forward(inputs, B, D, deg, C, outputs):
@@ -151,6 +170,7 @@ def install():
                                                march_rays_train=march_rays_train, march_rays_train_backward=march_rays_train_backward,
                                                composite_rays_train_forward=composite_rays_train_forward,
                                                composite_rays_train_backward=composite_rays_train_backward)
-    sys.modules["_gridencoder"] = _module("_gridencoder", grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward)
-    sys.modules["_shencoder"] = _module("_shencoder", sh_encode_forward=sh_encode_forward)
-    sys.modules["_freqencoder"] = _module("_freqencoder", freq_encode_forward=freq_encode_forward)
+    sys.modules["_gridencoder"] = _module("_gridencoder", grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward,
+                                          grad_total_variation=grad_total_variation)
+    sys.modules["_shencoder"] = _module("_shencoder", sh_encode_forward=sh_encode_forward, sh_encode_backward=sh_encode_backward)
+    sys.modules["_freqencoder"] = _module("_freqencoder", freq_encode_forward=freq_encode_forward, freq_encode_backward=freq_encode_backward)

@@ -63,6 +63,7 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src and "radnerf_oracle" not in src, f
+                assert "build_ref" not in src and "oracle/_ref" not in src, f      # the compiled reference kernels are a checker too
 
 
 def test_host_interface_matches_reference():
