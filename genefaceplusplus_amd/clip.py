@@ -236,13 +236,14 @@ class _NullContext:
         return False
 
 
-def render_clip_distributed(renderer, clip, n_frames=None, interleaved=False, group=None):
+def render_clip_distributed(renderer, clip, n_frames=None, interleaved=False, group=None, dst=None):
     """Frame-parallel clip over the ranks of `group`: every rank renders its shard into a device uint8 stack and
-    the one exchange step is the all_gather of those stacks (RCCL over xGMI).  Returns the whole clip [F,h,w,3] on every rank."""
+    the one exchange step is the gather of those stacks (RCCL over xGMI).  dst=None: all_gather, the whole clip [F,h,w,3] on every rank;
+    dst=r: gather to the writer rank r only (None elsewhere) -- what a single video writer needs (genefacepp_infer.py:454-518)."""
     import torch.distributed as dist
     F = clip["frames"] if n_frames is None else n_frames
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return renderer.render_to_device(clip, range(F))
     mine = frames.shard_frames(F, dist.get_rank(group), dist.get_world_size(group), interleaved)
     local = renderer.render_to_device(clip, mine)
-    return frames.gather_clip(local, F, interleaved, group)
+    return frames.gather_clip(local, F, interleaved, group, dst=dst)

@@ -67,6 +67,13 @@ _VARIANTS = {
                      "torso_head_aware": True},
 }
 
+# The audio-conditioned family (egs/egs_bases/radnerf/radnerf.yaml on base.yaml: esperanto features, a 16-frame window per smoothing
+# step, AudioNet strides 2,2,2,2, base.yaml:100 ambient_coord_dim 2).  No May yaml ships for it; kept so that this architecture is built
+# and tested (`ambient D = 2` kernels, `t_win = 16` conditioning kernel).
+_AUDIO = {"cond_type": "esperanto", "cond_win_size": 16, "smo_win_size": 8, "ambient_coord_dim": 2}
+_VARIANTS["audio_head"] = dict(_AUDIO)
+_VARIANTS["audio_torso"] = dict(_AUDIO)
+
 #: reference yaml each variant was derived from (relative to the reference root)
 VARIANT_YAML = {
     "may_head": "egs/datasets/May/lm3d_radnerf.yaml",
@@ -77,7 +84,7 @@ VARIANT_YAML = {
 
 
 def may_hparams(variant="may_torso"):
-    """Return a fresh hparams dict for one of: may_head, may_head_sr, may_torso, may_torso_sr."""
+    """Return a fresh hparams dict for one of: may_head, may_head_sr, may_torso, may_torso_sr, audio_head, audio_torso."""
     if variant not in _VARIANTS:
         raise KeyError(f"unknown variant {variant!r}; choose from {sorted(_VARIANTS)}")
     hp = copy.deepcopy(_BASE)

@@ -658,7 +658,7 @@ GFPP_API int gfpp_head_eval_samples(const gfpp_head_model *model, const gfpp_fra
     a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.frame_consts = ws->frame_consts;
-    a.density_scale = model->density_scale;
+    a.density_scale = 1.0f;      // forward() returns the unscaled density; render() applies density_scale (renderer.py:376)
     e.positions = positions; e.directions = directions; e.sigma = sigma; e.color = color; e.ambient = ambient; e.M = M;
     uint32_t grid = div_up(M, 32u * (kThreads / 64));
     if (grid > 1024u) grid = 1024u;

@@ -85,6 +85,7 @@ struct LpTripArgs {
     const float *frame_consts;
     float T_thresh, density_scale;
     uint32_t N, trip, trip_end, max_steps;   // this launch runs the trips [trip, trip_end)
+    float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
 
@@ -261,7 +262,7 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 }
 
 // RADNeRF.forward for the 32 occupied samples [first, first+32) of this wavefront's tile.
-template <int AMB_D, typename H, bool SLOW>
+template <int AMB_D, typename H, bool SLOW, bool DBG = false>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, uint32_t first, uint32_t n_valid,
                                                   uint32_t n_step, int lane_in, unsigned long long (&sub)[4]) {
     const bool prof = a.phase_cycles != nullptr;
@@ -304,7 +305,11 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
         lap(1);
 #pragma unroll
-        for (int d = 0; d < AMB_D; ++d) ua[d] = (tanhf(amb[d]) + 1.0f) / 2.0f;
+        for (int d = 0; d < AMB_D; ++d) {
+            const float th = tanhf(amb[d]);
+            if constexpr (DBG) { if (a.dbg_ambient && valid && hi == 0) a.dbg_ambient[(size_t)c * AMB_D + d] = th; }
+            ua[d] = (th + 1.0f) / 2.0f;
+        }
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
     lap(2);
@@ -336,6 +341,22 @@ __device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+}
+
+// Weights, skinny rows, folded biases and level descriptors -> LDS (once per launch; the caller synchronises the workgroup afterwards).
+__device__ __forceinline__ void lp_fill_shared(LpShared &sh, const LpTripArgs &a, int tid, int lane) {
+    // 124 KB of fragments: direct global -> LDS transfers (no register round trip, all 16 requests of a thread in flight at once); the
+    // LDS address of such a load is wave-uniform base + lane x 16, which is exactly the fragment layout
+    static_assert(kLpWeightChunks % 64 == 0, "whole wavefront rows");
+    for (int i = tid; i < kLpWeightChunks; i += kLpThreads)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w16 + i),
+                                         (__attribute__((address_space(3))) void *)(&sh.w[i - lane]), 16, 0, 0);
+    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
+    for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
+    for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
+        const int which = k >> 7, w = k & 127;
+        reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
+    }
 }
 
 // One launch runs the trips [a.trip, a.trip_end) (renderer.py:352-384: one loop iteration each).  The host issues the first few trips as
@@ -396,18 +417,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
     };
     // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
     if (!weights_resident) {
-        // 124 KB of fragments: direct global -> LDS transfers (no register round trip, all 16 requests of a thread in flight at once); the
-        // LDS address of such a load is wave-uniform base + lane x 16, which is exactly the fragment layout
-        static_assert(kLpWeightChunks % 64 == 0, "whole wavefront rows");
-        for (int i = tid; i < kLpWeightChunks; i += kLpThreads)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w16 + i),
-                                             (__attribute__((address_space(3))) void *)(&sh.w[i - lane]), 16, 0, 0);
-        for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
-        for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
-        for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
-            const int which = k >> 7, w = k & 127;
-            reinterpret_cast<uint32_t *>(&sh.lv[which][0])[w] = reinterpret_cast<const uint32_t *>(which ? a.amb.levels : a.pos.levels)[w];
-        }
+        lp_fill_shared(sh, a, tid, lane);
         __syncthreads();
         weights_resident = true;
     }
@@ -522,6 +532,55 @@ __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }
 
+// ---- per-sample evaluation (RADNeRF.forward, radnerf.py:108-141) with the 16-bit trip kernel's own arithmetic -----------------------------
+// 32 caller-supplied (position, direction) pairs per wavefront pass, laid out as a one-sample-per-ray tile for evaluate_block_lp -- the function
+// the trips run.  Pins the fragment layouts (weights, skinny rows, merged geo/colour matrix, folded biases) sample by sample.
+struct LpEvalArgs {
+    LpTripArgs t;
+    const float *positions;
+    float *sigma, *color, *ambient;
+    uint32_t M;
+};
+
+template <int AMB_D, typename H, bool SLOW>
+__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_eval_lp(LpEvalArgs e) {
+    __shared__ LpShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31;
+    lp_fill_shared(sh, e.t, tid, lane);
+    __syncthreads();
+    LpWaveTile &wt = sh.tile[wave];
+    unsigned long long sub[4] = {0ull, 0ull, 0ull, 0ull};
+    for (uint32_t base = (blockIdx.x * kLpWaves + wave) * 32u; base < e.M; base += gridDim.x * kLpWaves * 32u) {
+        const uint32_t idx = base + (uint32_t)j;
+        const bool ok = idx < e.M;
+        if (lane < 32) {
+            wt.px[j] = ok ? e.positions[3ull * idx] : 0.0f;
+            wt.py[j] = ok ? e.positions[3ull * idx + 1] : 0.0f;
+            wt.pz[j] = ok ? e.positions[3ull * idx + 2] : 0.0f;
+            wt.ray[j] = ok ? idx : 0u;          // the direction of "ray" idx is read from t.rays_d = directions
+            wt.order[j] = (uint8_t)j;
+        }
+        wave_sync();
+        LpTripArgs a = e.t;
+        a.dbg_ambient = e.ambient ? e.ambient + (size_t)base * AMB_D : nullptr;
+        const uint32_t n_valid = e.M - base < 32u ? e.M - base : 32u;
+        evaluate_block_lp<AMB_D, H, SLOW, true>(a, sh, wt, 0, n_valid, 1, lane, sub);
+        wave_sync();
+        if (lane < 32 && ok) {
+            e.sigma[idx] = wt.px[j];
+            e.color[3ull * idx] = wt.py[j];
+            e.color[3ull * idx + 1] = wt.pz[j];
+            e.color[3ull * idx + 2] = wt.cb[j];
+        }
+        wave_sync();
+    }
+}
+
+template <int AMB_D, typename H, bool SLOW>
+static void launch_eval_lp(uint32_t grid, hipStream_t st, const LpEvalArgs &e) {
+    hipLaunchKernelGGL((k_head_eval_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, e);
+}
+
 template <int AMB_D, typename H, bool SLOW>
 static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
     hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
@@ -568,6 +627,35 @@ static int lp_check_common(const char *who, const gfpp_head_model *model, const 
     return 0;
 }
 
+// The model-dependent part of the kernel arguments (grids, weight images); shared by the trip launches and the per-sample evaluation entry.
+static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripArgs &a) {
+    if (!model->lp_weights || !model->lp_skinny || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
+        set_error("%s: the model carries no 16-bit weight image (lp_weights / lp_skinny / lp_dtype)", who);
+        return GFPP_EINVAL;
+    }
+    if (!lp_grid_ok(model->pos_grid, 3) || !(lp_grid_ok(model->amb_grid, 2) || lp_grid_ok(model->amb_grid, 3))) {
+        set_error("%s: grids must be 16-level fp32 tables, position D=3, ambient D in {2,3}", who);
+        return GFPP_EUNSUPPORTED;
+    }
+    if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("%s: grid descriptors carry no host level table (levels_host)", who); return GFPP_EINVAL; }
+    for (int which = 0; which < 2; ++which) {
+        const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
+        LpGrid &g = which ? a.amb : a.pos;
+        g.any_slow = 0;
+        g.levels = gd.levels;
+        for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
+        if (!g.any_slow && !gd.row_padded) { set_error("%s: tables must be the per-level padded copy (row_padded)", who); return GFPP_EINVAL; }
+        g.table = (const float *)gd.table;
+        g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
+    }
+    a.w16 = (const uint4 *)model->lp_weights;
+    a.skinny16 = (const uint32_t *)model->lp_skinny;
+    a.density_scale = model->density_scale;
+    a.dbg_ambient = nullptr;
+    a.phase_cycles = nullptr;
+    return 0;
+}
+
 GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                       float dt_gamma, uint32_t max_steps, gfpp_stream_t stream) {
     const int bad = lp_check_common("gfpp_head_frame_premarch", model, ws, rays_o, rays_d, max_steps);
@@ -586,30 +674,10 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
                                       float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
     const int bad = lp_check_common("gfpp_head_frame_trips_lp", model, ws, rays_o, rays_d, max_steps);
     if (bad) return bad;
-    if (!model->lp_weights || !model->lp_skinny || (model->lp_dtype != GFPP_F16 && model->lp_dtype != GFPP_BF16)) {
-        set_error("gfpp_head_frame_trips_lp: the model carries no 16-bit weight image (lp_weights / lp_skinny / lp_dtype)");
-        return GFPP_EINVAL;
-    }
-    if (!lp_grid_ok(model->pos_grid, 3) || !(lp_grid_ok(model->amb_grid, 2) || lp_grid_ok(model->amb_grid, 3))) {
-        set_error("gfpp_head_frame_trips_lp: grids must be 16-level fp32 tables, position D=3, ambient D in {2,3}");
-        return GFPP_EUNSUPPORTED;
-    }
     if (!ws->alive[0] || !ws->alive[1] || !ws->rays_t || !ws->counters || !ws->frame_consts) { set_error("gfpp_head_frame_trips_lp: bad workspace"); return GFPP_EINVAL; }
     LpTripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
-    if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("gfpp_head_frame_trips_lp: grid descriptors carry no host level table (levels_host)"); return GFPP_EINVAL; }
-    for (int which = 0; which < 2; ++which) {
-        const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
-        LpGrid &g = which ? a.amb : a.pos;
-        g.any_slow = 0;
-        g.levels = gd.levels;
-        for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
-        if (!g.any_slow && !gd.row_padded) { set_error("gfpp_head_frame_trips_lp: tables must be the per-level padded copy (row_padded)"); return GFPP_EINVAL; }
-        g.table = (const float *)gd.table;
-        g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
-    }
-    a.w16 = (const uint4 *)model->lp_weights;
-    a.skinny16 = (const uint32_t *)model->lp_skinny;
+    { const int rc = lp_model_args("gfpp_head_frame_trips_lp", model, a); if (rc) return rc; }
     a.rays_o = rays_o; a.rays_d = rays_d;
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
     a.consumed = (uint32_t *)ws->rays_t;   // the per-ray cursor takes the place of rays_t
@@ -638,6 +706,29 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
         if (rc) return rc;
     }
     return 0;
+}
+
+GFPP_API int gfpp_head_eval_samples_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *positions, const float *directions, uint32_t M,
+                                       float *sigma, float *color, float *ambient, gfpp_stream_t stream) {
+    if (M == 0) return 0;
+    if (!model || !ws || !positions || !directions || !sigma || !color || !ws->frame_consts) { set_error("gfpp_head_eval_samples_lp: null argument"); return GFPP_EINVAL; }
+    LpEvalArgs e{};
+    LpTripArgs &a = e.t;
+    a.mp = make_march_params(model->bound, 0.0f, 16, model->cascade, model->grid_size);
+    { const int rc = lp_model_args("gfpp_head_eval_samples_lp", model, a); if (rc) return rc; }
+    a.rays_d = directions;
+    a.frame_consts = ws->frame_consts;
+    a.density_scale = 1.0f;      // forward() returns the unscaled density; render() applies density_scale (renderer.py:376)
+    e.positions = positions; e.sigma = sigma; e.color = color; e.ambient = ambient; e.M = M;
+    uint32_t grid = div_up(M, 32u * kLpWaves);
+    const uint32_t cus = (uint32_t)lp_cu_count();
+    if (grid > cus) grid = cus;
+    const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
+    void (*launch)(uint32_t, hipStream_t, const LpEvalArgs &) =
+        amb3 ? (bf ? (slow ? launch_eval_lp<3, __bf16, true> : launch_eval_lp<3, __bf16, false>) : (slow ? launch_eval_lp<3, _Float16, true> : launch_eval_lp<3, _Float16, false>))
+             : (bf ? (slow ? launch_eval_lp<2, __bf16, true> : launch_eval_lp<2, __bf16, false>) : (slow ? launch_eval_lp<2, _Float16, true> : launch_eval_lp<2, _Float16, false>));
+    launch(grid, (hipStream_t)stream, e);
+    return check_launch("gfpp_head_eval_samples_lp");
 }
 
 GFPP_API int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,

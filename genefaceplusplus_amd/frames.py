@@ -42,8 +42,12 @@ def to_uint8_hwc(rgb, out=None):
     return out
 
 
-def gather_clip(local_frames, n_frames, interleaved=False, group=None):
-    """all_gather the per-rank uint8 frame stacks [F_local, H, W, 3] and reassemble the clip in frame order on every rank.
+def gather_clip(local_frames, n_frames, interleaved=False, group=None, dst=None):
+    """Exchange step of the frame-parallel clip: the per-rank uint8 frame stacks [F_local, H, W, 3] are reassembled in frame order.
+
+    dst=None: all_gather -- every rank gets the clip.  dst=<group rank>: gather to that rank only -- the reference has ONE consumer of the
+    frames (the video writer, genefacepp_infer.py:454-518), so the other ranks need not receive world x F frames each: over xGMI's
+    point-to-point links every rank then sends its stack once, to the writer (returns None on the other ranks).
     Ranks may own different numbers of frames (last block shorter): stacks are padded to the longest."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
@@ -56,8 +60,14 @@ def gather_clip(local_frames, n_frames, interleaved=False, group=None):
     if local_frames.shape[0] < longest:
         pad = torch.zeros(longest - local_frames.shape[0], *local_frames.shape[1:], dtype=local_frames.dtype, device=local_frames.device)
         local_frames = torch.cat([local_frames, pad], dim=0)
-    parts = [torch.empty_like(local_frames) for _ in range(world)]
-    dist.all_gather(parts, local_frames.contiguous(), group=group)
+    if dst is None:
+        parts = [torch.empty_like(local_frames) for _ in range(world)]
+        dist.all_gather(parts, local_frames.contiguous(), group=group)
+    else:
+        parts = [torch.empty_like(local_frames) for _ in range(world)] if rank == dst else None
+        dist.gather(local_frames.contiguous(), parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if rank != dst:
+            return None
     clip = torch.empty(n_frames, *local_frames.shape[1:], dtype=local_frames.dtype, device=local_frames.device)
     for r in range(world):
         idx = shard_frames(n_frames, r, world, interleaved)
@@ -100,6 +110,7 @@ def share_driving_signals(tensors, src=0):
     return tensors
 
 
-def gather_identity_clip(local_frames, n_frames, my_group, interleaved=False):
-    """Frame gather inside one identity's rank block (the only collective of the multi-identity job besides the one broadcast)."""
-    return gather_clip(local_frames, n_frames, interleaved, group=my_group)
+def gather_identity_clip(local_frames, n_frames, my_group, interleaved=False, dst=None):
+    """Frame gather inside one identity's rank block (the only collective of the multi-identity job besides the one broadcast);
+    dst = rank INSIDE the block that writes the identity's video (None: every rank of the block gets the clip)."""
+    return gather_clip(local_frames, n_frames, interleaved, group=my_group, dst=dst)

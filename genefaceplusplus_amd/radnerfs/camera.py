@@ -11,9 +11,25 @@ import torch
 from .._lib import call, GfppError
 
 
+class _TruncExp(torch.autograd.Function):
+    """utils.py:34-47: forward exp(x) in float32; backward g * exp(clamp(x, -15, 15)) -- the clamp exists ONLY in the backward pass and
+    keeps sigma gradients finite once a logit passes ~15."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
 def trunc_exp(x):
-    """exp evaluated in float32 (utils.py:36-49; the clamp only exists in the backward pass)."""
-    return torch.exp(x.float())
+    """exp evaluated in float32 with the reference's clamped backward (utils.py:34-49)."""
+    return _TruncExp.apply(x)
 
 
 def nerf_matrix_to_ngp(pose, scale=4, offset=(0, 0, 0)):

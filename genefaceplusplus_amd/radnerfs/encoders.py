@@ -53,7 +53,9 @@ class _GridEncodeFn(torch.autograd.Function):
         L, C = offsets.shape[0] - 1, emb.shape[1]
         S = float(np.log2(per_level_scale))
         out = torch.empty(L, B, C, device=inputs01.device, dtype=torch.float32)
-        dy_dx = torch.empty(B, L * D * C, device=inputs01.device, dtype=torch.float32) if inputs01.requires_grad else None
+        # decide from autograd's own bookkeeping: `inputs01` may be a fresh no-grad copy after the cast above (a non-fp32 or non-contiguous
+        # input), whose requires_grad flag says nothing about the caller's tensor
+        dy_dx = torch.empty(B, L * D * C, device=inputs01.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         call("gfpp_grid_encode_forward", inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S, int(base_resolution),
              dy_dx.data_ptr() if dy_dx is not None else None, int(gridtype_id), int(bool(align_corners)), int(interp_id), 0, _stream())
         ctx.save_for_backward(inputs01, emb, offsets, dy_dx)

@@ -74,6 +74,8 @@ _lib.register("gfpp_head_frame_premarch", [ctypes.POINTER(HeadModel), ctypes.POI
 _lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_eval_samples", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
+_lib.register("gfpp_head_eval_samples_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
 
 
@@ -593,6 +595,25 @@ class FramePipeline:
         call("gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march"), ctypes.byref(self.head), ctypes.byref(ws),
              rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
         return ws, t
+
+    def eval_samples(self, position, direction, cond_feat, ind_code):
+        """RADNeRF.forward on a sample list through the trip kernels' own evaluate_block (gfpp_head_eval_samples[_lp], current precision)
+        -> sigma [M], color [M,3], ambient [M, amb_D]."""
+        position = self._dev_f32(position, "position").reshape(-1, 3)
+        direction = self._dev_f32(direction, "direction").reshape(-1, 3)
+        M = position.shape[0]
+        ws, _ = self.workspace(1)
+        cf = self._dev_f32(cond_feat.reshape(-1), "cond_feat")
+        if cf.numel() != self.head.cond_dim:
+            raise GfppError(f"cond_feat must have {self.head.cond_dim} values, got {cf.numel()}")
+        ind = self._dev_f32(ind_code.reshape(-1), "ind_code") if ind_code is not None else None
+        st = torch.cuda.current_stream().cuda_stream
+        call("gfpp_head_frame_fold", ctypes.byref(self.head), ctypes.byref(ws), cf.data_ptr(), ind.data_ptr() if ind is not None else None, st)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        sigma, color, ambient = f(M), f(M, 3), f(M, int(self.head.amb_grid.D))
+        call("gfpp_head_eval_samples" if self.precision == "fp32" else "gfpp_head_eval_samples_lp", ctypes.byref(self.head), ctypes.byref(ws),
+             position.data_ptr(), direction.data_ptr(), M, sigma.data_ptr(), color.data_ptr(), ambient.data_ptr(), st)
+        return sigma, color, ambient
 
     def render_head(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color):
         ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh)

@@ -8,6 +8,7 @@ HIP pipeline (frame_pipeline.py: device-side loop control, no host syncs); the r
 the "unfused" baseline for measurements.
 """
 import copy
+import warnings
 import math
 import random
 
@@ -179,6 +180,29 @@ class NeRFRenderer(nn.Module):
         weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient.abs().sum(-1), deltas, rays)
         return weights_sum, ambient_sum, depth, image, xyzs
 
+    _warned = set()
+
+    def _fused_ok(self, perturb=False, max_steps=16, cond_mask=None):
+        """Can this call run on the fused frame pipeline?  Otherwise render() falls back to the reference-shaped `staged` executor (same
+        results, one host-visible trip per loop iteration, ~40x slower) -- and says so once per reason."""
+        from .frame_pipeline import supports
+        why = None
+        if not supports(self):
+            why = "architecture outside the fused kernels' family (hidden 128, layers 3/3/2, 16x2 grids)"
+        elif perturb:
+            why = "perturb=True"
+        elif cond_mask is not None:
+            why = "cond_mask given"
+        elif max_steps > 63:
+            why = f"max_steps={max_steps} > 63"
+        if why is None:
+            return True
+        if why not in NeRFRenderer._warned:
+            NeRFRenderer._warned.add(why)
+            warnings.warn(f"genefaceplusplus_amd: render() uses the staged executor ({why}); the fused hipGraph path covers "
+                          f"perturb=False, cond_mask=None, max_steps<=63 on the shipped architecture", RuntimeWarning, stacklevel=3)
+        return False
+
     def pipeline(self):
         """Lazily build the fused frame pipeline (packs weights for the HIP kernels; rebuilt if parameters move)."""
         from .frame_pipeline import FramePipeline
@@ -244,7 +268,7 @@ class NeRFRenderer(nn.Module):
             image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3).clamp(0, 1)
             depth = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
             return {"weights_sum": weights_sum, "ambient": ambient_sum, "position": xyzs, "depth_map": depth, "rgb_map": image}
-        if self.executor == "fused" and cond_mask is None and not perturb and max_steps <= 63:
+        if self.executor == "fused" and self._fused_ok(perturb, max_steps, cond_mask):
             def frame(rays_o, rays_d, cond, eye, bg_color):
                 cond_feat = lambda: self.cal_cond_feat(cond, eye_area_percent=eye)     # runs on the pipeline's side stream
                 return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
@@ -352,8 +376,17 @@ class RADNeRF(NeRFRenderer):
         h = self.sigma_net(torch.cat([pos_feat, ambient_feat], dim=-1))
         return trunc_exp(h[..., 0]), h[..., 1:], ambient_pos
 
+    def _fused_eval_ok(self, position, cond_mask):
+        if not (self.executor == "fused" and not self.training and not torch.is_grad_enabled() and cond_mask is None and position.is_cuda):
+            return False
+        from .frame_pipeline import supports
+        return supports(self)
+
     def forward(self, position, direction, cond_feat, individual_code, cond_mask=None):
-        """-> sigma [M] f32, color [M,3], ambient_pos [M, ambient_coord_dim] f32 (radnerf.py:108-141)."""
+        """-> sigma [M] f32, color [M,3], ambient_pos [M, ambient_coord_dim] f32 (radnerf.py:108-141).  At inference (no grad, fused
+        executor) the samples go through the trip kernels' own evaluate_block (gfpp_head_eval_samples[_lp], precision as for render())."""
+        if self._fused_eval_ok(position, cond_mask):
+            return self.pipeline().eval_samples(position, direction, cond_feat, individual_code)
         sigma, geo_feat, ambient_pos = self._sigma_trunk(position, cond_feat)
         parts = [self.direction_embedder(direction).to(geo_feat.dtype), geo_feat]
         if individual_code is not None:

@@ -141,6 +141,8 @@ class _TorsoBase(RADNeRF):
         torso_color = torch.zeros(N, 3, device=dev)
         deform = None
         if mask.any():
+            if use_head_for_torso is None:          # radnerf_torso.py:177-180: the coin is drawn only when there is a masked pixel
+                use_head_for_torso = random.random() < 0.5
             if self.hparams["torso_head_aware"] and use_head_for_torso:
                 a, col, deform = self._forward_torso(bg_coords[mask], poses, code, image[mask], weights_sum.unsqueeze(-1)[mask], lm68)
             else:
@@ -159,7 +161,10 @@ class _TorsoBase(RADNeRF):
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
-        if self.executor == "fused" and not self.training and not perturb and max_steps <= 63:
+        fused = self.executor == "fused" and not self.training and self._fused_ok(perturb, max_steps)
+        if fused:
+            if use_head_for_torso is None:
+                use_head_for_torso = random.random() < 0.5
             ind_code, torso_code = self._individual_code(index), self._torso_code(index)
 
             def frame(rays_o, rays_d, cond, eye, bg_coords, poses, lm68, bg_color):
@@ -212,8 +217,10 @@ class RADNeRFTorso(_TorsoBase):
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, **kwargs):
         prefix = rays_o.shape[:-1]
-        # the reference flips a host coin per frame when torso_head_aware (radnerf_torso.py:177-180); same RNG stream here
-        use_head = random.random() < 0.5 if self.hparams["torso_head_aware"] else False
+        # The reference flips a host coin when torso_head_aware, but only inside `if mask.any()` (radnerf_torso.py:177-180).  The staged
+        # executor (which knows the mask on the host) draws it exactly there: `use_head=None` = "draw when needed".  The fused executor never
+        # learns the mask on the host (no sync), so it draws once per frame: the RNG streams differ only on frames whose torso mask is empty.
+        use_head = None if self.hparams["torso_head_aware"] else False
         # NB: this variant calls cal_cond_feat(cond) without eye_area_percent (radnerf_torso.py:106)
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, None,
                                   None, use_head, force_all_rays=force_all_rays)
@@ -238,6 +245,24 @@ class RADNeRFTorsowithSR(_TorsoBase):
         self._build_torso_nets(hparams, cond_dim=self.lm68_embedding_dim)
         from .superres import Superresolution
         self.sr_net = Superresolution(channels=3)
+
+    # -- training-stage switches the reference trainer calls (tasks/radnerfs/radnerf_torso_sr.py:192; radnerf_torso_sr.py:58-73) -----------
+    def on_train_torso_nerf(self):
+        self.requires_grad_(False)
+        if self.torso_individual_embedding_dim > 0:
+            self.torso_individual_codes.requires_grad_(True)
+        self.torso_pose_embedder.requires_grad_(True)
+        self.torso_deform_pos_embedder.requires_grad_(True)
+        self.torso_embedder.requires_grad_(True)
+        if self.hparams["torso_head_aware"]:
+            self.head_color_weights_encoder.requires_grad_(True)
+        self.torso_deform_net.requires_grad_(True)
+        self.torso_canonicial_net.requires_grad_(True)
+        self.sr_net.requires_grad_(False)
+
+    def on_train_superresolution(self):
+        self.requires_grad_(False)
+        self.sr_net.requires_grad_(True)
 
     def _frame_constant_columns(self, poses, c, lm68):
         # the reference also encodes `poses` here but never uses the result (radnerf_torso_sr.py:84,89-96)
@@ -286,13 +311,22 @@ class RADNeRFTorsowithSR(_TorsoBase):
 
 class RADNeRFwithSR(RADNeRF):
     """Head-only model of the *_sr configs (reference: modules/radnerfs/radnerf_sr.py:45-210, which repeats RADNeRF's
-    networks and adds ``sr_net`` + the ``lambda_ambient`` scalar).  Renders 256x256 rays; the SR stage is "next"."""
+    networks and adds ``sr_net`` + the ``lambda_ambient`` scalar).  Renders 256x256 rays, then the SR stage (csrc/superres.hip) -> 512x512."""
 
     def __init__(self, hparams):
         super().__init__(hparams)
         from .superres import Superresolution
         self.sr_net = Superresolution(channels=3)
         self.lambda_ambient = nn.Parameter(torch.tensor([1.0]), requires_grad=False)
+
+    # -- training-stage switches (radnerf_sr.py:116-122) ----------------------------------------------------------------------------------
+    def on_train_nerf(self):
+        self.requires_grad_(True)
+        self.sr_net.requires_grad_(False)
+
+    def on_train_superresolution(self):
+        self.requires_grad_(False)
+        self.sr_net.requires_grad_(True)
 
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                max_steps=1024, T_thresh=1e-4, cond_mask=None, eye_area_percent=None, **kwargs):
@@ -302,5 +336,6 @@ class RADNeRFwithSR(RADNeRF):
         rgb = res["rgb_map"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
         res["rgb_map"] = rgb
         if self.sr_net.ready:
-            res["sr_rgb_map"] = self.sr_net(rgb.clone()).clamp(0, 1)
+            # the reference always renders with the layers' default noise ('random', radnerf_sr.py:30-43); `sr_noise_mode` is our test hook
+            res["sr_rgb_map"] = self.sr_net(rgb.clone(), noise_mode=kwargs.get("sr_noise_mode", "random")).clamp(0, 1)
         return res

@@ -91,6 +91,14 @@ def _mlp(sd, rng, prefix, dim_in, dim_out, dim_hidden, num_layers, gain=1.0):
         sd[f"{prefix}.net.{l}.weight"] = (_linear(rng, o, i, False)[0] * f32(gain)).astype(f32)
 
 
+def cond_input_dim(hp):
+    """radnerf.py:17-32: 44 (esperanto) / 29 (deepspeech) audio features, or 3-D landmarks (68 / 131 / 468 points)."""
+    ct = hp.get("cond_type", "idexp_lm3d_normalized")
+    if ct in ("esperanto", "deepspeech"):
+        return {"esperanto": 44, "deepspeech": 29}[ct]
+    return {"lm68": 68 * 3, "lm131": 131 * 3, "lm468": 468 * 3}[hp.get("nerf_keypoint_mode", "lm68")]
+
+
 def synthetic_state_dict(hp=None, variant="may_torso", seed=9999, table_scale=1.0, sigma_gain=6.0,
                          ellipsoid=(0.30, 0.22, 0.35), gains=None, table_decay=1.0):
     """Random-init parameters + buffers with the reference's key names / shapes / dtypes.
@@ -130,7 +138,7 @@ def synthetic_state_dict(hp=None, variant="may_torso", seed=9999, table_scale=1.
     sd["step_counter"] = np.zeros((16, 2), np.int32)
 
     # conditioning nets (cond_encoder.py:98-180)
-    cond_in = {"lm68": 68 * 3, "lm131": 131 * 3, "lm468": 468 * 3}[hp.get("nerf_keypoint_mode", "lm68")]
+    cond_in = cond_input_dim(hp)
     cond_out = hp["cond_out_dim"] // 2 * 2
     for i, (o, c) in zip((0, 2, 4, 6), ((32, cond_in), (32, 32), (64, 32), (64, 64))):
         sd[f"cond_prenet.encoder_conv.{i}.weight"], sd[f"cond_prenet.encoder_conv.{i}.bias"] = _conv(rng, o, c, 3)
@@ -207,10 +215,10 @@ def synthetic_pose(frame_idx=0, max_yaw_deg=5.0, distance=4.0, seed=0):
 
 
 def synthetic_frame_inputs(hp, frame_idx=0, seed=0):
-    """cond window [smo,1,204], lm68 [136], eye_area_percent [1,1] for one frame."""
+    """cond window [smo, cond_win_size, cond_in] ([smo,1,204] for the lm3d configs), lm68 [136], eye_area_percent [1,1] for one frame."""
     rng = np.random.default_rng((seed + 1) * 100003 + frame_idx)
-    cond_in = {"lm68": 68 * 3, "lm131": 131 * 3, "lm468": 468 * 3}[hp.get("nerf_keypoint_mode", "lm68")]
-    cond = np.clip(rng.standard_normal((hp["smo_win_size"], 1, cond_in)), -1.5, 1.5).astype(f32)
+    cond_in = cond_input_dim(hp)
+    cond = np.clip(rng.standard_normal((hp["smo_win_size"], hp.get("cond_win_size", 1), cond_in)), -1.5, 1.5).astype(f32)
     lm68 = rng.uniform(0.3, 0.7, (136,)).astype(f32)
     eye = np.array([[0.3]], f32)
     return {"cond": cond, "lm68": lm68, "eye_area_percent": eye}

@@ -343,6 +343,18 @@ int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *
 int gfpp_head_frame_finish(const gfpp_frame_ws *ws, const float *bg_color, float bg_scalar, float *out_image, float *out_depth,
                            gfpp_stream_t stream);
 
+/* Per-sample evaluation of the radiance field = RADNeRF.forward (modules/radnerfs/radnerf.py:108-141) on a caller-supplied
+ * sample list, run by the SAME device code as the trip kernels (evaluate_block / evaluate_block_lp): this is the hook the per-sample
+ * parity tests use (and what RADNeRF.forward()/density() call at inference).  The per-frame constants must have been folded into
+ * ws->frame_consts first (gfpp_head_frame_fold: cond_feat and the individual code).  positions [M,3] in [-bound, bound] (outside
+ * => zero grid features, grid.py:152 + gridencoder.cu:110-135), directions [M,3] unit vectors.
+ * Out: sigma [M] (= exp(h0), utils.py:36-49 forward; NOT multiplied by density_scale, like RADNeRF.forward), color [M,3] (sigmoid), ambient [M, amb_D] (tanh; may be NULL).
+ * `_lp`: 16-bit MFMA operands per model->lp_dtype (fp32 accumulate); the other entry is the exact-fp32 path. */
+int gfpp_head_eval_samples(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *positions, const float *directions,
+                           uint32_t M, float *sigma, float *color, float *ambient, gfpp_stream_t stream);
+int gfpp_head_eval_samples_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *positions, const float *directions,
+                              uint32_t M, float *sigma, float *color, float *ambient, gfpp_stream_t stream);
+
 /* Torso field + final compositing.  Weight matrices are stored K-MAJOR ([in][out], i.e. nn.Linear.weight transposed) so
  * that one input feeds a contiguous row of outputs; the *_c blocks (columns multiplying per-frame constants) stay row-major
  * [out][const_dim] and are folded into biases on the device at the start of every launch.

@@ -6,12 +6,16 @@ import torch
 from genefaceplusplus_amd import synthetic as syn
 from genefaceplusplus_amd.configs import may_hparams
 
-CLASSES = {"may_head": "RADNeRF", "may_torso": "RADNeRFTorso", "may_torso_sr": "RADNeRFTorsowithSR"}
+CLASSES = {"may_head": "RADNeRF", "may_torso": "RADNeRFTorso", "may_torso_sr": "RADNeRFTorsowithSR", "may_head_sr": "RADNeRFwithSR",
+           "audio_head": "RADNeRF", "audio_torso": "RADNeRFTorso"}
+# the state-dict family a variant's parameters follow (synthetic_state_dict's own variant switch)
+SD_FAMILY = {"audio_head": "may_head", "audio_torso": "may_torso"}
 
 
-def frame_case(variant, HW, frame_idx=0, **sd_kw):
+def frame_case(variant, HW, frame_idx=0, hp_over=None, **sd_kw):
     hp = may_hparams(variant)
-    sd = syn.synthetic_state_dict(hp, variant, **sd_kw)
+    hp.update(hp_over or {})
+    sd = syn.synthetic_state_dict(hp, SD_FAMILY.get(variant, variant), **sd_kw)
     fi = syn.synthetic_frame_inputs(hp, frame_idx)
     pose = syn.synthetic_pose(frame_idx)[None]
     return {"variant": variant, "hp": hp, "sd": sd, "HW": HW, "pose": pose, "intr": syn.intrinsics_for(HW, HW), **fi,
@@ -23,7 +27,7 @@ def oracle_render(orc, case, trace=None):
     rays = orc.get_rays(case["pose"], case["intr"], HW, HW)
     kw = dict(bg_color=case["bg_color"], dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=case["T_thresh"],
               eye_area_percent=case["eye_area_percent"], trace=trace)
-    if case["variant"] == "may_head":
+    if case["variant"] in ("may_head", "may_head_sr", "audio_head"):
         return orc.render_head(rays["rays_o"], rays["rays_d"], case["cond"], sd, hp, **kw)
     return orc.render_torso(rays["rays_o"], rays["rays_d"], case["cond"], orc.get_bg_coords(HW, HW), orc.convert_poses(case["pose"]),
                             sd, hp, lm68=case["lm68"], sr_variant=(case["variant"] == "may_torso_sr"), **kw)
@@ -64,7 +68,7 @@ def compare_frames(res, ref, variant, HW, rgb_tol=2e-4, depth_tol=1e-3, frac=5e-
     """SURVEY 8c tolerance: max-abs <= 2e-4 on rgb / 1e-3 on depth, allowing <= 0.05 % of pixels to exceed (rays whose
     transmittance crosses T_thresh within rounding)."""
     rgb = res["rgb_map"].float().cpu().numpy()
-    if variant == "may_torso_sr":
+    if variant in ("may_torso_sr", "may_head_sr"):
         rgb = np.transpose(rgb, (0, 2, 3, 1))
     rgb = rgb.reshape(-1, 3)
     err = np.abs(rgb - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
@@ -76,9 +80,16 @@ def compare_frames(res, ref, variant, HW, rgb_tol=2e-4, depth_tol=1e-3, frac=5e-
     derr = np.abs(d[ok] - dref[ok])
     stats["depth_frac_over"] = float((derr > depth_tol).mean())
     assert stats["depth_frac_over"] <= frac, stats
-    if variant != "may_head":
+    if "torso_alpha_map" in ref:
         ta = res["torso_alpha_map"].float().cpu().numpy().reshape(-1)
         taerr = np.abs(ta - ref["torso_alpha_map"].reshape(-1))
         stats["alpha_max"] = float(taerr.max())
         assert (taerr > rgb_tol).mean() <= frac, stats
+        # the torso field per pixel: composited torso colour (rgb * alpha + bg * (1 - alpha)), one torso sample per pixel
+        tb = res["torso_rgb_map"].float().cpu().numpy()
+        if variant == "may_torso_sr":
+            tb = np.transpose(tb, (0, 2, 3, 1))
+        tberr = np.abs(tb.reshape(-1, 3) - ref["torso_rgb_map"].reshape(-1, 3)).max(axis=1)
+        stats["torso_rgb_max"] = float(tberr.max())
+        assert (tberr > rgb_tol).mean() <= frac, stats
     return stats

@@ -1,0 +1,60 @@
+"""The N>1 path on real devices.  (1) RCCL, one rank per GPU (skipped on a 1-GPU box): the distributed clip equals the single-GPU clip byte
+for byte, through both exchange steps (all_gather / gather-to-writer).  (2) bench.py's own N=2 control flow on ONE GPU over gloo (two ranks
+sharing cuda:0): the JSON contract of a multi-rank run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(n, script_args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL); the driver's multi-GPU node runs it")
+def test_rccl_distributed_clip_equals_single_gpu_clip():
+    n = min(torch.cuda.device_count(), 4)
+    r = _torchrun(n, [os.path.join(ROOT, "tests", "dist_gpu_worker.py")])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    results = [json.loads(line.split("DISTRESULT ", 1)[1]) for line in r.stdout.splitlines() if "DISTRESULT " in line]
+    assert sorted(x["rank"] for x in results) == list(range(n))
+    for x in results:
+        assert x["world_seen"] == n and x["backend"] == "nccl" and x["replicas_agree"]
+        assert x["all_equal_False"] and x["all_equal_True"] and x["writer_equal_False"] and x["writer_equal_True"], x
+
+
+@pytest.mark.parametrize("gather", ["all", "writer"])
+def test_bench_two_ranks_on_one_gpu_gloo(gather):
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--gather", gather,
+                      "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
+
+
+def test_bench_identities_one_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--identities", "2", "--steps", "4", "--warmup", "2", "--hw", "128"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["config"]["identities"] == 2 and d["config"]["frames_total"] == 8 and d["value"] > 0

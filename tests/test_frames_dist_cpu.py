@@ -48,6 +48,10 @@ def _worker(rank, world, port, n_frames, inter, q):
     local = torch.stack([torch.full((4, 4, 3), i % 256, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
     clip = frames.gather_clip(local, n_frames, inter)
     ok = clip.shape == (n_frames, 4, 4, 3) and all(int(clip[i, 0, 0, 0]) == i % 256 for i in range(n_frames))
+    # gather-to-writer: only rank `dst` receives (the reference has a single video writer), byte-identical to the all_gather result
+    for dst in range(world):
+        w = frames.gather_clip(local, n_frames, inter, dst=dst)
+        ok = ok and ((w is None) if rank != dst else bool(torch.equal(w, clip)))
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -96,6 +100,8 @@ def _identity_worker(rank, world, port, n_ident, n_frames, q):
     local = torch.stack([torch.full((2, 2, 3), 16 * ident + i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 2, 2, 3, dtype=torch.uint8)
     clip = frames.gather_identity_clip(local, n_frames, group)
     clip_ok = clip.shape[0] == n_frames and all(int(clip[i, 0, 0, 0]) == 16 * ident + i for i in range(n_frames))
+    w = frames.gather_identity_clip(local, n_frames, group, dst=0)          # the block's rank 0 writes this identity's video
+    clip_ok = clip_ok and ((w is None) if local_rank != 0 else bool(torch.equal(w, clip)))
     q.put((rank, ident, shared_ok, bool(clip_ok)))
     dist.barrier()
     dist.destroy_process_group()

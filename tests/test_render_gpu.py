@@ -224,3 +224,103 @@ def test_full_size_frame_matches_oracle(dev, oracle_mod):
             compare_frames(res, ref, "may_torso", 512)
         else:
             assert _psnr(_rgb(res), rref) >= 45.0
+
+
+# ---- every kernel instantiation the library ships, at frame level -----------------------------------------------------
+FRAME_INSTANCES = [
+    ("hashgrid", "may_torso", 64, {"grid_type": "hashgrid"}),                        # k_head_trip_lp<3,*,SLOW=true>, generic lookup in fp32 kernels
+    ("smoothstep", "may_head", 64, {"grid_interpolation_type": "smoothstep"}),
+    ("bound2_cascade2", "may_head", 64, {"bound": 2}),                               # mip_from_pos / mip_from_dt (raymarching.cu:42-54), 2-level bitfield
+    ("audio_amb2_win16", "audio_head", 64, {}),                                      # ambient D = 2, AudioNet strides 2,2,2,2 on a 16-frame window, smo 8
+    ("audio_torso", "audio_torso", 64, {}),
+    ("audio_hash_smooth", "audio_head", 48, {"grid_type": "hashgrid", "grid_interpolation_type": "smoothstep"}),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("tag,variant,HW,over", FRAME_INSTANCES, ids=[i[0] for i in FRAME_INSTANCES])
+def test_frame_instantiations_match_oracle(dev, oracle_mod, tag, variant, HW, over, precision):
+    case = frame_case(variant, HW, hp_over=over)
+    ref = oracle_render(oracle_mod, case)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)          # a silent fall-back to the staged executor would be a test failure
+        res = product_render(model, case, dev, "oracle", oracle_mod)
+    assert model.pipeline().precision == precision
+    if precision == "fp32":
+        stats = compare_frames(res, ref, variant, HW)
+    else:
+        rgb = res["rgb_map"].float().cpu().numpy().reshape(-1, 3)
+        rref = ref["rgb_map"].reshape(-1, 3)
+        err = np.abs(rgb - rref).max(axis=1)
+        tol = {"fp16": 2e-2, "bf16": 5e-2}[precision]
+        stats = {"psnr": _psnr(rgb, rref), "rgb_max": float(err.max()), "frac_over_tol": float((err > tol).mean())}
+        assert stats["psnr"] >= 45.0 and stats["frac_over_tol"] <= 1e-3, stats
+    print(tag, precision, stats)
+
+
+def test_audio_cond_kernel_matches_oracle_and_torch(dev, oracle_mod):
+    """gfpp_cond_feat with t_win = 16 (strided convolutions, all three taps live) and smo = 8."""
+    case = frame_case("audio_head", 64)
+    model = build_model(case, dev, "fused")
+    cond = torch.from_numpy(case["cond"]).to(dev)
+    assert tuple(cond.shape) == (8, 16, 44)
+    ref = oracle_mod.cal_cond_feat(case["cond"], case["sd"], case["hp"], None)
+    with torch.no_grad():
+        got = model.cal_cond_feat(cond)
+        model.executor = "staged"
+        tp = model.cal_cond_feat(cond)
+    np.testing.assert_allclose(got.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), tp.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_head_only_sr_model_renders(dev, oracle_mod, precision):
+    """RADNeRFwithSR (radnerf_sr.py:45-210): 256^2 head rays + the SR stage -> rgb_map [1,3,256,256], sr_rgb_map [1,3,512,512]."""
+    from oracle import sr_oracle
+    from genefaceplusplus_amd import synthetic as syn
+    case = frame_case("may_head_sr", 256)
+    ref = oracle_render(oracle_mod, case)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    case2 = dict(case)
+    case2["hp"] = dict(case["hp"], sr_noise_mode="const")
+    with torch.no_grad():
+        res = product_render(model, case2, dev, "oracle", oracle_mod)
+    assert res["rgb_map"].shape == (1, 3, 256, 256) and res["sr_rgb_map"].shape == (1, 3, 512, 512)
+    rgb = np.transpose(res["rgb_map"].float().cpu().numpy(), (0, 2, 3, 1)).reshape(-1, 3)
+    rref = ref["rgb_map"].reshape(-1, 3)
+    if precision == "fp32":
+        err = np.abs(rgb - rref).max(axis=1)
+        assert (err > 2e-4).mean() <= 5e-4, float(err.max())
+    else:
+        assert _psnr(rgb, rref) >= 45.0
+    sr_ref = np.clip(sr_oracle.superresolution(np.transpose(rref.reshape(1, 256, 256, 3), (0, 3, 1, 2)), syn.synthetic_sr_state(), prefix="sr_net.",
+                                                noise_mode="const"), 0, 1)
+    sr = res["sr_rgb_map"].float().cpu().numpy()
+    psnr = _psnr(sr, sr_ref)
+    print("head-only SR", precision, "psnr", psnr)
+    assert psnr >= 40.0
+
+
+def test_fallback_to_staged_warns_once(dev, oracle_mod):
+    """perturb=True is outside the fused path: render() must still work (staged executor) and say so."""
+    from genefaceplusplus_amd.radnerfs.head import NeRFRenderer
+    case = frame_case("may_head", 32)
+    model = build_model(case, dev, "fused")
+    NeRFRenderer._warned.discard("perturb=True")
+    from genefaceplusplus_amd.radnerfs import camera
+    r = oracle_mod.get_rays(case["pose"], case["intr"], 32, 32)
+    args = (torch.from_numpy(r["rays_o"]).to(dev), torch.from_numpy(r["rays_d"]).to(dev), torch.from_numpy(case["cond"]).to(dev),
+            camera.get_bg_coords(32, 32, dev), camera.convert_poses(torch.from_numpy(case["pose"]).to(dev)))
+    with pytest.warns(RuntimeWarning, match="staged executor"):
+        with torch.no_grad():
+            out = model.render(*args, perturb=True, max_steps=16, T_thresh=0.01, dt_gamma=1 / 256)
+    assert out["rgb_map"].shape == (1, 32 * 32, 3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        with torch.no_grad():
+            model.render(*args, perturb=True, max_steps=16, T_thresh=0.01, dt_gamma=1 / 256)       # second time: silent
