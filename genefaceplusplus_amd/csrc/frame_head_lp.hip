@@ -166,32 +166,44 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
     }
     const bool smooth = g.interp == 1, ac = g.align_corners != 0;
     float f[16];
+    if constexpr (SLOW) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float o[2];
-        if constexpr (SLOW) {
+        for (int i = 0; i < 8; ++i) {
             // hash-addressed (or true-modulo) levels present: the generic lookup (separate kernel instantiation)
+            float o[2];
             const gfpp_grid_level lv = g.levels[2 * i + hi];
             grid_level_lookup<D, 2, float>(uc, g.table, lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
-        } else {
+            f[2 * i] = ok ? o[0] : 0.0f;
+            f[2 * i + 1] = ok ? o[1] : 0.0f;
+        }
+    } else {
+        // all eight descriptors of this half-wave first (LDS, two distinct addresses per wavefront), then the straight-line lookups: left to the
+        // compiler the descriptor of level i is read right before its use, one exposed LDS round trip per level in front of the gathers
+        LevelU lvs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
 #if GFPP_LP_LDS_LEVELS
-            const gfpp_grid_level &d = lvl[2 * i + hi];   // LDS, two distinct addresses per wavefront
-            const LevelU lv{d.scale, d.sy, d.sz, d.mask, d.offset};
+            const gfpp_grid_level &d = lvl[2 * i + hi];
+            lvs[i] = LevelU{d.scale, d.sy, d.sz, d.mask, d.offset};
 #else
             // both descriptors of the iteration with one scalar load (uniform address, constant address space), selected per lane
             typedef const __attribute__((address_space(4))) gfpp_grid_level *LevelsK;
             const LevelsK lk = (LevelsK)lvl;
-            LevelU lv;
-            lv.scale = hi ? lk[2 * i + 1].scale : lk[2 * i].scale;
-            lv.sy = hi ? lk[2 * i + 1].sy : lk[2 * i].sy;
-            lv.sz = hi ? lk[2 * i + 1].sz : lk[2 * i].sz;
-            lv.mask = hi ? lk[2 * i + 1].mask : lk[2 * i].mask;
-            lv.offset = hi ? lk[2 * i + 1].offset : lk[2 * i].offset;
+            lvs[i].scale = hi ? lk[2 * i + 1].scale : lk[2 * i].scale;
+            lvs[i].sy = hi ? lk[2 * i + 1].sy : lk[2 * i].sy;
+            lvs[i].sz = hi ? lk[2 * i + 1].sz : lk[2 * i].sz;
+            lvs[i].mask = hi ? lk[2 * i + 1].mask : lk[2 * i].mask;
+            lvs[i].offset = hi ? lk[2 * i + 1].offset : lk[2 * i].offset;
 #endif
-            level_fast_uniform<D>(uc, g.table, lv, ac, smooth, o);
         }
-        f[2 * i] = ok ? o[0] : 0.0f;
-        f[2 * i + 1] = ok ? o[1] : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float o[2];
+            level_fast_uniform<D>(uc, g.table, lvs[i], ac, smooth, o);
+            f[2 * i] = ok ? o[0] : 0.0f;
+            f[2 * i + 1] = ok ? o[1] : 0.0f;
+        }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -262,10 +274,10 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 }
 
 // RADNeRF.forward for the 32 occupied samples [first, first+32) of this wavefront's tile.
-template <int AMB_D, typename H, bool SLOW, bool DBG = false>
+template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool PROF = false>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, uint32_t first, uint32_t n_valid,
                                                   uint32_t n_step, int lane_in, unsigned long long (&sub)[4]) {
-    const bool prof = a.phase_cycles != nullptr;
+    constexpr bool prof = PROF;      // the phase counters are a separate kernel instantiation: no registers, scratch or s_memtime in the production kernel
     unsigned long long tm = prof ? __builtin_readcyclecounter() : 0ull;
     auto lap = [&](int k) {
         if (prof) {
@@ -362,12 +374,12 @@ __device__ __forceinline__ void lp_fill_shared(LpShared &sh, const LpTripArgs &a
 // One launch runs the trips [a.trip, a.trip_end) (renderer.py:352-384: one loop iteration each).  The host issues the first few trips as
 // separate launches (no barrier needed: the stream orders them) and the rest -- which most frames never reach -- as ONE launch that
 // finds its first counter at zero and returns, instead of ten empty launches.
-template <int AMB_D, typename H, bool SLOW>
+template <int AMB_D, typename H, bool SLOW, bool PROF = false>
 __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(LpTripArgs a) {
     __shared__ LpShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t waves_total = gridDim.x * kLpWaves;
-    const bool prof = a.phase_cycles != nullptr;
+    constexpr bool prof = PROF;
     bool weights_resident = false;
     uint32_t barriers = 0;
     // ---- loop state up to the first trip of this launch (renderer.py:354-384) ------------------------------------------------------
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         lap(1);
 
         // ---- phase 2: evaluate the radiance field on the occupied samples, 32 per pass --------------------------------
-        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW>(a, sh, wt, first, n_valid, n_step, lane, sub);
+        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW, false, PROF>(a, sh, wt, first, n_valid, n_step, lane, sub);
         evaluated += n_valid;
         wave_sync();
         lap(2);
@@ -583,7 +595,8 @@ static void launch_eval_lp(uint32_t grid, hipStream_t st, const LpEvalArgs &e) {
 
 template <int AMB_D, typename H, bool SLOW>
 static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
-    hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
 }
 
 static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {

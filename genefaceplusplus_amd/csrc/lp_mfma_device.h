@@ -103,6 +103,13 @@ __device__ __forceinline__ void act_pack(const v16f (&acc)[T], typename LpTraits
     }
 }
 
+// Sum of the two half-waves' values, in every lane: v_permlane32_swap exchanges lanes 32..63 of one register with lanes 0..31 of another
+// (gfx950), no LDS round trip like ds_bpermute (__shfl_xor).  a = b = t  ->  a = {t_lo, t_lo}, b = {t_hi, t_hi}.
+__device__ __forceinline__ float half_wave_sum(float t) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Skinny output rows on packed 16-bit dot products: out[c] = sum over this lane's 8 NV activations (operand registers b) of w * x,
 // fp32 accumulation (v_dot2c_f32_{f16,bf16}); the two half-waves are added.  `wrow`: LDS, rows of 4 NV 32-bit words, row index
 // hi * rows_per_half + c.  (Operand pairs are taken with shufflevector: bit-casting vector ELEMENTS to pairs is miscompiled by
@@ -111,20 +118,32 @@ template <int C, int NV, typename H>
 __device__ __forceinline__ void skinny_dot(const uint32_t *__restrict__ wrow, int rows_per_half, const typename LpTraits<H>::vec (&b)[NV], int hi,
                                            float (&out)[C]) {
     typedef typename LpTraits<H>::vec vec;
+    // The weights of a row are NV 16-byte LDS reads (two distinct addresses per wavefront).  All reads of a row are issued together and the
+    // next row's are in flight while this row's dot products run (the sched_barriers pin that order: left alone, the compiler issues
+    // read - wait - 4 dot2 - read - wait ..., i.e. NV x C exposed LDS round trips per block).
+    vec w[2][NV];
+    const vec *p0 = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half) * 4 * NV);
+#pragma unroll
+    for (int s = 0; s < NV; ++s) w[0][s] = p0[s];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const vec *p = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half + c) * 4 * NV);
+        if (c + 1 < C) {
+            const vec *p = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half + c + 1) * 4 * NV);
+#pragma unroll
+            for (int s = 0; s < NV; ++s) w[(c + 1) & 1][s] = p[s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
-            const vec w = p[s], x = b[s];
-            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), s0);
-            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), s1);
-            s0 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), s0);
-            s1 = LpTraits<H>::dot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), s1);
+            const vec ww = w[c & 1][s], x = b[s];
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(ww, ww, 0, 1), __builtin_shufflevector(x, x, 0, 1), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(ww, ww, 2, 3), __builtin_shufflevector(x, x, 2, 3), s1);
+            s0 = LpTraits<H>::dot2(__builtin_shufflevector(ww, ww, 4, 5), __builtin_shufflevector(x, x, 4, 5), s0);
+            s1 = LpTraits<H>::dot2(__builtin_shufflevector(ww, ww, 6, 7), __builtin_shufflevector(x, x, 6, 7), s1);
         }
-        const float t = s0 + s1;
-        out[c] = t + __shfl_xor(t, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        out[c] = half_wave_sum(s0 + s1);
     }
 }
 
