@@ -26,6 +26,18 @@
 #ifndef GFPP_LP_LDS_LEVELS
 #define GFPP_LP_LDS_LEVELS 1   // level descriptors: 0 = scalar loads + per-lane select, 1 = per-lane LDS reads
 #endif
+// Experiment builds only (tools/eval_bench.py; results are WRONG with any bit set): what a block's time is made of.
+//   1 = table gathers replaced by register values, 2 = wide MFMA layers (and their LDS reads) skipped, 4 = skinny rows + transcendentals skipped
+#ifndef GFPP_ABLATE
+#define GFPP_ABLATE 0
+#endif
+#if GFPP_ABLATE & 4
+#define GFPP_TANH(x) (x)
+#define GFPP_EXP(x) (x)
+#else
+#define GFPP_TANH(x) tanhf(x)
+#define GFPP_EXP(x) expf(x)
+#endif
 
 namespace gfpp {
 
@@ -91,6 +103,23 @@ struct LpTripArgs {
 
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
+#if GFPP_ABLATE & 2
+    for (int s = 0; s < NS; ++s) acc[s & 3][s & 15] += (float)b[s][0];
+    return;
+#endif
+#if GFPP_ABLATE & 8      // MFMAs kept, A operands from registers instead of the LDS stream
+    for (int s = 0; s < NS; ++s)
+        for (int t = 0; t < 4; ++t) acc[t] = LpTraits<H>::mfma(b[(s + t) % NS], b[s], acc[t]);
+    return;
+#endif
+#if GFPP_ABLATE & 16     // LDS stream kept, MFMAs replaced by one VALU op per fragment
+    {
+        const typename LpTraits<H>::vec *p = reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256 + lane;
+        for (int s = 0; s < NS; ++s)
+            for (int t = 0; t < 4; ++t) acc[t][s & 15] += (float)p[(s * 4 + t) * 64][t] * (float)b[s][0];
+        return;
+    }
+#endif
     mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);
 }
 
@@ -123,7 +152,9 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
         if (smooth) f = f * f * fmaf(-2.0f, f, 3.0f);
         frac[d] = f;
     }
-    const float *lt = table + 2ull * lv.offset;
+    // byte offsets in 32 bits against the wave-uniform table pointer (global_load with an SGPR base): one v_add_lshl_u32 per gather instead of a
+    // 64-bit per-lane address; the padded tables are far below 4 GiB
+    const char *lt = reinterpret_cast<const char *>(table);
     const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
     uint32_t z0 = 0, z1 = 0;
     if constexpr (D == 3) { z0 = __umul24(base[2], lv.sz); z1 = z0 + lv.sz; }
@@ -136,7 +167,12 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
         uint32_t row = base[0] + ((pair & 1) ? y1 : y0);
         if constexpr (D == 3) row += (pair & 2) ? z1 : z0;   // sz == 0 (z dropped by the tiled index): the same rows again, an L1 hit
         row &= lv.mask;
-        v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * row);
+#if GFPP_ABLATE & 1
+        v[pair] = f32x4_a8{frac[0], __uint_as_float(row), frac[1], lv.scale};
+        (void)lt;
+#else
+        v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
+#endif
     }
 #pragma unroll
     for (int pair = 0; pair < kPairs; ++pair) {
@@ -201,18 +237,30 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         for (int i = 0; i < 8; ++i) {
             float o[2];
             level_fast_uniform<D>(uc, g.table, lvs[i], ac, smooth, o);
-            f[2 * i] = ok ? o[0] : 0.0f;
-            f[2 * i + 1] = ok ? o[1] : 0.0f;
+            f[2 * i] = o[0];
+            f[2 * i + 1] = o[1];
         }
     }
+    // out-of-range / padding samples get zero features (gridencoder.cu:110-135): selected on the 8 packed operand words, not on the 16 floats
+    // (the hash / true-modulo path above already zeroed its own)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) b[s][e] = (H)f[8 * s + e];
+        if constexpr (!SLOW) {
+            const u32x4 w = __builtin_bit_cast(u32x4, b[s]);
+            b[s] = __builtin_bit_cast(typename LpTraits<H>::vec, ok ? w : u32x4{0u, 0u, 0u, 0u});
+        }
+    }
 }
 
 template <int C, typename H>
 __device__ __forceinline__ void skinny_rows(const uint32_t *__restrict__ wrow, const typename LpTraits<H>::vec (&b)[8], int hi, float (&out)[C]) {
+#if GFPP_ABLATE & 4
+    for (int c = 0; c < C; ++c) out[c] = (float)b[c][0];
+    return;
+#endif
     skinny_dot<C, 8, H>(wrow, kSkinnyRows, b, hi, out);
 }
 
@@ -249,7 +297,7 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     relu_pack<H>(acc, bh);   // the hidden state feeds both the density row and the (merged) colour layer
     float logit[1];
     skinny_rows<1, H>(sh.skinny + 3 * 32, bh, hi, logit);
-    const float sigma = a.density_scale * expf(logit[0]);
+    const float sigma = a.density_scale * GFPP_EXP(logit[0]);
     {
         vec bcol[9];
         float shv[16];
@@ -267,9 +315,9 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     skinny_rows<3, H>(sh.skinny + 4 * 32, bh, hi, rgb);
     if (valid && hi == 0) {
         wt.px[slot] = sigma;
-        wt.py[slot] = 1.0f / (1.0f + expf(-rgb[0]));
-        wt.pz[slot] = 1.0f / (1.0f + expf(-rgb[1]));
-        wt.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
+        wt.py[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[0]));
+        wt.pz[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[1]));
+        wt.cb[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[2]));
     }
 }
 
@@ -318,7 +366,7 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         lap(1);
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) {
-            const float th = tanhf(amb[d]);
+            const float th = GFPP_TANH(amb[d]);
             if constexpr (DBG) { if (a.dbg_ambient && valid && hi == 0) a.dbg_ambient[(size_t)c * AMB_D + d] = th; }
             ua[d] = (th + 1.0f) / 2.0f;
         }
@@ -552,6 +600,7 @@ struct LpEvalArgs {
     const float *positions;
     float *sigma, *color, *ambient;
     uint32_t M;
+    uint32_t waves;   // wavefronts per workgroup that take samples (8; fewer only in occupancy experiments, GFPP_EVAL_WAVES)
 };
 
 template <int AMB_D, typename H, bool SLOW>
@@ -562,7 +611,9 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_eval_lp(L
     __syncthreads();
     LpWaveTile &wt = sh.tile[wave];
     unsigned long long sub[4] = {0ull, 0ull, 0ull, 0ull};
-    for (uint32_t base = (blockIdx.x * kLpWaves + wave) * 32u; base < e.M; base += gridDim.x * kLpWaves * 32u) {
+    if ((uint32_t)wave >= e.waves) return;
+    // experiment order (waves < 8): wave w of the workgroup sits on SIMD w % 4, so waves 0..3 are one per SIMD
+    for (uint32_t base = (blockIdx.x * e.waves + wave) * 32u; base < e.M; base += gridDim.x * e.waves * 32u) {
         const uint32_t idx = base + (uint32_t)j;
         const bool ok = idx < e.M;
         if (lane < 32) {
@@ -736,6 +787,9 @@ GFPP_API int gfpp_head_eval_samples_lp(const gfpp_head_model *model, const gfpp_
     uint32_t grid = div_up(M, 32u * kLpWaves);
     const uint32_t cus = (uint32_t)lp_cu_count();
     if (grid > cus) grid = cus;
+    e.waves = kLpWaves;
+    if (const char *g = getenv("GFPP_EVAL_GRID")) { const int v = atoi(g); if (v > 0 && (uint32_t)v < grid) grid = (uint32_t)v; }     // occupancy experiments (tools/eval_bench.py)
+    if (const char *w = getenv("GFPP_EVAL_WAVES")) { const int v = atoi(w); if (v > 0 && v < kLpWaves) e.waves = (uint32_t)v; }
     const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
     void (*launch)(uint32_t, hipStream_t, const LpEvalArgs &) =
         amb3 ? (bf ? (slow ? launch_eval_lp<3, __bf16, true> : launch_eval_lp<3, __bf16, false>) : (slow ? launch_eval_lp<3, _Float16, true> : launch_eval_lp<3, _Float16, false>))
