@@ -271,7 +271,7 @@ def main():
     total = K + W
     my_frames = frames.shard_frames(total * world, rank, world, interleaved=True)
     intr = syn.intrinsics_for(HW, HW)
-    bg_coords = camera.get_bg_coords(HW, HW, dev)
+    bg_coords = camera.get_bg_coords(HW, HW, "cpu").to(dev)          # host-computed like the reference dataset (dataset_utils.py:240)
     bg_color = torch.full((1, N, 3), 0.5, device=dev)
     fi_all = [syn.synthetic_frame_inputs(hp, fidx) for fidx in my_frames]
     batch = {"ngp_poses": np.stack([syn.synthetic_pose(fidx) for fidx in my_frames]).astype(np.float32),

@@ -48,7 +48,9 @@ class ClipRenderer:
                 raise GfppError(f"ClipRenderer: the super-resolution models render {model.sr_net.input_resolution}^2 rays")
             scale = 2                                   # Superresolution: 256 -> 512 (radnerf_sr.py:14-43)
         self.out_hw = (H * scale, W * scale)
-        self.bg_coords = camera.get_bg_coords(H, W, dev)
+        # computed on the host like the reference's dataset does (dataset_utils.py:240, `.cuda()` afterwards): the GPU's division by a host scalar is a
+        # multiplication by the reciprocal, 1 ulp away, which the torso field turns into single-LSB differences of the uint8 frame
+        self.bg_coords = camera.get_bg_coords(H, W, "cpu").to(dev)
         self.bg_img = None if bg_img is None else bg_img.to(dev).float().reshape(1, H * W, 3).contiguous()
         fused = getattr(model, "executor", "fused") == "fused"
         if lanes is None:

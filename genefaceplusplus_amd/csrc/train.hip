@@ -21,22 +21,47 @@ __global__ __launch_bounds__(kTrBlock) void k_march_rays_train(const float *__re
                                                               int32_t *__restrict__ rays, int32_t *__restrict__ counter,
                                                               const float *__restrict__ noises) {
     const uint32_t n = blockIdx.x * kTrBlock + threadIdx.x;
-    if (n >= N) return;
-    const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;
-    const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
-    const float far = fars[n];
-    float t0 = nears[n];
-    t0 = fmaf(clampf(t0 * mp.dt_gamma, mp.dt_min, mp.dt_max), noises[n], t0);
-    float t = t0;
-    const uint32_t num_steps = march_one_ray(ox, oy, oz, dx, dy, dz, t, far, max_steps, bitfield, mp, [](uint32_t, const Sample &) {});
-    const uint32_t point_index = (uint32_t)atomicAdd(&counter[0], (int)num_steps);
-    const uint32_t ray_index = (uint32_t)atomicAdd(&counter[1], 1);
+    const int lane = threadIdx.x & 63;
+    const bool active = n < N;             // every lane of a wavefront takes part in the range allocation below
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f, far = 0.0f, t0 = 0.0f;
+    uint32_t num_steps = 0;
+    if (active) {
+        const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;
+        ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+        far = fars[n];
+        t0 = nears[n];
+        t0 = fmaf(clampf(t0 * mp.dt_gamma, mp.dt_min, mp.dt_max), noises[n], t0);
+        float t = t0;
+        num_steps = march_one_ray(ox, oy, oz, dx, dy, dz, t, far, max_steps, bitfield, mp, [](uint32_t, const Sample &) {});
+    }
+    // The reference takes two device atomics per RAY (raymarching.cu:446-447).  Here a wavefront sums its rays' sample counts (shuffle scan) and
+    // takes ONE pair of atomics: its 64 rays get consecutive ray slots and back-to-back sample ranges, which is also what makes the second pass's
+    // writes and the compositor's reads of neighbouring rays land next to each other.  Same contract as the reference: rays[k] = (ray id,
+    // offset, count) in an order that depends on scheduling; a ray whose range would end beyond M keeps its entry and writes nothing.
+    uint32_t incl = num_steps;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63);
+    const unsigned long long act = __ballot(active);
+    uint32_t base_pt = 0, base_ray = 0;
+    if (lane == 0) {
+        base_pt = (uint32_t)atomicAdd(&counter[0], (int)wave_total);
+        base_ray = (uint32_t)atomicAdd(&counter[1], (int)__popcll(act));
+    }
+    base_pt = (uint32_t)__shfl((int)base_pt, 0);
+    base_ray = (uint32_t)__shfl((int)base_ray, 0);
+    if (!active) return;
+    const uint32_t point_index = base_pt + incl - num_steps;
+    const uint32_t ray_index = base_ray + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
     rays[3ull * ray_index] = (int32_t)n;
     rays[3ull * ray_index + 1] = (int32_t)point_index;
     rays[3ull * ray_index + 2] = (int32_t)num_steps;
     if (num_steps == 0 || point_index + num_steps > M) return;
     float *px = xyzs + 3ull * point_index, *pd = dirs + 3ull * point_index, *pt = deltas + 2ull * point_index;
-    t = t0;
+    float t = t0;
     march_one_ray(ox, oy, oz, dx, dy, dz, t, far, num_steps, bitfield, mp, [&](uint32_t s, const Sample &smp) {
         px[3 * s] = smp.x; px[3 * s + 1] = smp.y; px[3 * s + 2] = smp.z;
         pd[3 * s] = dx; pd[3 * s + 1] = dy; pd[3 * s + 2] = dz;
@@ -241,19 +266,21 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_dydx(const float *__restrict_
     }
 }
 
-// table gradient: grad [L, B, C] scattered into grad_table with atomics (gridencoder.cu:247-340)
+// table gradient: grad [L, B, C] scattered into grad_table with atomics (gridencoder.cu:247-340).
+// Two kernels share the levels.  A coarse level is a small table that EVERY point hits (level 0 of the 3-D grid: 4 920 rows for ~10^6 samples x 8
+// corners), so device atomics on it serialise on a few thousand addresses: levels whose table fits the LDS (<= kLdsGradFloats values) are
+// accumulated per workgroup in LDS (ds_add_f32) over a long run of points and flushed with one device atomic per touched value; the fine levels,
+// where collisions are rare, keep the direct scatter.  Which kernel owns a level is decided on the device from offsets[] (both are launched
+// over all levels; the wrong one returns at once).
+constexpr uint32_t kLdsGradFloats = 32768;     // 128 KiB of the CU's 160 KiB
+constexpr uint32_t kLdsGradPoints = 8192;      // points per workgroup of the LDS kernel
+
 template <int D, int C>
-__global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                           const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
-                                                           TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
-    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t level = blockIdx.y;
+__device__ __forceinline__ void grid_backward_point(const float *__restrict__ grad, const float *__restrict__ inputs, uint32_t b, uint32_t B, uint32_t level, float scale,
+                                                    uint32_t size, uint32_t res, uint32_t gridtype, bool align_corners, uint32_t interp, float *gg) {
     float pos[D], deriv[D];
     uint32_t pg[D];
-    if (!tr_locate<D>(inputs + (size_t)b * D, lv.scale[level], align_corners, interp, pos, deriv, pg)) return;
-    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
-    float *gg = grad_table + (size_t)off * C;
+    if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) return;
     float gc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) gc[c] = grad[((size_t)level * B + b) * C + c];
@@ -269,6 +296,40 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restr
         const uint32_t row = grid_row<D>(pl, gridtype, align_corners, size, res);
 #pragma unroll
         for (int c = 0; c < C; ++c) atomicAdd(&gg[(size_t)row * C + c], w * gc[c]);
+    }
+}
+
+template <int D, int C>
+__global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                           const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
+                                                           TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t lds_floats) {
+    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    if (size * C <= lds_floats) return;                        // owned by k_grid_backward_lds
+    grid_backward_point<D, C>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, grad_table + (size_t)off * C);
+}
+
+template <int D, int C>
+__global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                               const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
+                                                               TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    extern __shared__ float acc[];
+    const uint32_t level = blockIdx.y;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    const uint32_t n = size * C;
+    if (n > kLdsGradFloats) return;                            // owned by k_grid_backward
+    for (uint32_t i = threadIdx.x; i < n; i += kTrBlock) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kLdsGradPoints, last = first + kLdsGradPoints < B ? first + kLdsGradPoints : B;
+    for (uint32_t b = first + threadIdx.x; b < last; b += kTrBlock)
+        grid_backward_point<D, C>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, acc);
+    __syncthreads();
+    float *gg = grad_table + (size_t)off * C;
+    for (uint32_t i = threadIdx.x; i < n; i += kTrBlock) {
+        const float v = acc[i];
+        if (v != 0.0f) atomicAdd(&gg[i], v);
     }
 }
 
@@ -423,6 +484,32 @@ GFPP_API int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float r
         else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2, 4 or 8 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; } \
     } while (0)
 
+// the LDS-privatised kernel: a workgroup per kLdsGradPoints points and level, 128 KiB of dynamic LDS (opt-in above the 64 KiB default)
+#define GFPP_LDS_ONE(KERNEL, DD, CC, ...)                                                                                              \
+    do {                                                                                                                                \
+        static bool attr_set_ = false;                                                                                                  \
+        if (!attr_set_) {                                                                                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<DD, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                    (int)(kLdsGradFloats * sizeof(float))) != hipSuccess) {                                             \
+                set_error("grid encoder (training): cannot reserve %u bytes of LDS", (unsigned)(kLdsGradFloats * sizeof(float)));       \
+                return GFPP_EUNSUPPORTED;                                                                                                    \
+            }                                                                                                                           \
+            attr_set_ = true;                                                                                                           \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((KERNEL<DD, CC>), dim3(div_up(B, kLdsGradPoints), L), dim3(kTrBlock), kLdsGradFloats * sizeof(float), st, __VA_ARGS__); \
+    } while (0)
+#define GFPP_DISPATCH_LDS(KERNEL, ...)                                                                                                 \
+    do {                                                                                                                                \
+        if (D == 2 && C == 2) GFPP_LDS_ONE(KERNEL, 2, 2, __VA_ARGS__);                                                                  \
+        else if (D == 3 && C == 2) GFPP_LDS_ONE(KERNEL, 3, 2, __VA_ARGS__);                                                             \
+        else if (D == 2 && C == 1) GFPP_LDS_ONE(KERNEL, 2, 1, __VA_ARGS__);                                                             \
+        else if (D == 3 && C == 1) GFPP_LDS_ONE(KERNEL, 3, 1, __VA_ARGS__);                                                             \
+        else if (D == 2 && C == 4) GFPP_LDS_ONE(KERNEL, 2, 4, __VA_ARGS__);                                                             \
+        else if (D == 3 && C == 4) GFPP_LDS_ONE(KERNEL, 3, 4, __VA_ARGS__);                                                             \
+        else if (D == 2 && C == 8) GFPP_LDS_ONE(KERNEL, 2, 8, __VA_ARGS__);                                                             \
+        else if (D == 3 && C == 8) GFPP_LDS_ONE(KERNEL, 3, 8, __VA_ARGS__);                                                             \
+    } while (0)
+
 GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings, const int32_t *offsets, float *dy_dx, uint32_t B, uint32_t D, uint32_t C,
                                    uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
     if (B == 0) return 0;
@@ -446,8 +533,11 @@ GFPP_API int gfpp_grid_encode_backward(const float *grad, const float *inputs, c
     TrLevels lv;
     if (tr_levels(lv, L, S, H)) { set_error("gfpp_grid_encode_backward: 1 <= L <= 32"); return GFPP_EINVAL; }
     const hipStream_t st = (hipStream_t)stream;
-    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp);
+    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, kLdsGradFloats);
     int rc = check_launch("gfpp_grid_encode_backward(table)");
+    if (rc) return rc;
+    GFPP_DISPATCH_LDS(k_grid_backward_lds, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp);
+    rc = check_launch("gfpp_grid_encode_backward(coarse levels, LDS)");
     if (rc || !dy_dx) return rc;
     hipLaunchKernelGGL(k_grid_input_backward, dim3(div_up(B * D, kTrBlock)), dim3(kTrBlock), 0, st, grad, dy_dx, grad_inputs, B, D, C, L);
     return check_launch("gfpp_grid_encode_backward(inputs)");

@@ -33,7 +33,7 @@ def _reference_shaped_loop(model, case, batch, dev, HW, sr):
         pose = torch.from_numpy(batch["ngp_poses"][i:i + 1]).to(dev)
         rays = camera.get_rays(pose, case["intr"], HW, HW)
         with torch.no_grad():
-            res = model.render(rays["rays_o"], rays["rays_d"], torch.from_numpy(batch["cond_wins"][i]).to(dev), camera.get_bg_coords(HW, HW, dev),
+            res = model.render(rays["rays_o"], rays["rays_d"], torch.from_numpy(batch["cond_wins"][i]).to(dev), camera.get_bg_coords(HW, HW, "cpu").to(dev),
                                camera.convert_poses(pose), index=i, staged=False, bg_color=bg, lm68=torch.from_numpy(batch["lm68"][i]).to(dev),
                                perturb=False, force_all_rays=False, T_thresh=case["T_thresh"],
                                eye_area_percent=torch.from_numpy(batch["eye_area_percent"][i]).to(dev), sr_noise_mode="const", **hp)

@@ -1,0 +1,99 @@
+"""genefaceplusplus_amd.dataset.RADNeRFDataset on a synthetic trainval_dataset.npy (schema of binarizer_nerf.py:197-320): the fields the render path
+eats, against the formulas of tasks/radnerfs/dataset_utils.py:160-296 evaluated independently here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dataset_fixture import write_synthetic_dataset
+from genefaceplusplus_amd.configs import may_hparams
+from genefaceplusplus_amd.dataset import RADNeRFDataset, smooth_camera_path
+
+
+def _hp(variant="may_torso", **over):
+    hp = may_hparams(variant)
+    hp.update({"infer_bg_img_fname": "", "n_rays": 4096, "infer_smooth_camera_path": False, "polygon_face_mask": False, "load_imgs_to_memory": True})
+    hp.update(over)
+    return hp
+
+
+@pytest.fixture(scope="module")
+def npy(tmp_path_factory):
+    p = str(tmp_path_factory.mktemp("ds") / "trainval_dataset.npy")
+    return p, write_synthetic_dataset(p, T=22, H=64, W=64)
+
+
+def test_splits_intrinsics_poses_background(npy, oracle_mod):
+    path, d = npy
+    tr = RADNeRFDataset("train", _hp(), data_dir=path, training=True, device="cpu")
+    va = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device="cpu")
+    both = RADNeRFDataset("trainval", _hp(), data_dir=os.path.dirname(path), training=False, device="cpu")       # a directory works too
+    assert (len(tr), len(va), len(both)) == (20, 2, 22)
+    with pytest.raises(ValueError):
+        RADNeRFDataset("test", _hp(), data_dir=path, device="cpu")
+    # dataset_utils.py:216-230: centre H/2, focal rescaled by (H/2)/cx -> 1015 * 32/112 at 64 px (2320 at 512 px)
+    np.testing.assert_allclose(tr.intrinsics, [1015 * 32 / 112, 1015 * 32 / 112, 32, 32])
+    assert (tr.H, tr.W, tr.near, tr.far) == (64, 64, 0.3, 0.9)
+    for i in (0, 7, 19):
+        want = oracle_mod.nerf_matrix_to_ngp(d["train_samples"][i]["c2w"], scale=4.0, offset=(0, 0, 0))
+        np.testing.assert_array_equal(tr.poses[i].numpy(), want)
+    np.testing.assert_array_equal(va.poses[0].numpy(), oracle_mod.nerf_matrix_to_ngp(d["val_samples"][0]["c2w"], scale=4.0))
+    np.testing.assert_allclose(tr.bg_img.numpy(), d["bg_img"].astype(np.float32) / 255.0, atol=1e-6)      # same size: the antialiased resize is an identity
+    np.testing.assert_allclose(tr.bg_coords.numpy(), oracle_mod.get_bg_coords(64, 64), atol=1e-6)
+    sr = RADNeRFDataset("train", _hp("may_torso_sr"), data_dir=path, device="cpu")
+    assert (sr.H, sr.W) == (32, 32) and sr.bg_img.shape == (32, 32, 3) and sr.bg_img_512.shape == (64, 64, 3)
+    np.testing.assert_allclose(sr.intrinsics, [1015 * 16 / 112, 1015 * 16 / 112, 16, 16])
+    assert sr.lips_rect[0] == [16, 20, 14, 18]
+    assert RADNeRFDataset("train", _hp(infer_bg_img_fname="white"), data_dir=path, device="cpu").bg_img.min() == 1.0
+    assert len(RADNeRFDataset("train", _hp(num_train_samples=5), data_dir=path, device="cpu")) == 5
+
+
+def test_landmark_conditioning_windows(npy, golden):
+    path, d = npy
+    hp = _hp()
+    tr = RADNeRFDataset("train", hp, data_dir=path, device="cpu")
+    va = RADNeRFDataset("val", hp, data_dir=path, device="cpu")
+    arr = torch.from_numpy(d["idexp_lm3d"]).reshape(-1, 68, 3)
+    normed = ((arr - arr.mean(0, keepdim=True)) / arr.std(0, keepdim=True)).reshape(-1, 1, 204)      # over ALL frames, torch's unbiased std
+    assert tr.conds.shape == (20, 1, 204) and va.conds.shape == (2, 1, 204)
+    torch.testing.assert_close(tr.conds, normed[:20])
+    torch.testing.assert_close(va.conds, normed[-2:])
+    w0, w10, w19 = tr.cond_window(0), tr.cond_window(10), tr.cond_window(19)
+    assert w0.shape == w10.shape == (5, 1, 204)                                # smo_win_size 5, att_mode 2: [idx-2, idx+3), zero padded
+    assert float(w0[:2].abs().sum()) == 0 and torch.equal(w0[2:], tr.conds[0:3])
+    assert torch.equal(w10, tr.conds[8:13])
+    assert float(w19[3:].abs().sum()) == 0 and torch.equal(w19[:3], tr.conds[17:20])
+    # the reference's own get_audio_features on a toy array (tests/golden/make_golden.py) behaves the same way
+    feats = torch.from_numpy(golden["audio_features_in"])
+    from genefaceplusplus_amd.radnerfs.camera import get_audio_features
+    for idx in (0, 1, 5, 9):
+        np.testing.assert_array_equal(get_audio_features(feats, 2, idx, 5).numpy(), golden[f"audio_features_mode2_{idx}"])
+    torch.testing.assert_close(tr.eye_area_percents, torch.from_numpy(d["eye_area_percent"][:20]))
+    assert tr.lm68s.shape == (20, 68, 2)
+    with pytest.raises(NotImplementedError):
+        RADNeRFDataset("train", _hp(nerf_keypoint_mode="lm468"), data_dir=path, device="cpu")
+
+
+def test_audio_conditioning_and_clip_batch(npy):
+    path, d = npy
+    hp = _hp("audio_head")
+    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device="cpu")
+    assert ds.conds.shape == (22, 16, 44)
+    b = ds.clip_batch(range(3, 9))
+    assert b["ngp_poses"].shape == (6, 4, 4) and b["cond_wins"].shape == (6, 8, 16, 44) and b["eye_area_percent"].shape == (6, 1, 1)
+    np.testing.assert_array_equal(b["cond_wins"][0], ds.cond_window(3).numpy())
+    with pytest.raises(NotImplementedError):
+        RADNeRFDataset("train", _hp(cond_type="deepspeech"), data_dir=path, device="cpu")
+
+
+def test_smooth_camera_path_matches_the_formula(npy):
+    path, d = npy
+    c2w = np.stack([s["c2w"] for s in d["train_samples"]])
+    smo = smooth_camera_path(c2w, 7)
+    np.testing.assert_allclose(smo[5, :3, 3], c2w[2:9, :3, 3].mean(0), atol=1e-6)
+    np.testing.assert_allclose(smo[0, :3, 3], c2w[0:4, :3, 3].mean(0), atol=1e-6)
+    r = smo[5, :3, :3]
+    np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-6)
+    ds = RADNeRFDataset("train", _hp(infer_smooth_camera_path=True, infer_smooth_camera_path_kernel_size=7), data_dir=path, training=False, device="cpu")
+    np.testing.assert_allclose(ds.samples[5]["c2w"].numpy(), smo[5], atol=1e-6)

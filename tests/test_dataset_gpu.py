@@ -1,0 +1,66 @@
+"""RADNeRFDataset.__getitem__ on the device, and a clip rendered straight from the dataset's driving signals."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dataset_fixture import write_synthetic_dataset
+from genefaceplusplus_amd.dataset import RADNeRFDataset
+from helpers import frame_case, build_model
+from test_dataset_cpu import _hp
+
+
+@pytest.fixture(scope="module")
+def npy(tmp_path_factory):
+    p = str(tmp_path_factory.mktemp("ds") / "trainval_dataset.npy")
+    return p, write_synthetic_dataset(p, T=22, H=64, W=64)
+
+
+def test_getitem_inference_and_training(npy, oracle_mod):
+    path, d = npy
+    dev = torch.device("cuda:0")
+    ds = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device=dev)
+    s = ds[1]
+    assert s["rays_o"].shape == s["rays_d"].shape == (1, 64 * 64, 3) and s["rays_o"].is_cuda
+    ref = oracle_mod.get_rays(ds.poses[1][None].numpy(), ds.intrinsics, 64, 64)
+    np.testing.assert_array_equal(s["rays_o"].cpu().numpy(), ref["rays_o"])
+    np.testing.assert_allclose(s["rays_d"].cpu().numpy(), ref["rays_d"], atol=2e-7)
+    assert s["cond_wins"].shape == (5, 1, 204) and s["pose"].shape == (1, 6) and s["bg_img"].shape == (1, 4096, 3)
+    np.testing.assert_allclose(s["bg_img"].cpu().numpy().reshape(64, 64, 3), d["bg_img"].astype(np.float32) / 255, atol=1e-6)
+    # rectangle face mask (polygon_face_mask False): rows [16,48) x cols [16,48) of pixel centres
+    fm = s["face_mask"].reshape(64, 64).cpu().numpy()
+    assert fm[16:48, 16:48].all() and fm.sum() == 32 * 32
+    assert torch.equal(s["cond_mask"], s["face_mask"].reshape(-1))
+    tr = RADNeRFDataset("train", _hp(n_rays=500), data_dir=path, training=True, device=dev)
+    t = tr[3]
+    assert t["rays_o"].shape == (1, 500, 3) and t["bg_img"].shape == (1, 500, 3) and t["face_mask"].shape == (1, 500)
+    tr.finetune_lip_flag = True
+    t = tr[3]
+    assert t["rays_o"].shape == (1, 8 * 8, 3)                                  # the lip rectangle of the fixture
+
+
+def test_clip_from_dataset_equals_per_frame_render(npy):
+    """dataset.clip_batch -> ClipRenderer == model.render() per frame with the dataset's own rays / windows (the loop of genefacepp_infer.py)."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    from genefaceplusplus_amd import frames
+    path, _ = npy
+    dev = torch.device("cuda:0")
+    case = frame_case("may_torso", 64)
+    model = build_model(case, dev, "fused")
+    model.precision = "fp16"
+    hp = dict(case["hp"], **{k: v for k, v in _hp().items() if k not in case["hp"]})
+    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device=dev)
+    cr = ClipRenderer(model, ds.H, ds.W, ds.intrinsics, bg_img=ds.bg_img.reshape(1, -1, 3), T_thresh=0.01, use_graph=True, lanes=1)
+    clip = cr.prepare(ds.clip_batch(), dev)
+    got = cr.render_to_device(clip, [0, 5, 21]).cpu().numpy()
+    for k, i in enumerate((0, 5, 21)):
+        s = ds[i]
+        with torch.no_grad():
+            # (the 6-vector pose on the DEVICE, like the clip renderer derives it: the CPU's atan2 / asin differ from the GPU's in the last bit,
+            # which the pose-conditioned torso turns into single-LSB differences of the uint8 frame)
+            from genefaceplusplus_amd.radnerfs import camera
+            r = model.render(s["rays_o"], s["rays_d"], s["cond_wins"].to(dev), ds.bg_coords.to(dev), camera.convert_poses(ds.poses[i][None].float().to(dev)), index=0, bg_color=ds.bg_img.reshape(1, -1, 3),
+                             perturb=False, T_thresh=0.01, max_steps=16, dt_gamma=hp["dt_gamma"])
+        want = frames.to_uint8_hwc(r["rgb_map"].reshape(64, 64, 3)).cpu().numpy()
+        np.testing.assert_array_equal(got[k], want)
