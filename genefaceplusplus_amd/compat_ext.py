@@ -97,7 +97,9 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
         if grad_inputs is not None:
             grad_inputs.add_(gi32.to(grad_inputs.dtype))
         return
-    call("gfpp_grid_encode_backward", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), int(B), int(D), int(C), int(L), float(S), int(H),
+    rows = int(embeddings.shape[0])
+    copies = torch.empty(8, rows * int(C), device=grad_embeddings.device, dtype=torch.float32)       # XCD-private accumulation, see gfpp_grid_encode_backward_xcd
+    call("gfpp_grid_encode_backward_xcd", _p(grad), _p(inputs), _p(offsets), _p(grad_embeddings), rows, _p(copies), int(B), int(D), int(C), int(L), float(S), int(H),
          _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st())
 
 

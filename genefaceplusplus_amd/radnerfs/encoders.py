@@ -69,8 +69,11 @@ class _GridEncodeFn(torch.autograd.Function):
         grad = grad.float().contiguous()
         grad_emb = torch.zeros_like(emb)
         grad_inputs = torch.zeros_like(inputs01) if dy_dx is not None else None
-        call("gfpp_grid_encode_backward", grad.data_ptr(), inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), grad_emb.data_ptr(), B, D, C, L, S, H,
-             dy_dx.data_ptr() if dy_dx is not None else None, grad_inputs.data_ptr() if grad_inputs is not None else None, gridtype, ac, interp, _stream())
+        # XCD-private accumulation (gfpp_grid_encode_backward_xcd): eight scratch copies of the table gradient, one per L2
+        copies = torch.empty(8, emb.shape[0] * C, device=emb.device, dtype=torch.float32)
+        call("gfpp_grid_encode_backward_xcd", grad.data_ptr(), inputs01.data_ptr(), offsets.data_ptr(), grad_emb.data_ptr(), int(emb.shape[0]), copies.data_ptr(),
+             B, D, C, L, S, H, dy_dx.data_ptr() if dy_dx is not None else None, grad_inputs.data_ptr() if grad_inputs is not None else None, gridtype, ac, interp,
+             _stream())
         return grad_inputs, grad_emb, None, None, None, None, None, None
 
 

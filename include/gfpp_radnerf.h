@@ -457,6 +457,13 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                               int align_corners, uint32_t interp, gfpp_stream_t stream);
 
+/* The same gradient (gridencoder.cu:247-368) with XCD-private accumulation (no reference counterpart: MI355X has eight L2s): `xcd_copies` is caller-provided scratch of
+ * 8 x rows_total x C floats (cleared by the call); every workgroup scatters into the copy of the XCD it runs on, so a gradient line stays in one L2
+ * instead of migrating between eight, and the copies are summed into grad_embeddings (+=) at the end.  rows_total = embeddings.shape[0]. */
+int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
+                                  float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
+
 /* replaces grad_total_variation (gridencoder.h:15; gridencoder.cu:505-609): TV gradient of the cells visited by `inputs`, grad (+=, atomics). */
 int gfpp_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t D,
                               uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, gfpp_stream_t stream);
