@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--identities", type=int, default=1,
                     help="BASELINE configs[4]: this many person-specific models at once; the ranks are split into contiguous blocks (frames.identity_groups), "
                          "frame-parallel inside a block, driving signals broadcast once.  With --gpus 1 the identities share the one GPU")
+    ap.add_argument("--shard", default="frames", choices=["frames", "rays"],
+                    help="multi-GPU partition: 'frames' = frame-parallel (the default: independent frames, no data-path collective, weak scaling); 'rays' = "
+                         "latency mode, ALL ranks render each frame together as ray tiles (one int32 all_reduce per trip for the frame-wide alive count + "
+                         "an all_gather of the tiles per frame; strong scaling of one frame)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[0] / configs[1] entries")
     ap.add_argument("--long-run-frames", type=int, default=2000, help="frames of modes.long_run (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (control-flow checks of the N>1 path on one GPU)")
@@ -221,6 +225,62 @@ def run_identities(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def run_ray_tiles(args, rank, world, dev):
+    """--shard rays: every frame is rendered by ALL ranks together (frames.render_frame_tiled): rank r takes the r-th contiguous tile of the rays,
+    the frame-wide alive count is all-reduced once per trip so that every ray gets the single-GPU sample budget (renderer.py:364), the finished
+    tiles are all-gathered.  value = frames/s of the group (strong scaling of one frame: total work fixed); ms_per_step = latency of one frame."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from genefaceplusplus_amd import synthetic as syn, radnerfs, frames
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import camera
+    from tests.helpers import CLASSES
+    HW, K, W = args.hw, args.steps, args.warmup
+    hp = may_hparams(args.variant)
+    sd = syn.synthetic_state_dict(hp, args.variant)
+    model = getattr(radnerfs, CLASSES[args.variant])(hp)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    model.executor, model.precision, model.use_graph = "fused", args.precision, False
+    bg_coords = camera.get_bg_coords(HW, HW, "cpu").to(dev)
+    bg = torch.full((1, HW * HW, 3), 0.5, device=dev)
+    inputs = []
+    for j in range(min(K + W, 8)):
+        pose = torch.from_numpy(syn.synthetic_pose(j)).to(dev)[None]
+        fi = syn.synthetic_frame_inputs(hp, j)
+        r = camera.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+        inputs.append((r["rays_o"], r["rays_d"], torch.from_numpy(fi["cond"]).to(dev), camera.convert_poses(pose)))
+    kw = dict(index=0, perturb=False, T_thresh=0.01, max_steps=hp["max_steps"], dt_gamma=hp["dt_gamma"])
+
+    def frame(i):
+        ro, rd, cond, pose6 = inputs[i % len(inputs)]
+        return frames.render_frame_tiled(model, ro, rd, cond, bg_coords, pose6, bg_color=bg, **kw)
+    for i in range(W):
+        frame(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        frame(W + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(K / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K,
+                          "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic",
+                          "config": {"workload": f"{args.variant}: ONE {HW}x{HW} frame at a time rendered by all {world} GPUs as ray tiles (latency mode)",
+                                     "parallelism": f"ray tiles x{world}: int32 all_reduce of the alive count per trip + all_gather of the tiles per frame",
+                                     "launch": "eager (collectives between the trip launches)"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import numpy as np
@@ -250,6 +310,8 @@ def main():
 
     if args.identities > 1:
         return run_identities(args, rank, world, dev)
+    if args.shard == "rays" and world > 1:
+        return run_ray_tiles(args, rank, world, dev)
 
     HW, K, W = args.hw, args.steps, args.warmup
     N = HW * HW

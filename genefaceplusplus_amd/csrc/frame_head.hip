@@ -33,6 +33,8 @@ struct TripArgs {
     const int32_t *alive_in;
     int32_t *alive_out;
     int32_t *counters;
+    const int32_t *gcounters;   // frame-wide alive counts per trip (== counters unless this launch renders one ray tile of a shared frame)
+    uint32_t N_global;          // rays of the whole frame (== N on one GPU)
     const float *frame_consts;  // [0,128): ambient bias frag, [128,256): colour bias frag
     float T_thresh, density_scale;
     uint32_t N, trip, max_steps;
@@ -181,16 +183,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
     // ---- loop state, recomputed from the per-trip counters (renderer.py:354-384) ----------------------------------
     uint32_t step_before = 0;
     for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = (uint32_t)a.counters[k];
+        const uint32_t na = (uint32_t)a.gcounters[k];
         if (na == 0) return;
-        uint32_t ns = a.N / na;
+        uint32_t ns = a.N_global / na;
         ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
         step_before += ns;
     }
-    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
-    if (n_alive == 0 || step_before >= a.max_steps) return;
-    uint32_t n_step = a.N / n_alive;
+    // sample budget from the FRAME-wide alive count (renderer.py:364), work list from this launch's own (they coincide on one GPU)
+    const uint32_t n_alive_frame = (uint32_t)a.gcounters[a.trip];
+    if (n_alive_frame == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N_global / n_alive_frame;
     n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
+    if (n_alive == 0) return;
 
     const uint32_t rays_per_tile = kTile / n_step;
     const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
@@ -293,16 +298,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
     __shared__ WaveTile tiles[kThreads / 64];
     uint32_t step_before = 0;
     for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = (uint32_t)a.counters[k];
+        const uint32_t na = (uint32_t)a.gcounters[k];
         if (na == 0) return;
-        uint32_t ns = a.N / na;
+        uint32_t ns = a.N_global / na;
         ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
         step_before += ns;
     }
-    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
-    if (n_alive == 0 || step_before >= a.max_steps) return;
-    uint32_t n_step = a.N / n_alive;
+    // sample budget from the FRAME-wide alive count (renderer.py:364), work list from this launch's own (they coincide on one GPU)
+    const uint32_t n_alive_frame = (uint32_t)a.gcounters[a.trip];
+    if (n_alive_frame == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N_global / n_alive_frame;
     n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+    const uint32_t n_alive = (uint32_t)a.counters[a.trip];
+    if (n_alive == 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t kWaves = kThreads / 64;
@@ -575,6 +583,8 @@ GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_fram
     a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
     a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
     a.counters = ws->counters;
+    a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
+    a.N_global = ws->gcounters ? ws->N_global : ws->N;
     a.frame_consts = ws->frame_consts;
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
@@ -617,6 +627,8 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
     a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
     a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
     a.counters = ws->counters;
+    a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
+    a.N_global = ws->gcounters ? ws->N_global : ws->N;
     a.frame_consts = ws->frame_consts;
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
@@ -630,7 +642,9 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
     }
     const uint32_t grid = 2u * (uint32_t)cus;   // two resident workgroups per CU (register-bound), tiles are taken wave-stride
     const hipStream_t st = (hipStream_t)stream;
-    for (uint32_t trip = 0; trip < max_steps; ++trip) {
+    const uint32_t first = ws->trip_count ? ws->trip_first : 0u;
+    const uint32_t stop = ws->trip_count ? (first + ws->trip_count < max_steps ? first + ws->trip_count : max_steps) : max_steps;
+    for (uint32_t trip = first; trip < stop; ++trip) {
         a.trip = trip;
         a.alive_in = ws->alive[trip & 1];
         a.alive_out = ws->alive[(trip + 1) & 1];

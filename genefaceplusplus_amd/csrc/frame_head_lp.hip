@@ -93,6 +93,8 @@ struct LpTripArgs {
     float *weights_sum, *depth, *image;
     int32_t *alive[2];            // ping-pong survivor lists: trip k reads alive[k & 1], writes alive[(k + 1) & 1]
     int32_t *counters;
+    const int32_t *gcounters;     // frame-wide alive counts per trip (== counters unless this launch renders one ray tile of a frame shared between GPUs)
+    uint32_t N_global;            // rays of the whole frame (== N on one GPU)
     int32_t *sync;                // barrier word of multi-trip launches (counters[127], zeroed by k_frame_begin)
     const float *frame_consts;
     float T_thresh, density_scale;
@@ -433,18 +435,21 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
     // ---- loop state up to the first trip of this launch (renderer.py:354-384) ------------------------------------------------------
     uint32_t step_before = 0;
     for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = counter_load(a.counters + k);
+        const uint32_t na = counter_load(a.gcounters + k);
         if (na == 0) return;
-        uint32_t ns = a.N / na;
+        uint32_t ns = a.N_global / na;
         ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
         step_before += ns;
     }
   for (uint32_t trip = a.trip; trip < a.trip_end; ++trip) {
-    const uint32_t n_alive = counter_load(a.counters + trip);
-    if (n_alive == 0 || step_before >= a.max_steps) return;   // the same decision in every workgroup
-    uint32_t n_step = a.N / n_alive;
+    // the sample budget follows the FRAME-wide alive count (renderer.py:364); the work list is this launch's own
+    const uint32_t n_alive_frame = counter_load(a.gcounters + trip);
+    if (n_alive_frame == 0 || step_before >= a.max_steps) return;   // the same decision in every workgroup (and on every GPU of a shared frame)
+    uint32_t n_step = a.N_global / n_alive_frame;
     n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
     step_before += n_step;
+    const uint32_t n_alive = a.gcounters == a.counters ? n_alive_frame : counter_load(a.counters + trip);
+    if (n_alive == 0) return;                                       // (tile mode: every trip is its own launch) nothing left in this tile
     const int32_t *alive_in = a.alive[trip & 1];
     int32_t *alive_out = a.alive[(trip + 1) & 1];
 
@@ -747,6 +752,8 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     a.consumed = (uint32_t *)ws->rays_t;   // the per-ray cursor takes the place of rays_t
     a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
     a.counters = ws->counters;
+    a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
+    a.N_global = ws->gcounters ? ws->N_global : ws->N;
     a.frame_consts = ws->frame_consts;
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps;
@@ -761,10 +768,13 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     a.sync = ws->counters + 127;
     // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
     const uint32_t want_separate = ws->separate_trips ? ws->separate_trips : lp_separate_trips();
-    const uint32_t separate = want_separate < max_steps ? want_separate : max_steps;
-    for (uint32_t trip = 0; trip <= separate && trip < max_steps; ++trip) {
+    // a ray tile of a shared frame: the caller all-reduces the alive counts between trips, so every trip is a launch of its own
+    const uint32_t separate = ws->gcounters ? max_steps : (want_separate < max_steps ? want_separate : max_steps);
+    const uint32_t first = ws->trip_count ? ws->trip_first : 0u;
+    const uint32_t stop = ws->trip_count ? (first + ws->trip_count < max_steps ? first + ws->trip_count : max_steps) : max_steps;
+    for (uint32_t trip = first; trip <= separate && trip < stop; ++trip) {
         a.trip = trip;
-        a.trip_end = trip < separate ? trip + 1 : max_steps;
+        a.trip_end = trip < separate ? trip + 1 : stop;
         launch(grid, st, a);
         const int rc = check_launch("gfpp_head_frame_trips_lp");
         if (rc) return rc;

@@ -76,6 +76,50 @@ def gather_clip(local_frames, n_frames, interleaved=False, group=None, dst=None)
     return clip
 
 
+# ---- one frame shared between GPUs: ray tiles (north star: "within a frame, ray tiles"; SURVEY 8e caveat) -----------------------------------
+
+def ray_tile(n_rays, rank, world):
+    """Contiguous slice [lo, hi) of the frame's rays rendered by `rank` (whole image rows when n_rays / world is a multiple of the width)."""
+    per = -(-n_rays // world)
+    return min(rank * per, n_rays), min((rank + 1) * per, n_rays)
+
+
+def render_frame_tiled(model, rays_o, rays_d, cond, bg_coords, poses, group=None, bg_color=None, **render_kwargs):
+    """Latency mode: ONE frame rendered by all ranks of `group`, each taking a contiguous tile of the rays, then all_gather of the tiles.
+
+    Every rank passes the same full-frame inputs (rays [1,N,3], bg_coords [1,N,2], bg_color [1,N,3] or None).  Through the torso pass a pixel
+    only needs its own head colour / alpha, so tiles are independent except for the loop control: n_step = clamp(N // n_alive, 1, 8)
+    (renderer.py:364) uses the FRAME-wide alive count, which the pipeline all-reduces once per trip (`ray_shard`) -- the result equals the
+    single-GPU frame bit for bit.  Returns {'rgb_map' [1,N,3], 'depth_map' [1,N]} (+ 'torso_alpha_map' [N,1] for the torso models) on every rank.
+    Not for the *_sr models: the SR convolutions need the whole 256^2 image (gather first, then super-resolve on one rank)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    N = rays_o.shape[-2]
+    lo, hi = ray_tile(N, rank, world)
+    sl = slice(lo, hi)
+    kw = dict(render_kwargs)
+    if world > 1:
+        kw["ray_shard"] = (group, N)
+    bg = bg_color[..., sl, :] if torch.is_tensor(bg_color) and bg_color.shape[-2] == N else bg_color
+    with torch.no_grad():
+        res = model.render(rays_o[..., sl, :].contiguous(), rays_d[..., sl, :].contiguous(), cond, bg_coords[..., sl, :].contiguous(), poses, bg_color=bg, **kw)
+    if world == 1:
+        return res
+    per = -(-N // world)
+    out = {}
+    for key, width in (("rgb_map", 3), ("depth_map", 1), ("torso_alpha_map", 1)):
+        if key not in res:
+            continue
+        tile = res[key].reshape(-1, width).float()
+        pad = torch.zeros(per, width, device=tile.device)
+        pad[:tile.shape[0]] = tile
+        full = torch.empty(world * per, width, device=tile.device)
+        dist.all_gather_into_tensor(full, pad, group=group)
+        full = full[:N]
+        out[key] = full.view(1, N, 3) if key == "rgb_map" else (full.view(1, N) if key == "depth_map" else full.view(N, 1))
+    return out
+
+
 # ---- several identities on one node (SURVEY.md section 8f-4, BASELINE config 5: 4 person-specific models on 8 GPUs, 2 GPUs each) --------
 
 def identity_groups(world, n_identities):

@@ -40,7 +40,8 @@ class HeadModel(ctypes.Structure):
 class FrameWs(ctypes.Structure):
     _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("rays_t", c_p), ("weights_sum", c_p), ("depth", c_p), ("image", c_p),
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
-                ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32)]
+                ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
+                ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32)]
 
 
 class CondModel(ctypes.Structure):
@@ -525,6 +526,7 @@ class FramePipeline:
             ws.sample_t, ws.sample_cnt, ws.sample_stride = None, None, 0
             # lanes other than 0 only exist when several frames are in flight: no multi-trip launches then (see gfpp_frame_ws.separate_trips)
             ws.separate_trips = 0
+            ws.gcounters, ws.N_global, ws.trip_first, ws.trip_count = None, 0, 0, 0
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
         ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else (self.separate_trips or 0)
@@ -547,8 +549,13 @@ class FramePipeline:
             raise GfppError(f"{name} must be on the GPU")
         return t.detach().float().contiguous()
 
-    def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh):
+    def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=None):
         """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace.
+
+        shard = (process group, rays of the whole frame): `rays_o/rays_d` are ONE TILE of a frame that several GPUs render together.  The
+        sample budget of a ray depends on the frame-wide alive count (renderer.py:364), so the trips are issued one by one and the alive counts
+        of all tiles are summed (one int32 all_reduce per trip, RCCL) into `gcounters`, which the next trip's kernels read -- every ray then
+        gets exactly the samples it gets in a single-GPU frame.
 
         `cond_feat` is a tensor, or a callable returning it: the callable (the conditioning networks) is then issued on a side
         stream together with the constant folding, next to the slab test and the pre-march on the main stream, which do not depend
@@ -592,8 +599,30 @@ class FramePipeline:
                  int(max_steps), st)
         if side is not None:
             main.wait_stream(side)                      # join
-        call("gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march"), ctypes.byref(self.head), ctypes.byref(ws),
-             rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
+        trips = "gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march")
+        if shard is None:
+            call(trips, ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
+            return ws, t
+        import torch.distributed as dist
+        group, n_frame = shard
+        if not premarched:
+            raise GfppError("ray-tile sharding runs on the pre-marched trip kernels (fp32_kernel='wave' or a 16-bit precision)")
+        g = t.get("gcounters")
+        if g is None:
+            g = t["gcounters"] = torch.zeros(64, dtype=torch.int32, device=self.device)
+        g.zero_()
+        g[:1].fill_(int(n_frame))
+        ws.gcounters, ws.N_global = g.data_ptr(), int(n_frame)
+        try:
+            for trip in range(int(max_steps)):
+                ws.trip_first, ws.trip_count = trip, 1
+                call(trips, ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
+                if trip + 1 < int(max_steps):
+                    nxt = t["counters"][trip + 1:trip + 2].clone()
+                    dist.all_reduce(nxt, op=dist.ReduceOp.SUM, group=group)      # frame-wide n_alive of the next trip
+                    g[trip + 1:trip + 2].copy_(nxt)
+        finally:
+            ws.gcounters, ws.N_global, ws.trip_first, ws.trip_count = None, 0, 0, 0
         return ws, t
 
     def eval_samples(self, position, direction, cond_feat, ind_code):
@@ -615,8 +644,8 @@ class FramePipeline:
              position.data_ptr(), direction.data_ptr(), M, sigma.data_ptr(), color.data_ptr(), ambient.data_ptr(), st)
         return sigma, color, ambient
 
-    def render_head(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color):
-        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh)
+    def render_head(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color, shard=None):
+        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=shard)
         st = torch.cuda.current_stream().cuda_stream
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, ws.N)
         out_image, out_depth = torch.empty_like(t["out_image"]), torch.empty_like(t["out_depth"])
@@ -634,12 +663,12 @@ class FramePipeline:
         return None, float(bg_color), None
 
     def render_head_torso(self, rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma, max_steps, T_thresh,
-                          bg_color, use_head_for_torso):
+                          bg_color, use_head_for_torso, shard=None):
         """Head pass + torso pass + compositing -> dict(image [N,3], depth [N], torso_alpha [N,1], torso_bg [N,3],
         deform_dense [N,2], torso_mask [N] u8, deform=None)."""
         if self.torso is None:
             raise GfppError("this model has no torso networks")
-        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh)
+        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=shard)
         N = ws.N
         dev = self.device
         bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)

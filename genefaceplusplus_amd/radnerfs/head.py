@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import raymarching
+from .._lib import GfppError
 from .cond_nets import AudioNet, AudioAttNet, MLP
 from .encoders import get_encoder
 from .camera import trunc_exp, get_audio_features
@@ -268,16 +269,19 @@ class NeRFRenderer(nn.Module):
             image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3).clamp(0, 1)
             depth = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
             return {"weights_sum": weights_sum, "ambient": ambient_sum, "position": xyzs, "depth_map": depth, "rgb_map": image}
+        shard = kwargs.get("ray_shard")          # (process group, rays of the whole frame): this call renders one ray tile (frames.render_frame_tiled)
         if self.executor == "fused" and self._fused_ok(perturb, max_steps, cond_mask):
             def frame(rays_o, rays_d, cond, eye, bg_color):
                 cond_feat = lambda: self.cal_cond_feat(cond, eye_area_percent=eye)     # runs on the pipeline's side stream
-                return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color)
+                return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color, shard=shard)
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_color": bg_color}
-            if self.use_graph and not torch.is_grad_enabled():
+            if self.use_graph and not torch.is_grad_enabled() and shard is None:
                 out = self.pipeline().graphed(("head", float(dt_gamma), int(max_steps), float(T_thresh)), frame, inputs)
             else:
                 out = frame(**inputs)
             return {"depth_map": out["depth"].view(*prefix), "rgb_map": out["image"].view(*prefix, 3)}
+        if shard is not None:
+            raise GfppError("ray_shard needs the fused executor (the staged loop has no frame-wide alive count)")
         cond_feat = self.cal_cond_feat(cond, eye_area_percent=eye_area_percent)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum, depth, image = self._march_eval_composite_staged(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma,

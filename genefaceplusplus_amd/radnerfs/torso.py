@@ -8,6 +8,8 @@ head over torso over background.
 """
 import random
 
+from .._lib import GfppError
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -155,13 +157,15 @@ class _TorsoBase(RADNeRF):
         return {"image": image.clamp(0, 1), "depth": depth, "torso_alpha": torso_alpha, "torso_bg": torso_bg, "deform": deform, **extra}
 
     def _render_common(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
-                       eye_area_percent, use_head_for_torso, post=None, post_key=(), force_all_rays=False):
+                       eye_area_percent, use_head_for_torso, post=None, post_key=(), force_all_rays=False, shard=None):
         """`post(out)`: extra device work on the pipeline's result dict (the SR stage), issued inside the frame so that it is part of the
         captured graph; `post_key` distinguishes graphs captured with different post work."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
         fused = self.executor == "fused" and not self.training and self._fused_ok(perturb, max_steps)
+        if shard is not None and not fused:
+            raise GfppError("ray_shard needs the fused executor at inference (the staged loop has no frame-wide alive count)")
         if fused:
             if use_head_for_torso is None:
                 use_head_for_torso = random.random() < 0.5
@@ -172,13 +176,13 @@ class _TorsoBase(RADNeRF):
                     with torch.no_grad():
                         return self.cal_cond_feat(cond, eye_area_percent=eye)
                 o = self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
-                                                      max_steps, T_thresh, bg_color, use_head_for_torso)
+                                                      max_steps, T_thresh, bg_color, use_head_for_torso, shard=shard)
                 if post is not None:
                     post(o)
                 return o
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_coords": bg_coords, "poses": poses,
                       "lm68": lm68, "bg_color": bg_color}
-            if self.use_graph and not torch.is_grad_enabled():
+            if self.use_graph and not torch.is_grad_enabled() and shard is None:
                 out = self.pipeline().graphed(("torso", float(dt_gamma), int(max_steps), float(T_thresh), bool(use_head_for_torso)) + tuple(post_key),
                                               frame, inputs)
             else:
@@ -223,7 +227,7 @@ class RADNeRFTorso(_TorsoBase):
         use_head = None if self.hparams["torso_head_aware"] else False
         # NB: this variant calls cal_cond_feat(cond) without eye_area_percent (radnerf_torso.py:106)
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, None,
-                                  None, use_head, force_all_rays=force_all_rays)
+                                  None, use_head, force_all_rays=force_all_rays, shard=kwargs.get("ray_shard"))
         res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"], "depth_map": out["depth"].view(*prefix),
                "rgb_map": out["image"].view(*prefix, 3)}
         if out["deform"] is not None:

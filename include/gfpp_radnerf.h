@@ -291,6 +291,16 @@ typedef struct gfpp_frame_ws {
                               * between its trips) takes the rest; 0 = default (6).  Set it >= max_steps when frames are in flight on
                               * several streams at once (one workspace each): two multi-trip launches spinning at their barriers could
                               * keep each other's workgroups from ever becoming resident. */
+    /* Ray-tile sharding of ONE frame over several GPUs (renderer.py:364: n_step = clamp(N // n_alive, 1, 8) is a function of the FRAME-wide
+     * alive count, so a rank that renders only a tile of the rays needs the global numbers to give every ray the reference's sample budget):
+     * gcounters == NULL: single-GPU frame (everything above).  Otherwise this workspace holds one tile of N rays of a frame of N_global rays;
+     * gcounters [64] i32 holds the frame-wide alive counts per trip -- the caller sets gcounters[0] = N_global and, after issuing trip k
+     * (trip_first = k, trip_count = 1), all-reduces counters[k+1] of all ranks into gcounters[k+1] before issuing trip k+1.  The trip
+     * kernels take n_step / the loop exit from gcounters and their own work list from counters. */
+    const int32_t *gcounters;
+    uint32_t N_global;
+    uint32_t trip_first;   /* gfpp_head_frame_trips / _trips_lp issue the trips [trip_first, trip_first + trip_count) only; trip_count == 0: all */
+    uint32_t trip_count;
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

@@ -1,0 +1,60 @@
+"""Worker of tests/test_dist_gpu.py::test_ray_tile_sharding_*: every rank renders ONE frame together with the others (frames.render_frame_tiled, one
+int32 all_reduce per trip for the frame-wide alive count) and compares it with the same frame rendered alone -- bit for bit.  Backend from argv:
+gloo (ranks may share one GPU) or nccl (one GPU per rank)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    dev_id = local % torch.cuda.device_count()
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genefaceplusplus_amd import frames
+    from genefaceplusplus_amd.radnerfs import camera
+    from helpers import frame_case, build_model
+    res = {"rank": rank, "world": world}
+    for variant, HW, precision in (("may_head", 48, "fp32"), ("may_torso", 37, "fp16"), ("may_torso", 64, "bf16")):
+        case = frame_case(variant, HW)
+        model = build_model(case, dev, "fused")
+        model.precision = precision
+        model.use_graph = False
+        pose = torch.from_numpy(case["pose"]).to(dev)
+        r = camera.get_rays(pose, case["intr"], HW, HW)
+        args = (r["rays_o"], r["rays_d"], torch.from_numpy(case["cond"]).to(dev), camera.get_bg_coords(HW, HW, "cpu").to(dev), camera.convert_poses(pose))
+        kw = dict(index=0, perturb=False, T_thresh=0.01, max_steps=16, dt_gamma=case["hp"]["dt_gamma"])
+        bg = torch.from_numpy(case["bg_color"]).to(dev)
+        with torch.no_grad():
+            alone = model.render(*args, bg_color=bg, **kw)
+            alone = {k: v.clone() for k, v in alone.items() if torch.is_tensor(v)}
+            alive_alone = model.pipeline().trip_counters(HW * HW)[0].copy()
+        tiled = frames.render_frame_tiled(model, *args, bg_color=bg, **kw)
+        ok = bool(torch.equal(tiled["rgb_map"].reshape(-1, 3), alone["rgb_map"].reshape(-1, 3)) and torch.equal(tiled["depth_map"].reshape(-1), alone["depth_map"].reshape(-1)))
+        if "torso_alpha_map" in alone:
+            ok = ok and bool(torch.equal(tiled["torso_alpha_map"].reshape(-1), alone["torso_alpha_map"].reshape(-1)))
+        # the frame-wide alive counts the tiles agreed on == the single-GPU loop's
+        lo, hi = frames.ray_tile(HW * HW, rank, world)
+        g = model.pipeline().workspace(hi - lo)[1]["gcounters"].cpu().numpy()
+        res[f"{variant}_{HW}_{precision}"] = ok and bool(np.array_equal(g[:16], alive_alone[:16]))
+        res[f"{variant}_{HW}_{precision}_trips"] = int((alive_alone[:16] > 0).sum())
+    print("TILERESULT " + json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,3 +58,35 @@ def test_bench_identities_one_gpu():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
     assert d["config"]["identities"] == 2 and d["config"]["frames_total"] == 8 and d["value"] > 0
+
+
+def _tile_results(n, backend):
+    r = _torchrun(n, [os.path.join(ROOT, "tests", "dist_tile_worker.py"), backend])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = [json.loads(line.split("TILERESULT ", 1)[1]) for line in r.stdout.splitlines() if "TILERESULT " in line]
+    assert sorted(x["rank"] for x in out) == list(range(n))
+    for x in out:
+        for k, v in x.items():
+            if k.endswith(("fp32", "fp16", "bf16")):
+                assert v is True, (k, x)
+            if k.endswith("_trips"):
+                assert v >= 4, (k, x)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_ray_tile_sharding_equals_single_gpu_frame_gloo(n):
+    """ONE frame rendered by n ranks (ray tiles, frame-wide alive count all-reduced per trip) == the single-GPU frame, bit for bit; the ranks share
+    this box's GPU over gloo (the RCCL variant below needs one GPU per rank)."""
+    _tile_results(n, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL)")
+def test_ray_tile_sharding_equals_single_gpu_frame_rccl():
+    _tile_results(min(torch.cuda.device_count(), 4), "nccl")
+
+
+def test_bench_ray_tile_mode_two_ranks_gloo():
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--shard", "rays"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
