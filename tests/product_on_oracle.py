@@ -48,6 +48,12 @@ def dispatch(name, *a):
                                           ctypes.c_int(ac), u32(interp)) == 0
         if dy_dx:
             L.orc_grid_input_backward(fp(grad), fp(dy_dx), fp(grad_inputs), u32(B), u32(D), u32(C), u32(Lv))
+    elif name == "gfpp_grid_encode_backward_xcd":      # same gradient; the XCD-private scratch copies are a device-side detail
+        grad, inputs, offsets, grad_emb, rows, copies, B, D, C, Lv, S, H, dy_dx, grad_inputs, gridtype, ac, interp = a[:17]
+        assert L.orc_grid_encode_backward(fp(grad), fp(inputs), ip(offsets), fp(grad_emb), u32(B), u32(D), u32(C), u32(Lv), cf(S), u32(H), u32(gridtype),
+                                          ctypes.c_int(ac), u32(interp)) == 0
+        if dy_dx:
+            L.orc_grid_input_backward(fp(grad), fp(dy_dx), fp(grad_inputs), u32(B), u32(D), u32(C), u32(Lv))
     elif name == "gfpp_sh_encode_forward":
         assert not a[5]
         assert L.orc_sh_encode_forward(fp(a[0]), fp(a[1]), u32(a[2]), u32(a[4])) == 0
