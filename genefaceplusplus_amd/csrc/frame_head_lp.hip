@@ -140,18 +140,19 @@ struct LevelU {   // one level's descriptor in scalar registers
     uint32_t sy, sz, mask, offset;
 };
 
-template <int D>
+template <int D, bool SMOOTH>
 __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
-                                                   bool smooth, float (&out)[2]) {
+                                                   float (&out)[2]) {
     float frac[D];
     uint32_t base[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
+        // pos >= 0 here (u is clamped to [0,1]): truncation IS floor, and v_fract_f32 returns pos - floor(pos) exactly (the subtraction is exact
+        // in fp32 and < 1) -- two instructions instead of floor + convert + subtract, same bits
         const float pos = fmaf(u[d], lv.scale, align_corners ? 0.0f : 0.5f);
-        const float fl = floorf(pos);
-        base[d] = (uint32_t)fl;
-        float f = pos - fl;
-        if (smooth) f = f * f * fmaf(-2.0f, f, 3.0f);
+        base[d] = (uint32_t)pos;
+        float f = __builtin_amdgcn_fractf(pos);
+        if constexpr (SMOOTH) f = f * f * fmaf(-2.0f, f, 3.0f);
         frac[d] = f;
     }
     // byte offsets in 32 bits against the wave-uniform table pointer (global_load with an SGPR base): one v_add_lshl_u32 per gather instead of a
@@ -160,8 +161,6 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
     const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
     uint32_t z0 = 0, z1 = 0;
     if constexpr (D == 3) { z0 = __umul24(base[2], lv.sz); z1 = z0 + lv.sz; }
-    out[0] = 0.0f;
-    out[1] = 0.0f;
     constexpr int kPairs = 1 << (D - 1);
     f32x4_a8 v[kPairs];
 #pragma unroll
@@ -176,17 +175,23 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
         v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
 #endif
     }
+    // corner weights and accumulation on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): (w0, w1) = ((1 - fx) * yf * zf, fx * yf * zf) with the
+    // products in grid_level_lookup's order, so the (1 - fx, fx) * yf halves are shared by the two z planes -- 6 packed multiplies per 3-D level
+    // instead of 16 scalar ones, same bits
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 wx = {1.0f - frac[0], frac[0]};
+    f32x2 wxy[2] = {wx * (1.0f - frac[1]), wx * frac[1]};
+    f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
     for (int pair = 0; pair < kPairs; ++pair) {
-        float w0 = 1.0f - frac[0], w1 = frac[0];
-#pragma unroll
-        for (int d = 1; d < D; ++d) {
-            if (pair & (1 << (d - 1))) { w0 *= frac[d]; w1 *= frac[d]; }
-            else { w0 *= 1.0f - frac[d]; w1 *= 1.0f - frac[d]; }
-        }
-        out[0] = fmaf(w1, v[pair][2], fmaf(w0, v[pair][0], out[0]));
-        out[1] = fmaf(w1, v[pair][3], fmaf(w0, v[pair][1], out[1]));
+        f32x2 w = wxy[pair & 1];
+        if constexpr (D == 3) w = w * ((pair & 2) ? frac[2] : 1.0f - frac[2]);
+        const f32x2 c0 = {v[pair][0], v[pair][1]}, c1 = {v[pair][2], v[pair][3]};
+        acc = __builtin_elementwise_fma(f32x2{w[0], w[0]}, c0, acc);
+        acc = __builtin_elementwise_fma(f32x2{w[1], w[1]}, c1, acc);
     }
+    out[0] = acc[0];
+    out[1] = acc[1];
 }
 
 // This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..:
@@ -235,12 +240,23 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
+        // the interpolation type is wave-uniform: one branch around two specialised bodies instead of a smoothstep polynomial + select per coordinate
+        if (smooth) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float o[2];
-            level_fast_uniform<D>(uc, g.table, lvs[i], ac, smooth, o);
-            f[2 * i] = o[0];
-            f[2 * i + 1] = o[1];
+            for (int i = 0; i < 8; ++i) {
+                float o[2];
+                level_fast_uniform<D, true>(uc, g.table, lvs[i], ac, o);
+                f[2 * i] = o[0];
+                f[2 * i + 1] = o[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float o[2];
+                level_fast_uniform<D, false>(uc, g.table, lvs[i], ac, o);
+                f[2 * i] = o[0];
+                f[2 * i + 1] = o[1];
+            }
         }
     }
     // out-of-range / padding samples get zero features (gridencoder.cu:110-135): selected on the 8 packed operand words, not on the 16 floats

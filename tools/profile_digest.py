@@ -2,7 +2,7 @@
 """Turn the raw outputs of tools/profile_round.sh (gpurun_out/<tag>_*) into the summaries committed under profiles/:
    profiles/<tag>_kernel_stats.md   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + the bench JSON line)
    profiles/<tag>_pmc.md            per-kernel PMC sums of the last rendered frame, per counter pass
-   profiles/r01_pmc_traffic_<precision>.json   fabric-side bytes of the trip launches per frame (read back by bench.py as roofline.traffic)
+   profiles/<round>_pmc_traffic_<precision>.json   fabric-side bytes of the trip launches per frame (read back by bench.py as roofline.traffic)
 Usage: profile_digest.py <tag> <precision>"""
 import csv
 import json
@@ -36,7 +36,7 @@ def main(tag, precision, bench_args=None):
     out = [f"# rocprofv3 --kernel-trace --stats -- {tag}",
            "",
            f"Command (1x MI355X via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
-           + (bench_args or f"--steps 40 --warmup 4 --precision {precision} --no-cpu-baseline --no-modes") + "`",
+           + (bench_args or f"--steps 40 --warmup 4 --precision {precision} --no-cpu-baseline --no-modes --no-configs") + "`",
            "",
            "bench line of the profiled run (profiling costs a few % of wall time):", "", "```", bench_line, "```", "",
            "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
@@ -112,7 +112,8 @@ def main(tag, precision, bench_args=None):
                "note": "fabric-side (L2 <-> Infinity Cache / HBM) traffic; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950 (calibrated there on "
                        "coalesced streams; the 16-byte gathers here are the same instruction width), Infinity-Cache hits are counted, not excluded.  Algorithmic gather bytes per "
                        "frame = samples x 2060 B (~1.9 GB): the tables are L2 / Infinity-Cache resident, so fabric traffic is a fraction of the algorithmic stream"}
-    json.dump(traffic, open(os.path.join(dst, f"r01_pmc_traffic_{precision}.json"), "w"), indent=1)
+    rnd = tag.split("_")[0] if re.match(r"r\d\d", tag) else "r01"
+    json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic_{precision}.json"), "w"), indent=1)
     print(json.dumps(traffic))
 
 

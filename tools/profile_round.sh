@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; prec=$2
 out=gpurun_out/${tag}
 rm -rf ${out}_stats ${out}_pmc*
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o bench -- python bench.py --steps 40 --warmup 4 --precision $prec --no-cpu-baseline --no-modes > ${out}_bench.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o bench -- python bench.py --steps 40 --warmup 4 --precision $prec --no-cpu-baseline --no-modes --no-configs > ${out}_bench.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
   timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d ${out}_pmc$i -o p -- python tools/profile_frame.py may_torso 512 3 $prec > ${out}_pmc$i.log 2>&1
