@@ -29,7 +29,7 @@ struct TripArgs {
     HeadWeights w;
     const uint8_t *bitfield;
     const float *rays_o, *rays_d, *fars;
-    float *rays_t, *weights_sum, *depth, *image;
+    float *state;               // [N, kRayRec] ray records (march_device.h)
     const int32_t *alive_in;
     int32_t *alive_out;
     int32_t *counters;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
             const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
             const float dx = d[0], dy = d[1], dz = d[2];
             sh.dx[tid] = dx; sh.dy[tid] = dy; sh.dz[tid] = dz;
-            t = a.rays_t[ray];
+            t = ray_state_t(a.state, ray);
             const uint32_t base = tid * n_step;
             cnt = march_one_ray(o[0], o[1], o[2], dx, dy, dz, t, a.fars[ray], n_step, a.bitfield, a.mp, [&](uint32_t s, const Sample &smp) {
                 sh.px[base + s] = smp.x; sh.py[base + s] = smp.y; sh.pz[base + s] = smp.z;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
         // ---- phase 3: composite, ray state update, survivor compaction -------------------------------------------------
         bool survives = false;
         if (has_ray) {
-            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            RayAccum acc = ray_state_load(a.state, ray);
             const uint32_t base = tid * n_step;
             uint32_t s = 0;
             float t_last = t;
@@ -254,10 +254,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip(TripArgs a) {
             }
             // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
             survives = (s == n_step);
-            if (survives) a.rays_t[ray] = t_last;
-            a.weights_sum[ray] = acc.wsum;
-            a.depth[ray] = acc.depth;
-            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+            ray_state_store(a.state, ray, acc, survives ? t_last : t);
         }
         const unsigned long long ballot = __ballot(survives);
         const uint32_t wave_cnt = (uint32_t)__popcll(ballot);
@@ -374,7 +371,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
         // ---- phase 3: composite, survivor compaction ------------------------------------------------------------------------------------------
         bool survives = false;
         if (has_ray) {
-            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            RayAccum acc = ray_state_load(a.state, ray);
             const uint32_t base = lane * n_step;
             uint32_t s = 0;
             for (; s < cnt; ++s) {
@@ -382,9 +379,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
                 if (composite_sample(acc, wt.sigma[k], wt.dt[k], wt.tend[k], wt.cr[k], wt.cg[k], wt.cb[k], a.T_thresh)) break;
             }
             survives = (s == n_step);
-            a.weights_sum[ray] = acc.wsum;
-            a.depth[ray] = acc.depth;
-            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+            ray_state_store(a.state, ray, acc, 0.0f);        // (this kernel's cursor is the loop's cumulative step count, not stored per ray)
         }
         const unsigned long long ballot = __ballot(survives);
         const uint32_t total = (uint32_t)__popcll(ballot);
@@ -443,8 +438,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_eval(EvalArgs e) {
 
 __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, uint32_t N,
                                                          float min_near, float ax0, float ay0, float az0, float ax1, float ay1, float az1,
-                                                         float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ rays_t,
-                                                         float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                                         float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ state,
                                                          int32_t *__restrict__ counters) {
     const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 128) counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)N : 0;
@@ -454,10 +448,10 @@ __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restric
     const RayBox rb = ray_box(o[0], o[1], o[2], d[0], d[1], d[2], aabb, min_near);
     nears[n] = rb.near;
     fars[n] = rb.far;
-    rays_t[n] = rb.near;
-    weights_sum[n] = 0.0f;
-    depth[n] = 0.0f;
-    image[3ull * n] = 0.0f; image[3ull * n + 1] = 0.0f; image[3ull * n + 2] = 0.0f;
+    // word 5: t = near for the kernel that marches inside the trips; the pre-marched 16-bit kernel keeps its sample cursor in the same word
+    // (written at the end of trip 0, never read before)
+    *reinterpret_cast<float4 *>(state + (size_t)kRayRec * n) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<float4 *>(state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
 }
 
 // out[row] = sum_k W[row, k] * v[k] for 128 rows, written in bias-fragment order Bf[h][16*m+r] <- row 32*m+rr(r)+4*h.
@@ -478,18 +472,19 @@ __global__ __launch_bounds__(128) void k_fold_constants(const float *__restrict_
 }
 
 __global__ __launch_bounds__(kThreads) void k_head_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
-                                                         const float *__restrict__ weights_sum, const float *__restrict__ depth,
-                                                         const float *__restrict__ image, const float *__restrict__ bg_color, float bg_scalar,
+                                                         const float *__restrict__ state, const float *__restrict__ bg_color, float bg_scalar,
                                                          float *__restrict__ out_image, float *__restrict__ out_depth) {
     const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
     if (n >= N) return;
-    const float T = 1.0f - weights_sum[n];
+    const RayAccum acc = ray_state_load(state, n);
+    const float T = 1.0f - acc.wsum;
+    const float img[3] = {acc.r, acc.g, acc.b};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float bg = bg_color ? bg_color[3ull * n + c] : bg_scalar;
-        out_image[3ull * n + c] = clampf(image[3ull * n + c] + T * bg, 0.0f, 1.0f);
+        out_image[3ull * n + c] = clampf(img[c] + T * bg, 0.0f, 1.0f);
     }
-    out_depth[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+    out_depth[n] = fmaxf(acc.depth - nears[n], 0.0f) / (fars[n] - nears[n]);
 }
 
 static bool grid_ok(const gfpp_grid_desc &g, uint32_t D) {
@@ -540,14 +535,13 @@ GFPP_API int gfpp_grid_levels_fill(uint32_t D, uint32_t L, float S, uint32_t H, 
 GFPP_API int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                    const float *cond_feat, const float *ind_code, gfpp_stream_t stream) {
     if (!model || !ws || !rays_o || !rays_d) { set_error("gfpp_head_frame_begin: null argument"); return GFPP_EINVAL; }
-    if (!ws->nears || !ws->fars || !ws->rays_t || !ws->weights_sum || !ws->depth || !ws->image || !ws->counters || !ws->frame_consts || ws->N == 0) {
+    if (!ws->nears || !ws->fars || !ws->ray_state || !ws->counters || !ws->frame_consts || ws->N == 0) {
         set_error("gfpp_head_frame_begin: incomplete workspace");
         return GFPP_EINVAL;
     }
     const hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_frame_begin, dim3(div_up(ws->N, kThreads)), dim3(kThreads), 0, st, rays_o, rays_d, ws->N, model->min_near, model->aabb[0],
-                       model->aabb[1], model->aabb[2], model->aabb[3], model->aabb[4], model->aabb[5], ws->nears, ws->fars, ws->rays_t,
-                       ws->weights_sum, ws->depth, ws->image, ws->counters);
+                       model->aabb[1], model->aabb[2], model->aabb[3], model->aabb[4], model->aabb[5], ws->nears, ws->fars, ws->ray_state, ws->counters);
     int rc = check_launch("gfpp_head_frame_begin(init)");
     if (rc || !cond_feat) return rc;   // cond_feat == NULL: the caller folds later with gfpp_head_frame_fold (possibly on another stream)
     return gfpp_head_frame_fold(model, ws, cond_feat, ind_code, stream);
@@ -581,7 +575,7 @@ GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_fram
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.bitfield = model->density_bitfield;
     a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
-    a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.state = ws->ray_state;
     a.counters = ws->counters;
     a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
     a.N_global = ws->gcounters ? ws->N_global : ws->N;
@@ -625,7 +619,7 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.bitfield = model->density_bitfield;
     a.rays_o = rays_o; a.rays_d = rays_d; a.fars = ws->fars;
-    a.rays_t = ws->rays_t; a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.state = ws->ray_state;
     a.counters = ws->counters;
     a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
     a.N_global = ws->gcounters ? ws->N_global : ws->N;
@@ -685,6 +679,6 @@ GFPP_API int gfpp_head_frame_finish(const gfpp_frame_ws *ws, const float *bg_col
                                     gfpp_stream_t stream) {
     if (!ws || !out_image || !out_depth || ws->N == 0) { set_error("gfpp_head_frame_finish: null argument"); return GFPP_EINVAL; }
     hipLaunchKernelGGL(k_head_finish, dim3(div_up(ws->N, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, ws->N, ws->nears, ws->fars,
-                       ws->weights_sum, ws->depth, ws->image, bg_color, bg_scalar, out_image, out_depth);
+                       ws->ray_state, bg_color, bg_scalar, out_image, out_depth);
     return check_launch("gfpp_head_frame_finish");
 }

@@ -88,9 +88,8 @@ struct LpTripArgs {
     const float *rays_o, *rays_d;
     const float *sample_t;        // [N, sample_stride]: t of every occupied sample of the ray, in march order (k_premarch)
     const uint32_t *sample_cnt;   // [N]: how many of them exist (capped at max_steps + 7, more can never be consumed)
-    uint32_t *consumed;           // [N]: how many the previous trips used up (the role of rays_t)
     uint32_t sample_stride;
-    float *weights_sum, *depth, *image;
+    float *state;                 // [N, kRayRec] ray records (march_device.h); word 5 = how many samples the previous trips used up (the role of rays_t)
     int32_t *alive[2];            // ping-pong survivor lists: trip k reads alive[k & 1], writes alive[(k + 1) & 1]
     int32_t *counters;
     const int32_t *gcounters;     // frame-wide alive counts per trip (== counters unless this launch renders one ray tile of a frame shared between GPUs)
@@ -515,7 +514,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         uint32_t ray = 0, cnt = 0, used = 0;
         if (has_ray) {
             ray = trip == 0 ? n : (uint32_t)alive_in[n];
-            used = trip == 0 ? 0u : a.consumed[ray];
+            used = trip == 0 ? 0u : __float_as_uint(ray_state_t(a.state, ray));
             const uint32_t avail = a.sample_cnt[ray] - used;
             cnt = avail < n_step ? avail : n_step;
             wt.ray[lane] = ray;
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         // ---- phase 3: composite, ray state update, survivor compaction -------------------------------------------------
         bool survives = false;
         if (has_ray) {
-            RayAccum acc{a.weights_sum[ray], a.depth[ray], a.image[3ull * ray], a.image[3ull * ray + 1], a.image[3ull * ray + 2]};
+            RayAccum acc = ray_state_load(a.state, ray);
             const uint32_t base = lane * n_step;
             uint32_t s = 0;
             for (; s < cnt; ++s) {
@@ -564,10 +563,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
             }
             // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
             survives = (s == n_step);
-            if (survives) a.consumed[ray] = used + n_step;
-            a.weights_sum[ray] = acc.wsum;
-            a.depth[ray] = acc.depth;
-            a.image[3ull * ray] = acc.r; a.image[3ull * ray + 1] = acc.g; a.image[3ull * ray + 2] = acc.b;
+            ray_state_store(a.state, ray, acc, __uint_as_float(survives ? used + n_step : used));
         }
         const unsigned long long ballot = __ballot(survives);
         const uint32_t total = (uint32_t)__popcll(ballot);
@@ -759,14 +755,13 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
                                       float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
     const int bad = lp_check_common("gfpp_head_frame_trips_lp", model, ws, rays_o, rays_d, max_steps);
     if (bad) return bad;
-    if (!ws->alive[0] || !ws->alive[1] || !ws->rays_t || !ws->counters || !ws->frame_consts) { set_error("gfpp_head_frame_trips_lp: bad workspace"); return GFPP_EINVAL; }
+    if (!ws->alive[0] || !ws->alive[1] || !ws->ray_state || !ws->counters || !ws->frame_consts) { set_error("gfpp_head_frame_trips_lp: bad workspace"); return GFPP_EINVAL; }
     LpTripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
     { const int rc = lp_model_args("gfpp_head_frame_trips_lp", model, a); if (rc) return rc; }
     a.rays_o = rays_o; a.rays_d = rays_d;
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
-    a.consumed = (uint32_t *)ws->rays_t;   // the per-ray cursor takes the place of rays_t
-    a.weights_sum = ws->weights_sum; a.depth = ws->depth; a.image = ws->image;
+    a.state = ws->ray_state;
     a.counters = ws->counters;
     a.gcounters = ws->gcounters ? ws->gcounters : ws->counters;
     a.N_global = ws->gcounters ? ws->N_global : ws->N;

@@ -25,9 +25,8 @@ struct TorsoArgs {
     const float *density_grid;  // [G*G]
     const float *cond_in;       // poses [6] (variant 0) or lm68 [136] (variant 1)
     const float *code;          // [code_dim] or null
-    const float *head_image;    // [N,3] premultiplied head colour
-    const float *weights_sum;   // [N]
-    const float *depth_acc, *nears, *fars;  // [N]
+    const float *state;         // [N,8] ray records of the head pass: {weights_sum, depth, r, g, b (premultiplied head colour), ...} (march_device.h::kRayRec)
+    const float *nears, *fars;  // [N]
     const float *bg_color;      // [N,3] or null
     float bg_scalar, shrink, thresh;
     uint32_t N, G, variant, code_dim, const_dim, head_aware, use_head;
@@ -107,8 +106,8 @@ __global__ __launch_bounds__(kTorsoThreads) void k_torso(TorsoArgs a) {
     const float cx = a.bg_coords[2ull * n], cy = a.bg_coords[2ull * n + 1];
     const float occ = bilinear_occupancy(a.density_grid, a.G, cx, cy);
     const bool masked = occ > a.thresh;
-    const float hr = a.head_image[3ull * n], hg = a.head_image[3ull * n + 1], hb = a.head_image[3ull * n + 2];
-    const float wsum = a.weights_sum[n];
+    const float hr = a.state[8ull * n + 2], hg = a.state[8ull * n + 3], hb = a.state[8ull * n + 4];
+    const float wsum = a.state[8ull * n];
 
     float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
     if (masked) {
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(kTorsoThreads) void k_torso(TorsoArgs a) {
     a.deform[2ull * n] = ddx;
     a.deform[2ull * n + 1] = ddy;
     a.mask_out[n] = masked ? 1 : 0;
-    a.out_depth[n] = fmaxf(a.depth_acc[n] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+    a.out_depth[n] = fmaxf(a.state[8ull * n + 1] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
 }
 
 }  // namespace gfpp
@@ -235,7 +234,7 @@ GFPP_API int gfpp_torso_frame(const gfpp_torso_model *m, const gfpp_frame_ws *ws
     }
     TorsoArgs a;
     a.bg_coords = bg_coords; a.density_grid = m->density_grid; a.cond_in = cond_in; a.code = code;
-    a.head_image = ws->image; a.weights_sum = ws->weights_sum; a.depth_acc = ws->depth; a.nears = ws->nears; a.fars = ws->fars;
+    a.state = ws->ray_state; a.nears = ws->nears; a.fars = ws->fars;
     a.bg_color = bg_color; a.bg_scalar = bg_scalar; a.shrink = m->torso_shrink; a.thresh = m->density_thresh;
     a.N = ws->N; a.G = m->grid_size; a.variant = m->variant; a.code_dim = m->code_dim; a.const_dim = m->const_dim;
     a.head_aware = m->head_aware; a.use_head = use_head;

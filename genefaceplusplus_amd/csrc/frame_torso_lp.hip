@@ -33,7 +33,7 @@ constexpr int kTlFrags = kTlCan1 + 2;        // 28 fragments-of-64-lanes
 constexpr int kTlSkinnyWords = 2 * 2 * 16 + 2 * 4 * 8;   // def2 [2 halves][2 rows][32 values] + can2 [2][4][16], 16-bit pairs
 
 struct TorsoLpArgs {
-    const float *bg_coords, *density_grid, *cond_in, *code, *head_image, *weights_sum, *depth_acc, *nears, *fars, *bg_color;
+    const float *bg_coords, *density_grid, *cond_in, *code, *state /* [N,8] ray records of the head pass, march_device.h::kRayRec */, *nears, *fars, *bg_color;
     float bg_scalar, shrink, thresh;
     uint32_t N, G, variant, code_dim, const_dim, head_aware, use_head;
     const float *table;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     if (in_frame) {
         cx = a.bg_coords[2ull * n]; cy = a.bg_coords[2ull * n + 1];
         masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
-        hr = a.head_image[3ull * n]; hg = a.head_image[3ull * n + 1]; hb = a.head_image[3ull * n + 2];
-        wsum = a.weights_sum[n];
+        hr = a.state[8ull * n + 2]; hg = a.state[8ull * n + 3]; hb = a.state[8ull * n + 4];
+        wsum = a.state[8ull * n];
     }
     const bool block_has_work = __syncthreads_or(masked ? 1 : 0) != 0;
 
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     a.deform[2ull * n] = ddx;
     a.deform[2ull * n + 1] = ddy;
     a.mask_out[n] = masked ? 1 : 0;
-    a.out_depth[n] = fmaxf(a.depth_acc[n] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+    a.out_depth[n] = fmaxf(a.state[8ull * n + 1] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
 }
 
 }  // namespace gfpp
@@ -340,7 +340,7 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     }
     TorsoLpArgs a;
     a.bg_coords = bg_coords; a.density_grid = m->density_grid; a.cond_in = cond_in; a.code = code;
-    a.head_image = ws->image; a.weights_sum = ws->weights_sum; a.depth_acc = ws->depth; a.nears = ws->nears; a.fars = ws->fars;
+    a.state = ws->ray_state; a.nears = ws->nears; a.fars = ws->fars;
     a.bg_color = bg_color; a.bg_scalar = bg_scalar; a.shrink = m->torso_shrink; a.thresh = m->density_thresh;
     a.N = ws->N; a.G = m->grid_size; a.variant = m->variant; a.code_dim = m->code_dim; a.const_dim = m->const_dim;
     a.head_aware = m->head_aware; a.use_head = use_head;

@@ -133,6 +133,21 @@ struct RayAccum {
     float wsum, depth, r, g, b;
 };
 
+// Per-ray state of the fused frame pipeline: ONE 32-byte record per ray {weights_sum, depth, r, g, b, t (or the sample cursor of the pre-marched
+// kernels), -, -} instead of five arrays indexed by ray id.  A trip touches the rays of its alive list, i.e. scattered ids: with separate arrays
+// every 4-byte store dirtied its own 32-byte sector (measured 4-8x write amplification, profiles/r01_fp16_pmc.md); a record is read with one
+// 16-byte + one 8-byte load and written back as exactly one sector.
+constexpr uint32_t kRayRec = 8;   // floats per record
+__device__ __forceinline__ RayAccum ray_state_load(const float *__restrict__ state, uint32_t ray) {
+    const float4 a = *reinterpret_cast<const float4 *>(state + (size_t)kRayRec * ray);
+    return RayAccum{a.x, a.y, a.z, a.w, state[(size_t)kRayRec * ray + 4]};
+}
+__device__ __forceinline__ void ray_state_store(float *__restrict__ state, uint32_t ray, const RayAccum &acc, float t_or_cursor_bits) {
+    *reinterpret_cast<float4 *>(state + (size_t)kRayRec * ray) = float4{acc.wsum, acc.depth, acc.r, acc.g};
+    *reinterpret_cast<float2 *>(state + (size_t)kRayRec * ray + 4) = float2{acc.b, t_or_cursor_bits};
+}
+__device__ __forceinline__ float ray_state_t(const float *__restrict__ state, uint32_t ray) { return state[(size_t)kRayRec * ray + 5]; }
+
 // Fold one sample into the accumulators.  Returns true if the ray must stop AFTER this sample (the test uses the
 // transmittance from before the sample, as the reference does).
 __device__ __forceinline__ bool composite_sample(RayAccum &a, float sigma, float dt, float t_end, float cr, float cg, float cb,

@@ -38,7 +38,7 @@ class HeadModel(ctypes.Structure):
 
 
 class FrameWs(ctypes.Structure):
-    _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("rays_t", c_p), ("weights_sum", c_p), ("depth", c_p), ("image", c_p),
+    _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("ray_state", c_p),
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32)]
@@ -512,14 +512,14 @@ class FramePipeline:
         if ent is None:
             dev = self.device
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-            t = {"nears": f(N), "fars": f(N), "rays_t": f(N), "weights_sum": f(N), "depth": f(N), "image": f(N, 3),
+            t = {"nears": f(N), "fars": f(N), "ray_state": f(N, 8),       # one 32-byte record per ray (gfpp_frame_ws.ray_state)
                  "alive0": torch.empty(N, dtype=torch.int32, device=dev), "alive1": torch.empty(N, dtype=torch.int32, device=dev),
                  "counters": torch.zeros(128, dtype=torch.int32, device=dev), "frame_consts": f(256),
                  "out_image": f(N, 3), "out_depth": f(N)}
             self._ws_bytes = sum(v.numel() * v.element_size() for v in t.values())
             ws = FrameWs()
             ws.N = N
-            for k in ("nears", "fars", "rays_t", "weights_sum", "depth", "image", "counters", "frame_consts"):
+            for k in ("nears", "fars", "ray_state", "counters", "frame_consts"):
                 setattr(ws, k, t[k].data_ptr())
             ws.alive[0], ws.alive[1] = t["alive0"].data_ptr(), t["alive1"].data_ptr()
             ws.phase_cycles = None

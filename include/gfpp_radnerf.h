@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 1
+#define GFPP_ABI_VERSION 2
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -273,10 +273,10 @@ typedef struct gfpp_frame_ws {
     uint32_t N;          /* rays in the frame */
     float *nears;        /* [N] */
     float *fars;         /* [N] */
-    float *rays_t;       /* [N] */
-    float *weights_sum;  /* [N] */
-    float *depth;        /* [N] */
-    float *image;        /* [N,3] premultiplied head colour */
+    float *ray_state;    /* [N,8] f32: ONE 32-byte record per ray {weights_sum, depth, r, g, b (premultiplied head colour), t or sample cursor, -, -}
+                          * -- the running state that raymarching.cu:942-1029 keeps in the separate rays_t / weights_sum / depth / image arrays.
+                          * A trip touches scattered ray ids: a record is one 16-byte + one 8-byte access and one dirty 32-byte sector per ray,
+                          * where five arrays cost five sectors (measured 4-8x write amplification) */
     int32_t *alive[2];   /* [N] each: ping-pong lists of alive ray ids */
     int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated;
                           * counters[127] = barrier word of the 16-bit kernel's multi-trip launch (negative = a barrier timed out) */
