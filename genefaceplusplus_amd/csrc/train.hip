@@ -312,8 +312,14 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restr
                                                            const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
                                                            TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t lds_floats,
                                                            float *__restrict__ xcd_copies, uint32_t total_floats) {
-    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
-    if (b >= B) return;
+    // Points arrive ray-major (consecutive samples of one ray are neighbours in space and hit the SAME table rows at the coarse and middle levels):
+    // handing neighbouring points to neighbouring lanes makes the 64 atomics of a wavefront instruction queue up on a handful of addresses.  The
+    // point index is therefore transposed -- lane l of the i-th wavefront takes point l * ceil(B / 64) + i -- so that one instruction's atomics go
+    // to 64 different places.
+    const uint32_t i = blockIdx.x * kTrBlock + threadIdx.x;
+    const uint32_t chunk = (B + 63u) / 64u;
+    const uint32_t b = (i & 63u) * chunk + (i >> 6);
+    if ((i >> 6) >= chunk || b >= B) return;
     const uint32_t level = blockIdx.y;
     const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
     if (size * C <= lds_floats) return;                        // owned by k_grid_backward_lds
