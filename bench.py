@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--no-grid-stage", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5, help="multi-GPU: all_gather the finished uint8 frames every this many frames, "
                                                                 "overlapped with the rendering of the next chunk")
-    ap.add_argument("--lanes", type=int, default=None, help="frames in flight per GPU (default: 2 at 512x512 rays, 3 at 256x256): consecutive frames alternate between this many streams, each with "
+    ap.add_argument("--lanes", type=int, default=None, help="frames in flight per GPU (default: 3): consecutive frames alternate between this many streams, each with "
                                                          "its own workspace and hipGraph (weights / tables shared), so one frame's small prologue launches and "
                                                          "sparse late trips overlap the other's full-width launches; 1 = strictly one frame at a time")
     ap.add_argument("--gather", default="writer", choices=["writer", "all"],

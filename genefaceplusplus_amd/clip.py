@@ -18,7 +18,7 @@ import torch
 from . import frames
 from ._lib import GfppError, call
 from .radnerfs import camera
-from .radnerfs.frame_pipeline import GraphedFrame
+from .radnerfs.frame_pipeline import GraphedFrame, shared_stream
 
 
 class ClipRenderer:
@@ -31,8 +31,8 @@ class ClipRenderer:
     def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None):
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
         workspace and graph; weights and tables are shared), so one frame's prologue (slab test, pre-march, conditioning nets: small
-        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches.  None = 2 for
-        512x512 rays, 3 for the 256x256 frames of the super-resolution models (measured: a third lane adds 12 % there, nothing at 512^2)."""
+        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches.  None = 3
+        (round 2: +10 % over two lanes at 512^2, +12 % for the 256^2 frames of the super-resolution models; a fourth lane loses 13 %)."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
@@ -54,19 +54,19 @@ class ClipRenderer:
         self.bg_img = None if bg_img is None else bg_img.to(dev).float().reshape(1, H * W, 3).contiguous()
         fused = getattr(model, "executor", "fused") == "fused"
         if lanes is None:
-            lanes = 3 if H * W <= 256 * 256 else 2
+            lanes = 3        # measured (round 2, after the trip kernel got faster): 512^2 frames 2 300 / 2 530 / 2 010 frames/s with 2 / 3 / 4 lanes
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "u8": torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev),
-                       "stream": torch.cuda.Stream(device=dev) if self.lanes > 1 else None,
-                       "graph": None, "key": None, "static_in": None} for _ in range(self.lanes)]
+                       "stream": shared_stream(dev, "lane", _i) if self.lanes > 1 else None,
+                       "graph": None, "key": None, "static_in": None} for _i in range(self.lanes)]
         self.ring = max(2, int(ring), self.lanes)
         self._dev_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev) for _ in range(self.ring)]
         self._host_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8).pin_memory() for _ in range(self.ring)]
         self._ready = [torch.cuda.Event() for _ in range(self.ring)]
         self._done = [torch.cuda.Event() for _ in range(self.ring)]
-        self._copy_stream = torch.cuda.Stream(device=dev)
+        self._copy_stream = shared_stream(dev, "copy")
 
     # -- one frame of device work --------------------------------------------------------------------------------------------
     def _enter_lane(self, lane):
@@ -211,8 +211,11 @@ class ClipRenderer:
             sink(idx[k], self._host_ring[slot].numpy())
 
         main = self._fork()
+        # the device->host copies need a stream (and a hardware queue) of their own: with it, two rendering lanes are the measured optimum
+        # (1 900-2 100 frames/s delivered; three lanes + the copy stream: 1 250-1 400)
+        host_lanes = min(self.lanes, 2)
         for k, i in enumerate(idx):
-            slot, lane = k % self.ring, k % self.lanes
+            slot, lane = k % self.ring, k % host_lanes
             if k >= self.ring:
                 retire(k - self.ring)
             with self._on_lane(lane):

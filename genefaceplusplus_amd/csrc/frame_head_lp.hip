@@ -511,10 +511,12 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         // ---- phase 1: this trip's samples of every ray (one lane per ray), from the frame's pre-marched list -----------------
         const uint32_t n = tile * rays_per_tile + lane;
         const bool has_ray = (uint32_t)lane < rays_per_tile && n < n_alive;
-        uint32_t ray = 0, cnt = 0, used = 0;
+        // every ray that is still alive took the full n_step samples in each earlier trip (a shorter take declares it dead), so its cursor into the
+        // pre-marched list is the loop's cumulative step count -- no per-ray cursor to fetch behind the alive-list load
+        uint32_t ray = 0, cnt = 0;
+        const uint32_t used = step_before - n_step;
         if (has_ray) {
             ray = trip == 0 ? n : (uint32_t)alive_in[n];
-            used = trip == 0 ? 0u : __float_as_uint(ray_state_t(a.state, ray));
             const uint32_t avail = a.sample_cnt[ray] - used;
             cnt = avail < n_step ? avail : n_step;
             wt.ray[lane] = ray;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
             }
             // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
             survives = (s == n_step);
-            ray_state_store(a.state, ray, acc, __uint_as_float(survives ? used + n_step : used));
+            ray_state_store(a.state, ray, acc, __uint_as_float(survives ? used + n_step : used));   // (cursor kept in the record for inspection; nobody reads it)
         }
         const unsigned long long ballot = __ballot(survives);
         const uint32_t total = (uint32_t)__popcll(ballot);

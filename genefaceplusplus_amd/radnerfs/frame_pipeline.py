@@ -239,6 +239,21 @@ def supports(model):
     return ok
 
 
+# HIP multiplexes a process's streams onto a handful of hardware queues (4 by default, round-robin at creation); two streams that land on the same
+# queue serialise.  Every renderer / pipeline of a process therefore shares ONE set of streams per (device, role, lane) instead of drawing fresh
+# ones from torch's pool: a second model in the same process (bench.py's SR mode, several identities on one GPU) keeps the lane <-> queue mapping
+# of the first (measured: a second ClipRenderer with its own streams ran 30 % slower than alone).
+_STREAMS = {}
+
+
+def shared_stream(device, role, lane=0):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), role, int(lane))
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class GraphedFrame:
     """One frame of C-ABI launches captured in a hipGraph (torch.cuda.CUDAGraph is a hipGraph on ROCm) and replayed.
 
@@ -587,7 +602,7 @@ class FramePipeline:
         if callable(cond_feat):
             side = self._side_stream.get(self.lane)
             if side is None:
-                side = self._side_stream[self.lane] = torch.cuda.Stream(device=self.device)
+                side = self._side_stream[self.lane] = shared_stream(self.device, "side", self.lane)
             side.wait_stream(main)                      # fork: everything the caller queued so far (input copies) is visible
             with torch.cuda.stream(side):
                 t["cond_feat"] = fold(cond_feat(), side.cuda_stream)
