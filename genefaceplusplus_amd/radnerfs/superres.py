@@ -293,7 +293,11 @@ class Superresolution(nn.Module):
         if noise_mode == "const":
             noises = [l.noise_const.detach().float().contiguous() for l in layers]
         elif noise_mode == "random":
-            noises = [torch.randn(l.resolution, l.resolution, device=x.device) for l in layers]
+            # one generator launch for the four layers' noise fields (655 k unit normals per frame) instead of four; like the reference's
+            # per-layer torch.randn calls the values are fresh per frame and per layer, their position in the generator stream is not the same
+            sizes = [l.resolution * l.resolution for l in layers]
+            flat = torch.randn(sum(sizes), device=x.device)
+            noises = [c.view(l.resolution, l.resolution) for c, l in zip(flat.split(sizes), layers)]
         else:
             noises = None
         arr = (c_p * 4)(*[n.data_ptr() for n in noises]) if noises is not None else None
