@@ -20,6 +20,11 @@
 #include "gfpp_common.h"
 #include "lp_mfma_device.h"
 
+// experiment builds only (tools/sr_bench.py; wrong results): 1 = no MFMA loop, 2 = no epilogue stores, 4 = no halo load, 8 = no next-tap weight staging
+#ifndef GFPP_SR_ABLATE
+#define GFPP_SR_ABLATE 0
+#endif
+
 namespace gfpp {
 
 constexpr int kSrThreads = 256;
@@ -50,6 +55,17 @@ __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
     return fminf(fmaxf(v, -clamp), clamp);
 }
 
+// One tap's weight fragments (PER_THREAD x 256 x 16 B, already in [step][tile][lane] order) from global memory straight into LDS: the LDS address
+// of a direct load is wave-uniform base + lane x 16, which is exactly the fragment layout.
+template <int PER_THREAD>
+__device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint4 *dst, int tid, int lane) {
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) {
+        const int i = q * kSrThreads + tid;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i), (__attribute__((address_space(3))) void *)(dst + (i - lane)), 16, 0, 0);
+    }
+}
+
 template <int CIN, int NT, int EPI>
 __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     typedef LpTraits<_Float16>::vec vec;
@@ -61,6 +77,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 patch[kSrHalo * kSrHalo * PS];
     __shared__ uint4 wbuf[2][TAPFRAGS];
     __shared__ float s_rgb[(EPI == kSrRgbAdd || EPI == kSrFinal) ? NT * 32 * 3 + 4 : 1];
+    __shared__ __attribute__((aligned(16))) float s_bias[NT * 32];   // this pass's output-channel biases (UpPhases: the 64 channels, twice)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
@@ -68,14 +85,39 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     const uint32_t pass = blockIdx.z;
     const uint4 *wg = a.w + (size_t)pass * 9 * TAPFRAGS;
 
-    // ---- first tap's weights straight to LDS, input halo to LDS (zero padding outside the image) ----------------------------------
-    for (int i = tid; i < TAPFRAGS; i += kSrThreads) wbuf[0][i] = wg[i];
-    for (int i = tid; i < kSrHalo * kSrHalo * (CIN / 8); i += kSrThreads) {
-        const int p = i / (CIN / 8), c8 = i % (CIN / 8);
-        const int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) v = *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + c8 * 8);
-        *reinterpret_cast<uint4 *>(&patch[p * PS + c8 * 8]) = v;
+    // ---- first tap's weights and the input halo -> LDS (zero padding outside the image) ---------------------------------------------------------
+    // All loads are issued before the first LDS store: the addresses are clamped into the image and the zero padding is a select on the loaded
+    // value, so there is no branch around a load (a conditional load makes the compiler wait vmcnt(0) per element: 20 serial memory round
+    // trips per thread, ~20 us of the 44 us this kernel took in round 1).
+    {
+        constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CIN / 8);
+        constexpr int HALO_ITERS = (HALO_CHUNKS + kSrThreads - 1) / kSrThreads;
+        uint4 hv[HALO_ITERS];
+        sr_stage_tap<PER_THREAD>(wg, wbuf[0], tid, lane);
+#pragma unroll
+        for (int q = 0; q < HALO_ITERS; ++q) {
+            const int i = q * kSrThreads + tid;
+            const int ic = i < HALO_CHUNKS ? i : HALO_CHUNKS - 1;
+            const int pp = ic / (CIN / 8), c8 = ic % (CIN / 8);
+            int py = y0 - 1 + pp / kSrHalo, px = x0 - 1 + pp % kSrHalo;
+            py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
+            px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
+            hv[q] = (GFPP_SR_ABLATE & 4) ? make_uint4(py, px, c8, 1) : *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + c8 * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < HALO_ITERS; ++q) {
+            const int i = q * kSrThreads + tid;
+            if (i < HALO_CHUNKS) {
+                const int pp = i / (CIN / 8), c8 = i % (CIN / 8);
+                const int py = y0 - 1 + pp / kSrHalo, px = x0 - 1 + pp % kSrHalo;
+                const bool in = py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W;
+                *reinterpret_cast<uint4 *>(&patch[pp * PS + c8 * 8]) = in ? hv[q] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    for (int i = tid; i < NT * 32; i += kSrThreads) {
+        const int ng = (int)blockIdx.z * NT * 32 + i;
+        s_bias[i] = a.bias[EPI == kSrUpPhases ? (ng & 63) : ng];
     }
     if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
         for (int i = tid; i < NT * 32 * 3; i += kSrThreads) s_rgb[i] = a.w_rgb[i];
@@ -94,35 +136,60 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     // this lane's two pixels (one per column tile): rows 4 wave + 2 u + (j >> 4), column j & 15 of the patch
     const int prow = 4 * wave + (j >> 4), pcol = j & 15;
     int cur = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-        uint4 nxt[PER_THREAD];
-        if (tap + 1 < 9) {
-#pragma unroll
-            for (int q = 0; q < PER_THREAD; ++q) nxt[q] = wg[(size_t)(tap + 1) * TAPFRAGS + q * kSrThreads + tid];
-        }
+    for (int tap = 0; tap < ((GFPP_SR_ABLATE & 1) ? 0 : 9); ++tap) {
+        // the next tap's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
+        // cost half of the tap loop), into the buffer the previous tap's MFMAs released at the last barrier; they land while this tap computes
+        if (tap + 1 < 9 && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD>(wg + (size_t)(tap + 1) * TAPFRAGS, wbuf[cur ^ 1], tid, lane);
         const int dy = tap / 3, dx = tap % 3;
         const _Float16 *b0 = &patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi];
         const _Float16 *b1 = b0 + 2 * kSrHalo * PS;
         const vec *wl = reinterpret_cast<const vec *>(wbuf[cur]) + lane;
+        // operands of step s + 1 are read while the 2 NT MFMAs of step s run (one wavefront per SIMD here: nobody else hides the LDS latency);
+        // the sched_barriers pin that order, as in lp_mfma_device.h::mfma_layer_lds
+        vec Bq[2][2], Aq[2][NT];
+        Bq[0][0] = *reinterpret_cast<const vec *>(b0);
+        Bq[0][1] = *reinterpret_cast<const vec *>(b1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Aq[0][t] = wl[t * 64];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            const vec B0 = *reinterpret_cast<const vec *>(b0 + 16 * s), B1 = *reinterpret_cast<const vec *>(b1 + 16 * s);
+            if (s + 1 < STEPS) {
+                Bq[(s + 1) & 1][0] = *reinterpret_cast<const vec *>(b0 + 16 * (s + 1));
+                Bq[(s + 1) & 1][1] = *reinterpret_cast<const vec *>(b1 + 16 * (s + 1));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Aq[(s + 1) & 1][t] = wl[((s + 1) * NT + t) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const vec A = wl[(s * NT + t) * 64];
-                acc[0][t] = LpTraits<_Float16>::mfma(A, B0, acc[0][t]);
-                acc[1][t] = LpTraits<_Float16>::mfma(A, B1, acc[1][t]);
+                acc[0][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][0], acc[0][t]);
+                acc[1][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][1], acc[1][t]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (tap + 1 < 9) {
-#pragma unroll
-            for (int q = 0; q < PER_THREAD; ++q) wbuf[cur ^ 1][q * kSrThreads + tid] = nxt[q];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the next tap has landed in LDS
         __syncthreads();
         cur ^= 1;
     }
 
     // ---- epilogue: noise + bias, leaky relu * gain, clamp; store / ToRGB ----------------------------------------------------------
+    // The noise value depends on the output pixel only (for the up-sampling layer: on the pixel and the phase = pair of row tiles), the bias on
+    // the channel: both are fetched BEFORE the 2 x NT x 4 store loop (noise: at most 4 loads per lane; bias: LDS).  Inside the loop a
+    // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
+    constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
+    float nzv[2][NPH];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            const int Y = y0 + prow + 2 * u, X = x0 + pcol;
+            size_t at = (size_t)Y * a.W + X;
+            if constexpr (EPI == kSrUpPhases) {
+                const int phase = ((int)pass * NT * 32 + 64 * ph) >> 6;
+                at = (size_t)(2 * Y + (phase >> 1)) * (2 * a.W) + 2 * X + (phase & 1);
+            }
+            nzv[u][ph] = a.noise ? a.noise[at] * a.noise_strength : 0.0f;
+        }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int Y = y0 + prow + 2 * u, X = x0 + pcol;          // position at the patch-grid (input) resolution
@@ -141,10 +208,13 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
                     oy = 2 * Y + (phase >> 1); ox = 2 * X + (phase & 1); oc = ng & 63;
                     OW = 2 * a.W; OC = 64;
                 }
-                const float nz = a.noise ? a.noise[(size_t)oy * OW + ox] * a.noise_strength : 0.0f;
+                const float nz = nzv[u][EPI == kSrUpPhases ? t / 2 : 0];
+                const float4 bq = *reinterpret_cast<const float4 *>(&s_bias[n0]);
+                const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = sr_act(acc[u][t][4 * q + e] + nz + a.bias[oc + e], a.act_gain, a.clamp);
-                if constexpr (EPI != kSrFinal) {
+                for (int e = 0; e < 4; ++e) v[e] = sr_act(acc[u][t][4 * q + e] + nz + bv[e], a.act_gain, a.clamp);
+
+                if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 o;
 #pragma unroll
@@ -166,24 +236,39 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
             if (hi == 0) {
+                float base[3];
+                if constexpr (EPI == kSrRgbAdd) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) base[k] = a.img_in[((size_t)Y * a.W + X) * 3 + k];
+                } else {
+                    // upsample2d(img256) at (Y, X): zero insertion, [1,3,3,1] FIR, gain 4 (upfirdn2d.py:330-355) = two taps per axis.  The four source
+                    // pixels are loaded unconditionally from clamped coordinates and zeroed by a select (no branch around a load, see the halo)
+                    const int h2 = (int)a.H / 2, w2 = (int)a.W / 2;
+                    const int ya = (Y & 1) ? (Y - 1) / 2 : Y / 2 - 1, xa = (X & 1) ? (X - 1) / 2 : X / 2 - 1;
+                    const float wy[2] = {(Y & 1) ? a.fir[1] : a.fir[0], (Y & 1) ? a.fir[3] : a.fir[2]};
+                    const float wx[2] = {(X & 1) ? a.fir[1] : a.fir[0], (X & 1) ? a.fir[3] : a.fir[2]};
+                    float src[2][2][3];
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                        for (int ix = 0; ix < 2; ++ix) {
+                            const int yy = ya + iy, xx = xa + ix;
+                            const int yc = yy < 0 ? 0 : (yy >= h2 ? h2 - 1 : yy), xc = xx < 0 ? 0 : (xx >= w2 ? w2 - 1 : xx);
+                            const bool in = yy >= 0 && yy < h2 && xx >= 0 && xx < w2;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float v = a.img_in[((size_t)yc * w2 + xc) * 3 + k];
+                                src[iy][ix][k] = in ? v : 0.0f;
+                            }
+                        }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        base[k] = wy[0] * (wx[0] * src[0][0][k] + wx[1] * src[0][1][k]) + wy[1] * (wx[0] * src[1][0][k] + wx[1] * src[1][1][k]);
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float t = fminf(fmaxf(rgb[k] + s_rgb[NT * 32 * 3 + k], -a.clamp), a.clamp);
-                    float base;
-                    if constexpr (EPI == kSrRgbAdd) {
-                        base = a.img_in[((size_t)Y * a.W + X) * 3 + k];
-                    } else {
-                        // upsample2d(img256) at (Y, X): zero insertion, [1,3,3,1] FIR, gain 4 (upfirdn2d.py:330-355) = two taps per axis
-                        const int h2 = (int)a.H / 2, w2 = (int)a.W / 2;
-                        const int ya = (Y & 1) ? (Y - 1) / 2 : Y / 2 - 1, xa = (X & 1) ? (X - 1) / 2 : X / 2 - 1;
-                        const float wy0 = (Y & 1) ? a.fir[1] : a.fir[0], wy1 = (Y & 1) ? a.fir[3] : a.fir[2];
-                        const float wx0 = (X & 1) ? a.fir[1] : a.fir[0], wx1 = (X & 1) ? a.fir[3] : a.fir[2];
-                        auto px = [&](int yy, int xx) -> float {
-                            return (yy >= 0 && yy < h2 && xx >= 0 && xx < w2) ? a.img_in[((size_t)yy * w2 + xx) * 3 + k] : 0.0f;
-                        };
-                        base = wy0 * (wx0 * px(ya, xa) + wx1 * px(ya, xa + 1)) + wy1 * (wx0 * px(ya + 1, xa) + wx1 * px(ya + 1, xa + 1));
-                    }
-                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = base + t;
+                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = base[k] + t;
                 }
             }
         }
@@ -206,15 +291,35 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
     typedef LpTraits<_Float16>::vec vec;
     __shared__ float patch[kSrHalo * kSrHalo * 3];
     __shared__ uint4 wl[2 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float s_bias[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
     for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) wl[i] = a.w[i];
-    for (int i = tid; i < kSrHalo * kSrHalo * 3; i += kSrThreads) {
-        const int p = i / 3, c = i % 3;
-        const int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
-        // the reference casts the block input to fp16 before the first convolution (superresolution.py:216)
-        patch[i] = (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) ? (float)(_Float16)a.rgb[((size_t)py * a.W + px) * 3 + c] : 0.0f;
+    if (tid < 128) s_bias[tid] = a.bias[tid];
+    {
+        // unconditional loads from clamped coordinates, zero padding by select (no branch around a load)
+        constexpr int N = kSrHalo * kSrHalo * 3, IT = (N + kSrThreads - 1) / kSrThreads;
+        float hv[IT];
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * kSrThreads + tid, ic = i < N ? i : N - 1;
+            const int p = ic / 3, c = ic % 3;
+            int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
+            py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
+            px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
+            hv[q] = a.rgb[((size_t)py * a.W + px) * 3 + c];
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * kSrThreads + tid;
+            if (i < N) {
+                const int p = i / 3;
+                const int py = y0 - 1 + p / kSrHalo, px = x0 - 1 + p % kSrHalo;
+                // the reference casts the block input to fp16 before the first convolution (superresolution.py:216)
+                patch[i] = (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) ? (float)(_Float16)hv[q] : 0.0f;
+            }
+        }
     }
     __syncthreads();
     const int prow = 4 * wave + (j >> 4), pcol = j & 15;
@@ -260,7 +365,7 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 h4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)sr_act(acc[u][t][4 * q + e] + nz + a.bias[n0 + e], a.act_gain, a.clamp);
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)sr_act(acc[u][t][4 * q + e] + nz + s_bias[n0 + e], a.act_gain, a.clamp);
                 *reinterpret_cast<h4 *>(a.y + ((size_t)Y * a.W + X) * 128 + n0) = o;
             }
     }
