@@ -495,7 +495,8 @@ def main():
             # HBM peak (the north star's yardstick for the hash-grid stage) and the MFMA fraction beside it
             gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
             tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
-            result["roofline"] = {"kernel": f"k_head_trip_lp<3,{args.precision}> (fused march + grid encode + 16-bit MFMA MLP + composite)", "bound": "hbm",
+            kname = "k_head_trip_lp" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" else "k_head_trip_pool"
+            result["roofline"] = {"kernel": f"{kname}<3,{args.precision}> (fused march + grid encode + 16-bit MFMA MLP + composite)", "bound": "hbm",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                                   "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
                                   "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",

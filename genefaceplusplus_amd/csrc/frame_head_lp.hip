@@ -65,12 +65,30 @@ struct LpWaveTile {
     uint8_t order[kLpSlots];                          // compact index -> slot
 };
 
+// The sample pool of one workgroup round (k_head_trip_pool): the eight wavefront tiles side by side, compacted TOGETHER, so that the
+// 32-sample blocks are full and any wavefront can evaluate any of them.  Same member names as LpWaveTile: evaluate_block_lp works on either.
+constexpr int kPoolSlots = kLpWaves * kLpSlots;   // 1024
+constexpr uint32_t kNoRay = 0xFFu;
+struct LpPool {
+    float px[kPoolSlots], py[kPoolSlots], pz[kPoolSlots];
+    float cb[kPoolSlots], dt[kPoolSlots], tend[kPoolSlots];
+    uint32_t ray[kPoolSlots];        // ray id by local ray (wavefront w owns the local rays [w * rw, (w + 1) * rw))
+    uint16_t order[kPoolSlots];      // compact index -> slot, over the whole workgroup
+    uint8_t cnt[kPoolSlots];         // samples the local ray takes in this trip; kNoRay: no such ray
+    uint32_t wave_valid[kLpWaves];   // occupied samples per wavefront tile
+    uint32_t wave_surv[kLpWaves];    // surviving rays per wavefront tile
+    uint32_t out_base;               // where the workgroup's survivors go in the next trip's list
+};
+
 struct LpShared {
     uint4 w[kLpWeightChunks];      // 126 976 B
     uint32_t skinny[kSkinnyWords]; //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
     gfpp_grid_level lv[2][16];     //   1 024 B  level descriptors of the position / ambient grid
     float bias[256];               //   1 024 B
-    LpWaveTile tile[kLpWaves];     //  27 648 B
+    union {
+        LpWaveTile tile[kLpWaves]; //  27 648 B  one tile per wavefront (k_head_trip_lp, k_head_eval_lp)
+        LpPool pool;               //  31 776 B  one pool per workgroup (k_head_trip_pool)
+    };
 };
 static_assert(sizeof(LpShared) <= 163840, "one workgroup per CU: everything must fit the 160 KiB LDS");
 
@@ -296,8 +314,8 @@ __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename
 }
 
 // sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
-template <typename H>
-__device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, const typename LpTraits<H>::vec (&bpos)[2],
+template <typename H, typename Tile>
+__device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, Tile &wt, const typename LpTraits<H>::vec (&bpos)[2],
                                                const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi) {
     typedef typename LpTraits<H>::vec vec;
     const bool valid = c < n_valid;
@@ -338,9 +356,9 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     }
 }
 
-// RADNeRF.forward for the 32 occupied samples [first, first+32) of this wavefront's tile.
-template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool PROF = false>
-__device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, LpWaveTile &wt, uint32_t first, uint32_t n_valid,
+// RADNeRF.forward for the 32 occupied samples [first, first+32) of a tile (one wavefront's LpWaveTile or the workgroup's LpPool).
+template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool PROF = false, typename Tile>
+__device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, Tile &wt, uint32_t first, uint32_t n_valid,
                                                   uint32_t n_step, int lane_in, unsigned long long (&sub)[4]) {
     constexpr bool prof = PROF;      // the phase counters are a separate kernel instantiation: no registers, scratch or s_memtime in the production kernel
     unsigned long long tm = prof ? __builtin_readcyclecounter() : 0ull;
@@ -587,6 +605,203 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
   }
 }
 
+// The same trips with the samples of a whole workgroup pooled (the production kernel; k_head_trip_lp above is kept for the phase-cycle
+// instantiation and as the A/B partner, GFPP_TRIP_POOL=0).  Why: a wavefront of k_head_trip_lp owns its tile's blocks, a tile holds 0..4
+// blocks, and the workgroup keeps its CU until its slowest wavefront is done -- at 512x512 a trip carries ~2.4 blocks per wavefront on
+// average but lasts 4 block times.  Here every workgroup takes an equal share of the alive rays (wavefront tiles dealt out through a
+// multiplicative permutation, so that in trip 0 no workgroup gets only the empty image border), compacts the occupied samples of all
+// eight tiles into one list -- every block but the last is full -- and deals the blocks out to its wavefronts round-robin: a round lasts
+// ceil(blocks / 8) block times.  Per sample nothing changes (same evaluate_block_lp, same compositing order along a ray).
+// PROF: phase_cycles[trip][0..4] = shader cycles summed over wavefronts: gather samples | the two compaction barriers | evaluate | wait for the
+// workgroup's last block | composite;  [5] = wavefront rounds, [6] = blocks evaluated, [7] = the longest workgroup round of the trip (cycles)
+template <int AMB_D, typename H, bool SLOW, bool PROF = false>
+__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool(LpTripArgs a) {
+    __shared__ LpShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool prof = PROF;
+    bool weights_resident = false;
+    uint32_t barriers = 0;
+    uint32_t step_before = 0;
+    for (uint32_t k = 0; k < a.trip; ++k) {
+        const uint32_t na = counter_load(a.gcounters + k);
+        if (na == 0) return;
+        uint32_t ns = a.N_global / na;
+        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
+        step_before += ns;
+    }
+    for (uint32_t trip = a.trip; trip < a.trip_end; ++trip) {
+        const uint32_t n_alive_frame = counter_load(a.gcounters + trip);
+        if (n_alive_frame == 0 || step_before >= a.max_steps) return;
+        uint32_t n_step = a.N_global / n_alive_frame;
+        n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+        step_before += n_step;
+        const uint32_t used = step_before - n_step;
+        const uint32_t n_alive = a.gcounters == a.counters ? n_alive_frame : counter_load(a.counters + trip);
+        if (n_alive == 0) return;
+        const int32_t *alive_in = a.alive[trip & 1];
+        int32_t *alive_out = a.alive[(trip + 1) & 1];
+
+        // equal shares: `rounds` rounds of gridDim.x * 8 wavefront tiles of rw rays (rw * n_step <= 128 slots per wavefront)
+        const uint32_t tiles_per_round = gridDim.x * kLpWaves;
+        const uint32_t rw_max = (uint32_t)kLpSlots / n_step;
+        const uint32_t rounds = (n_alive + tiles_per_round * rw_max - 1) / (tiles_per_round * rw_max);
+        const uint32_t rw = (n_alive + tiles_per_round * rounds - 1) / (tiles_per_round * rounds);
+        const uint32_t n_tiles = (n_alive + rw - 1) / rw;
+        const uint32_t mult = n_tiles % 1237u ? 1237u : 1u;   // q -> q * mult mod n_tiles is a permutation of the tiles (1237 is prime)
+        LpPool &pool = sh.pool;
+        unsigned long long sub4[4] = {0ull, 0ull, 0ull, 0ull};
+        unsigned long long t_mark = 0ull, cyc[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, longest = 0ull;
+        auto lap = [&](int phase) {
+            if (prof) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                cyc[phase] += now - t_mark;
+                t_mark = now;
+            }
+        };
+
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t q0 = (r * gridDim.x + blockIdx.x) * kLpWaves;
+            if (q0 >= n_tiles) break;   // nothing for this workgroup in this round (the same decision in all its wavefronts)
+            const unsigned long long t_round = prof ? __builtin_readcyclecounter() : 0ull;
+            t_mark = t_round;
+            if (!weights_resident) {
+                lp_fill_shared(sh, a, tid, lane);
+                weights_resident = true;   // (the first __syncthreads below publishes them)
+            }
+            const uint32_t q = q0 + (uint32_t)wave;
+            const bool has_tile = q < n_tiles;
+            const uint32_t tile = has_tile ? (uint32_t)(((unsigned long long)q * mult) % n_tiles) : 0u;
+
+            // ---- phase 1: this trip's samples of the wavefront's rw rays (one or two rays per lane) into the pool ---------------
+            uint32_t my_valid = 0, cnt_r[2], pos_r[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint32_t i = (uint32_t)(sub * 64 + lane);
+                const uint32_t local = (uint32_t)wave * rw + i;
+                const uint32_t n = tile * rw + i;
+                const bool in_tile = i < rw;
+                const bool has_ray = in_tile && has_tile && n < n_alive;
+                uint32_t cnt = 0;
+                if (has_ray) {
+                    const uint32_t ray = trip == 0 ? n : (uint32_t)alive_in[n];
+                    const uint32_t avail = a.sample_cnt[ray] - used;
+                    cnt = avail < n_step ? avail : n_step;
+                    pool.ray[local] = ray;
+                    if (cnt) {
+                        const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+                        const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+                        const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
+                        const uint32_t base = local * n_step;
+                        for (uint32_t s = 0; s < cnt; ++s) {
+                            // the same expressions as march_one_ray (raymarching.cu:873-882, 905-913) evaluated at the stored t
+                            const float t0 = ts[s];
+                            const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);
+                            pool.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                            pool.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                            pool.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                            pool.dt[base + s] = dt;
+                            pool.tend[base + s] = t0 + dt;
+                        }
+                    }
+                }
+                if (in_tile) pool.cnt[local] = (uint8_t)(has_ray ? cnt : kNoRay);
+                const uint32_t incl = wave_inclusive_scan(cnt, lane);
+                cnt_r[sub] = cnt;
+                pos_r[sub] = my_valid + incl - cnt;
+                my_valid += (uint32_t)__shfl((int)incl, 63);
+            }
+            if (lane == 0) pool.wave_valid[wave] = my_valid;
+            lap(0);
+            __syncthreads();
+            // compaction over the workgroup: wavefront tiles in order, rays in order inside a tile
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < kLpWaves; ++v) {
+                const uint32_t x = pool.wave_valid[v];
+                before += v < wave ? x : 0u;
+                total += x;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint32_t slot0 = ((uint32_t)wave * rw + (uint32_t)(sub * 64 + lane)) * n_step;
+                for (uint32_t s = 0; s < cnt_r[sub]; ++s) pool.order[before + pos_r[sub] + s] = (uint16_t)(slot0 + s);
+            }
+            __syncthreads();
+            lap(1);
+
+            // ---- phase 2: the pooled blocks, dealt out round-robin -----------------------------------------------------------------
+            for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves) {
+                evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
+                if (prof) cyc[6] += 1ull;
+            }
+            lap(2);
+            __syncthreads();
+            lap(3);
+
+            // ---- phase 3: composite, ray state update (the owner of the ray); survivor compaction over the workgroup ---------------
+            // ONE list-append atomic per workgroup round: the 2 x 2048 per-wavefront appends of a trip all hit one address at the same time
+            // after the barrier and queue up behind each other (~10 ns each, measured: the phase took as long as the evaluation)
+            unsigned long long alive_bits[2] = {0ull, 0ull};
+            uint32_t ray_r[2] = {0u, 0u};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint32_t i = (uint32_t)(sub * 64 + lane);
+                if ((uint32_t)(sub * 64) >= rw) break;   // wavefront-uniform
+                const uint32_t local = (uint32_t)wave * rw + i;
+                const uint32_t cnt = i < rw ? (uint32_t)pool.cnt[local] : kNoRay;
+                bool survives = false;
+                if (cnt != kNoRay) {
+                    const uint32_t ray = pool.ray[local];
+                    ray_r[sub] = ray;
+                    RayAccum acc = ray_state_load(a.state, ray);
+                    const uint32_t base = local * n_step;
+                    uint32_t s = 0;
+                    for (; s < cnt; ++s) {
+                        const uint32_t k = base + s;
+                        if (composite_sample(acc, pool.px[k], pool.dt[k], pool.tend[k], pool.py[k], pool.pz[k], pool.cb[k], a.T_thresh)) break;
+                    }
+                    // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
+                    survives = (s == n_step);
+                    ray_state_store(a.state, ray, acc, __uint_as_float(survives ? used + n_step : used));
+                }
+                alive_bits[sub] = __ballot(survives);
+            }
+            const uint32_t surv0 = (uint32_t)__popcll(alive_bits[0]), surv1 = (uint32_t)__popcll(alive_bits[1]);
+            if (lane == 0) pool.wave_surv[wave] = surv0 + surv1;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int v = 0; v < kLpWaves; ++v) sum += pool.wave_surv[v];
+                pool.out_base = sum ? (uint32_t)atomicAdd(&a.counters[trip + 1], (int)sum) : 0u;
+            }
+            __syncthreads();
+            {
+                uint32_t out = pool.out_base;
+#pragma unroll
+                for (int v = 0; v < kLpWaves; ++v) out += v < wave ? pool.wave_surv[v] : 0u;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if ((alive_bits[0] >> lane) & 1ull) alive_out[out + (uint32_t)__popcll(alive_bits[0] & below)] = (int32_t)ray_r[0];
+                if ((alive_bits[1] >> lane) & 1ull) alive_out[out + surv0 + (uint32_t)__popcll(alive_bits[1] & below)] = (int32_t)ray_r[1];
+            }
+            if (tid == 0 && total) atomicAdd(&a.counters[64 + trip], (int)total);   // evaluated samples of this trip
+            lap(4);
+            if (prof) {
+                cyc[5] += 1ull;
+                const unsigned long long dur = __builtin_readcyclecounter() - t_round;
+                longest = dur > longest ? dur : longest;
+            }
+            // (no barrier here: the next round's phase 1 writes only the wavefront's own rays and slots, which nobody else reads after phase 2,
+            // and its first barrier comes before wave_surv / out_base are written again)
+        }
+        if (prof && lane == 0) {
+            for (int ph = 0; ph < 7; ++ph) atomicAdd(&a.phase_cycles[8 * trip + ph], cyc[ph]);
+            atomicMax(&a.phase_cycles[8 * trip + 7], longest);
+        }
+        if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
+    }
+}
+
 // The sample positions of a ray do not depend on the radiance field (only on the occupancy bitfield), and the reference's marcher
 // carries nothing but t from one loop iteration to the next (raymarching.cu:857, renderer.py:366), so the whole per-ray sample
 // sequence can be marched ONCE per frame, at full occupancy, instead of piecewise inside the register- and LDS-heavy trip kernel:
@@ -663,9 +878,18 @@ static void launch_eval_lp(uint32_t grid, hipStream_t st, const LpEvalArgs &e) {
     hipLaunchKernelGGL((k_head_eval_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, e);
 }
 
+// GFPP_TRIP_POOL=0 selects the per-wavefront-tile kernel (A/B runs)
+static bool lp_pool_enabled() {
+    const char *e = getenv("GFPP_TRIP_POOL");   // read at every issue (a captured graph keeps what it was captured with)
+    return e ? atoi(e) != 0 : true;
+}
+
 template <int AMB_D, typename H, bool SLOW>
 static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
-    if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    if (lp_pool_enabled()) {
+        if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    } else if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
     else hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
 }
 

@@ -43,7 +43,7 @@ def main():
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     res["replicas_agree"] = bool(lo.item() == hi.item())
-    print("DISTRESULT " + json.dumps(res), flush=True)
+    sys.stdout.write("\nDISTRESULT " + json.dumps(res) + "\n"); sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -51,7 +51,7 @@ def main():
         g = model.pipeline().workspace(hi - lo)[1]["gcounters"].cpu().numpy()
         res[f"{variant}_{HW}_{precision}"] = ok and bool(np.array_equal(g[:16], alive_alone[:16]))
         res[f"{variant}_{HW}_{precision}_trips"] = int((alive_alone[:16] > 0).sum())
-    print("TILERESULT " + json.dumps(res), flush=True)
+    sys.stdout.write("\nTILERESULT " + json.dumps(res) + "\n"); sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()
 

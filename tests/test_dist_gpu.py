@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _tagged(stdout, tag):
+    """The ranks share one stdout and their lines can land on top of each other: pick the (flat) JSON objects out by tag, not by line."""
+    import re
+    return [json.loads(m) for m in re.findall(tag + r" (\{[^{}]*\})", stdout)]
+
+
 def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -33,7 +40,7 @@ def test_rccl_distributed_clip_equals_single_gpu_clip():
     n = min(torch.cuda.device_count(), 4)
     r = _torchrun(n, [os.path.join(ROOT, "tests", "dist_gpu_worker.py")])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    results = [json.loads(line.split("DISTRESULT ", 1)[1]) for line in r.stdout.splitlines() if "DISTRESULT " in line]
+    results = _tagged(r.stdout, "DISTRESULT")
     assert sorted(x["rank"] for x in results) == list(range(n))
     for x in results:
         assert x["world_seen"] == n and x["backend"] == "nccl" and x["replicas_agree"]
@@ -63,7 +70,7 @@ def test_bench_identities_one_gpu():
 def _tile_results(n, backend):
     r = _torchrun(n, [os.path.join(ROOT, "tests", "dist_tile_worker.py"), backend])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    out = [json.loads(line.split("TILERESULT ", 1)[1]) for line in r.stdout.splitlines() if "TILERESULT " in line]
+    out = _tagged(r.stdout, "TILERESULT")
     assert sorted(x["rank"] for x in out) == list(range(n))
     for x in out:
         for k, v in x.items():

@@ -114,6 +114,29 @@ def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
     assert not np.array_equal(outs["graph"][0]["rgb_map"], outs["graph"][1]["rgb_map"])
 
 
+@pytest.mark.parametrize("variant,HW,precision,over", [("may_torso", 512, "bf16", None), ("may_head", 96, "fp16", None),
+                                                        ("may_head", 37, "bf16", None), ("may_torso", 96, "fp16", {"sigma_gain": 0.05})])
+def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, variant, HW, precision, over):
+    """k_head_trip_pool (workgroup-wide sample pool, the production kernel) against k_head_trip_lp (one tile per wavefront,
+    GFPP_TRIP_POOL=0): the same samples through the same evaluate_block_lp, only grouped into blocks differently, so every
+    output must be equal bit for bit -- also in the thin scene that runs the multi-trip launch with its device-wide barrier."""
+    import numpy as np
+    outs = {}
+    for pool in ("1", "0"):
+        monkeypatch.setenv("GFPP_TRIP_POOL", pool)
+        case = frame_case(variant, HW, **(over or {}))
+        model = build_model(case, dev, "fused")
+        model.precision = precision
+        model.use_graph = False
+        r = product_render(model, case, dev, "oracle", oracle_mod)
+        torch.cuda.synchronize()
+        outs[pool] = {k: v.detach().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)}
+        outs[pool]["_counters"] = np.concatenate(model.pipeline().trip_counters(HW * HW))   # alive per trip | samples evaluated per trip
+    for k in outs["1"]:
+        np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)
+    assert outs["1"]["_counters"][64] > 0
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_sr_frame_end_to_end(dev, oracle_mod, precision):
     """RADNeRFTorsowithSR.render with the super-resolution stage on (the configuration of the released May checkpoint): sr_rgb_map

@@ -26,9 +26,16 @@ if precision != "fp32" and os.environ.get("GFPP_PHASES"):
     product_render(model, case, dev, "hip")
     torch.cuda.synchronize()
     pc = pc.cpu().numpy()
-    print("trip: cycles summed over wavefronts (k = 1e3) copy / samples / evaluate / composite | pos-enc / amb-MLP / amb-enc / sigma+colour")
-    for k in range(16):
-        if pc[k].sum():
-            print(k, [int(v // 1000) for v in pc[k]])
+    if os.environ.get("GFPP_TRIP_POOL", "1") != "0":
+        print("trip: k-cycles summed over wavefronts: gather / compaction barriers / evaluate / wait for last block / composite | wavefront rounds, blocks, "
+              "longest workgroup round (cycles); per block = evaluate / blocks")
+        for k in range(16):
+            if pc[k].sum():
+                print(k, [int(v // 1000) for v in pc[k][:5]], int(pc[k][5]), int(pc[k][6]), int(pc[k][7]), "per block", int(pc[k][2] // max(pc[k][6], 1)))
+    else:
+        print("trip: cycles summed over wavefronts (k = 1e3) copy / samples / evaluate / composite | pos-enc / amb-MLP / amb-enc / sigma+colour")
+        for k in range(16):
+            if pc[k].sum():
+                print(k, [int(v // 1000) for v in pc[k]])
 alive, smp = model.pipeline().trip_counters(HW * HW)
 print("alive", alive[:8], "samples", smp[:8], "total", smp.sum())
