@@ -411,6 +411,7 @@ def main():
         cr.render_to_device(clip, range(W + b, W + e), out=out_u8[b:e], after_caller_stream=(c == 0))
         if world > 1:
             pending.append(exchange(c, b, e, True))
+    t_issue = time.perf_counter() - t0           # host time to queue every frame (no synchronisation yet): the launch-rate ceiling of the frame loop
     for work in pending:
         work.wait()
     torch.cuda.synchronize()
@@ -439,7 +440,8 @@ def main():
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + ((" + RCCL " + ("gather to the writer rank" if args.gather == "writer" else "all_gather")
                                                                            + f" of uint8 frames every {chunk} frames, overlapped with rendering") if world > 1 else ""),
                              "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: pose -> rays on device -> model.render() -> uint8 HWC on device",
-                             "frames_in_flight": cr.lanes, **({"gather_note": gather_note} if gather_note else {}),
+                             "frames_in_flight": cr.lanes, "host_issue_ms_per_frame": round(1e3 * t_issue / K, 4),
+                             **({"gather_note": gather_note} if gather_note else {}),
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 

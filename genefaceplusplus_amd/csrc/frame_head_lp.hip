@@ -28,6 +28,7 @@
 #endif
 // Experiment builds only (tools/eval_bench.py; results are WRONG with any bit set): what a block's time is made of.
 //   1 = table gathers replaced by register values, 2 = wide MFMA layers (and their LDS reads) skipped, 4 = skinny rows + transcendentals skipped
+//   64 = (k_head_trip_pool) every block evaluated twice, results right: trip time minus the normal build's = the evaluation's share of a trip
 #ifndef GFPP_ABLATE
 #define GFPP_ABLATE 0
 #endif
@@ -316,7 +317,8 @@ __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename
 // sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
 template <typename H, typename Tile>
 __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, Tile &wt, const typename LpTraits<H>::vec (&bpos)[2],
-                                               const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi) {
+                                               const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi,
+                                               bool commit = true) {
     typedef typename LpTraits<H>::vec vec;
     const bool valid = c < n_valid;
     const uint32_t slot = valid ? wt.order[c] : 0u;
@@ -348,7 +350,10 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     relu_pack<H>(acc, bh);
     float rgb[3];
     skinny_rows<3, H>(sh.skinny + 4 * 32, bh, hi, rgb);
-    if (valid && hi == 0) {
+#if GFPP_ABLATE & 64
+    if (!commit) asm volatile("" :: "v"(sigma), "v"(rgb[0]), "v"(rgb[1]), "v"(rgb[2]));   // the uncommitted pass must not be optimised away
+#endif
+    if (valid && hi == 0 && commit) {
         wt.px[slot] = sigma;
         wt.py[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[0]));
         wt.pz[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[1]));
@@ -359,7 +364,7 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 // RADNeRF.forward for the 32 occupied samples [first, first+32) of a tile (one wavefront's LpWaveTile or the workgroup's LpPool).
 template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool PROF = false, typename Tile>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, Tile &wt, uint32_t first, uint32_t n_valid,
-                                                  uint32_t n_step, int lane_in, unsigned long long (&sub)[4]) {
+                                                  uint32_t n_step, int lane_in, unsigned long long (&sub)[4], bool commit = true) {
     constexpr bool prof = PROF;      // the phase counters are a separate kernel instantiation: no registers, scratch or s_memtime in the production kernel
     unsigned long long tm = prof ? __builtin_readcyclecounter() : 0ull;
     auto lap = [&](int k) {
@@ -408,7 +413,7 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
     lap(2);
-    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi);
+    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi, commit);
     lap(3);
 }
 
@@ -622,15 +627,18 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
     bool weights_resident = false;
     uint32_t barriers = 0;
     uint32_t step_before = 0;
+    // the alive counts of every trip up to this launch's first are final: ONE parallel fetch (lane k takes trip k; trips < 64), not a loop of
+    // uncached loads that costs a memory latency per earlier trip
+    const uint32_t fetched = (uint32_t)lane <= a.trip ? counter_load(a.gcounters + lane) : 0u;
     for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = counter_load(a.gcounters + k);
+        const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)fetched, (int)k);
         if (na == 0) return;
         uint32_t ns = a.N_global / na;
         ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
         step_before += ns;
     }
     for (uint32_t trip = a.trip; trip < a.trip_end; ++trip) {
-        const uint32_t n_alive_frame = counter_load(a.gcounters + trip);
+        const uint32_t n_alive_frame = trip == a.trip ? (uint32_t)__builtin_amdgcn_readlane((int)fetched, (int)a.trip) : counter_load(a.gcounters + trip);
         if (n_alive_frame == 0 || step_before >= a.max_steps) return;
         uint32_t n_step = a.N_global / n_alive_frame;
         n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
@@ -731,6 +739,9 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
 
             // ---- phase 2: the pooled blocks, dealt out round-robin -----------------------------------------------------------------
             for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves) {
+#if GFPP_ABLATE & 64
+                evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4, false);   // every block twice: the difference to the normal build is the evaluation's share of a trip
+#endif
                 evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
                 if (prof) cyc[6] += 1ull;
             }
