@@ -52,7 +52,7 @@ def main(tag, precision, bench_args=None):
         calls = sum(int(r["Calls"]) for r in trip)
         per_frame = 16 if precision == "fp32" else 7      # launches per frame of the roofline section (one frame at a time): fp32 = one per trip; 16-bit = 6 + 1 multi-trip
         tot_ms = sum(int(r["TotalDurationNs"]) for r in trip) / 1e6
-        out += ["", f"Trip launches in this trace: {calls} dispatches, {tot_ms:.3f} ms in total.  The timed loop keeps two frames in flight (two streams), so a launch there "
+        out += ["", f"Trip launches in this trace: {calls} dispatches, {tot_ms:.3f} ms in total.  The timed loop keeps several frames in flight (one stream per lane), so a launch there "
                     "shares the GPU with the other frame's kernels and its duration is not a property of the kernel alone; the roofline is therefore quoted on the launches of "
                     "bench.py's roofline section, which renders one frame at a time after the timed loop:"]
         tpath = os.path.join(src, f"{tag}_stats", "bench_kernel_trace.csv")
