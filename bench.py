@@ -489,7 +489,9 @@ def main():
                   "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
         if args.precision == "fp32":
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
-            result["roofline"] = {"kernel": "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)", "bound": "mfma",
+            kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
+                else "k_head_trip_wp<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, workgroup sample pool)"
+            result["roofline"] = {"kernel": kname, "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         else:

@@ -14,6 +14,8 @@
 // previous trips left in memory, so the host never synchronises.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "head_eval_device.h"
 
 namespace gfpp {
@@ -392,6 +394,170 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_trip_w(TripArgs a) {
     if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + a.trip], (int)evaluated);
 }
 
+// The same trip with the samples of a whole workgroup pooled -- the fp32 twin of k_head_trip_pool (frame_head_lp.hip, where the reasons and
+// the measurements are): every workgroup takes an equal share of the alive rays (wavefront tiles dealt out through a multiplicative
+// permutation), the occupied samples of its four tiles are compacted together so that every 32-sample block but the last is full, the
+// blocks are dealt out round-robin, and the survivors of the workgroup are appended with ONE atomic.  k_head_trip_w stays as the A/B
+// partner (GFPP_TRIP_POOL=0); per sample nothing changes (same evaluate_block, same order along a ray).
+constexpr int kWaveCount = kThreads / 64;
+constexpr int kPoolW = kWaveCount * kWSlots;   // 512 sample slots of one workgroup round
+constexpr uint32_t kNoRayW = 0xFFu;
+struct WavePool {
+    float px[kPoolW], py[kPoolW], pz[kPoolW], dt[kPoolW], tend[kPoolW];   // by slot = ray_local * n_step + s
+    float sigma[kPoolW], cr[kPoolW], cg[kPoolW], cb[kPoolW];              // by slot
+    float dx[kPoolW], dy[kPoolW], dz[kPoolW];                             // by ray_local (wavefront w owns [w * rw, (w + 1) * rw))
+    uint32_t ray[kPoolW];                                                 // by ray_local
+    uint16_t order[kPoolW];                                               // compact index -> slot, over the whole workgroup
+    uint8_t cnt[kPoolW];                                                  // samples the local ray takes in this trip; kNoRayW: no such ray
+    uint32_t wave_valid[kWaveCount], wave_surv[kWaveCount];
+    uint32_t n_valid, out_base;
+};
+
+template <int AMB_D>
+__global__ __launch_bounds__(kThreads, 2) void k_head_trip_wp(TripArgs a) {
+    __shared__ WavePool pool;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the alive counts of every trip up to this one are final: one parallel fetch (lane k takes trip k; trips < 64)
+    const uint32_t fetched = (uint32_t)lane <= a.trip ? (uint32_t)a.gcounters[lane] : 0u;
+    uint32_t step_before = 0;
+    for (uint32_t k = 0; k < a.trip; ++k) {
+        const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)fetched, (int)k);
+        if (na == 0) return;
+        uint32_t ns = a.N_global / na;
+        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
+        step_before += ns;
+    }
+    const uint32_t n_alive_frame = (uint32_t)__builtin_amdgcn_readlane((int)fetched, (int)a.trip);
+    if (n_alive_frame == 0 || step_before >= a.max_steps) return;
+    uint32_t n_step = a.N_global / n_alive_frame;
+    n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+    const uint32_t n_alive = a.gcounters == a.counters ? n_alive_frame : (uint32_t)a.counters[a.trip];
+    if (n_alive == 0) return;
+    const uint32_t used = step_before;   // samples every alive ray has consumed so far
+
+    // equal shares: `rounds` rounds of gridDim.x * 4 wavefront tiles of rw rays (rw * n_step <= 128 slots per wavefront)
+    const uint32_t tiles_per_round = gridDim.x * kWaveCount;
+    const uint32_t rw_max = (uint32_t)kWSlots / n_step;
+    const uint32_t rounds = (n_alive + tiles_per_round * rw_max - 1) / (tiles_per_round * rw_max);
+    const uint32_t rw = (n_alive + tiles_per_round * rounds - 1) / (tiles_per_round * rounds);
+    const uint32_t n_tiles = (n_alive + rw - 1) / rw;
+    const uint32_t mult = n_tiles % 1237u ? 1237u : 1u;   // q -> q * mult mod n_tiles is a permutation of the tiles (1237 is prime)
+
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t q0 = (r * gridDim.x + blockIdx.x) * kWaveCount;
+        if (q0 >= n_tiles) break;   // nothing for this workgroup in this round (the same decision in all its wavefronts)
+        const uint32_t q = q0 + (uint32_t)wave;
+        const bool has_tile = q < n_tiles;
+        const uint32_t tile = has_tile ? (uint32_t)(((unsigned long long)q * mult) % n_tiles) : 0u;
+
+        // ---- phase 1: this trip's samples of the wavefront's rw rays (one or two rays per lane) into the pool -----------------------
+        uint32_t my_valid = 0, cnt_r[2], pos_r[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t i = (uint32_t)(sub * 64 + lane);
+            const uint32_t local = (uint32_t)wave * rw + i;
+            const uint32_t n = tile * rw + i;
+            const bool in_tile = i < rw;
+            const bool has_ray = in_tile && has_tile && n < n_alive;
+            uint32_t cnt = 0;
+            if (has_ray) {
+                const uint32_t ray = a.trip == 0 ? n : (uint32_t)a.alive_in[n];
+                const uint32_t avail = a.sample_cnt[ray] - used;
+                cnt = avail < n_step ? avail : n_step;
+                pool.ray[local] = ray;
+                const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+                const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+                pool.dx[local] = dx; pool.dy[local] = dy; pool.dz[local] = dz;
+                const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
+                const uint32_t base = local * n_step;
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    // the same expressions as march_one_ray (raymarching.cu:873-882, 905-913) evaluated at the stored t
+                    const float t0 = ts[s];
+                    const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);
+                    pool.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                    pool.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                    pool.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                    pool.dt[base + s] = dt;
+                    pool.tend[base + s] = t0 + dt;
+                }
+            }
+            if (in_tile) pool.cnt[local] = (uint8_t)(has_ray ? cnt : kNoRayW);
+            const uint32_t incl = wave_inclusive_scan(cnt, lane);
+            cnt_r[sub] = cnt;
+            pos_r[sub] = my_valid + incl - cnt;
+            my_valid += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (lane == 0) pool.wave_valid[wave] = my_valid;
+        __syncthreads();
+        // compaction over the workgroup: wavefront tiles in order, rays in order inside a tile
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < kWaveCount; ++v) {
+            const uint32_t x = pool.wave_valid[v];
+            before += v < wave ? x : 0u;
+            total += x;
+        }
+        if (tid == 0) pool.n_valid = total;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t slot0 = ((uint32_t)wave * rw + (uint32_t)(sub * 64 + lane)) * n_step;
+            for (uint32_t s = 0; s < cnt_r[sub]; ++s) pool.order[before + pos_r[sub] + s] = (uint16_t)(slot0 + s);
+        }
+        __syncthreads();
+
+        // ---- phase 2: the pooled blocks, dealt out round-robin --------------------------------------------------------------------------
+        for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kWaveCount) evaluate_block<AMB_D>(a, pool, first, n_step, lane);
+        __syncthreads();
+
+        // ---- phase 3: composite, ray state update (the owner of the ray); survivor compaction over the workgroup, one append ----------
+        unsigned long long alive_bits[2] = {0ull, 0ull};
+        uint32_t ray_r[2] = {0u, 0u};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t i = (uint32_t)(sub * 64 + lane);
+            if ((uint32_t)(sub * 64) >= rw) break;   // wavefront-uniform
+            const uint32_t local = (uint32_t)wave * rw + i;
+            const uint32_t cnt = i < rw ? (uint32_t)pool.cnt[local] : kNoRayW;
+            bool survives = false;
+            if (cnt != kNoRayW) {
+                const uint32_t ray = pool.ray[local];
+                ray_r[sub] = ray;
+                RayAccum acc = ray_state_load(a.state, ray);
+                const uint32_t base = local * n_step;
+                uint32_t s = 0;
+                for (; s < cnt; ++s) {
+                    const uint32_t k = base + s;
+                    if (composite_sample(acc, pool.sigma[k], pool.dt[k], pool.tend[k], pool.cr[k], pool.cg[k], pool.cb[k], a.T_thresh)) break;
+                }
+                survives = (s == n_step);
+                ray_state_store(a.state, ray, acc, 0.0f);
+            }
+            alive_bits[sub] = __ballot(survives);
+        }
+        const uint32_t surv0 = (uint32_t)__popcll(alive_bits[0]), surv1 = (uint32_t)__popcll(alive_bits[1]);
+        if (lane == 0) pool.wave_surv[wave] = surv0 + surv1;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int v = 0; v < kWaveCount; ++v) sum += pool.wave_surv[v];
+            pool.out_base = sum ? (uint32_t)atomicAdd(&a.counters[a.trip + 1], (int)sum) : 0u;
+            if (total) atomicAdd(&a.counters[64 + a.trip], (int)total);   // evaluated samples of this trip
+        }
+        __syncthreads();
+        {
+            uint32_t out = pool.out_base;
+#pragma unroll
+            for (int v = 0; v < kWaveCount; ++v) out += v < wave ? pool.wave_surv[v] : 0u;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((alive_bits[0] >> lane) & 1ull) a.alive_out[out + (uint32_t)__popcll(alive_bits[0] & below)] = (int32_t)ray_r[0];
+            if ((alive_bits[1] >> lane) & 1ull) a.alive_out[out + surv0 + (uint32_t)__popcll(alive_bits[1] & below)] = (int32_t)ray_r[1];
+        }
+        // (no barrier here: the next round's phase 1 writes only the wavefront's own rays and slots, and its first barrier comes before
+        // wave_valid / n_valid / wave_surv / out_base are read or written again)
+    }
+}
+
 // ---- frame begin: slab test + state reset + constant folding ------------------------------------------------------
 // ---- per-sample evaluation (RADNeRF.forward, radnerf.py:108-141) with the trip kernels' own arithmetic ---------------------------------
 // A wavefront takes 32 caller-supplied (position, direction) pairs, lays them out as a one-sample-per-ray tile and runs evaluate_block --
@@ -642,8 +808,14 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
         a.trip = trip;
         a.alive_in = ws->alive[trip & 1];
         a.alive_out = ws->alive[(trip + 1) & 1];
-        if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(grid), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(grid), dim3(kThreads), 0, st, a);
+        const char *pool_env = getenv("GFPP_TRIP_POOL");   // 0 = the tile-per-wavefront kernel (A/B runs)
+        if (pool_env && atoi(pool_env) == 0) {
+            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(grid), dim3(kThreads), 0, st, a);
+            else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(grid), dim3(kThreads), 0, st, a);
+        } else {
+            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_wp<3>, dim3(grid), dim3(kThreads), 0, st, a);
+            else hipLaunchKernelGGL(k_head_trip_wp<2>, dim3(grid), dim3(kThreads), 0, st, a);
+        }
         const int rc = check_launch("gfpp_head_frame_trips");
         if (rc) return rc;
     }

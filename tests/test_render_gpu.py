@@ -115,11 +115,14 @@ def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
 
 
 @pytest.mark.parametrize("variant,HW,precision,over", [("may_torso", 512, "bf16", None), ("may_head", 96, "fp16", None),
-                                                        ("may_head", 37, "bf16", None), ("may_torso", 96, "fp16", {"sigma_gain": 0.05})])
+                                                        ("may_head", 37, "bf16", None), ("may_torso", 96, "fp16", {"sigma_gain": 0.05}),
+                                                        ("may_torso", 512, "fp32", None), ("may_head", 37, "fp32", None),
+                                                        ("may_torso", 96, "fp32", {"sigma_gain": 0.05})])
 def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, variant, HW, precision, over):
-    """k_head_trip_pool (workgroup-wide sample pool, the production kernel) against k_head_trip_lp (one tile per wavefront,
-    GFPP_TRIP_POOL=0): the same samples through the same evaluate_block_lp, only grouped into blocks differently, so every
-    output must be equal bit for bit -- also in the thin scene that runs the multi-trip launch with its device-wide barrier."""
+    """k_head_trip_pool / k_head_trip_wp (workgroup-wide sample pool, the production kernels of the 16-bit and the fp32 mode)
+    against k_head_trip_lp / k_head_trip_w (one tile per wavefront, GFPP_TRIP_POOL=0): the same samples through the same
+    evaluate_block, only grouped into blocks differently, so every output must be equal bit for bit -- also in the thin scene
+    that runs the multi-trip launch with its device-wide barrier."""
     import numpy as np
     outs = {}
     for pool in ("1", "0"):
