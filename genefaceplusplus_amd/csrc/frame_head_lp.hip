@@ -825,6 +825,10 @@ struct PremarchArgs {
     float *sample_t;
     uint32_t *sample_cnt;
     uint32_t N, stride, max_samples;
+    // fused frame begin (k_begin_premarch): slab test + state / counter reset in the same pass over the rays
+    float min_near, aabb[6];
+    float *nears_out, *fars_out, *state;
+    int32_t *counters;
 };
 
 __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
@@ -834,6 +838,25 @@ __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
     float t = p.nears[n];
     float *out = p.sample_t + (size_t)n * p.stride;
     p.sample_cnt[n] = march_one_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, p.fars[n], p.max_samples, p.bitfield, p.mp,
+                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+}
+
+// k_frame_begin (frame_head.hip) and k_premarch in one pass: the slab test's near is the marcher's start, so the rays are read once and one
+// launch (and the gap behind it) leaves the frame's critical path.  Same expressions, same bits as the two kernels.
+__global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 128) p.counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)p.N : 0;
+    if (n >= p.N) return;
+    const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
+    const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+    const RayBox rb = ray_box(ox, oy, oz, dx, dy, dz, p.aabb, p.min_near);
+    p.nears_out[n] = rb.near;
+    p.fars_out[n] = rb.far;
+    *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
+    float t = rb.near;
+    float *out = p.sample_t + (size_t)n * p.stride;
+    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, rb.far, p.max_samples, p.bitfield, p.mp,
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }
 
@@ -984,8 +1007,28 @@ GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_f
     p.rays_o = rays_o; p.rays_d = rays_d; p.nears = ws->nears; p.fars = ws->fars;
     p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
     p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
+    p.min_near = 0.0f; p.nears_out = nullptr; p.fars_out = nullptr; p.state = nullptr; p.counters = nullptr;
+    for (int i = 0; i < 6; ++i) p.aabb[i] = 0.0f;
     hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gfpp_head_frame_premarch");
+}
+
+GFPP_API int gfpp_head_frame_begin_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                            float dt_gamma, uint32_t max_steps, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_frame_begin_premarch", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    if (!ws->ray_state || !ws->counters || ws->N == 0) { set_error("gfpp_head_frame_begin_premarch: incomplete workspace"); return GFPP_EINVAL; }
+    PremarchArgs p;
+    p.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    p.bitfield = model->density_bitfield;
+    p.rays_o = rays_o; p.rays_d = rays_d; p.nears = nullptr; p.fars = nullptr;
+    p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
+    p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
+    p.min_near = model->min_near;
+    for (int i = 0; i < 6; ++i) p.aabb[i] = model->aabb[i];
+    p.nears_out = ws->nears; p.fars_out = ws->fars; p.state = ws->ray_state; p.counters = ws->counters;
+    hipLaunchKernelGGL(k_begin_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("gfpp_head_frame_begin_premarch");
 }
 
 GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,

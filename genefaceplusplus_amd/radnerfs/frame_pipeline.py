@@ -6,6 +6,7 @@ grid tables, fills the C descriptor structs, and owns the per-resolution device 
 frame of a resolution), no host synchronisation, hence capturable in a hipGraph (see ``GraphedFrame``).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -72,6 +73,7 @@ _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTE
 _lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_fold", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
+_lib.register("gfpp_head_frame_begin_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
 _lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
@@ -551,6 +553,9 @@ class FramePipeline:
     #: kernel that marches inside the trip (gfpp_head_frame_march); same bits per sample
     fp32_kernel = "wave"
 
+    #: slab test + state reset + pre-march as one launch (gfpp_head_frame_begin_premarch); False = the two separate launches (tests compare them)
+    fuse_begin = os.environ.get("GFPP_FUSE_BEGIN", "1") != "0"
+
     #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
     separate_trips = None
 
@@ -606,12 +611,19 @@ class FramePipeline:
             side.wait_stream(main)                      # fork: everything the caller queued so far (input copies) is visible
             with torch.cuda.stream(side):
                 t["cond_feat"] = fold(cond_feat(), side.cuda_stream)
-        call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), None, None, st)
-        if side is None:
-            fold(cond_feat, st)
-        if premarched:
-            call("gfpp_head_frame_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
+        if premarched and self.fuse_begin:
+            # slab test + state reset + pre-march in one launch (the rays are read once)
+            call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
                  int(max_steps), st)
+            if side is None:
+                fold(cond_feat, st)
+        else:
+            call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), None, None, st)
+            if side is None:
+                fold(cond_feat, st)
+            if premarched:
+                call("gfpp_head_frame_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
+                     int(max_steps), st)
         if side is not None:
             main.wait_stream(side)                      # join
         trips = "gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march")

@@ -344,6 +344,12 @@ int gfpp_head_frame_march_lp(const gfpp_head_model *model, const gfpp_frame_ws *
 int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                              float dt_gamma, uint32_t max_steps, gfpp_stream_t stream);
 
+/* gfpp_head_frame_begin (without the fold) and gfpp_head_frame_premarch in ONE launch: near/far of every ray (near_far_from_aabb,
+ * raymarching.cu:91-145), ray-state and counter reset, then the pre-march from that near (raymarching.cu:827-929) -- the rays are read
+ * once.  Same results as the two calls.  The caller folds the conditioning with gfpp_head_frame_fold (any stream, before the trips). */
+int gfpp_head_frame_begin_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                   float dt_gamma, uint32_t max_steps, gfpp_stream_t stream);
+
 /* Second stage: the trip launches of gfpp_head_frame_march_lp, consuming the pre-marched lists (renderer.py:354-384 loop). */
 int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                              float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);

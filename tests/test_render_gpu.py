@@ -140,6 +140,24 @@ def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, va
     assert outs["1"]["_counters"][64] > 0
 
 
+@pytest.mark.parametrize("variant,HW,precision", [("may_torso", 128, "bf16"), ("may_head", 37, "fp32")])
+def test_fused_begin_premarch_equals_separate_launches(dev, oracle_mod, variant, HW, precision):
+    """gfpp_head_frame_begin_premarch (one pass over the rays) against gfpp_head_frame_begin + gfpp_head_frame_premarch: every output bit for bit."""
+    import numpy as np
+    outs = []
+    for fuse in (True, False):
+        case = frame_case(variant, HW)
+        model = build_model(case, dev, "fused")
+        model.precision = precision
+        model.use_graph = False
+        model.pipeline().fuse_begin = fuse
+        r = product_render(model, case, dev, "oracle", oracle_mod)
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)})
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_sr_frame_end_to_end(dev, oracle_mod, precision):
     """RADNeRFTorsowithSR.render with the super-resolution stage on (the configuration of the released May checkpoint): sr_rgb_map
