@@ -32,7 +32,7 @@ def main(dirs):
             disp[k][r["Counter_Name"]] = float(r["Counter_Value"])
             names[k] = short(r["Kernel_Name"])
         ids = sorted(disp)
-        begins = [k for k in ids if "k_frame_begin" in names[k]]
+        begins = [k for k in ids if "k_frame_begin" in names[k] or "k_begin_premarch" in names[k]]
         last = [k for k in ids if not begins or k >= begins[-1]]
         counters = sorted({c for k in last for c in disp[k]})
         print("#", d)

@@ -25,7 +25,7 @@ def main(path):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ours = [r for r in rows if "gfpp" in r["Kernel_Name"]]
     # last frame = from the last k_frame_begin on
-    starts = [i for i, r in enumerate(ours) if "k_frame_begin" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(ours) if "k_frame_begin" in r["Kernel_Name"] or "k_begin_premarch" in r["Kernel_Name"]]
     last = ours[starts[-1]:] if starts else ours
     t0 = int(last[0]["Start_Timestamp"])
     print(f"# {path}\n# last frame, launch order: start us | duration us | gap to previous end us | kernel")
