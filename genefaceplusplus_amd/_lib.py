@@ -89,8 +89,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
         got = handle.gfpp_abi_version()
-        if got != 2:
-            raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected 2 (rebuild: make -C genefaceplusplus_amd/csrc)")
+        if got != 3:
+            raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected 3 (rebuild: make -C genefaceplusplus_amd/csrc)")
         _lib = handle
     return _lib
 

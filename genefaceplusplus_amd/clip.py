@@ -28,15 +28,22 @@ class ClipRenderer:
     bg_img [1, H*W, 3] float in [0,1] or None (white), as `sample['bg_img']` in the reference.
     """
 
-    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None):
+    def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None,
+                 calibrate_trips=True):
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
         workspace and graph; weights and tables are shared), so one frame's prologue (slab test, pre-march, conditioning nets: small
         launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches.  None = 3
-        (round 2: +10 % over two lanes at 512^2, +12 % for the 256^2 frames of the super-resolution models; a fourth lane loses 13 %)."""
+        (round 2: +10 % over two lanes at 512^2, +12 % for the 256^2 frames of the super-resolution models; a fourth lane loses 13 %).
+        calibrate_trips: with several lanes every possible trip of the render loop is a launch of its own (gfpp_frame_ws.separate_trips); when a
+        lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given a small grid, because a launch that finds
+        nothing left still needs a whole CU per workgroup (+5 % frames/s at 512^2; results never depend on it, a later frame that needs more
+        trips is rendered by the small grid)."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
         self.model, self.H, self.W, self.device = model, H, W, dev
+        self.rays_per_frame = H * W
+        self.calibrate = bool(calibrate_trips)
         self.intrinsics = tuple(float(v) for v in intrinsics)
         self.T_thresh = float(T_thresh)
         self.use_graph = use_graph
@@ -115,7 +122,8 @@ class ClipRenderer:
                 # all driving signals of a frame travel as ONE small row (a few KB): one device-to-device copy per frame feeds the graph
                 L["static_in"] = clip["packed"][i].clone()
                 views = self._views(L["static_in"], clip["layout"])
-                L["graph"] = GraphedFrame(lambda **v: self._frame(lane, **v), views, copy_inputs=False)
+                L["graph"] = GraphedFrame(lambda **v: self._frame(lane, **v), views, copy_inputs=False,
+                                          before_capture=(lambda: self._calibrate_trip_launches()) if self.calibrate else None)
                 L["graph"].fn = None     # only needed for the capture; keeping it would tie the renderer into a reference cycle, and a cycle
                 L["key"] = key           # is freed by the garbage collector at a random time -- destroying a hipGraph during someone's capture fails
             L["static_in"].copy_(clip["packed"][i], non_blocking=True)
@@ -124,6 +132,13 @@ class ClipRenderer:
         finally:
             self._leave_lane()
             self.model.use_graph = inner
+
+    def _calibrate_trip_launches(self):
+        """Between the warm-up frames and the capture of a lane's graph: the trips beyond the ones the warm-up frame needed (+ 1) get a small grid
+        (FramePipeline.calibrate_trip_launches; results never depend on it)."""
+        pipe = self.model.pipeline()
+        if getattr(pipe, "calibrate_trip_launches", None) is not None and self.lanes > 1:
+            pipe.calibrate_trip_launches(self.rays_per_frame)
 
     def _fork(self):
         """Lane streams start after everything queued on the caller's stream."""

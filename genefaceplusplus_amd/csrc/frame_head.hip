@@ -804,17 +804,19 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t first = ws->trip_count ? ws->trip_first : 0u;
     const uint32_t stop = ws->trip_count ? (first + ws->trip_count < max_steps ? first + ws->trip_count : max_steps) : max_steps;
+    const uint32_t late_grid = grid < 64u ? grid : 64u;   // trips the caller expects to find nothing left: gfpp_frame_ws.full_grid_trips
     for (uint32_t trip = first; trip < stop; ++trip) {
         a.trip = trip;
         a.alive_in = ws->alive[trip & 1];
         a.alive_out = ws->alive[(trip + 1) & 1];
+        const uint32_t g = ws->full_grid_trips && trip >= ws->full_grid_trips ? late_grid : grid;
         const char *pool_env = getenv("GFPP_TRIP_POOL");   // 0 = the tile-per-wavefront kernel (A/B runs)
         if (pool_env && atoi(pool_env) == 0) {
-            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(grid), dim3(kThreads), 0, st, a);
-            else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(grid), dim3(kThreads), 0, st, a);
+            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(g), dim3(kThreads), 0, st, a);
+            else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(g), dim3(kThreads), 0, st, a);
         } else {
-            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_wp<3>, dim3(grid), dim3(kThreads), 0, st, a);
-            else hipLaunchKernelGGL(k_head_trip_wp<2>, dim3(grid), dim3(kThreads), 0, st, a);
+            if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_wp<3>, dim3(g), dim3(kThreads), 0, st, a);
+            else hipLaunchKernelGGL(k_head_trip_wp<2>, dim3(g), dim3(kThreads), 0, st, a);
         }
         const int rc = check_launch("gfpp_head_frame_trips");
         if (rc) return rc;

@@ -606,6 +606,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
         }
     if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + trip], (int)evaluated);   // evaluated samples of this trip
    }
+    if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs, no barrier needed
     if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
   }
 }
@@ -809,6 +810,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
             for (int ph = 0; ph < 7; ++ph) atomicAdd(&a.phase_cycles[8 * trip + ph], cyc[ph]);
             atomicMax(&a.phase_cycles[8 * trip + 7], longest);
         }
+        if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs (every workgroup decides the same), no barrier needed
         if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
     }
 }
@@ -1063,10 +1065,14 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     const uint32_t separate = ws->gcounters ? max_steps : (want_separate < max_steps ? want_separate : max_steps);
     const uint32_t first = ws->trip_count ? ws->trip_first : 0u;
     const uint32_t stop = ws->trip_count ? (first + ws->trip_count < max_steps ? first + ws->trip_count : max_steps) : max_steps;
+    // trips the caller expects to find nothing left (gfpp_frame_ws.full_grid_trips) get a small grid: such a launch then needs 32 CUs for a
+    // moment instead of every CU of the device (a trip workgroup takes a CU's whole LDS); the kernels partition by gridDim, so a late trip
+    // that does have work is still rendered, by 32 workgroups
+    const uint32_t late_grid = grid < 32u ? grid : 32u;
     for (uint32_t trip = first; trip <= separate && trip < stop; ++trip) {
         a.trip = trip;
         a.trip_end = trip < separate ? trip + 1 : stop;
-        launch(grid, st, a);
+        launch(ws->full_grid_trips && trip >= ws->full_grid_trips ? late_grid : grid, st, a);
         const int rc = check_launch("gfpp_head_frame_trips_lp");
         if (rc) return rc;
     }

@@ -42,7 +42,7 @@ class FrameWs(ctypes.Structure):
     _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("ray_state", c_p),
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
-                ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32)]
+                ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32)]
 
 
 class CondModel(ctypes.Structure):
@@ -264,8 +264,9 @@ class GraphedFrame:
     which is how the reference's caller uses them (it moves every frame to the host right away, genefacepp_infer.py:465-469).
     Host cost per frame: a handful of small device-to-device copies + one graph launch instead of ~25 launches and their Python."""
 
-    def __init__(self, fn, inputs, copy_inputs=True):
-        """copy_inputs=False: `inputs` already ARE the static buffers (the caller refreshes them itself before `graph.replay()`)."""
+    def __init__(self, fn, inputs, copy_inputs=True, before_capture=None):
+        """copy_inputs=False: `inputs` already ARE the static buffers (the caller refreshes them itself before `graph.replay()`).
+        before_capture: called after the warm-up runs and before the capture (launch parameters that are learnt from a rendered frame)."""
         self.fn = fn
         self.static = {k: (v.detach().clone() if torch.is_tensor(v) and copy_inputs else v) for k, v in inputs.items()}
         stream = torch.cuda.Stream()
@@ -274,6 +275,8 @@ class GraphedFrame:
             for _ in range(2):                       # warm-up: allocates the workspaces, packs weights, loads code objects
                 fn(**self.static)
         torch.cuda.current_stream().wait_stream(stream)
+        if before_capture is not None:
+            before_capture()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (RCCL's watchdog in multi-GPU runs, a video writer) may keep calling into HIP while this
         # thread captures; only this thread's calls have to be capturable
@@ -544,10 +547,38 @@ class FramePipeline:
             # lanes other than 0 only exist when several frames are in flight: no multi-trip launches then (see gfpp_frame_ws.separate_trips)
             ws.separate_trips = 0
             ws.gcounters, ws.N_global, ws.trip_first, ws.trip_count = None, 0, 0, 0
+            ws.full_grid_trips = 0
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
-        ent[0].separate_trips = 0xFFFF if self.frames_in_flight > 1 else (self.separate_trips or 0)
+        if self.frames_in_flight <= 1:
+            ent[0].full_grid_trips = 0
+            ent[0].separate_trips = self.separate_trips or 0
+        elif ent[0].full_grid_trips and self.frames_in_flight * 32 <= self.cu_count:
+            # calibrated (calibrate_trip_launches): the trips the frames normally need are launches of their own, the rest is ONE multi-trip launch
+            # on 32 workgroups.  Launches of that size cannot starve each other at their device-wide barriers (all lanes' together fit the device
+            # several times), and the usual one finds nothing left and returns before any barrier
+            ent[0].separate_trips = ent[0].full_grid_trips
+        else:
+            # every trip a launch of its own: two full-width multi-trip launches spinning at their barriers could keep each other's workgroups
+            # from ever becoming resident (see gfpp_frame_ws.separate_trips)
+            ent[0].separate_trips = 0xFFFF
         return ent
+
+    @property
+    def cu_count(self):
+        return torch.cuda.get_device_properties(self.device).multi_processor_count
+
+    def calibrate_trip_launches(self, N, margin=1):
+        """Several frames in flight issue every possible trip as a launch of its own (16 for the shipped max_steps); most of them find nothing left
+        (the step budget of renderer.py:364 is used up after ~6 trips) and cost ~2 us each of every frame.  Call this after a frame of the clip has
+        been rendered on this lane (synchronises): the trips beyond the ones that frame used (+ margin) then become ONE multi-trip launch on a small
+        grid (gfpp_frame_ws.full_grid_trips / separate_trips).  Results never depend on it: a later frame that needs more trips is rendered by the
+        small grid.  Returns the number of full-grid trips."""
+        torch.cuda.synchronize(self.device)
+        ws, t = self.workspace(N)
+        used = int((t["counters"][64:127] > 0).sum().item())
+        ws.full_grid_trips = max(1, used + int(margin)) if self.frames_in_flight > 1 else 0
+        return int(ws.full_grid_trips)
 
     #: exact-fp32 mode: 'wave' = autonomous wavefronts over pre-marched samples (gfpp_head_frame_trips), 'tile' = the workgroup-synchronous
     #: kernel that marches inside the trip (gfpp_head_frame_march); same bits per sample

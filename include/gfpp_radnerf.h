@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 2
+#define GFPP_ABI_VERSION 3
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -301,6 +301,14 @@ typedef struct gfpp_frame_ws {
     uint32_t N_global;
     uint32_t trip_first;   /* gfpp_head_frame_trips / _trips_lp issue the trips [trip_first, trip_first + trip_count) only; trip_count == 0: all */
     uint32_t trip_count;
+    uint32_t full_grid_trips; /* 0: every trip launch covers the whole device.  k > 0: trips >= k are launched on a small grid (32 workgroups of the
+                               * 16-bit kernel, 64 of the fp32 kernel) -- for callers with several frames in flight that know from an earlier frame
+                               * that the loop normally ends after k trips (renderer.py:364: n_step grows as rays die, the step budget is used up
+                               * after ~6 trips of 16).  With separate_trips = k the 16-bit entry then issues k full launches and ONE multi-trip launch
+                               * of 32 workgroups for the rest, which normally finds nothing left and returns before any barrier: launches of that
+                               * size from a few streams cannot starve each other (together they fit the device several times), and the ten
+                               * launches per frame that would find nothing left (~2 us each) are gone.  Results do not depend on it: a late
+                               * trip that does have work is rendered by the small grid, just more slowly. */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

@@ -78,3 +78,43 @@ def test_clip_bytes_equal_per_frame_calls(dev, variant, HW, precision, graph, la
     # device-resident stack (what the multi-GPU gather consumes)
     stack = r.render_to_device(clip, [1, 3])
     np.testing.assert_array_equal(stack.cpu().numpy(), want[[1, 3]])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_late_trips_on_the_small_grid_render_the_same_frames(dev, precision):
+    """gfpp_frame_ws.full_grid_trips: trips beyond the calibrated count are launched on a small grid.  Force the count below what the frames
+    need (trips 2.. of 6 on 32 / 64 workgroups): the bytes must not change -- the kernels partition by gridDim."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    HW = 128
+    case = frame_case("may_torso", HW)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    batch = _clip_batch(case["hp"], 5)
+    mk = lambda **kw: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], ring=3,
+                                   use_graph=True, render_kwargs=dict(case["hp"]), lanes=2, **kw)
+    plain = mk(calibrate_trips=False)
+    clip = plain.prepare(batch, dev)
+    want = plain.render_to_device(clip).cpu().numpy()
+    pipe = model.pipeline()
+    alive, evaluated = pipe.trip_counters(HW * HW)
+    assert int((evaluated > 0).sum()) >= 4, "the frames must need more trips than the forced count"
+
+    calibrated = mk(calibrate_trips=True)
+    seen = []
+    calibrated._calibrate_trip_launches = lambda: seen.append(pipe.calibrate_trip_launches(HW * HW))
+    got = calibrated.render_to_device(clip).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert seen and all(v == int((evaluated > 0).sum()) + 1 for v in seen), seen     # the trips the warm-up frame used + 1
+
+    forced = mk(calibrate_trips=True)
+
+    def force():
+        ws, _ = pipe.workspace(HW * HW)
+        ws.full_grid_trips = 2
+    forced._calibrate_trip_launches = force
+    got = forced.render_to_device(clip).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    for lane in range(2):               # leave the shared workspaces as they were
+        pipe.lane, pipe.frames_in_flight = lane, 2
+        pipe.workspace(HW * HW)[0].full_grid_trips = 0
+    pipe.lane, pipe.frames_in_flight = 0, 1

@@ -117,7 +117,9 @@ def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
 @pytest.mark.parametrize("variant,HW,precision,over", [("may_torso", 512, "bf16", None), ("may_head", 96, "fp16", None),
                                                         ("may_head", 37, "bf16", None), ("may_torso", 96, "fp16", {"sigma_gain": 0.05}),
                                                         ("may_torso", 512, "fp32", None), ("may_head", 37, "fp32", None),
-                                                        ("may_torso", 96, "fp32", {"sigma_gain": 0.05})])
+                                                        ("may_torso", 96, "fp32", {"sigma_gain": 0.05}),
+                                                        # more rays than one round of workgroup pools holds (256 CUs x 8 x 128 slots): two rounds per trip
+                                                        ("may_head", 640, "bf16", None), ("may_head", 640, "fp32", None)])
 def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, variant, HW, precision, over):
     """k_head_trip_pool / k_head_trip_wp (workgroup-wide sample pool, the production kernels of the 16-bit and the fp32 mode)
     against k_head_trip_lp / k_head_trip_w (one tile per wavefront, GFPP_TRIP_POOL=0): the same samples through the same
@@ -207,13 +209,17 @@ def test_long_loop_scene_and_launch_splits(dev, oracle_mod, precision):
     err = np.abs(_rgb(res) - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
     assert (err > 2e-2).mean() <= 5e-4 and _psnr(_rgb(res), ref["rgb_map"].reshape(-1, 3)) >= 45.0
     pipe = model.pipeline()
-    assert int(pipe.workspace(96 * 96)[1]["counters"][127]) > 0, "the multi-trip launch must have passed at least one barrier"
+    # default split: trips 0-5 one launch each, trip 6 in the multi-trip launch -- which uses up the step budget and returns without a barrier
+    assert int(pipe.workspace(96 * 96)[1]["counters"][127]) == 0
     base = _rgb(res).copy()
     for split in (1, 3, 64):                     # 1: trips 1..15 in one launch; 64: every trip its own launch
         pipe.separate_trips = split
         again = product_render(model, case, dev, "oracle", oracle_mod)
         np.testing.assert_array_equal(_rgb(again), base)
-        assert int(pipe.workspace(96 * 96)[1]["counters"][127]) >= 0, "barrier timed out"
+        passed = int(pipe.workspace(96 * 96)[1]["counters"][127])
+        assert passed >= 0, "barrier timed out"
+        if split < 6:
+            assert passed > 0, "the multi-trip launch must have passed its device-wide barriers"
     pipe.separate_trips = None
 
 
