@@ -20,6 +20,7 @@ c_i = ctypes.c_int
 _SIGNATURES = {
     "gfpp_abi_version": [],
     "gfpp_last_error": [],
+    "gfpp_struct_size": [ctypes.c_char_p],
     "gfpp_near_far_from_aabb": [c_p, c_p, c_p, c_u32, c_f, c_p, c_p, c_p],
     "gfpp_morton3D": [c_p, c_u32, c_p, c_p],
     "gfpp_morton3D_invert": [c_p, c_u32, c_p, c_p],
@@ -45,7 +46,7 @@ _SIGNATURES = {
     "gfpp_get_rays_at": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_u32, c_p, c_p, c_p],
     "gfpp_rgb_to_u8": [c_p, ctypes.c_uint64, c_p, c_p],
 }
-_RESTYPES = {"gfpp_last_error": ctypes.c_char_p}
+_RESTYPES = {"gfpp_last_error": ctypes.c_char_p, "gfpp_struct_size": ctypes.c_uint}
 
 
 class GfppError(RuntimeError):
@@ -93,6 +94,14 @@ def lib():
             raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected 3 (rebuild: make -C genefaceplusplus_amd/csrc)")
         _lib = handle
     return _lib
+
+
+def check_struct(name, mirror):
+    """A ctypes mirror of a header struct must have the size the library was compiled with (a silent mismatch would corrupt memory)."""
+    want = lib().gfpp_struct_size(name.encode())
+    got = ctypes.sizeof(mirror)
+    if want != got:
+        raise GfppError(f"ctypes mirror of gfpp_{name} is {got} bytes, the library's struct is {want}: binding and libgfpp_radnerf.so are out of step")
 
 
 def call(name, *args):

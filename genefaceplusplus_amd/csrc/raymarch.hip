@@ -2,6 +2,7 @@
 // (near_far_from_aabb, morton3D(_invert), packbits, march_rays, composite_rays) plus on-device ray generation.
 // One thread per ray; 256-thread workgroups (4 wavefronts) so that a 262 144-ray frame is 1024 workgroups.
 #include <stdarg.h>
+#include <string.h>
 
 #include "march_device.h"
 
@@ -158,6 +159,17 @@ using namespace gfpp;
 
 GFPP_API int gfpp_abi_version(void) { return GFPP_ABI_VERSION; }
 GFPP_API const char *gfpp_last_error(void) { return gfpp::g_err; }
+GFPP_API unsigned gfpp_struct_size(const char *name) {
+    if (!name) return 0;
+    const struct { const char *n; unsigned s; } table[] = {
+        {"frame_ws", (unsigned)sizeof(gfpp_frame_ws)},       {"head_model", (unsigned)sizeof(gfpp_head_model)}, {"torso_model", (unsigned)sizeof(gfpp_torso_model)},
+        {"cond_model", (unsigned)sizeof(gfpp_cond_model)},   {"grid_desc", (unsigned)sizeof(gfpp_grid_desc)},   {"grid_level", (unsigned)sizeof(gfpp_grid_level)},
+        {"sr_model", (unsigned)sizeof(gfpp_sr_model)},       {"sr_ws", (unsigned)sizeof(gfpp_sr_ws)},
+    };
+    for (const auto &e : table)
+        if (strcmp(e.n, name) == 0) return e.s;
+    return 0;
+}
 
 #define GFPP_REQUIRE(cond, what)                                  \
     do {                                                          \

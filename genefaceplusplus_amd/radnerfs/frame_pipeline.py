@@ -303,8 +303,23 @@ class GraphedFrame:
         return self.out
 
 
+#: header struct name -> ctypes mirror (checked against the library's own sizeof the first time a pipeline is built, _lib.check_struct)
+STRUCT_MIRRORS = {"grid_level": GridLevel, "grid_desc": GridDesc, "head_model": HeadModel, "frame_ws": FrameWs, "cond_model": CondModel,
+                  "torso_model": TorsoModel}
+_layout_checked = False
+
+
+def check_layout():
+    global _layout_checked
+    if not _layout_checked:
+        for name, mirror in STRUCT_MIRRORS.items():
+            _lib.check_struct(name, mirror)
+        _layout_checked = True
+
+
 class FramePipeline:
     def __init__(self, model):
+        check_layout()
         if not supports(model):
             raise GfppError("fused pipeline: unsupported architecture (needs hidden 128, layers 3/3/2, 16x2 grids); "
                             "set model.executor = 'staged'")

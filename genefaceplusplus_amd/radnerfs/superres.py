@@ -33,6 +33,7 @@ class SrWs(ctypes.Structure):
 
 
 _lib.register("gfpp_sr_forward", [ctypes.POINTER(SrModel), ctypes.POINTER(SrWs), c_p, c_p, c_p, c_p])
+STRUCT_MIRRORS = {"sr_model": SrModel, "sr_ws": SrWs}
 
 
 def _setup_filter():

@@ -45,6 +45,10 @@ typedef void *gfpp_stream_t; /* hipStream_t */
 
 int gfpp_abi_version(void);
 const char *gfpp_last_error(void);
+/* sizeof() of a struct of this header as the library was compiled, by name without the gfpp_ prefix ("frame_ws", "head_model", "torso_model",
+ * "cond_model", "grid_desc", "grid_level", "sr_model", "sr_ws"); 0 for an unknown name.  A binding that mirrors the structs (ctypes, cgo, JNI)
+ * checks its own layout against this at load time instead of corrupting memory on a mismatch. */
+unsigned gfpp_struct_size(const char *name);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section A.1 -- _raymarching_face

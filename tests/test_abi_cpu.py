@@ -35,10 +35,29 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.gfpp_abi_version() == 3
 
 
+def test_ctypes_mirrors_have_the_librarys_struct_sizes(built_lib):
+    """Every struct of the header that the Python binding mirrors must have the size the library was compiled with
+    (gfpp_struct_size): a field added on one side only would otherwise corrupt memory silently."""
+    from genefaceplusplus_amd.radnerfs import frame_pipeline, superres
+    mirrors = dict(frame_pipeline.STRUCT_MIRRORS)
+    mirrors.update(superres.STRUCT_MIRRORS)
+    text = open(os.path.join(ROOT, "include", "gfpp_radnerf.h")).read()
+    declared = set(re.findall(r"^\} gfpp_(\w+);", text, flags=re.M))
+    assert declared == set(mirrors), (declared, set(mirrors))
+    lib = built_lib.lib()
+    for name, mirror in mirrors.items():
+        want = lib.gfpp_struct_size(name.encode())
+        assert want > 0, name
+        assert ctypes.sizeof(mirror) == want, (name, ctypes.sizeof(mirror), want)
+        built_lib.check_struct(name, mirror)
+    assert lib.gfpp_struct_size(b"no_such_struct") == 0
+    frame_pipeline.check_layout()
+
+
 def test_every_declaration_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "gfpp_radnerf.h")).read()
     for n in _declared_in_header():
-        if n in ("gfpp_abi_version", "gfpp_last_error"):
+        if n in ("gfpp_abi_version", "gfpp_last_error", "gfpp_struct_size"):
             continue
         i = text.index(n + "(")
         comment = text[text.rfind("/*", 0, i):i]
