@@ -94,6 +94,15 @@ def _identity_worker(rank, world, port, n_ident, n_frames, q):
            "eye": torch.full((3, 1), 0.25) if rank == 0 else torch.zeros(3, 1)}
     frames.share_driving_signals(sig, src=0)
     shared_ok = bool(torch.equal(sig["cond"], torch.arange(12, dtype=torch.float32).reshape(3, 4)) and float(sig["eye"].sum()) == 0.75)
+    # per-identity conditioning of the shared landmarks (postnet.IdentityConditioner): every rank of an identity's block must arrive at the same
+    # windows, and they must be what one process computes for that person
+    from genefaceplusplus_amd.postnet import IdentityConditioner
+    lm = {"idexp_lm3d": 0.3 * torch.randn(n_frames, 68, 3, generator=torch.Generator().manual_seed(5)) if rank == 0 else torch.zeros(n_frames, 68, 3)}
+    frames.share_driving_signals(lm, src=0)
+    person = IdentityConditioner(0.3 * torch.randn(300, 68, 3, generator=torch.Generator().manual_seed(100 + ident)))
+    wins = person.cond_wins(lm["idexp_lm3d"], 3)
+    want = person.cond_wins(0.3 * torch.randn(n_frames, 68, 3, generator=torch.Generator().manual_seed(5)), 3)
+    shared_ok = shared_ok and bool(torch.equal(wins, want)) and tuple(wins.shape) == (n_frames, 3, 1, 204)
     # every identity renders the whole clip, frame-parallel inside its block; a frame's pixels encode (identity, frame)
     local_rank, local_world = blocks[ident].index(rank), len(blocks[ident])
     mine = frames.shard_frames(n_frames, local_rank, local_world)
