@@ -218,7 +218,8 @@ class NeRFRenderer(nn.Module):
         if self.precision != "auto":
             return self.precision
         if torch.is_autocast_enabled():
-            return "bf16" if torch.get_autocast_gpu_dtype() == torch.bfloat16 else "fp16"
+            dtype = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+            return "bf16" if dtype == torch.bfloat16 else "fp16"
         return "fp32"
 
     def _march_eval_composite_staged(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, max_steps, T_thresh,
