@@ -611,8 +611,8 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
   }
 }
 
-// The same trips with the samples of a whole workgroup pooled (the production kernel; k_head_trip_lp above is kept for the phase-cycle
-// instantiation and as the A/B partner, GFPP_TRIP_POOL=0).  Why: a wavefront of k_head_trip_lp owns its tile's blocks, a tile holds 0..4
+// The same trips with the samples of a whole workgroup pooled (the production kernel; k_head_trip_lp above is kept as the A/B partner,
+// GFPP_TRIP_POOL=0).  Why: a wavefront of k_head_trip_lp owns its tile's blocks, a tile holds 0..4
 // blocks, and the workgroup keeps its CU until its slowest wavefront is done -- at 512x512 a trip carries ~2.4 blocks per wavefront on
 // average but lasts 4 block times.  Here every workgroup takes an equal share of the alive rays (wavefront tiles dealt out through a
 // multiplicative permutation, so that in trip 0 no workgroup gets only the empty image border), compacts the occupied samples of all
