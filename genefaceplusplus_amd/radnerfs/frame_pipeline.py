@@ -583,7 +583,7 @@ class FramePipeline:
     def cu_count(self):
         return torch.cuda.get_device_properties(self.device).multi_processor_count
 
-    def calibrate_trip_launches(self, N, margin=1):
+    def calibrate_trip_launches(self, N, margin=int(os.environ.get("GFPP_TRIP_MARGIN", "1"))):
         """Several frames in flight issue every possible trip as a launch of its own (16 for the shipped max_steps); most of them find nothing left
         (the step budget of renderer.py:364 is used up after ~6 trips) and cost ~2 us each of every frame.  Call this after a frame of the clip has
         been rendered on this lane (synchronises): the trips beyond the ones that frame used (+ margin) then become ONE multi-trip launch on a small

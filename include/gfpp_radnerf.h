@@ -292,7 +292,7 @@ typedef struct gfpp_frame_ws {
                              * cycles its wavefronts spent in {weight copy, sample fetch, evaluate, composite} and, splitting evaluate,
                              * {position encode, ambient MLP, ambient encode, sigma + colour MLP} -- a profiling aid */
     uint32_t separate_trips; /* 16-bit kernel: how many trips get a launch of their own before ONE multi-trip launch (device-wide barrier
-                              * between its trips) takes the rest; 0 = default (6).  Set it >= max_steps when frames are in flight on
+                              * between its trips) takes the rest; 0 = default (5: with the shipped schedule the sixth trip uses up the step budget, so the multi-trip launch runs it and returns without a barrier).  Set it >= max_steps when frames are in flight on
                               * several streams at once (one workspace each): two multi-trip launches spinning at their barriers could
                               * keep each other's workgroups from ever becoming resident. */
     /* Ray-tile sharding of ONE frame over several GPUs (renderer.py:364: n_step = clamp(N // n_alive, 1, 8) is a function of the FRAME-wide

@@ -50,7 +50,7 @@ def main(tag, precision, bench_args=None):
     trip = [r for r in rows if "k_head_trip" in r["Name"]]
     if trip:
         calls = sum(int(r["Calls"]) for r in trip)
-        per_frame = 16 if precision == "fp32" else 7      # launches per frame of the roofline section (one frame at a time): fp32 = one per trip; 16-bit = 6 + 1 multi-trip
+        per_frame = 16 if precision == "fp32" else 6      # launches per frame of the roofline section (one frame at a time): fp32 = one per trip; 16-bit = 5 + 1 multi-trip
         tot_ms = sum(int(r["TotalDurationNs"]) for r in trip) / 1e6
         out += ["", f"Trip launches in this trace: {calls} dispatches, {tot_ms:.3f} ms in total.  The timed loop keeps several frames in flight (one stream per lane), so a launch there "
                     "shares the GPU with the other frame's kernels and its duration is not a property of the kernel alone; the roofline is therefore quoted on the launches of "
@@ -83,7 +83,7 @@ def main(tag, precision, bench_args=None):
     head = [f"# rocprofv3 --pmc passes -- {tag}", "",
             f"Each counter group in its own run (`rocprofv3 --pmc <group> --kernel-trace -- python tools/profile_frame.py may_torso 512 3 {precision}`), summed per kernel over the",
             ("dispatches of the LAST rendered frame (16 trip launches, 6 of them non-empty);" if precision == "fp32" else
-             "dispatches of the LAST rendered frame (trip launches: one per trip for the first six trips, then one multi-trip launch that finds nothing left);"),
+             "dispatches of the LAST rendered frame (trip launches: one per trip for the first five trips, then one multi-trip launch for the rest);"),
             "`per trip` lists those launches in order.",
             "Units as rocprofv3 reports them: FETCH_SIZE / WRITE_SIZE in KiB of fabric-side (L2 <-> Infinity Cache / HBM) traffic -- on gfx950 a wide coalesced read",
             "is under-reported by 2x and other access shapes are uncalibrated (MI355X_MICROARCH.md, HBM section), so read them as lower bounds and compare runs, not absolutes;",
