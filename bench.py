@@ -139,7 +139,57 @@ def cpu_crop_config():
             "rays_per_s": round(1024 / float(times.mean()), 1), "crop_ms": round(4e3 * float(times.mean()), 2), "cores": threads, "host_cpus": os.cpu_count()}
 
 
-def run_identities(args, rank, world, dev):
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (the driver's command shape): start the N ranks ourselves, one process per GPU -- what
+    `torch.distributed.run --standalone --nproc-per-node N` would do, and what the reference's trainer does with mp.spawn
+    (utils/commons/trainer.py:137-141, 587-599).  Rank r gets RANK = LOCAL_RANK = r, a common MASTER_ADDR/PORT on 127.0.0.1; rank 0 inherits our
+    stdout, so the job still prints ONE JSON line.  Returns the exit code of the job (first non-zero child, the others are then stopped)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GFPP_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                     # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dist_evidence(dev, backend):
+    """What the job itself saw of its ranks (so a multi-GPU line is self-evidencing): ranks counted by an all_reduce of ones on the device,
+    every rank's device uuid / name / index by all_gather."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": dist.get_rank(), "device": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name, "pid": os.getpid()}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    uuids = [x["uuid"] for x in seen]
+    return {"backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "launcher": os.environ.get("GFPP_BENCH_LAUNCHER", "external (torch.distributed.run)"),
+            "world_size": world, "ranks_seen": int(ones.item()), "device_uuids": uuids, "distinct_devices": len(set((x["device"], x["uuid"]) for x in seen)),
+            "device_index_per_rank": [x["device"] for x in seen], "device_name": props.name}
+
+
+def run_identities(args, rank, world, dev, dinfo=None):
     """BASELINE configs[4]: several person-specific models at once (4 identities on 8 GPUs, 2 GPUs each), shared audio2motion.
 
     The ranks are split into contiguous blocks, one per identity (frames.make_identity_groups); the upstream result -- the driving signals of
@@ -236,13 +286,13 @@ def run_identities(args, rank, world, dev):
                                                  f"{'ranks in contiguous blocks of ' + str(local_world) if world > 1 else 'taking turns on one GPU'}, driving signals "
                                                  f"broadcast once (shared audio2motion), frames gathered to each block's writer rank",
                                      "identities": n_id, "frames_per_rank_and_identity": K, "frames_total": total,
-                                     "parallelism": f"{n_id} identity blocks x frame-parallel x{local_world}"}}))
+                                     "parallelism": f"{n_id} identity blocks x frame-parallel x{local_world}", **({"dist": dinfo} if dinfo else {})}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def run_ray_tiles(args, rank, world, dev):
+def run_ray_tiles(args, rank, world, dev, dinfo=None):
     """--shard rays: every frame is rendered by ALL ranks together (frames.render_frame_tiled): rank r takes the r-th contiguous tile of the rays,
     the frame-wide alive count is all-reduced once per trip so that every ray gets the single-GPU sample budget (renderer.py:364), the finished
     tiles are all-gathered.  value = frames/s of the group (strong scaling of one frame: total work fixed); ms_per_step = latency of one frame."""
@@ -293,13 +343,15 @@ def run_ray_tiles(args, rank, world, dev):
                           "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic",
                           "config": {"workload": f"{args.variant}: ONE {HW}x{HW} frame at a time rendered by all {world} GPUs as ray tiles (latency mode)",
                                      "parallelism": f"ray tiles x{world}: int32 all_reduce of the alive count per trip + all_gather of the tiles per frame",
-                                     "launch": "eager (collectives between the trip launches)"}}))
+                                     "launch": "eager (collectives between the trip launches)", **({"dist": dinfo} if dinfo else {})}}))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -309,6 +361,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    if world > 1 and args.dist_backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: RCCL needs one GPU per rank, this node shows {torch.cuda.device_count()} "
+                         f"(--dist-backend gloo lets the ranks share a GPU for control-flow checks)")
     local_dev = local_rank % torch.cuda.device_count()          # (== local_rank on a real node; lets the gloo check share one GPU)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -318,6 +373,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    dinfo = dist_evidence(dev, args.dist_backend) if world > 1 else None
 
     from genefaceplusplus_amd import synthetic as syn
     from genefaceplusplus_amd.configs import may_hparams
@@ -326,9 +382,9 @@ def main():
     from tests.helpers import CLASSES
 
     if args.identities > 1:
-        return run_identities(args, rank, world, dev)
+        return run_identities(args, rank, world, dev, dinfo)
     if args.shard == "rays" and world > 1:
-        return run_ray_tiles(args, rank, world, dev)
+        return run_ray_tiles(args, rank, world, dev, dinfo)
 
     HW, K, W = args.hw, args.steps, args.warmup
     N = HW * HW
@@ -429,9 +485,13 @@ def main():
         if world > 1:
             pending.append(exchange(c, b, e, True))
     t_issue = time.perf_counter() - t0           # host time to queue every frame (no synchronisation yet): the launch-rate ceiling of the frame loop
+    ev_rendered, ev_gathered = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_rendered.record()                          # caller's stream, after the join of the lanes: every frame of this rank is rendered
     for work in pending:
         work.wait()
+    ev_gathered.record()                          # ... and every chunk's exchange has completed (what the rendering did not hide = exposed)
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0            # this rank's own time (before the closing barrier)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -439,6 +499,21 @@ def main():
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+        per_rank[rank] = K / t_local
+        dist.all_reduce(per_rank)
+        exposed = torch.tensor([ev_rendered.elapsed_time(ev_gathered)], dtype=torch.float64, device=dev)
+        dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+        frame_bytes = HWO * HWO * 3
+        dinfo.update({"gather": args.gather, "gather_chunks": len(bounds), "frames_per_chunk_and_rank": chunk,
+                      "gathered_MB": round(world * K * frame_bytes / 1e6, 2),       # bytes that arrived at the writer (gather 'all': at every rank)
+                      "gather_ms_exposed": round(float(exposed.item()), 3),
+                      "per_rank_fps": [round(float(v), 2) for v in per_rank.tolist()]})
+        if gathered is not None:                   # the writer (gather 'all': every rank) checks that it really holds every rank's frames
+            got = gathered[-1] if args.gather == "all" else torch.cat(gathered[-1])
+            b, e = bounds[-1]
+            dinfo["writer_holds_own_frames"] = bool(torch.equal(got[rank * (e - b):(rank + 1) * (e - b)], out_u8[b:e]))
+            dinfo["writer_frames_nonzero_per_rank"] = [bool(got[r * (e - b):(r + 1) * (e - b)].any().item()) for r in range(world)]
     elapsed = float(t_max.item())
 
     result = None
@@ -459,6 +534,7 @@ def main():
                              "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: pose -> rays on device -> model.render() -> uint8 HWC on device",
                              "frames_in_flight": cr.lanes, "host_issue_ms_per_frame": round(1e3 * t_issue / K, 4),
                              **({"gather_note": gather_note} if gather_note else {}),
+                             **({"dist": dinfo} if dinfo else {}),
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 

@@ -514,16 +514,14 @@ GFPP_API int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float r
 // the LDS-privatised kernel: a workgroup per kLdsGradPoints points and level, 128 KiB of dynamic LDS (opt-in above the 64 KiB default)
 #define GFPP_LDS_ONE(KERNEL, DD, CC, ...)                                                                                              \
     do {                                                                                                                                \
-        static bool attr_set_ = false;                                                                                                  \
-        if (!attr_set_) {                                                                                                               \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<DD, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                    (int)(kLdsGradFloats * sizeof(float))) != hipSuccess) {                                             \
-                set_error("grid encoder (training): cannot reserve %u bytes of LDS", (unsigned)(kLdsGradFloats * sizeof(float)));       \
-                return GFPP_EUNSUPPORTED;                                                                                                    \
-            }                                                                                                                           \
-            attr_set_ = true;                                                                                                           \
+        /* per call, not once per process: the attribute is per device and a process may train on several (it costs a table write) */   \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<DD, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                (int)(kLdsGradFloats * sizeof(float))) != hipSuccess) {                                                 \
+            (void)hipGetLastError();                                                                                                    \
+            lds_ok_ = false;                                                                                                            \
+        } else {                                                                                                                        \
+            hipLaunchKernelGGL((KERNEL<DD, CC>), dim3(div_up(B, kLdsGradPoints), L), dim3(kTrBlock), kLdsGradFloats * sizeof(float), st, __VA_ARGS__); \
         }                                                                                                                               \
-        hipLaunchKernelGGL((KERNEL<DD, CC>), dim3(div_up(B, kLdsGradPoints), L), dim3(kTrBlock), kLdsGradFloats * sizeof(float), st, __VA_ARGS__); \
     } while (0)
 #define GFPP_DISPATCH_LDS(KERNEL, ...)                                                                                                 \
     do {                                                                                                                                \
@@ -561,10 +559,14 @@ static int grid_backward_impl(const char *who, const float *grad, const float *i
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t total_floats = rows_total * C;
     if (xcd_copies && hipMemsetAsync(xcd_copies, 0, (size_t)kXcds * total_floats * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear the XCD copies", who); return GFPP_EINVAL; }
-    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, kLdsGradFloats, xcd_copies, total_floats);
+    // levels whose table fits kLdsGradFloats go through the LDS-privatised kernel (128 KiB of dynamic LDS); a device that cannot reserve that much
+    // (64 KiB parts) scatters every level directly instead (lds_floats = 0) -- slower, same result
+    bool lds_ok_ = true;
+    GFPP_DISPATCH_LDS(k_grid_backward_lds, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, xcd_copies, total_floats);
     int rc = check_launch(who);
     if (rc) return rc;
-    GFPP_DISPATCH_LDS(k_grid_backward_lds, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, xcd_copies, total_floats);
+    const uint32_t lds_floats = lds_ok_ ? kLdsGradFloats : 0u;
+    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, lds_floats, xcd_copies, total_floats);
     rc = check_launch(who);
     if (rc) return rc;
     if (xcd_copies) {

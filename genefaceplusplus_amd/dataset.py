@@ -12,10 +12,12 @@ What it yields is exactly what the renderer and ``clip.ClipRenderer.prepare`` ea
 
 Two things of the reference need assets that are not part of this path and are therefore OPTIONAL inputs here:
   * the 3DMM (``deep_3drecon`` BFM files behind ``Face3DHelper``): the reference re-derives the landmark conditioning and the 2-D landmarks from
-    'id'/'exp'/'euler'/'trans' with it.  Pass ``face3d_helper=<the reference's object>`` to get the same arrays; without it the conditioning comes
-    from the file's own 'idexp_lm3d' (the binarizer stored the lm68 reconstruction, so ``nerf_keypoint_mode='lm68'`` is exact) and ``lm68s`` from
-    an 'lm68' / 'lm2d' array in the file if present, else None (the SR torso model then needs ``lm68=`` from the caller, as at inference where it
-    comes from audio2motion, genefacepp_infer.py:420-431);
+    'id'/'exp'/'euler'/'trans' with it.  Pass ``face3d_helper=<the reference's object>`` to get the same arrays.  Without it the reader REFUSES
+    the landmark conditioning unless ``allow_bfm68_fallback=True``: the file's own 'idexp_lm3d' is the binarizer's Face3DHelper(keypoint_mode='lm68')
+    reconstruction = the BFM's 68 keypoint vertices (binarizer_nerf.py:241,335), whereas the reference dataset rebuilds in keypoint_mode='mediapipe'
+    and takes index_lm68_from_lm478 (dataset_utils.py:247-273) -- different mesh vertices, i.e. a different conditioning signal from the one
+    reference checkpoints were trained on.  ``lm68s`` then comes from an 'lm68' / 'lm2d' array in the file if present, else None (the SR torso
+    model then needs ``lm68=`` from the caller, as at inference where it comes from audio2motion, genefacepp_infer.py:420-431);
   * image decoding for ``gt_img`` / ``torso_img`` (training targets): PIL if importable; inference never reads them.
 """
 import os
@@ -56,14 +58,15 @@ def _load_image_u8(path):
 
 
 class RADNeRFDataset(torch.utils.data.Dataset):
-    """``RADNeRFDataset(prefix, hparams, data_dir=None | npy path, training=True, device=None, face3d_helper=None)``.
+    """``RADNeRFDataset(prefix, hparams, data_dir=None | npy path, training=True, device=None, face3d_helper=None, allow_bfm68_fallback=False)``.
 
     Attributes the reference's callers use (genefacepp_infer.py:246-275, tasks/radnerfs/*): ``H, W, focal, cx, cy, near, far, intrinsics, poses
     [F,4,4], bg_img [H,W,3], bg_img_512, bg_coords [1,HW,2], conds, eye_area_percents, lm68s, lips_rect, ds_dict, samples``."""
 
-    def __init__(self, prefix, hparams, data_dir=None, training=True, device=None, face3d_helper=None):
+    def __init__(self, prefix, hparams, data_dir=None, training=True, device=None, face3d_helper=None, allow_bfm68_fallback=False):
         super().__init__()
         self.hparams = hp = hparams
+        self.allow_bfm68_fallback = bool(allow_bfm68_fallback)
         if data_dir is None:
             data_dir = os.path.join(hp["binary_data_dir"], hp["video_id"])
         path = data_dir if data_dir.endswith(".npy") else os.path.join(data_dir, "trainval_dataset.npy")
@@ -147,14 +150,30 @@ class RADNeRFDataset(torch.utils.data.Dataset):
             normed = (arr - arr.mean(dim=0, keepdim=True)) / arr.std(dim=0, keepdim=True)
             self.lm2ds = take(helper.reconstruct_lm2d_nerf(id_, exp, _t(ds["euler"]), _t(ds["trans"])))
             self.lm68s = torch.as_tensor(self.lm2ds[:, index_lm68_from_lm478, :])
+            try:                                                                # sample['camera'] (dataset_utils.py:268-269, 335); only the eg3d-style tasks read it
+                from data_gen.eg3d.convert_to_eg3d_convention import get_eg3d_convention_camera_pose_intrinsic
+                cam = get_eg3d_convention_camera_pose_intrinsic({"euler": _t(ds["euler"]), "trans": _t(ds["trans"])})
+                self.eg3d_cameras = _t(np.concatenate([cam["c2w"].reshape([-1, 16]), cam["intrinsics"].reshape([-1, 9])], axis=-1))
+            except ImportError:
+                self.eg3d_cameras = None
             sel = {"lm68": index_lm68_from_lm478, "lm131": index_lm131_from_lm478, "lm468": slice(None)}.get(mode)
             if sel is None:
                 raise NotImplementedError()
             normed = normed[:, sel]
             self.keypoint_num = normed.shape[1]
         else:
+            # NOT what reference checkpoints were trained on: the binarizer stores ds['idexp_lm3d'] from Face3DHelper(keypoint_mode='lm68') = the BFM's own
+            # 68 keypoint vertices (binarizer_nerf.py:241,335), while the reference dataset rebuilds the landmarks in keypoint_mode='mediapipe' and takes
+            # index_lm68_from_lm478 of those (dataset_utils.py:247-273) -- different mesh vertices.  Served only on explicit request.
             if mode != "lm68":
                 raise NotImplementedError("without the reference's Face3DHelper only nerf_keypoint_mode='lm68' can be served (the file stores the lm68 reconstruction)")
+            if not self.allow_bfm68_fallback:
+                raise ValueError("RADNeRFDataset: no face3d_helper given.  The file's own 'idexp_lm3d' holds the BFM-68 keypoints, not the mediapipe-indexed lm68 "
+                                 "the reference conditions on (dataset_utils.py:247-273): pass the reference's Face3DHelper(keypoint_mode='mediapipe'), or "
+                                 "allow_bfm68_fallback=True to condition on the stored array anyway (a different signal from a reference checkpoint's)")
+            import warnings
+            warnings.warn("RADNeRFDataset: conditioning on the file's BFM-68 'idexp_lm3d' (allow_bfm68_fallback=True); reference checkpoints were trained on "
+                          "the mediapipe-indexed lm68 landmarks, so this is NOT the signal they expect", stacklevel=3)
             arr = _t(ds["idexp_lm3d"]).reshape(-1, 68, 3)
             normed = (arr - arr.mean(dim=0, keepdim=True)) / arr.std(dim=0, keepdim=True)
             self.keypoint_num = 68
@@ -237,6 +256,7 @@ class RADNeRFDataset(torch.utils.data.Dataset):
             torso_u8, gt_u8 = self._images(idx)
             torso, gt = torso_u8.to(dev).float() / 255.0, gt_u8.to(dev).float() / 255.0
             sample["gt_img_512"] = gt_u8.to(dev).unsqueeze(0).permute(0, 3, 1, 2) / 255.0
+            sample["torso_img"] = torso                                        # dataset_utils.py:352-355 (the full-size RGBA frame, before the SR halving)
             full = torso.shape[0]
             bt512 = torso[..., :3] * torso[..., 3:] + self.bg_img_512 * (1 - torso[..., 3:])
             if hp.get("with_sr"):
@@ -247,6 +267,11 @@ class RADNeRFDataset(torch.utils.data.Dataset):
             sample["bg_torso_img"] = torch.gather(bt, 1, inds3)
             sample["bg_torso_img_512"] = bt512.reshape(1, -1, 3)
             sample["gt_img"] = torch.gather(gt.reshape(1, -1, C), 1, torch.stack(C * [rays["inds"]], -1))
+        # dataset_utils.py:428-432: every task step reads sample['bg_coords'] (tasks/radnerfs/radnerf.py:115, radnerf_torso.py:83, ...)
+        if self.training:
+            sample["bg_coords"] = torch.gather(self.bg_coords.to(dev), 1, torch.stack(2 * [rays["inds"]], -1))
+        else:
+            sample["bg_coords"] = self.bg_coords
         return sample
 
     def collater(self, samples):

@@ -99,7 +99,19 @@ def render_frame_tiled(model, rays_o, rays_d, cond, bg_coords, poses, group=None
     sl = slice(lo, hi)
     kw = dict(render_kwargs)
     if world > 1:
+        from ._lib import GfppError
+        if hasattr(model, "sr_net"):
+            raise GfppError("render_frame_tiled: the *_sr models are not tileable (their render() does not take ray_shard and the SR convolutions "
+                            "need the whole image): render frame-parallel instead")
+        if (world - 1) * (-(-N // world)) >= N:
+            raise GfppError(f"render_frame_tiled: {N} rays over {world} ranks leaves a rank without rays (tiles are ceil(N / world) rays)")
         kw["ray_shard"] = (group, N)
+        if getattr(model, "hparams", {}).get("torso_head_aware") and hasattr(model, "torso_embedder") and kw.get("use_head_for_torso") is None:
+            # the head-aware torso draws a coin per call (radnerf_torso.py:135-139): ONE draw for the frame, made on the group's rank 0
+            import random
+            coin = torch.tensor([1 if random.random() < 0.5 else 0], dtype=torch.int32, device=rays_o.device)
+            dist.broadcast(coin, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            kw["use_head_for_torso"] = bool(coin.item())
     bg = bg_color[..., sl, :] if torch.is_tensor(bg_color) and bg_color.shape[-2] == N else bg_color
     with torch.no_grad():
         res = model.render(rays_o[..., sl, :].contiguous(), rays_d[..., sl, :].contiguous(), cond, bg_coords[..., sl, :].contiguous(), poses, bg_color=bg, **kw)

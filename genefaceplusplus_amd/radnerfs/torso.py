@@ -224,7 +224,9 @@ class RADNeRFTorso(_TorsoBase):
         # The reference flips a host coin when torso_head_aware, but only inside `if mask.any()` (radnerf_torso.py:177-180).  The staged
         # executor (which knows the mask on the host) draws it exactly there: `use_head=None` = "draw when needed".  The fused executor never
         # learns the mask on the host (no sync), so it draws once per frame: the RNG streams differ only on frames whose torso mask is empty.
-        use_head = None if self.hparams["torso_head_aware"] else False
+        # `use_head_for_torso=` (not a reference argument) lets a caller that renders ONE frame on several ranks make the draw once for all of them
+        # (frames.render_frame_tiled).
+        use_head = kwargs.get("use_head_for_torso") if self.hparams["torso_head_aware"] else False
         # NB: this variant calls cal_cond_feat(cond) without eye_area_percent (radnerf_torso.py:106)
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, None,
                                   None, use_head, force_all_rays=force_all_rays, shard=kwargs.get("ray_shard"))

@@ -28,8 +28,10 @@ def main():
     from genefaceplusplus_amd.radnerfs import camera
     from helpers import frame_case, build_model
     res = {"rank": rank, "world": world}
-    for variant, HW, precision in (("may_head", 48, "fp32"), ("may_torso", 37, "fp16"), ("may_torso", 64, "bf16")):
-        case = frame_case(variant, HW)
+    import random
+    for variant, HW, precision, head_aware in (("may_head", 48, "fp32", False), ("may_torso", 37, "fp16", False), ("may_torso", 64, "bf16", False),
+                                               ("may_torso", 40, "fp16", True)):
+        case = frame_case(variant, HW, hp_over={"torso_head_aware": True} if head_aware else None)
         model = build_model(case, dev, "fused")
         model.precision = precision
         model.use_graph = False
@@ -42,6 +44,21 @@ def main():
             alone = model.render(*args, bg_color=bg, **kw)
             alone = {k: v.clone() for k, v in alone.items() if torch.is_tensor(v)}
             alive_alone = model.pipeline().trip_counters(HW * HW)[0].copy()
+        if head_aware:
+            # the head-aware torso draws a coin per frame (radnerf_torso.py:177): the ranks' Python RNGs are deliberately out of step here, the tiled
+            # renderer must make ONE draw for the frame (group rank 0's) -- compare with the frame rendered alone under BOTH outcomes
+            both = {}
+            for coin in (False, True):
+                with torch.no_grad():
+                    a = model.render(*args, bg_color=bg, use_head_for_torso=coin, **kw)
+                both[coin] = {k: v.clone() for k, v in a.items() if torch.is_tensor(v)}
+            res["head_aware_branches_differ"] = not torch.equal(both[False]["rgb_map"], both[True]["rgb_map"])
+            random.seed(1000 + 7 * rank)
+            tiled = frames.render_frame_tiled(model, *args, bg_color=bg, **kw)
+            match = [c for c in (False, True) if torch.equal(tiled["rgb_map"].reshape(-1, 3), both[c]["rgb_map"].reshape(-1, 3))
+                     and torch.equal(tiled["torso_alpha_map"].reshape(-1), both[c]["torso_alpha_map"].reshape(-1))]
+            res[f"{variant}_{HW}_headaware_{precision}"] = len(match) == 1 and res["head_aware_branches_differ"]
+            continue
         tiled = frames.render_frame_tiled(model, *args, bg_color=bg, **kw)
         ok = bool(torch.equal(tiled["rgb_map"].reshape(-1, 3), alone["rgb_map"].reshape(-1, 3)) and torch.equal(tiled["depth_map"].reshape(-1), alone["depth_map"].reshape(-1)))
         if "torso_alpha_map" in alone:

@@ -25,3 +25,20 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher (the driver's command shape) starts two ranks itself; on this GPU-less box both fail loudly
+    ("needs MI355X GPUs") and the job's exit code says so -- no AssertionError about WORLD_SIZE any more."""
+    import subprocess
+    import sys
+    root = os.path.join(HERE, "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" not in r.stderr
+    assert r.stderr.count("bench.py needs MI355X GPUs") >= 1
+    assert not [line for line in r.stdout.splitlines() if line.startswith("{")]

@@ -26,12 +26,12 @@ def npy(tmp_path_factory):
 
 def test_splits_intrinsics_poses_background(npy, oracle_mod):
     path, d = npy
-    tr = RADNeRFDataset("train", _hp(), data_dir=path, training=True, device="cpu")
-    va = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device="cpu")
-    both = RADNeRFDataset("trainval", _hp(), data_dir=os.path.dirname(path), training=False, device="cpu")       # a directory works too
+    tr = RADNeRFDataset("train", _hp(), data_dir=path, training=True, device="cpu", allow_bfm68_fallback=True)
+    va = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device="cpu", allow_bfm68_fallback=True)
+    both = RADNeRFDataset("trainval", _hp(), data_dir=os.path.dirname(path), training=False, device="cpu", allow_bfm68_fallback=True)       # a directory works too
     assert (len(tr), len(va), len(both)) == (20, 2, 22)
     with pytest.raises(ValueError):
-        RADNeRFDataset("test", _hp(), data_dir=path, device="cpu")
+        RADNeRFDataset("test", _hp(), data_dir=path, device="cpu", allow_bfm68_fallback=True)
     # dataset_utils.py:216-230: centre H/2, focal rescaled by (H/2)/cx -> 1015 * 32/112 at 64 px (2320 at 512 px)
     np.testing.assert_allclose(tr.intrinsics, [1015 * 32 / 112, 1015 * 32 / 112, 32, 32])
     assert (tr.H, tr.W, tr.near, tr.far) == (64, 64, 0.3, 0.9)
@@ -41,19 +41,19 @@ def test_splits_intrinsics_poses_background(npy, oracle_mod):
     np.testing.assert_array_equal(va.poses[0].numpy(), oracle_mod.nerf_matrix_to_ngp(d["val_samples"][0]["c2w"], scale=4.0))
     np.testing.assert_allclose(tr.bg_img.numpy(), d["bg_img"].astype(np.float32) / 255.0, atol=1e-6)      # same size: the antialiased resize is an identity
     np.testing.assert_allclose(tr.bg_coords.numpy(), oracle_mod.get_bg_coords(64, 64), atol=1e-6)
-    sr = RADNeRFDataset("train", _hp("may_torso_sr"), data_dir=path, device="cpu")
+    sr = RADNeRFDataset("train", _hp("may_torso_sr"), data_dir=path, device="cpu", allow_bfm68_fallback=True)
     assert (sr.H, sr.W) == (32, 32) and sr.bg_img.shape == (32, 32, 3) and sr.bg_img_512.shape == (64, 64, 3)
     np.testing.assert_allclose(sr.intrinsics, [1015 * 16 / 112, 1015 * 16 / 112, 16, 16])
     assert sr.lips_rect[0] == [16, 20, 14, 18]
-    assert RADNeRFDataset("train", _hp(infer_bg_img_fname="white"), data_dir=path, device="cpu").bg_img.min() == 1.0
-    assert len(RADNeRFDataset("train", _hp(num_train_samples=5), data_dir=path, device="cpu")) == 5
+    assert RADNeRFDataset("train", _hp(infer_bg_img_fname="white"), data_dir=path, device="cpu", allow_bfm68_fallback=True).bg_img.min() == 1.0
+    assert len(RADNeRFDataset("train", _hp(num_train_samples=5), data_dir=path, device="cpu", allow_bfm68_fallback=True)) == 5
 
 
 def test_landmark_conditioning_windows(npy, golden):
     path, d = npy
     hp = _hp()
-    tr = RADNeRFDataset("train", hp, data_dir=path, device="cpu")
-    va = RADNeRFDataset("val", hp, data_dir=path, device="cpu")
+    tr = RADNeRFDataset("train", hp, data_dir=path, device="cpu", allow_bfm68_fallback=True)
+    va = RADNeRFDataset("val", hp, data_dir=path, device="cpu", allow_bfm68_fallback=True)
     arr = torch.from_numpy(d["idexp_lm3d"]).reshape(-1, 68, 3)
     normed = ((arr - arr.mean(0, keepdim=True)) / arr.std(0, keepdim=True)).reshape(-1, 1, 204)      # over ALL frames, torch's unbiased std
     assert tr.conds.shape == (20, 1, 204) and va.conds.shape == (2, 1, 204)
@@ -72,19 +72,19 @@ def test_landmark_conditioning_windows(npy, golden):
     torch.testing.assert_close(tr.eye_area_percents, torch.from_numpy(d["eye_area_percent"][:20]))
     assert tr.lm68s.shape == (20, 68, 2)
     with pytest.raises(NotImplementedError):
-        RADNeRFDataset("train", _hp(nerf_keypoint_mode="lm468"), data_dir=path, device="cpu")
+        RADNeRFDataset("train", _hp(nerf_keypoint_mode="lm468"), data_dir=path, device="cpu", allow_bfm68_fallback=True)
 
 
 def test_audio_conditioning_and_clip_batch(npy):
     path, d = npy
     hp = _hp("audio_head")
-    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device="cpu")
+    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device="cpu", allow_bfm68_fallback=True)
     assert ds.conds.shape == (22, 16, 44)
     b = ds.clip_batch(range(3, 9))
     assert b["ngp_poses"].shape == (6, 4, 4) and b["cond_wins"].shape == (6, 8, 16, 44) and b["eye_area_percent"].shape == (6, 1, 1)
     np.testing.assert_array_equal(b["cond_wins"][0], ds.cond_window(3).numpy())
     with pytest.raises(NotImplementedError):
-        RADNeRFDataset("train", _hp(cond_type="deepspeech"), data_dir=path, device="cpu")
+        RADNeRFDataset("train", _hp(cond_type="deepspeech"), data_dir=path, device="cpu", allow_bfm68_fallback=True)
 
 
 def test_smooth_camera_path_matches_the_formula(npy):
@@ -95,5 +95,22 @@ def test_smooth_camera_path_matches_the_formula(npy):
     np.testing.assert_allclose(smo[0, :3, 3], c2w[0:4, :3, 3].mean(0), atol=1e-6)
     r = smo[5, :3, :3]
     np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-6)
-    ds = RADNeRFDataset("train", _hp(infer_smooth_camera_path=True, infer_smooth_camera_path_kernel_size=7), data_dir=path, training=False, device="cpu")
+    ds = RADNeRFDataset("train", _hp(infer_smooth_camera_path=True, infer_smooth_camera_path_kernel_size=7), data_dir=path, training=False, device="cpu", allow_bfm68_fallback=True)
     np.testing.assert_allclose(ds.samples[5]["c2w"].numpy(), smo[5], atol=1e-6)
+
+
+def test_bfm68_fallback_is_refused_unless_asked_for(npy):
+    """The file's own 'idexp_lm3d' (BFM-68 keypoints, binarizer_nerf.py:241) is NOT the mediapipe-indexed lm68 the reference conditions on
+    (dataset_utils.py:247-273): without the reference's Face3DHelper the reader refuses it, and warns when explicitly allowed."""
+    path, _ = npy
+    with pytest.raises(ValueError, match="allow_bfm68_fallback"):
+        RADNeRFDataset("train", _hp(), data_dir=path, device="cpu")
+    with pytest.warns(UserWarning, match="BFM-68"):
+        RADNeRFDataset("train", _hp(), data_dir=path, device="cpu", allow_bfm68_fallback=True)
+    RADNeRFDataset("train", _hp("audio_head"), data_dir=path, device="cpu")            # the audio conditioning needs no landmarks: no flag needed
+
+
+# keys the reference's __getitem__ returns (dataset_utils.py:318-434)
+REF_SAMPLE_KEYS = {"H", "W", "focal", "cx", "cy", "near", "far", "idx", "face_rect", "lip_rect", "bg_img", "c2w", "camera", "gt_img_512", "cond_wins",
+                   "cond_wins_prev", "cond_wins_next", "pose", "pose_matrix", "torso_img", "gt_img", "rays_o", "rays_d", "eye_area_percent", "face_mask",
+                   "cond_mask", "bg_torso_img", "bg_torso_img_512", "lm68", "bg_coords"}

@@ -20,7 +20,7 @@ def npy(tmp_path_factory):
 def test_getitem_inference_and_training(npy, oracle_mod):
     path, d = npy
     dev = torch.device("cuda:0")
-    ds = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device=dev)
+    ds = RADNeRFDataset("val", _hp(), data_dir=path, training=False, device=dev, allow_bfm68_fallback=True)
     s = ds[1]
     assert s["rays_o"].shape == s["rays_d"].shape == (1, 64 * 64, 3) and s["rays_o"].is_cuda
     ref = oracle_mod.get_rays(ds.poses[1][None].numpy(), ds.intrinsics, 64, 64)
@@ -32,7 +32,7 @@ def test_getitem_inference_and_training(npy, oracle_mod):
     fm = s["face_mask"].reshape(64, 64).cpu().numpy()
     assert fm[16:48, 16:48].all() and fm.sum() == 32 * 32
     assert torch.equal(s["cond_mask"], s["face_mask"].reshape(-1))
-    tr = RADNeRFDataset("train", _hp(n_rays=500), data_dir=path, training=True, device=dev)
+    tr = RADNeRFDataset("train", _hp(n_rays=500), data_dir=path, training=True, device=dev, allow_bfm68_fallback=True)
     t = tr[3]
     assert t["rays_o"].shape == (1, 500, 3) and t["bg_img"].shape == (1, 500, 3) and t["face_mask"].shape == (1, 500)
     tr.finetune_lip_flag = True
@@ -50,7 +50,7 @@ def test_clip_from_dataset_equals_per_frame_render(npy):
     model = build_model(case, dev, "fused")
     model.precision = "fp16"
     hp = dict(case["hp"], **{k: v for k, v in _hp().items() if k not in case["hp"]})
-    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device=dev)
+    ds = RADNeRFDataset("trainval", hp, data_dir=path, training=False, device=dev, allow_bfm68_fallback=True)
     cr = ClipRenderer(model, ds.H, ds.W, ds.intrinsics, bg_img=ds.bg_img.reshape(1, -1, 3), T_thresh=0.01, use_graph=True, lanes=1)
     clip = cr.prepare(ds.clip_batch(), dev)
     got = cr.render_to_device(clip, [0, 5, 21]).cpu().numpy()
@@ -64,3 +64,35 @@ def test_clip_from_dataset_equals_per_frame_render(npy):
                              perturb=False, T_thresh=0.01, max_steps=16, dt_gamma=hp["dt_gamma"])
         want = frames.to_uint8_hwc(r["rgb_map"].reshape(64, 64, 3)).cpu().numpy()
         np.testing.assert_array_equal(got[k], want)
+
+
+def test_sample_key_set_matches_the_reference(tmp_path):
+    """Every key the reference's __getitem__ returns (dataset_utils.py:318-434; the task steps read sample['bg_coords'], tasks/radnerfs/radnerf.py:115)
+    -- 'camera' excepted, which needs the reference's Face3DHelper route."""
+    from PIL import Image
+    from test_dataset_cpu import REF_SAMPLE_KEYS
+    p = str(tmp_path / "trainval_dataset.npy")
+    d = write_synthetic_dataset(p, T=11, H=64, W=64)
+    rng = np.random.default_rng(3)
+    for s in d["train_samples"] + d["val_samples"]:
+        s["torso_img_fname"] = str(tmp_path / f"torso_{s['idx']}.png")
+        s["gt_img_fname"] = str(tmp_path / f"gt_{s['idx']}.png")
+        Image.fromarray(rng.integers(0, 256, (64, 64, 4)).astype(np.uint8), "RGBA").save(s["torso_img_fname"])
+        Image.fromarray(rng.integers(0, 256, (64, 64, 3)).astype(np.uint8), "RGB").save(s["gt_img_fname"])
+    np.save(p, d, allow_pickle=True)
+    dev = torch.device("cuda:0")
+    for variant in ("may_torso", "may_torso_sr"):
+        for training in (True, False):
+            ds = RADNeRFDataset("train", _hp(variant, n_rays=300), data_dir=p, training=training, device=dev, allow_bfm68_fallback=True)
+            s = ds[2]
+            assert set(s.keys()) == REF_SAMPLE_KEYS - {"camera"}, (variant, training, set(s.keys()) ^ REF_SAMPLE_KEYS)
+            n = s["rays_o"].shape[1]
+            assert s["bg_coords"].shape == (1, n, 2) and s["bg_img"].shape == (1, n, 3) and s["gt_img"].shape == (1, n, 3) and s["bg_torso_img"].shape == (1, n, 3)
+            assert s["torso_img"].shape == (64, 64, 4) and s["gt_img_512"].shape == (1, 3, 64, 64)
+            if training and variant == "may_torso":
+                assert n == 300                                                # gathered by rays['inds'] like the reference (dataset_utils.py:428-430)
+                full = ds.bg_coords.to(dev)
+                # the sampled coordinates are rows of the full table
+                assert bool((s["bg_coords"][0, :, None, :] == full[0, None, :, :]).all(-1).any(-1).all())
+            else:
+                assert torch.equal(s["bg_coords"].cpu(), ds.bg_coords.cpu())

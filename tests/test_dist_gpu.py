@@ -47,16 +47,50 @@ def test_rccl_distributed_clip_equals_single_gpu_clip():
         assert x["all_equal_False"] and x["all_equal_True"] and x["writer_equal_False"] and x["writer_equal_True"], x
 
 
+def _bench(args, timeout=900):
+    """The driver's command shape: `python bench.py --gpus N ...` with no launcher around it (bench.py starts its own ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
 @pytest.mark.parametrize("gather", ["all", "writer"])
 def test_bench_two_ranks_on_one_gpu_gloo(gather):
-    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--gather", gather,
-                      "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
+    r = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--gather", gather,
+                "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
+    ev = d["config"]["dist"]                       # the line evidences its own ranks
+    assert ev["launcher"] == "self" and ev["backend"] == "gloo" and ev["world_size"] == 2 and ev["ranks_seen"] == 2
+    assert len(ev["device_uuids"]) == 2 and len(ev["per_rank_fps"]) == 2 and all(v > 0 for v in ev["per_rank_fps"])
+    assert ev["gathered_MB"] == round(2 * 6 * 128 * 128 * 3 / 1e6, 2) and ev["gather_ms_exposed"] >= 0
+    assert ev["writer_holds_own_frames"] and all(ev["writer_frames_nonzero_per_rank"])
+
+
+def test_bench_under_an_external_launcher_still_works():
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo",
+                      "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["dist"]["launcher"].startswith("external") and d["config"]["dist"]["ranks_seen"] == 2
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="1-GPU box only")
+def test_bench_rccl_on_too_few_gpus_fails_loudly():
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--hw", "64", "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"], timeout=300)
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL); the driver's multi-GPU node runs it")
+def test_bench_rccl_two_gpus_self_launched():
+    r = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    ev = d["config"]["dist"]
+    assert ev["backend"].startswith("rccl") and ev["ranks_seen"] == 2 and ev["distinct_devices"] == 2 and ev["writer_holds_own_frames"]
 
 
 def test_bench_identities_one_gpu():
@@ -93,7 +127,14 @@ def test_ray_tile_sharding_equals_single_gpu_frame_rccl():
 
 
 def test_bench_ray_tile_mode_two_ranks_gloo():
-    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--shard", "rays"])
+    r = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--shard", "rays"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["dist"]["ranks_seen"] == 2
+
+
+def test_bench_identities_two_ranks_gloo():
+    r = _bench(["--gpus", "2", "--identities", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["identities"] == 2 and d["config"]["dist"]["ranks_seen"] == 2 and d["value"] > 0
