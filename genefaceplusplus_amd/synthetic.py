@@ -259,3 +259,70 @@ def synthetic_sr_state(seed=4321, prefix="sr_net.", w_dim=16):
             sd[p + ".resample_filter"] = filt.copy()
             sd[p + ".noise_const"] = rng.standard_normal((res, res)).astype(f32)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the on-disk boundary: a checkpoint directory in the reference's layout
+# ---------------------------------------------------------------------------------------------------------------------
+def write_checkpoint(work_dir, variant="may_torso", hp=None, steps=250000, seed=9999, extra_hparams=None, state_dict=None):
+    """Write ``work_dir/model_ckpt_steps_<steps>.ckpt`` + ``work_dir/config.yaml`` the way the reference's trainer leaves them, so that
+    the reference's own loader takes them: ``set_hparams(f"{dir}/config.yaml")`` (utils/commons/hparams.py:80-190: the saved file is the
+    flat, fully-resolved hparams dict, hparams.py:167-170) and ``load_ckpt(model, dir, model_name='model', strict=True)``
+    (utils/commons/ckpt_utils.py:29-76: newest ``model_ckpt_steps_*.ckpt``, ``checkpoint['state_dict']['model']``).
+
+    File format = ``Trainer._atomic_save`` / ``dump_checkpoint`` (utils/commons/trainer.py:542-567): a LEGACY-pickle ``torch.save``
+    (``_use_new_zipfile_serialization=False``) of ``{'epoch', 'global_step', 'checkpoint_callback_best', 'optimizer_states',
+    'state_dict': {<task child name>: <its state_dict>}}`` written to ``.part`` and renamed.  The weights are the deterministic synthetic
+    ones of ``synthetic_state_dict`` (+ ``synthetic_sr_state`` for the *_sr variants) unless ``state_dict`` is given.
+    Returns (ckpt_path, config_path)."""
+    import os
+    import torch
+    import yaml
+    hp = dict(may_hparams(variant) if hp is None else hp)
+    hp.update(extra_hparams or {})
+    sd = state_dict
+    if sd is None:
+        sd = dict(synthetic_state_dict(hp, variant, seed=seed))
+        if hp.get("with_sr"):
+            sd.update(synthetic_sr_state())
+    tensors = {k: (v.detach().cpu().clone() if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items()}
+    os.makedirs(work_dir, exist_ok=True)
+    ckpt = {"epoch": 0, "global_step": int(steps), "checkpoint_callback_best": None, "optimizer_states": [],
+            "state_dict": {"model": tensors}}
+    ckpt_path = os.path.join(work_dir, f"model_ckpt_steps_{int(steps)}.ckpt")
+    torch.save(ckpt, ckpt_path + ".part", _use_new_zipfile_serialization=False)
+    os.replace(ckpt_path + ".part", ckpt_path)
+    config_path = os.path.join(work_dir, "config.yaml")
+    plain = {k: (list(v) if isinstance(v, tuple) else v) for k, v in hp.items()}
+    plain["work_dir"] = work_dir
+    with open(config_path, "w") as f:
+        yaml.safe_dump(plain, f)
+    return ckpt_path, config_path
+
+
+def read_checkpoint(work_dir_or_file, model_name="model", steps=None):
+    """What ``get_last_checkpoint`` + the key handling of ``load_ckpt`` do (utils/commons/ckpt_utils.py:7-50), for callers that do not run the
+    reference's loader: newest ``model_ckpt_steps_*.ckpt`` of a directory (or the file itself), ``state_dict[model_name]`` (nested layout) or
+    the ``'<model_name>.'``-prefixed keys (flat layout).  Returns (state_dict, path)."""
+    import glob
+    import os
+    import re
+    import torch
+    if os.path.isfile(work_dir_or_file):
+        path = work_dir_or_file
+    else:
+        pattern = f"{work_dir_or_file}/model_ckpt_steps_{'*' if steps is None else steps}.ckpt"
+        paths = sorted(glob.glob(pattern), key=lambda x: -int(re.findall(r".*steps_(\d+)\.ckpt", x)[0]))
+        if not paths:
+            raise FileNotFoundError(f"| ckpt not found in {work_dir_or_file}.")
+        path = paths[0]
+    try:
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)      # the reference's files are legacy pickles of plain dicts
+    except TypeError:                                                               # pragma: no cover  (torch < 1.13)
+        checkpoint = torch.load(path, map_location="cpu")
+    sd = checkpoint["state_dict"]
+    if any("." in k for k in sd):
+        sd = {k[len(model_name) + 1:]: v for k, v in sd.items() if k.startswith(model_name + ".")}
+    else:
+        sd = sd[model_name]
+    return sd, path

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Generate tests/golden/caller_golden.npz: the uint8 frames the REFERENCE'S OWN CALLER hands to its video writer
+(inference/genefacepp_infer.py: load_secc2video :163-191 + forward_secc2video :433-519, run unmodified from /root/reference by
+tests/ref_caller.py) for a synthetic on-disk checkpoint (genefaceplusplus_amd.synthetic.write_checkpoint), CPU, native kernels = the oracle.
+
+Run in the build container only (the GPU box has no /root/reference):   python tests/golden/make_golden_caller.py
+
+Two passes per model: --mode reference (the reference's own RADNeRFTorso / RADNeRFTorsowithSR classes) and --mode product (this package's
+drop-in classes behind the same import paths).  The script asserts what the CPU test re-checks:
+  * RADNeRFTorso, 512x512 rays, 2 frames: the two passes deliver the SAME BYTES;
+  * RADNeRFTorsowithSR (256x256 rays + super-resolution -> 512x512, `sr_rgb_map`), 2 frames: <= 1 LSB apart on <= 0.1 % of the values (the
+    SR stage runs as fp32 torch ops in two formulations of the same network on the CPU; its kernels are GPU-tested against oracle/sr_oracle.py).
+Recorded per model: sha256 of the reference pass's frames, every 4th pixel of them, the loader's report (class, torch.compile wrapper)."""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(HERE)
+FRAMES = 2
+SUB = 4
+
+
+def run(mode, variant, work):
+    out = os.path.join(work, f"{variant}_{mode}.npz")
+    r = subprocess.run([sys.executable, os.path.join(TESTS, "ref_caller.py"), "--mode", mode, "--variant", variant, "--frames", str(FRAMES), "--work", work,
+                        "--out", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = np.load(out)
+    return d["frames"], str(d["info"][0])
+
+
+def main():
+    out = {"sub": np.array([SUB], np.int32)}
+    with tempfile.TemporaryDirectory() as work:
+        for variant in ("may_torso", "may_torso_sr"):
+            ref, ref_info = run("reference", variant, work)
+            got, got_info = run("product", variant, work)
+            diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+            print(variant, "reference:", ref_info)
+            print(variant, "product:  ", got_info)
+            print(variant, "values that differ:", int((diff != 0).sum()), "of", diff.size, "max", int(diff.max()))
+            if variant == "may_torso":
+                assert np.array_equal(ref, got), "the drop-in does not deliver the reference's bytes"
+            else:
+                assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+            assert "modules.radnerfs" in ref_info and "genefaceplusplus_amd.radnerfs" in got_info and "OptimizedModule" in got_info
+            out[f"{variant}.sha256"] = np.array([hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest()])
+            out[f"{variant}.sub"] = ref[:, ::SUB, ::SUB].copy()
+            out[f"{variant}.mean"] = ref.astype(np.float64).mean(axis=(1, 2))
+            out[f"{variant}.product_differs"] = np.array([int((diff != 0).sum()), int(diff.max())])
+    np.savez_compressed(os.path.join(HERE, "caller_golden.npz"), **out)
+    print("wrote caller_golden.npz")
+
+
+if __name__ == "__main__":
+    main()
