@@ -44,6 +44,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense f16 / bf16 MFMA, /opt/skills/guides/MI
 GRID_BYTES_PER_POINT = 1164       # 3-D, 16 levels x 8 corners x 8 B + 12 B in + 128 B out
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
+PEAK_L2_GBPS = 34500.0          # aggregate L2, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -480,8 +481,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pending = []
+    cr.start(clip, range(W, W + K), out_u8)      # ONE job for the K timed frames: every frame's graph finds its inputs / output slot through the device-side cursor
     for c, (b, e) in enumerate(bounds):
-        cr.render_to_device(clip, range(W + b, W + e), out=out_u8[b:e], after_caller_stream=(c == 0))
+        cr.issue(e - b)                           # the frame loop proper: e - b graph launches issued from C (gfpp_graph_replay), lanes round-robin
+        cr.join()                                 # caller's stream waits for these frames; the lanes go on with the next chunk
         if world > 1:
             pending.append(exchange(c, b, e, True))
     t_issue = time.perf_counter() - t0           # host time to queue every frame (no synchronisation yet): the launch-rate ceiling of the frame loop
@@ -531,7 +534,8 @@ def main():
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + ((" + RCCL " + ("gather to the writer rank" if args.gather == "writer" else "all_gather")
                                                                            + f" of uint8 frames every {chunk} frames, overlapped with rendering") if world > 1 else ""),
-                             "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: pose -> rays on device -> model.render() -> uint8 HWC on device",
+                             "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: per frame ONE graph launch issued from C (gfpp_graph_replay); inside the graph: fetch the "
+                                           "frame's row of driving signals by a device-side cursor -> rays on device -> model.render() -> uint8 HWC into the output stack",
                              "frames_in_flight": cr.lanes, "host_issue_ms_per_frame": round(1e3 * t_issue / K, 4),
                              **({"gather_note": gather_note} if gather_note else {}),
                              **({"dist": dinfo} if dinfo else {}),
@@ -552,13 +556,17 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         ind = model.individual_embeddings[0].detach().float().contiguous()
         cf = cond_feat.detach().float().contiguous()
-        trips_fn = "gfpp_head_frame_trips" if args.precision == "fp32" else "gfpp_head_frame_trips_lp"
+        persist = args.precision != "fp32" and pipe.lp_kernel == "persist"
+        trips_fn = "gfpp_head_frame_trips" if args.precision == "fp32" else ("gfpp_head_frame_persist_lp" if persist else "gfpp_head_frame_trips_lp")
+        if persist and "snapshots" not in tbuf:
+            tbuf["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=dev)
+            ws.snapshots = tbuf["snapshots"].data_ptr()
 
         def one_frame(ev=None):
-            call("gfpp_head_frame_begin", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), cf.data_ptr(), ind.data_ptr(), st)
-            # the once-per-frame bitfield walk is its own kernel; the roofline is about the trip launches
-            call("gfpp_head_frame_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
+            # the production prologue (slab test + state reset + pre-march in one launch, then the bias fold), then the launches the roofline is about
+            call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
                  int(hp["max_steps"]), st)
+            call("gfpp_head_frame_fold", ctypes.byref(pipe.head), ctypes.byref(ws), cf.data_ptr(), ind.data_ptr(), st)
             if ev is not None:
                 ev[0].record()
             call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), int(hp["max_steps"]), 0.01, st)
@@ -576,10 +584,15 @@ def main():
         t_march = sum(a0.elapsed_time(a1) for a0, a1 in events) * 1e-3
         alive, smp = pipe.trip_counters(N)                       # the same frame every time: counters of the last one
         samples = reps * int(smp.sum())
-        launches = reps * int((smp > 0).sum())
-        common = {"samples_per_frame": samples // reps, "nonempty_trips_per_frame": launches // reps,
+        launches = reps * (1 if persist else int((smp > 0).sum()))
+        common = {"samples_per_frame": samples // reps, ("launches_per_frame" if persist else "nonempty_trips_per_frame"): launches // reps,
                   "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4), "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4),
                   "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
+        if persist:
+            b = pipe.budget(N)
+            common["workgroup_rounds"] = {"max": b["rounds_max"], "mean": round(b["rounds_sum"] / max(pipe.cu_count, 1), 2)}
+            common["workgroup_balance"] = {"samples_busiest": b["samples_max_wg"], "samples_mean": round(b["samples"] / max(pipe.cu_count, 1), 1)}
+            common["workgroup_kcycles"] = b["kcycles"]        # thread 0's shader clock by phase, summed over the workgroups (units of 1024 cycles)
         if args.precision == "fp32":
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
             kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
@@ -592,10 +605,18 @@ def main():
             # HBM peak (the north star's yardstick for the hash-grid stage) and the MFMA fraction beside it
             gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
             tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
-            kname = "k_head_trip_lp" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" else "k_head_trip_pool"
-            result["roofline"] = {"kernel": f"{kname}<3,{args.precision}> (fused march + grid encode + 16-bit MFMA MLP + composite)", "bound": "hbm",
+            kname = "k_head_frame_persist" if persist else ("k_head_trip_lp" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" else "k_head_trip_pool")
+            what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
+                    else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
+            result["roofline"] = {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
+                                  "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (algorithmic gather bytes vs the 8 TB/s HBM peak), not what "
+                                                "limits the kernel: the tables are L2 / Infinity-Cache resident (fabric traffic 0.17x the algorithmic bytes, `traffic`), "
+                                                "the counters show an issue / latency bound (VALU : MFMA = 15 : 1, ~half the wave-cycles waiting), see `limiter`",
+                                  "limiter": "instruction issue + LDS-fed MFMA + gather latency (no single saturated unit)",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                                   "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
+                                  "l2": {"achieved": round(gbps, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L2_GBPS, 4),
+                                         "what": "the same algorithmic gather stream against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves it"},
                                   "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP}, **common}
 
@@ -751,7 +772,7 @@ def main():
     # ---- HBM-side traffic of the trip launches: from the committed rocprofv3 --pmc pass of this same workload ---------------------------
     if rank == 0 and "roofline" in result:
         tfile = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.precision}.json")
             if os.path.exists(cand):
                 tfile = cand
@@ -760,10 +781,13 @@ def main():
             try:
                 detail = json.load(open(tfile))
                 # per launch, like `achieved`: fabric-side bytes (FETCH_SIZE x 2 as the guide prescribes for 16-B-per-lane reads, + WRITE_SIZE)
-                result["roofline"]["traffic"] = detail.get("bytes_per_launch")
+                nl = result["roofline"].get("launches_per_frame") or result["roofline"].get("nonempty_trips_per_frame") or 1
+                # the committed pass counted per FRAME where available (the launch structure changed in round 3: one launch per frame)
+                per_frame = detail.get("bytes_per_frame") or (detail.get("bytes_per_launch") or 0) * (detail.get("launches_per_frame") or detail.get("nonempty_launches_per_frame") or 1)
+                result["roofline"]["traffic"] = int(per_frame / nl) if per_frame else detail.get("bytes_per_launch")
                 result["roofline"]["traffic_source"] = "committed rocprofv3 --pmc pass of this workload: " + os.path.relpath(tfile, ROOT) + " (not measured in this run)"
                 result["roofline"]["algorithmic_bytes_per_launch"] = int(result["roofline"]["samples_per_frame"] * GATHER_BYTES_PER_SAMPLE
-                                                                         / max(result["roofline"]["nonempty_trips_per_frame"], 1))
+                                                                         / max(nl, 1))
                 result["roofline"]["traffic_detail"] = detail
             except Exception:
                 pass

@@ -9,6 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgfpp_radnerf.so")
+ABI_VERSION = 4          # include/gfpp_radnerf.h GFPP_ABI_VERSION (4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
 _lib = None
 
 c_u32 = ctypes.c_uint32
@@ -90,8 +91,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
         got = handle.gfpp_abi_version()
-        if got != 3:
-            raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected 3 (rebuild: make -C genefaceplusplus_amd/csrc)")
+        if got != ABI_VERSION:
+            raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected {ABI_VERSION} (rebuild: make -C genefaceplusplus_amd/csrc)")
         _lib = handle
     return _lib
 

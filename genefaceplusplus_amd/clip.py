@@ -10,15 +10,34 @@ What changes against the reference's loop, and why:
 * frames leave through a ring of pinned host buffers filled by asynchronous copies on a second stream: the host never blocks
   on the frame it has just launched, only on the one `ring` frames back, which is when the consumer (video writer) gets it.
 
+* the loop itself runs below Python (round 3): a frame's graph fetches its own row of driving signals and stores its own uint8 frame through a
+  device-side cursor (gfpp_clip_job), so a frame needs nothing from the host but its graph launch, and those are issued from C for a whole run
+  of frames (gfpp_graph_replay) -- the reference's `for i in range(num_frames)` costs ~0.2 ms of Python per frame next to 0.3-0.4 ms of GPU time.
+
 The per-frame device work is untouched by this file: it calls `model.render()` with exactly the arguments the reference passes.
 """
+import ctypes
+
 import numpy as np
 import torch
 
-from . import frames
+from . import _lib, frames
 from ._lib import GfppError, call
 from .radnerfs import camera
 from .radnerfs.frame_pipeline import GraphedFrame, shared_stream
+
+
+class ClipJob(ctypes.Structure):
+    """gfpp_clip_job (include/gfpp_radnerf.h): the device-resident record through which a frame's graph finds its inputs and its output slot."""
+    _fields_ = [("packed", ctypes.c_void_p), ("order", ctypes.c_void_p), ("out", ctypes.c_void_p), ("frame_bytes", ctypes.c_uint64),
+                ("row_floats", ctypes.c_uint32), ("n", ctypes.c_uint32), ("lanes", ctypes.c_uint32), ("ring_frames", ctypes.c_uint32),
+                ("cursor", ctypes.c_uint32 * 8)]
+
+
+_lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
+_lib.register("gfpp_clip_store_u8", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
+_lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32])
+STRUCT_MIRRORS = {"clip_job": ClipJob}
 
 
 class ClipRenderer:
@@ -69,11 +88,16 @@ class ClipRenderer:
                        "stream": shared_stream(dev, "lane", _i) if self.lanes > 1 else None,
                        "graph": None, "key": None, "static_in": None} for _i in range(self.lanes)]
         self.ring = max(2, int(ring), self.lanes)
-        self._dev_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev) for _ in range(self.ring)]
-        self._host_ring = [torch.empty(*self.out_hw, 3, dtype=torch.uint8).pin_memory() for _ in range(self.ring)]
-        self._ready = [torch.cuda.Event() for _ in range(self.ring)]
-        self._done = [torch.cuda.Event() for _ in range(self.ring)]
         self._copy_stream = shared_stream(dev, "copy")
+        # the job record (gfpp_clip_job) in device memory + a small ring of pinned staging copies (a staging slot is rewritten only after the
+        # asynchronous upload that read it has completed)
+        _lib.check_struct("clip_job", ClipJob)
+        self._job_dev = torch.zeros(ctypes.sizeof(ClipJob), dtype=torch.uint8, device=dev)
+        self._job_stage = [torch.zeros(ctypes.sizeof(ClipJob), dtype=torch.uint8).pin_memory() for _ in range(8)]
+        self._job_stage_ev = [None] * 8
+        self._job_calls = 0
+        self._job = None                          # host-side state of the running job
+        self._host_bufs = None
 
     # -- one frame of device work --------------------------------------------------------------------------------------------
     def _enter_lane(self, lane):
@@ -92,10 +116,13 @@ class ClipRenderer:
             self.model.sr_net.lane = 0
 
     def _frame(self, lane, pose, pose6, cond, lm68, eye):
+        """One frame on the current stream: the job's next row of this lane -> the lane's static input -> rays -> model.render() -> uint8 into
+        the job's output slot (the views `pose` .. `eye` are views of the lane's static input)."""
         L = self._lane[lane]
+        st = torch.cuda.current_stream().cuda_stream
+        call("gfpp_clip_fetch", self._job_dev.data_ptr(), lane, L["static_in"].data_ptr(), int(L["static_in"].numel()), st)
         fx, fy, cx, cy = self.intrinsics
-        call("gfpp_get_rays", pose.data_ptr(), fx, fy, cx, cy, self.H, self.W, L["rays_o"].data_ptr(), L["rays_d"].data_ptr(),
-             torch.cuda.current_stream().cuda_stream)
+        call("gfpp_get_rays", pose.data_ptr(), fx, fy, cx, cy, self.H, self.W, L["rays_o"].data_ptr(), L["rays_d"].data_ptr(), st)
         kw = dict(self.render_kwargs)
         kw.update(index=0, staged=False, bg_color=self.bg_img, lm68=lm68, perturb=False, force_all_rays=False, T_thresh=self.T_thresh,
                   eye_area_percent=eye)
@@ -104,34 +131,125 @@ class ClipRenderer:
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1)        # [1,3,h,w] view of NHWC memory
         else:
             rgb = res["rgb_map"]
-        frames.to_uint8_hwc(rgb.reshape(*self.out_hw, 3), L["u8"])
-        return {"u8": L["u8"]}
+        rgb = rgb.reshape(*self.out_hw, 3)
+        if not rgb.is_contiguous() or rgb.dtype != torch.float32:
+            rgb = rgb.float().contiguous()
+        call("gfpp_clip_store_u8", self._job_dev.data_ptr(), lane, rgb.data_ptr(), int(rgb.numel()), torch.cuda.current_stream().cuda_stream)
+        return {}
 
-    def _launch(self, clip, i, lane=0):
-        """Issue frame i of a prepared clip on the CURRENT stream with lane `lane`'s buffers; returns that lane's static uint8 frame
-        buffer (overwritten by the lane's next launch)."""
-        L = self._lane[lane]
+    # -- the job: which frames, where to ----------------------------------------------------------------------------------------------------------
+    def _upload_job(self, job):
+        slot = self._job_calls % len(self._job_stage)
+        self._job_calls += 1
+        if self._job_stage_ev[slot] is not None:
+            self._job_stage_ev[slot].synchronize()
+        stage = self._job_stage[slot]
+        ctypes.memmove(stage.data_ptr(), ctypes.addressof(job), ctypes.sizeof(ClipJob))
+        self._job_dev.copy_(stage, non_blocking=True)
+        ev = self._job_stage_ev[slot] = torch.cuda.Event()
+        ev.record()
+
+    def _ensure_graphs(self, clip):
+        """Capture the lanes' frame graphs (first use, or another clip layout / precision).  The warm-up runs and the capture execute the frame with
+        an EMPTY job (n = 0: fetch and store do nothing, the static input keeps a copy of the clip's first row), so they cannot disturb a job."""
+        key = (clip["layout"], self.model.resolved_precision())
+        todo = [k for k, L in enumerate(self._lane) if L["static_in"] is None or L["key"] != key or (self.use_graph and L["graph"] is None)]
+        if not todo:
+            return
+        dry = ClipJob()
+        dry.lanes, dry.ring_frames = self.lanes, 1
+        self._upload_job(dry)
         inner, self.model.use_graph = self.model.use_graph, False           # a frame here is one graph of its own (or plain launches)
-        self._enter_lane(lane)
         try:
-            if not self.use_graph:
-                with torch.no_grad():
-                    return self._frame(lane, **self._views(clip["packed"][i], clip["layout"]))["u8"]
-            key = (clip["layout"], self.model.resolved_precision())
-            if L["graph"] is None or L["key"] != key:
-                # all driving signals of a frame travel as ONE small row (a few KB): one device-to-device copy per frame feeds the graph
-                L["static_in"] = clip["packed"][i].clone()
-                views = self._views(L["static_in"], clip["layout"])
-                L["graph"] = GraphedFrame(lambda **v: self._frame(lane, **v), views, copy_inputs=False,
-                                          before_capture=(lambda: self._calibrate_trip_launches()) if self.calibrate else None)
-                L["graph"].fn = None     # only needed for the capture; keeping it would tie the renderer into a reference cycle, and a cycle
-                L["key"] = key           # is freed by the garbage collector at a random time -- destroying a hipGraph during someone's capture fails
-            L["static_in"].copy_(clip["packed"][i], non_blocking=True)
-            L["graph"].graph.replay()
-            return L["u8"]
+            for lane in todo:
+                L = self._lane[lane]
+                L["static_in"] = clip["packed"][0].clone()
+                L["views"] = self._views(L["static_in"], clip["layout"])
+                L["key"] = key
+                L["graph"] = None
+                if self.use_graph:
+                    self._enter_lane(lane)
+                    try:
+                        g = GraphedFrame(lambda **v: self._frame(lane, **v), L["views"], copy_inputs=False,
+                                         before_capture=(lambda: self._calibrate_trip_launches()) if self.calibrate else None)
+                    finally:
+                        self._leave_lane()
+                    g.fn = None           # only needed for the capture; keeping it would tie the renderer into a reference cycle, and a cycle
+                    L["graph"] = g        # is freed by the garbage collector at a random time -- destroying a hipGraph during someone's capture fails
         finally:
-            self._leave_lane()
             self.model.use_graph = inner
+        torch.cuda.current_stream().synchronize()
+        self._execs = None
+
+    def start(self, clip, frame_indices, out, ring_frames=None):
+        """Begin a job: the frames `frame_indices` of `clip` (any order, repeats allowed) are rendered into `out` [ring_frames or len, h, w, 3] uint8
+        (device), position k of the job into slot k % ring_frames.  Everything queued on the caller's stream so far is visible to the frames.
+        Follow with issue(count) -- any number of times, until all frames are issued -- and join()."""
+        idx = list(frame_indices)
+        if out.dtype != torch.uint8 or not out.is_contiguous() or tuple(out.shape[1:]) != (*self.out_hw, 3):
+            raise GfppError(f"ClipRenderer.start: out must be a contiguous uint8 [F, {self.out_hw[0]}, {self.out_hw[1]}, 3] stack")
+        ring_frames = len(idx) if ring_frames is None else int(ring_frames)
+        if out.shape[0] < min(ring_frames, max(len(idx), 1)):
+            raise GfppError("ClipRenderer.start: out is smaller than the job's ring")
+        self._ensure_graphs(clip)
+        order = torch.tensor(idx if idx else [0], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+        job = ClipJob()
+        job.packed, job.order, job.out = clip["packed"].data_ptr(), order.data_ptr(), out.data_ptr()
+        job.frame_bytes = self.out_hw[0] * self.out_hw[1] * 3
+        job.row_floats, job.n, job.lanes, job.ring_frames = int(clip["packed"].shape[1]), len(idx), self.lanes, max(ring_frames, 1)
+        for l in range(8):
+            job.cursor[l] = l
+        self._upload_job(job)
+        main = self._fork()
+        self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip}
+        return self
+
+    def _exec_arrays(self):
+        if getattr(self, "_execs", None) is None:
+            execs = (ctypes.c_void_p * self.lanes)(*[int(L["graph"].graph.raw_cuda_graph_exec()) for L in self._lane])
+            streams = (ctypes.c_void_p * self.lanes)(*[(L["stream"].cuda_stream if L["stream"] is not None else torch.cuda.current_stream().cuda_stream)
+                                                      for L in self._lane])
+            self._execs = (execs, streams)
+        return self._execs
+
+    #: frames of a graph that draws from torch's generator (the SR stage's random noise) must be replayed by torch (it advances the generator's
+    #: offset before every launch); everything else is launched from C
+    def _replay_from_c(self):
+        return self.use_graph and not (self.with_sr and self.render_kwargs.get("sr_noise_mode", "random") == "random") and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
+
+    def issue(self, count=None):
+        """Issue the next `count` frames of the job (all that are left by default): frame k runs on lane k % lanes.  No host synchronisation."""
+        J = self._job
+        count = J["n"] - J["issued"] if count is None else min(int(count), J["n"] - J["issued"])
+        if count <= 0:
+            return 0
+        first = J["issued"] % self.lanes
+        if self._replay_from_c():
+            execs, streams = self._exec_arrays()
+            if self.lanes == 1:
+                streams[0] = torch.cuda.current_stream().cuda_stream
+            call("gfpp_graph_replay", execs, streams, self.lanes, first, count)
+        else:
+            inner, self.model.use_graph = self.model.use_graph, False
+            try:
+                for k in range(count):
+                    lane = (first + k) % self.lanes
+                    with self._on_lane(lane):
+                        if self.use_graph:
+                            self._lane[lane]["graph"].graph.replay()
+                        else:
+                            self._enter_lane(lane)
+                            with torch.no_grad():
+                                self._frame(lane, **self._lane[lane]["views"])
+            finally:
+                self._leave_lane()
+                self.model.use_graph = inner
+        J["issued"] += count
+        return count
+
+    def join(self):
+        """The caller's stream waits for every frame issued so far (the lanes keep running: more frames may be issued afterwards)."""
+        self._join(torch.cuda.current_stream())
 
     def _calibrate_trip_launches(self):
         """Between the warm-up frames and the capture of a lane's graph: the trips beyond the ones the warm-up frame needed (+ 1) get a small grid
@@ -194,23 +312,22 @@ class ClipRenderer:
     def render_to_device(self, clip, frame_indices=None, out=None, after_caller_stream=True):
         """Render frames (all, or the given indices) into a uint8 stack [F,h,w,3] that stays on the GPU (the multi-GPU path
         gathers these with frames.gather_clip).  No host synchronisation; the stack is complete in the caller's stream order.
-        after_caller_stream=False: the frames do not wait for work queued on the caller's stream (use it for the second and later chunks
-        of a clip rendered chunk by chunk, so that frames keep overlapping across chunk boundaries; `clip` and `out` must already exist)."""
+        (= start + issue + join; callers that exchange finished chunks while later frames render use those three directly.)"""
         idx = list(range(clip["frames"])) if frame_indices is None else list(frame_indices)
         if out is None:
             out = torch.empty(len(idx), *self.out_hw, 3, dtype=torch.uint8, device=self.device)
-        main = self._fork() if after_caller_stream else torch.cuda.current_stream()
-        for k, i in enumerate(idx):
-            lane = k % self.lanes
-            with self._on_lane(lane):
-                out[k].copy_(self._launch(clip, i, lane), non_blocking=True)
-        self._join(main)
+        if not idx:
+            return out
+        self.start(clip, idx, out)
+        self.issue()
+        self.join()
         return out
 
-    def render_to_host(self, clip, sink=None, frame_indices=None):
-        """Render frames and hand each one to `sink(frame_index, uint8 ndarray [h,w,3])` in order, as soon as its copy has landed
-        in pinned memory (the array is only valid during the call -- the ring slot is reused).  With sink=None the frames are
-        collected and returned as one ndarray [F,h,w,3].  This is the PCIe-inclusive path."""
+    def render_to_host(self, clip, sink=None, frame_indices=None, chunk=16):
+        """Render frames and hand each one to `sink(frame_index, uint8 ndarray [h,w,3])` in order, once its chunk has landed in pinned memory (the
+        array is only valid during the call -- the buffer is reused two chunks later).  With sink=None the frames are collected and returned as one
+        ndarray [F,h,w,3].  This is the PCIe-inclusive path: frames are stored into a device ring of two chunks, a finished chunk leaves with ONE
+        asynchronous copy on a stream of its own while the next chunk renders, and the consumer runs while both are in flight."""
         idx = list(range(clip["frames"])) if frame_indices is None else list(frame_indices)
         collected = None
         if sink is None:
@@ -219,32 +336,41 @@ class ClipRenderer:
             def sink(k, arr, _pos=[0]):
                 collected[_pos[0]] = arr
                 _pos[0] += 1
+        if not idx:
+            return collected
+        M = max(1, int(chunk))
+        if self._host_bufs is None or self._host_bufs["M"] != M:
+            self._host_bufs = {"M": M, "ring": torch.empty(2 * M, *self.out_hw, 3, dtype=torch.uint8, device=self.device),
+                               "host": [torch.empty(M, *self.out_hw, 3, dtype=torch.uint8).pin_memory() for _ in range(2)],
+                               "copied": [torch.cuda.Event(), torch.cuda.Event()], "rendered": [torch.cuda.Event() for _ in range(self.lanes)]}
+        B = self._host_bufs
+        self.start(clip, idx, B["ring"], ring_frames=2 * M)
+        bounds = [(c, min(c + M, len(idx))) for c in range(0, len(idx), M)]
 
-        def retire(k):
-            slot = k % self.ring
-            self._done[slot].synchronize()
-            sink(idx[k], self._host_ring[slot].numpy())
+        def deliver(c):
+            lo, hi = bounds[c]
+            B["copied"][c & 1].synchronize()
+            host = B["host"][c & 1].numpy()
+            for k in range(lo, hi):
+                sink(idx[k], host[k - lo])
 
-        main = self._fork()
-        # the device->host copies need a stream (and a hardware queue) of their own: with it, two rendering lanes are the measured optimum
-        # (1 900-2 100 frames/s delivered; three lanes + the copy stream: 1 250-1 400)
-        host_lanes = min(self.lanes, 2)
-        for k, i in enumerate(idx):
-            slot, lane = k % self.ring, k % host_lanes
-            if k >= self.ring:
-                retire(k - self.ring)
-            with self._on_lane(lane):
-                st = torch.cuda.current_stream()
-                st.wait_event(self._done[slot])             # the slot's previous device->host copy has drained (no-op the first time round)
-                self._dev_ring[slot].copy_(self._launch(clip, i, lane), non_blocking=True)
-                self._ready[slot].record(st)
-            self._copy_stream.wait_event(self._ready[slot])
+        for c, (lo, hi) in enumerate(bounds):
+            buf = c & 1
+            if c >= 2:                                   # this half of the device ring is free once its previous chunk has left
+                for L in self._lane:
+                    (L["stream"] if L["stream"] is not None else torch.cuda.current_stream()).wait_event(B["copied"][buf])
+            self.issue(hi - lo)
+            for L, ev in zip(self._lane, B["rendered"]):
+                st = L["stream"] if L["stream"] is not None else torch.cuda.current_stream()
+                ev.record(st)
+                self._copy_stream.wait_event(ev)
             with torch.cuda.stream(self._copy_stream):
-                self._host_ring[slot].copy_(self._dev_ring[slot], non_blocking=True)
-                self._done[slot].record(self._copy_stream)
-        for k in range(max(0, len(idx) - self.ring), len(idx)):
-            retire(k)
-        self._join(main)
+                B["host"][buf][:hi - lo].copy_(B["ring"][buf * M:buf * M + hi - lo], non_blocking=True)
+                B["copied"][buf].record(self._copy_stream)
+            if c >= 1:
+                deliver(c - 1)
+        deliver(len(bounds) - 1)
+        self.join()
         return collected
 
 

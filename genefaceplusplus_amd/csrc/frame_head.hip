@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restric
                                                          float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ state,
                                                          int32_t *__restrict__ counters) {
     const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 128) counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)N : 0;
+    if (blockIdx.x == 0 && threadIdx.x < kCounterWords) counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)N : 0;
     if (n >= N) return;
     const float aabb[6] = {ax0, ay0, az0, ax1, ay1, az1};
     const float *o = rays_o + 3ull * n, *d = rays_d + 3ull * n;

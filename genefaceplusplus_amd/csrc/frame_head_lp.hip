@@ -81,6 +81,25 @@ struct LpPool {
     uint32_t out_base;               // where the workgroup's survivors go in the next trip's list
 };
 
+// The pool of the persistent launch (k_head_frame_persist): the workgroup's alive list lives here too, dt / t_end are recomputed from t0 when
+// compositing (same expressions, same bits) to make room for it.
+constexpr uint32_t kPTile = 8;            // rays of one ownership tile (8 consecutive rays: 32-ray tiles left the busiest workgroup 22-44 % above the mean, 8-ray tiles 6-10 %)
+constexpr uint32_t kPTilesPerSub = 512u / kPTile;          // candidate tiles of one 512-thread pass of the ingest step
+constexpr uint32_t kPTilesPerStep = 2u * kPTilesPerSub;
+constexpr uint32_t kPRayBits = 22;        // alive entry: ray id | samples consumed << 22 | samples the ray owns << 27
+constexpr uint32_t kPRayMask = (1u << kPRayBits) - 1u;
+struct LpPoolP {
+    float px[kPoolSlots], py[kPoolSlots], pz[kPoolSlots], cb[kPoolSlots];   // sample position; after evaluation: sigma, r, g, b of the slot
+    float t0[kPoolSlots];                                                    // t of the sample
+    uint32_t ray[kPoolSlots];        // ray id by local ray of the round (= index into the alive list)
+    uint32_t alive[kPoolSlots];      // the workgroup's alive list
+    uint16_t order[kPoolSlots];      // compact index -> slot
+    uint8_t cnt[kPoolSlots];         // samples the local ray takes in this round; kNoRay: no such ray
+    uint32_t wave_valid[kLpWaves], wave_surv[kLpWaves];
+    uint32_t tile_cnt[kPTilesPerStep];   // ingest: occupied rays | empty rays << 16 of each candidate tile
+    uint32_t hist[32];               // rays by the sample index their compositing ends at
+};
+
 struct LpShared {
     uint4 w[kLpWeightChunks];      // 126 976 B
     uint32_t skinny[kSkinnyWords]; //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
@@ -89,6 +108,7 @@ struct LpShared {
     union {
         LpWaveTile tile[kLpWaves]; //  27 648 B  one tile per wavefront (k_head_trip_lp, k_head_eval_lp)
         LpPool pool;               //  31 776 B  one pool per workgroup (k_head_trip_pool)
+        LpPoolP poolp;             //  32 448 B  pool + alive list of the persistent launch (k_head_frame_persist)
     };
 };
 static_assert(sizeof(LpShared) <= 163840, "one workgroup per CU: everything must fit the 160 KiB LDS");
@@ -117,6 +137,11 @@ struct LpTripArgs {
     const float *frame_consts;
     float T_thresh, density_scale;
     uint32_t N, trip, trip_end, max_steps;   // this launch runs the trips [trip, trip_end)
+    // persistent launch (k_head_frame_persist)
+    int32_t *budget;                    // counters + 128: histogram [32], evaluated samples, rounds
+    float *snaps;                       // [N, 7, 5] ray state after max_steps .. max_steps + 6 composited samples
+    uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
+    uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
@@ -815,6 +840,261 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
     }
 }
 
+// ---- the whole frame as ONE launch with workgroup-local trips (gfpp_head_frame_persist_lp) ----------------------------------------------
+// Per ray the reference's loop composites the first min(c, e + 1, B) of its occupied samples (c = samples the ray owns, e = first sample whose
+// pre-sample transmittance is below T_thresh, B = step budget = sum of n_step over the trips that ran), and a ray is alive after the trip window
+// that ends at sample S exactly if m = min(c, e) >= S (raymarching.cu:978-1022: a shorter take, or a break, declares it dead).  Neither depends
+// on HOW the loop cut the samples into trips, so a workgroup can own rays for the whole frame and loop on its own: no alive list in global
+// memory, no list-append atomics, one weight copy per workgroup and frame, no device-wide dependency (any number of these launches can overlap).
+// What the schedule decides -- B and the n_alive sequence -- is reconstructed from the histogram of m (k_head_budget_resolve); rays that go past
+// max_steps samples leave a snapshot of their state after each of the samples max_steps .. max_steps + 6, and the resolve step picks the one at B.
+// Same evaluate_block_lp, same composite_sample, same order along a ray as k_head_trip_pool: results are bit-identical to the trip launches.
+template <int AMB_D, typename H, bool SLOW>
+__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_persist(LpTripArgs a) {
+    __shared__ LpShared sh;
+    LpPoolP &pool = sh.poolp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    // this workgroup owns the tile slots [q0, q0 + my_tiles): equal counts of CONSECUTIVE slots, whose tiles the multiplicative permutation spreads
+    // over the rows and columns of the image (slots strided by G would all land in one column block: (G * mult) % n_tiles has a large common
+    // factor with n_tiles)
+    const uint32_t per_wg = a.n_tiles / G, extra = a.n_tiles % G;
+    const uint32_t my_tiles = per_wg + (b < extra ? 1u : 0u), q0 = b * per_wg + (b < extra ? b : extra);
+    if (my_tiles == 0u) return;                                   // tiny frames: fewer tiles than workgroups
+    lp_fill_shared(sh, a, tid, lane);
+    if (tid < 32) pool.hist[tid] = 0u;
+    const uint32_t cap = a.max_steps + 7u;                        // a ray can never composite more samples than that (k_premarch stores no more)
+    uint32_t j_next = 0, A = 0, evaluated = 0, round = 0;
+    unsigned long long sub4[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long t_mark = __builtin_readcyclecounter(), cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
+    auto lap = [&](int k) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        cyc[k] += now - t_mark;
+        t_mark = now;
+    };
+    __syncthreads();                                              // weights, descriptors, zeroed histogram
+
+    for (;;) {
+        // ---- ingest: the next (up to 128) tiles of this workgroup, whole tiles as long as their occupied rays fit the list --------------------
+        if (j_next < my_tiles && kPoolSlots - A >= 256u) {
+            uint32_t ent[2], rank[2];
+            bool occupied[2];
+            const uint32_t in_tile = (uint32_t)tid % kPTile, seg = ((uint32_t)lane / kPTile) * kPTile;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint32_t ts = (uint32_t)sub * kPTilesPerSub + (uint32_t)tid / kPTile, j = j_next + ts;
+                uint32_t ray = 0, c = 0;
+                bool in_range = false;
+                if (j < my_tiles) {
+                    const uint32_t tile = ((q0 + j) * a.tile_mult) % a.n_tiles;
+                    ray = tile * kPTile + in_tile;
+                    if (ray < a.N) {
+                        in_range = true;
+                        const uint32_t cc = a.sample_cnt[ray];
+                        c = cc < cap ? cc : cap;
+                    }
+                }
+                occupied[sub] = c > 0u;
+                const unsigned long long bo = __ballot(occupied[sub]), be = __ballot(in_range && c == 0u);
+                const uint32_t so = (uint32_t)(bo >> seg) & ((1u << kPTile) - 1u), se = (uint32_t)(be >> seg) & ((1u << kPTile) - 1u);
+                if (in_tile == 0u) pool.tile_cnt[ts] = (uint32_t)__popc(so) | ((uint32_t)__popc(se) << 16);
+                rank[sub] = (uint32_t)__popc(so & ((1u << in_tile) - 1u));
+                ent[sub] = ray | (c << 27);
+            }
+            __syncthreads();
+            const uint32_t room = kPoolSlots - A, ts0 = (uint32_t)tid / kPTile, ts1 = ts0 + kPTilesPerSub;
+            uint32_t acc = 0, accepted = 0, off0 = 0, off1 = 0;
+            for (uint32_t t = 0; t < kPTilesPerStep; ++t) {
+                const uint32_t x = pool.tile_cnt[t], n = x & 0xFFFFu;
+                if (j_next + t >= my_tiles || acc + n > room) break;          // tiles are taken in order: the first that does not fit ends the step
+                if (t == ts0) off0 = acc;
+                if (t == ts1) off1 = acc;
+                acc += n;
+                accepted = t + 1u;
+                if ((uint32_t)tid == t && (x >> 16)) atomicAdd(&pool.hist[0], x >> 16);   // rays without any occupied sample: m = 0
+            }
+            if (ts0 < accepted && occupied[0]) pool.alive[A + off0 + rank[0]] = ent[0];
+            if (ts1 < accepted && occupied[1]) pool.alive[A + off1 + rank[1]] = ent[1];
+            A += acc;
+            j_next += accepted;
+            __syncthreads();
+        }
+        if (A == 0u) {
+            if (j_next >= my_tiles) break;
+            continue;                                             // the tiles taken so far were all empty (image border): take more
+        }
+
+        // ---- one local trip over the A alive rays: wavefront w takes the list entries [w * rw, (w + 1) * rw) -----------------------------------
+        const uint32_t rw = (A + (uint32_t)kLpWaves - 1u) / (uint32_t)kLpWaves;   // <= 128
+        uint32_t n_step = (uint32_t)kLpSlots / rw;
+        {
+            const uint32_t capr = (a.step_caps >> (4u * (round < 7u ? round : 7u))) & 15u;
+            n_step = n_step < capr ? n_step : capr;
+            n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
+        }
+        // phase 1: the next samples of every ray (one or two rays per lane) into the pool
+        uint32_t my_valid = 0, cnt_r[2], pos_r[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t i = (uint32_t)(sub * 64 + lane);
+            const uint32_t idx = (uint32_t)wave * rw + i;
+            const bool in_tile = i < rw;
+            const bool has_ray = in_tile && idx < A;
+            uint32_t cnt = 0;
+            if (has_ray) {
+                const uint32_t e = pool.alive[idx];
+                const uint32_t ray = e & kPRayMask, used = (e >> kPRayBits) & 31u, c = e >> 27;
+                const uint32_t rem = c - used;                    // >= 1: a ray without samples left never stays on the list
+                cnt = rem < n_step ? rem : n_step;
+                pool.ray[idx] = ray;
+                const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
+                const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+                const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
+                const uint32_t base = idx * n_step;
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    // the same expressions as march_one_ray (raymarching.cu:873-882) evaluated at the stored t
+                    const float t0 = ts[s];
+                    pool.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                    pool.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                    pool.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                    pool.t0[base + s] = t0;
+                }
+            }
+            if (in_tile) pool.cnt[idx] = (uint8_t)(has_ray ? cnt : kNoRay);
+            const uint32_t incl = wave_inclusive_scan(cnt, lane);
+            cnt_r[sub] = cnt;
+            pos_r[sub] = my_valid + incl - cnt;
+            my_valid += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (lane == 0) pool.wave_valid[wave] = my_valid;
+        lap(0);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < kLpWaves; ++v) {
+            const uint32_t x = pool.wave_valid[v];
+            before += v < wave ? x : 0u;
+            total += x;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t slot0 = ((uint32_t)wave * rw + (uint32_t)(sub * 64 + lane)) * n_step;
+            for (uint32_t s = 0; s < cnt_r[sub]; ++s) pool.order[before + pos_r[sub] + s] = (uint16_t)(slot0 + s);
+        }
+        __syncthreads();
+        lap(1);
+
+        // phase 2: the pooled 32-sample blocks, dealt out round-robin
+        for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
+            evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
+        __syncthreads();
+        lap(2);
+
+        // phase 3: composite (the lane that fetched the ray), snapshots past max_steps, histogram of the rays that end here
+        unsigned long long alive_bits[2] = {0ull, 0ull};
+        uint32_t keep[2] = {0u, 0u};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t i = (uint32_t)(sub * 64 + lane);
+            if ((uint32_t)(sub * 64) >= rw) break;                // wavefront-uniform
+            const uint32_t idx = (uint32_t)wave * rw + i;
+            const uint32_t cnt = i < rw ? (uint32_t)pool.cnt[idx] : kNoRay;
+            bool survives = false;
+            if (cnt != kNoRay) {
+                const uint32_t e = pool.alive[idx];
+                const uint32_t ray = e & kPRayMask, used = (e >> kPRayBits) & 31u, c = e >> 27;
+                RayAccum acc = ray_state_load(a.state, ray);
+                const uint32_t base = idx * n_step;
+                uint32_t s = 0;
+                bool stop = false;
+                for (; s < cnt; ++s) {
+                    const uint32_t k = base + s;
+                    const float t0 = pool.t0[k];
+                    const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);   // (raymarching.cu:905-913)
+                    stop = composite_sample(acc, pool.px[k], dt, t0 + dt, pool.py[k], pool.pz[k], pool.cb[k], a.T_thresh);
+                    const uint32_t done = used + s + 1u;
+                    if (done >= a.max_steps && done < cap) {      // the budget B may end this ray here: keep the state after `done` samples
+                        float *sp = a.snaps + ((size_t)ray * 7u + (done - a.max_steps)) * 5u;
+                        sp[0] = acc.wsum; sp[1] = acc.depth; sp[2] = acc.r; sp[3] = acc.g; sp[4] = acc.b;
+                    }
+                    if (stop) break;
+                }
+                const uint32_t used2 = used + (stop ? s + 1u : cnt);
+                survives = !stop && used2 < c;
+                if (!survives) atomicAdd(&pool.hist[stop ? used + s : c], 1u);     // m = min(c, e) <= cap <= 31
+                ray_state_store(a.state, ray, acc, __uint_as_float(used2));
+                a.state[(size_t)kRayRec * ray + 7] = __uint_as_float(used2);        // word 7 (zero since the frame began): samples composited, for k_head_budget_resolve
+                keep[sub] = (e & ~(31u << kPRayBits)) | (used2 << kPRayBits);
+            }
+            alive_bits[sub] = __ballot(survives);
+        }
+        const uint32_t surv0 = (uint32_t)__popcll(alive_bits[0]), surv1 = (uint32_t)__popcll(alive_bits[1]);
+        if (lane == 0) pool.wave_surv[wave] = surv0 + surv1;
+        evaluated += total;
+        ++round;
+        __syncthreads();
+        {   // the survivors, compacted in place (every read of the old list happened before the barrier)
+            uint32_t out = 0, all = 0;
+#pragma unroll
+            for (int v = 0; v < kLpWaves; ++v) {
+                const uint32_t x = pool.wave_surv[v];
+                out += v < wave ? x : 0u;
+                all += x;
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((alive_bits[0] >> lane) & 1ull) pool.alive[out + (uint32_t)__popcll(alive_bits[0] & below)] = keep[0];
+            if ((alive_bits[1] >> lane) & 1ull) pool.alive[out + surv0 + (uint32_t)__popcll(alive_bits[1] & below)] = keep[1];
+            A = all;
+        }
+        __syncthreads();
+        lap(3);
+    }
+    if (tid < 32 && pool.hist[tid]) atomicAdd(&a.budget[tid], (int)pool.hist[tid]);
+    if (tid == 0) {
+        if (evaluated) atomicAdd(&a.budget[kBudgetSamples], (int)evaluated);
+        atomicAdd(&a.budget[kBudgetRounds], (int)round);
+        atomicMax(&a.budget[kBudgetRoundsMax], (int)round);
+        atomicMax(&a.budget[kBudgetSamplesMax], (int)evaluated);
+        // where this workgroup's time went (thread 0's clock, units of 1024 shader cycles; sums over the workgroups + the longest workgroup)
+        for (int k = 0; k < 4; ++k) atomicAdd(&a.budget[kBudgetCycles + k], (int)(cyc[k] >> 10));
+        atomicMax(&a.budget[kBudgetCycles + 4], (int)((cyc[0] + cyc[1] + cyc[2] + cyc[3]) >> 10));
+    }
+}
+
+// renderer.py:359-364,384 replayed on the histogram: alive rays at the start of every trip and the step budget.  Every thread that calls this
+// computes the same numbers from <= max_steps + 8 cached loads.
+__device__ __forceinline__ uint32_t budget_from_hist(const int32_t *__restrict__ hist, uint32_t N_global, uint32_t max_steps, int32_t *counters_out) {
+    uint32_t S = 0, gone = 0, alive = N_global, trip = 0;
+    while (S < max_steps && alive > 0u) {
+        if (counters_out) counters_out[trip] = (int32_t)alive;
+        uint32_t n = N_global / alive;
+        n = n < 1u ? 1u : (n > 8u ? 8u : n);
+        for (uint32_t j = S; j < S + n; ++j) gone += (uint32_t)hist[j];     // rays whose m lies inside this window are dead after it
+        S += n;
+        alive = N_global - gone;
+        ++trip;
+    }
+    if (counters_out) counters_out[trip] = (int32_t)alive;   // what the last trip appended for a next one (0 when the loop ended for lack of rays)
+    return S;
+}
+
+__global__ __launch_bounds__(256) void k_head_budget_resolve(float *__restrict__ state, const float *__restrict__ snaps, const int32_t *__restrict__ hist,
+                                                             int32_t *__restrict__ counters, uint32_t N, uint32_t N_global, uint32_t max_steps) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n == 0) {
+        (void)budget_from_hist(hist, N_global, max_steps, counters);
+        counters[64] = counters[kBudgetBase + kBudgetSamples];          // the launch's evaluated samples, where trip 0's count used to be
+    }
+    if (n >= N) return;
+    const uint32_t done = __float_as_uint(state[(size_t)kRayRec * n + 7]);   // 0: the ray never had a sample (the frame's begin kernel zeroes the word)
+    if (done <= max_steps || done > max_steps + 7u) return;            // B >= max_steps whenever a ray got this far
+    const uint32_t B = budget_from_hist(hist, N_global, max_steps, nullptr);
+    if (done <= B || B < max_steps) return;
+    const float *sp = snaps + ((size_t)n * 7u + (B - max_steps)) * 5u;
+    *reinterpret_cast<float4 *>(state + (size_t)kRayRec * n) = float4{sp[0], sp[1], sp[2], sp[3]};
+    *reinterpret_cast<float2 *>(state + (size_t)kRayRec * n + 4) = float2{sp[4], __uint_as_float(B)};
+}
+
 // The sample positions of a ray do not depend on the radiance field (only on the occupancy bitfield), and the reference's marcher
 // carries nothing but t from one loop iteration to the next (raymarching.cu:857, renderer.py:366), so the whole per-ray sample
 // sequence can be marched ONCE per frame, at full occupancy, instead of piecewise inside the register- and LDS-heavy trip kernel:
@@ -847,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
 // launch (and the gap behind it) leaves the frame's critical path.  Same expressions, same bits as the two kernels.
 __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 128) p.counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)p.N : 0;
+    if (blockIdx.x == 0 && threadIdx.x < kCounterWords) p.counters[threadIdx.x] = threadIdx.x == 0 ? (int32_t)p.N : 0;
     if (n >= p.N) return;
     const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
     const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
@@ -1080,6 +1360,84 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
         if (rc) return rc;
     }
     return 0;
+}
+
+template <int AMB_D, typename H, bool SLOW>
+static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
+    hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
+}
+
+// upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8,8,8,8" overrides, experiments): the shape of the
+// reference's own schedule (1, 2, 2, 2, 4, 8 for the bench scene) -- a larger first take only evaluates samples behind a ray's termination
+static uint32_t persist_step_caps() {
+    static uint32_t caps = 0;
+    if (caps == 0) {
+        uint32_t v[8] = {2, 2, 2, 4, 8, 8, 8, 8};
+        if (const char *e = getenv("GFPP_PERSIST_CAPS")) {
+            int k = 0;
+            for (const char *p = e; *p && k < 8; ++k) {
+                const int x = atoi(p);
+                v[k] = (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+            for (; k > 0 && k < 8; ++k) v[k] = v[k - 1];
+        }
+        for (int k = 0; k < 8; ++k) caps |= v[k] << (4 * k);
+    }
+    return caps;
+}
+
+GFPP_API int gfpp_head_frame_resolve(const gfpp_frame_ws *ws, uint32_t max_steps, gfpp_stream_t stream) {
+    if (!ws || !ws->ray_state || !ws->counters || !ws->snapshots || ws->N == 0) { set_error("gfpp_head_frame_resolve: incomplete workspace (ray_state, counters [192], snapshots)"); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > 24u) { set_error("gfpp_head_frame_resolve: max_steps must be in 1..24"); return GFPP_EUNSUPPORTED; }
+    const int32_t *hist = ws->gcounters ? ws->gcounters : ws->counters + kBudgetBase;
+    const uint32_t n_global = ws->gcounters ? ws->N_global : ws->N;
+    hipLaunchKernelGGL(k_head_budget_resolve, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, ws->ray_state, ws->snapshots, hist, ws->counters, ws->N,
+                       n_global, max_steps);
+    return check_launch("gfpp_head_frame_resolve");
+}
+
+GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                        float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_frame_persist_lp", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    if (!ws->ray_state || !ws->counters || !ws->frame_consts || !ws->snapshots) {
+        set_error("gfpp_head_frame_persist_lp: the workspace needs ray_state, counters [192], frame_consts and snapshots [N, 7, 5]");
+        return GFPP_EINVAL;
+    }
+    if (max_steps > 24u || ws->N > (1u << kPRayBits)) { set_error("gfpp_head_frame_persist_lp: max_steps <= 24 and N <= 2^22 (use gfpp_head_frame_trips_lp beyond)"); return GFPP_EUNSUPPORTED; }
+    LpTripArgs a;
+    a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    { const int rc = lp_model_args("gfpp_head_frame_persist_lp", model, a); if (rc) return rc; }
+    a.rays_o = rays_o; a.rays_d = rays_d;
+    a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
+    a.state = ws->ray_state;
+    a.alive[0] = a.alive[1] = nullptr;
+    a.counters = ws->counters; a.gcounters = ws->counters; a.N_global = ws->N; a.sync = nullptr;
+    a.frame_consts = ws->frame_consts;
+    a.T_thresh = T_thresh; a.density_scale = model->density_scale;
+    a.N = ws->N; a.max_steps = max_steps; a.trip = 0; a.trip_end = 0;
+    a.budget = ws->counters + kBudgetBase;
+    a.snaps = ws->snapshots;
+    a.n_tiles = div_up(ws->N, kPTile);
+    // q -> (q * mult) % n_tiles is a permutation of the tiles when gcd(mult, n_tiles) = 1: consecutive slots land ~1237 tiles apart, so that every
+    // workgroup's share (slots b, b + G, ...) is spread over the whole image (equal work without any exchange between workgroups)
+    a.tile_mult = 1u;
+    for (const uint32_t m : {1237u, 251u, 61u, 7u})
+        if (a.n_tiles % m != 0u && (unsigned long long)a.n_tiles * m < (1ull << 32)) { a.tile_mult = m; break; }
+    a.step_caps = persist_step_caps();
+    uint32_t grid = (uint32_t)lp_cu_count();
+    if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
+    if (grid > a.n_tiles) grid = a.n_tiles;
+    const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
+    void (*launch)(uint32_t, hipStream_t, const LpTripArgs &) =
+        amb3 ? (bf ? (slow ? launch_persist<3, __bf16, true> : launch_persist<3, __bf16, false>) : (slow ? launch_persist<3, _Float16, true> : launch_persist<3, _Float16, false>))
+             : (bf ? (slow ? launch_persist<2, __bf16, true> : launch_persist<2, __bf16, false>) : (slow ? launch_persist<2, _Float16, true> : launch_persist<2, _Float16, false>));
+    launch(grid, (hipStream_t)stream, a);
+    const int rc = check_launch("gfpp_head_frame_persist_lp");
+    if (rc || ws->gcounters) return rc;          // a ray tile of a shared frame: the caller sums the histograms of all tiles first
+    return gfpp_head_frame_resolve(ws, max_steps, stream);
 }
 
 GFPP_API int gfpp_head_eval_samples_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *positions, const float *directions, uint32_t M,

@@ -153,9 +153,69 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_u8(const float *__restrict__ 
     }
 }
 
+#define GFPP_REQUIRE_EARLY(cond, what)                            \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            gfpp::set_error("%s: invalid argument (%s)", what, #cond); \
+            return GFPP_EINVAL;                                   \
+        }                                                         \
+    } while (0)
+
+// ---- clip job: a frame's graph fetches its inputs and stores its output by a device-side cursor ---------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_clip_fetch(const gfpp_clip_job *__restrict__ job, uint32_t lane, float *__restrict__ static_in, uint32_t row_floats) {
+    const uint32_t pos = job->cursor[lane];
+    if (pos >= job->n) return;
+    const float *row = job->packed + (size_t)job->order[pos] * job->row_floats;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < row_floats; i += gridDim.x * kBlock) static_in[i] = row[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restrict__ job, uint32_t lane, const float *__restrict__ rgb, size_t n) {
+    const uint32_t pos = job->cursor[lane];
+    if (pos < job->n) {
+        uint8_t *out = job->out + (size_t)(pos % job->ring_frames) * job->frame_bytes;
+        const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4 *>(rgb + i);
+            uchar4 o;
+            o.x = (uint8_t)clampf(v.x * 255.0f, 0.0f, 255.0f); o.y = (uint8_t)clampf(v.y * 255.0f, 0.0f, 255.0f);
+            o.z = (uint8_t)clampf(v.z * 255.0f, 0.0f, 255.0f); o.w = (uint8_t)clampf(v.w * 255.0f, 0.0f, 255.0f);
+            *reinterpret_cast<uchar4 *>(out + i) = o;
+        } else {
+            for (size_t k = i; k < n; ++k) out[k] = (uint8_t)clampf(rgb[k] * 255.0f, 0.0f, 255.0f);
+        }
+    }
+}
+
+// the cursor moves on only when every block of the store kernel has read it: a second, one-thread launch in the same stream
+__global__ void k_clip_advance(gfpp_clip_job *__restrict__ job, uint32_t lane) { job->cursor[lane] += job->lanes; }
+
 }  // namespace gfpp
 
 using namespace gfpp;
+
+GFPP_API int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {
+    GFPP_REQUIRE_EARLY(job && static_in && lane < 8 && row_floats > 0, "gfpp_clip_fetch");
+    hipLaunchKernelGGL(k_clip_fetch, dim3((row_floats + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, job, lane, static_in, row_floats);
+    return check_launch("gfpp_clip_fetch");
+}
+
+GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {
+    GFPP_REQUIRE_EARLY(job && rgb && lane < 8 && n_values > 0 && ((uintptr_t)rgb & 15u) == 0 && (n_values & 3u) == 0, "gfpp_clip_store_u8");
+    const uint64_t threads = (n_values + 3) / 4;
+    hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, job, lane, rgb, (size_t)n_values);
+    hipLaunchKernelGGL(k_clip_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, job, lane);
+    return check_launch("gfpp_clip_store_u8");
+}
+
+GFPP_API int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count) {
+    GFPP_REQUIRE_EARLY(execs && streams && lanes > 0 && lanes <= 8, "gfpp_graph_replay");
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t lane = (first_lane + k) % lanes;
+        const hipError_t err = hipGraphLaunch((hipGraphExec_t)execs[lane], (hipStream_t)streams[lane]);
+        if (err != hipSuccess) { set_error("gfpp_graph_replay: hipGraphLaunch failed at frame %u (%s)", k, hipGetErrorString(err)); return (int)err; }
+    }
+    return 0;
+}
 
 GFPP_API int gfpp_abi_version(void) { return GFPP_ABI_VERSION; }
 GFPP_API const char *gfpp_last_error(void) { return gfpp::g_err; }
@@ -164,7 +224,7 @@ GFPP_API unsigned gfpp_struct_size(const char *name) {
     const struct { const char *n; unsigned s; } table[] = {
         {"frame_ws", (unsigned)sizeof(gfpp_frame_ws)},       {"head_model", (unsigned)sizeof(gfpp_head_model)}, {"torso_model", (unsigned)sizeof(gfpp_torso_model)},
         {"cond_model", (unsigned)sizeof(gfpp_cond_model)},   {"grid_desc", (unsigned)sizeof(gfpp_grid_desc)},   {"grid_level", (unsigned)sizeof(gfpp_grid_level)},
-        {"sr_model", (unsigned)sizeof(gfpp_sr_model)},       {"sr_ws", (unsigned)sizeof(gfpp_sr_ws)},
+        {"sr_model", (unsigned)sizeof(gfpp_sr_model)},       {"sr_ws", (unsigned)sizeof(gfpp_sr_ws)},         {"clip_job", (unsigned)sizeof(gfpp_clip_job)},
     };
     for (const auto &e : table)
         if (strcmp(e.n, name) == 0) return e.s;

@@ -42,7 +42,8 @@ class FrameWs(ctypes.Structure):
     _fields_ = [("N", c_u32), ("nears", c_p), ("fars", c_p), ("ray_state", c_p),
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
-                ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32)]
+                ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
+                ("snapshots", c_p)]
 
 
 class CondModel(ctypes.Structure):
@@ -77,6 +78,8 @@ _lib.register("gfpp_head_frame_begin_premarch", [ctypes.POINTER(HeadModel), ctyp
 _lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_persist_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_resolve", [ctypes.POINTER(FrameWs), c_u32, c_p])
 _lib.register("gfpp_head_eval_samples", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_eval_samples_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
@@ -549,7 +552,7 @@ class FramePipeline:
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             t = {"nears": f(N), "fars": f(N), "ray_state": f(N, 8),       # one 32-byte record per ray (gfpp_frame_ws.ray_state)
                  "alive0": torch.empty(N, dtype=torch.int32, device=dev), "alive1": torch.empty(N, dtype=torch.int32, device=dev),
-                 "counters": torch.zeros(128, dtype=torch.int32, device=dev), "frame_consts": f(256),
+                 "counters": torch.zeros(192, dtype=torch.int32, device=dev), "frame_consts": f(256),
                  "out_image": f(N, 3), "out_depth": f(N)}
             self._ws_bytes = sum(v.numel() * v.element_size() for v in t.values())
             ws = FrameWs()
@@ -563,6 +566,7 @@ class FramePipeline:
             ws.separate_trips = 0
             ws.gcounters, ws.N_global, ws.trip_first, ws.trip_count = None, 0, 0, 0
             ws.full_grid_trips = 0
+            ws.snapshots = None
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
         if self.frames_in_flight <= 1:
@@ -589,8 +593,11 @@ class FramePipeline:
         been rendered on this lane (synchronises): the trips beyond the ones that frame used (+ margin) then become ONE multi-trip launch on a small
         grid (gfpp_frame_ws.full_grid_trips / separate_trips).  Results never depend on it: a later frame that needs more trips is rendered by the
         small grid.  Returns the number of full-grid trips."""
-        torch.cuda.synchronize(self.device)
         ws, t = self.workspace(N)
+        if self.precision != "fp32" and self.lp_kernel == "persist":
+            ws.full_grid_trips = 0                       # one launch per frame: nothing to calibrate
+            return 0
+        torch.cuda.synchronize(self.device)
         used = int((t["counters"][64:127] > 0).sum().item())
         ws.full_grid_trips = max(1, used + int(margin)) if self.frames_in_flight > 1 else 0
         return int(ws.full_grid_trips)
@@ -604,6 +611,10 @@ class FramePipeline:
 
     #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
     separate_trips = None
+
+    #: 16-bit modes: 'persist' = the whole loop as ONE launch with workgroup-local trips (gfpp_head_frame_persist_lp, the production path since
+    #: round 3), 'trips' = one launch per trip (gfpp_head_frame_trips_lp, the A/B partner; also taken for max_steps > 24 or more than 2^22 rays)
+    lp_kernel = os.environ.get("GFPP_LP_KERNEL", "persist")
 
     #: set > 1 by a caller that keeps frames of several lanes in flight at once (ClipRenderer)
     frames_in_flight = 1
@@ -673,6 +684,12 @@ class FramePipeline:
         if side is not None:
             main.wait_stream(side)                      # join
         trips = "gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march")
+        persist = lp and self.lp_kernel == "persist" and int(max_steps) <= 24 and N <= (1 << 22)
+        if persist:
+            trips = "gfpp_head_frame_persist_lp"
+            if "snapshots" not in t:
+                t["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=self.device)
+            ws.snapshots = t["snapshots"].data_ptr()
         if shard is None:
             call(trips, ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
             return ws, t
@@ -683,6 +700,18 @@ class FramePipeline:
         g = t.get("gcounters")
         if g is None:
             g = t["gcounters"] = torch.zeros(64, dtype=torch.int32, device=self.device)
+        if persist:
+            # workgroup-local trips: the tiles need nothing from each other while they render; what the frame-wide loop control needs -- the step
+            # budget and the alive counts -- is a function of the histogram of the rays' end points, summed over the tiles with ONE all_reduce
+            ws.gcounters, ws.N_global = g.data_ptr(), int(n_frame)
+            try:
+                call(trips, ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
+                g.copy_(t["counters"][128:192])
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+                call("gfpp_head_frame_resolve", ctypes.byref(ws), int(max_steps), st)
+            finally:
+                ws.gcounters, ws.N_global = None, 0
+            return ws, t
         g.zero_()
         g[:1].fill_(int(n_frame))
         ws.gcounters, ws.N_global = g.data_ptr(), int(n_frame)
@@ -790,7 +819,18 @@ class FramePipeline:
             t.pop("phase_cycles", None)
         return t.get("phase_cycles")
 
+    def budget(self, N):
+        """The persistent 16-bit launch's own record of the last frame: histogram of the rays' end points [32], evaluated samples, workgroup rounds
+        (sum, max); synchronises."""
+        c = self.workspace(N)[1]["counters"].cpu().numpy()
+        return {"hist": c[128:160].copy(), "samples": int(c[168]), "rounds_sum": int(c[169]), "rounds_max": int(c[170]), "samples_max_wg": int(c[171]),
+                # thread 0's shader clock per workgroup, summed over the workgroups, in units of 1024 cycles: fetch (+ ingest) | compaction | evaluate |
+                # composite + list upkeep; and the longest workgroup
+                "kcycles": {"fetch": int(c[172]), "compact": int(c[173]), "evaluate": int(c[174]), "composite": int(c[175]), "longest_wg": int(c[176])}}
+
     def trip_counters(self, N):
-        """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises."""
+        """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises.  After the persistent 16-bit
+        launch the alive counts are the ones gfpp_head_frame_resolve reconstructed (what the trip launches would have left), and the samples of the
+        whole frame are reported under trip 0 (a workgroup's local trips are not the reference's)."""
         c = self.workspace(N)[1]["counters"].cpu().numpy()
         return c[:64], c[64:127]

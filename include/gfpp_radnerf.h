@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 3
+#define GFPP_ABI_VERSION 4
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -137,6 +137,37 @@ int gfpp_get_rays_at(const float *pose, float fx, float fy, float cx, float cy, 
 /* replaces the per-frame `(pred_rgb * 255.).int() ... astype(np.uint8)` host conversion of the caller
  * (inference/genefacepp_infer.py:468): rgb [n_values] f32 in [0,1] -> out [n_values] u8, truncating. rgb 16-byte aligned. */
 int gfpp_rgb_to_u8(const float *rgb, uint64_t n_values, uint8_t *out, gfpp_stream_t stream);
+
+/* ---- the caller's frame loop below Python (inference/genefacepp_infer.py:460-469: `for i in range(num_frames): render(...)`, then the uint8
+ * conversion of :468 / :505) ---------------------------------------------------------------------------------------------------------------
+ * A clip's driving signals are device-resident, one packed row per frame (clip.ClipRenderer.prepare).  With the job record below -- also in
+ * DEVICE memory, written by the host once per render call -- a frame's captured graph fetches its own inputs and stores its own output:
+ * gfpp_clip_fetch copies row order[cursor[lane]] of `packed` into the graph's static input buffer, gfpp_clip_store_u8 converts the frame to uint8
+ * straight into slot cursor[lane] % ring_frames of `out` and advances the lane's cursor by `lanes`.  Per frame the host then issues nothing but
+ * the graph launch, and gfpp_graph_replay issues those from C for a whole run of frames (lane = frame % lanes, one stream per lane). */
+typedef struct gfpp_clip_job {
+    const float *packed;      /* [frames, row_floats] f32 */
+    const int32_t *order;     /* [n] i32: clip frame index of the k-th frame of this job */
+    uint8_t *out;             /* [ring_frames, frame_bytes] u8 */
+    uint64_t frame_bytes;
+    uint32_t row_floats;
+    uint32_t n;               /* frames of the job (positions >= n fetch and store nothing) */
+    uint32_t lanes;           /* frames in flight: lane l renders the positions l, l + lanes, ... */
+    uint32_t ring_frames;     /* positions wrap around in `out` (= n: no wrap) */
+    uint32_t cursor[8];       /* per lane: position of the lane's next frame (host: cursor[l] = l) */
+} gfpp_clip_job;
+
+/* job (DEVICE pointer) -> static_in [row_floats] f32 (device); replaces the per-frame indexing `cond_inp[i], poses[i], lm68s[i]`
+ * of inference/genefacepp_infer.py:461-463 */
+int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
+
+/* the conversion of gfpp_rgb_to_u8 (inference/genefacepp_infer.py:468) written to the job's output slot of this lane's frame, then
+ * cursor[lane] += lanes.  rgb [n_values] f32 16-byte aligned; n_values must equal the job's frame_bytes. */
+int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
+
+/* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
+ * (first_lane + k) % lanes on that lane's stream.  execs: [lanes] hipGraphExec_t, streams: [lanes] hipStream_t (host arrays). */
+int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section B -- fused frame pipeline (no native counterpart in the reference; replaces the Python loop of
@@ -282,8 +313,14 @@ typedef struct gfpp_frame_ws {
                           * A trip touches scattered ray ids: a record is one 16-byte + one 8-byte access and one dirty 32-byte sector per ray,
                           * where five arrays cost five sectors (measured 4-8x write amplification) */
     int32_t *alive[2];   /* [N] each: ping-pong lists of alive ray ids */
-    int32_t *counters;   /* [128] i32: counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated;
-                          * counters[127] = barrier word of the 16-bit kernel's multi-trip launch (negative = a barrier timed out) */
+    int32_t *counters;   /* [192] i32 (ABI 4; 128 before): counters[k] = rays alive at the start of trip k; counters[64+k] = samples trip k evaluated;
+                          * counters[127] = barrier word of the 16-bit kernel's multi-trip launch (negative = a barrier timed out);
+                          * counters[128 + m], m < 32 = the budget histogram of gfpp_head_frame_persist_lp: rays whose compositing ends at
+                          * sample index m = min(samples the ray owns, index of the first sample whose pre-sample transmittance is below
+                          * T_thresh) -- the whole (n_alive, n_step) sequence of renderer.py:359-364,384 is a function of it;
+                          * counters[168] = samples that launch evaluated, counters[169] / [170] = workgroup rounds (sum / max), [171] = most samples of one
+                          * workgroup, [172..175] = shader cycles / 1024 by phase (fetch, compaction, evaluate, composite; summed over workgroups), [176] longest workgroup.
+                          * All 192 are zeroed by gfpp_head_frame_begin / gfpp_head_frame_begin_premarch (counters[0] = N). */
     float *frame_consts; /* [256] f32: folded biases of ambient_net.0 and color_net.0 in fragment order */
     float *sample_t;        /* 16-bit kernel only: [N, sample_stride] f32, t of every occupied sample of each ray in march order */
     uint32_t *sample_cnt;   /* 16-bit kernel only: [N] u32 */
@@ -313,6 +350,8 @@ typedef struct gfpp_frame_ws {
                                * size from a few streams cannot starve each other (together they fit the device several times), and the ten
                                * launches per frame that would find nothing left (~2 us each) are gone.  Results do not depend on it: a late
                                * trip that does have work is rendered by the small grid, just more slowly. */
+    float *snapshots;      /* gfpp_head_frame_persist_lp only: [N, 7, 5] f32 -- {weights_sum, depth, r, g, b} of a ray after max_steps .. max_steps + 6
+                            * composited samples (only rays that get that far write it; gfpp_head_frame_resolve reads it) */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state
@@ -365,6 +404,30 @@ int gfpp_head_frame_begin_premarch(const gfpp_head_model *model, const gfpp_fram
 /* Second stage: the trip launches of gfpp_head_frame_march_lp, consuming the pre-marched lists (renderer.py:354-384 loop). */
 int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                              float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
+/* The whole loop of renderer.py:354-384 for the 16-bit mode as ONE launch without any device-wide dependency (replaces the six-plus launches
+ * of gfpp_head_frame_trips_lp; same per-sample arithmetic, results bit-identical to it).  What makes that possible: along a ray the
+ * compositing recurrence (raymarching.cu:978-1022) is sequential and the marcher carries nothing but t (raymarching.cu:857), so the state of a
+ * ray after its first k samples does not depend on how the loop cut those samples into trips; the trip schedule only decides (a) the total
+ * step budget B = sum of n_step over the trips that run (a ray composites its first min(c, e + 1, B) samples, c = occupied samples it owns, e =
+ * first sample whose pre-sample transmittance is < T_thresh) and (b) the n_alive sequence, and both are functions of the histogram of
+ * m = min(c, e) over the rays: a ray is alive after the window ending at sample S  <=>  m >= S.  So every workgroup takes its own tiles of 32
+ * rays (dealt out through a multiplicative permutation), keeps the weight image in LDS for the whole frame and loops LOCALLY: next samples of
+ * its alive rays -> workgroup sample pool -> evaluate (the trip kernels' evaluate_block_lp) -> composite -> local compaction, with a local
+ * n_step.  A ray that composites more than max_steps samples snapshots its state after samples max_steps .. max_steps + 6 (B lies in
+ * [max_steps, max_steps + 7]); gfpp_head_frame_resolve then replays renderer.py:359-364,384 on the histogram, writes counters[k] (alive rays
+ * at the start of trip k, as the trip launches would have left them) and gives every ray with more than B composited samples its snapshot.
+ * Needs gfpp_head_frame_begin_premarch (or _begin + _premarch) and gfpp_head_frame_fold first; max_steps <= 24, N <= 2^22.
+ * ws->gcounters != NULL (one ray tile of a frame shared between GPUs): the resolve step is NOT issued -- the caller sums counters[128..191] of
+ * all tiles into gcounters[0..63] (ONE all-reduce per frame instead of one per trip) and then calls gfpp_head_frame_resolve. */
+int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                               float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
+/* Second step of gfpp_head_frame_persist_lp (issued by it unless ws->gcounters is set): replays the loop control of renderer.py:359-364,384
+ * (n_step = clamp(N // n_alive, 1, 8), step += n_step, exit at max_steps or when nobody is alive) on the histogram -- ws->gcounters[0..63] if set
+ * (the frame-wide sums, with ws->N_global rays), else ws->counters[128..191] -- which yields the budget B and counters[k]; then the snapshot
+ * selection for rays that composited more than B samples (raymarching.cu:978-1022 stops them at the end of the last trip's window). */
+int gfpp_head_frame_resolve(const gfpp_frame_ws *ws, uint32_t max_steps, gfpp_stream_t stream);
 
 /* Head-only epilogue (renderer.py:385-397): image = clamp(image + (1 - weights_sum) * bg, 0, 1),
  * depth = clamp(depth - near, 0) / (far - near).  bg_color [N,3] or NULL (then bg_scalar is used; reference default 1). */

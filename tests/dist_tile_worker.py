@@ -65,7 +65,14 @@ def main():
             ok = ok and bool(torch.equal(tiled["torso_alpha_map"].reshape(-1), alone["torso_alpha_map"].reshape(-1)))
         # the frame-wide alive counts the tiles agreed on == the single-GPU loop's
         lo, hi = frames.ray_tile(HW * HW, rank, world)
-        g = model.pipeline().workspace(hi - lo)[1]["gcounters"].cpu().numpy()
+        pipe = model.pipeline()
+        if precision != "fp32" and pipe.lp_kernel == "persist":
+            # one launch per tile + ONE all_reduce of the end-point histogram: the resolve step leaves the frame-wide alive counts in the tile's counters
+            g = pipe.workspace(hi - lo)[1]["counters"].cpu().numpy()
+            hist = pipe.workspace(hi - lo)[1]["gcounters"].cpu().numpy()
+            ok = ok and int(hist[:32].sum()) == HW * HW
+        else:
+            g = pipe.workspace(hi - lo)[1]["gcounters"].cpu().numpy()
         res[f"{variant}_{HW}_{precision}"] = ok and bool(np.array_equal(g[:16], alive_alone[:16]))
         res[f"{variant}_{HW}_{precision}_trips"] = int((alive_alone[:16] > 0).sum())
     sys.stdout.write("\nTILERESULT " + json.dumps(res) + "\n"); sys.stdout.flush()

@@ -32,15 +32,17 @@ def test_library_exports_every_declared_symbol(built_lib):
     # and the ctypes table binds exactly the declared set
     assert set(built_lib.declared_symbols()) <= set(names)
     lib = built_lib.lib()
-    assert lib.gfpp_abi_version() == 3
+    assert lib.gfpp_abi_version() == 4
 
 
 def test_ctypes_mirrors_have_the_librarys_struct_sizes(built_lib):
     """Every struct of the header that the Python binding mirrors must have the size the library was compiled with
     (gfpp_struct_size): a field added on one side only would otherwise corrupt memory silently."""
     from genefaceplusplus_amd.radnerfs import frame_pipeline, superres
+    from genefaceplusplus_amd import clip
     mirrors = dict(frame_pipeline.STRUCT_MIRRORS)
     mirrors.update(superres.STRUCT_MIRRORS)
+    mirrors.update(clip.STRUCT_MIRRORS)
     text = open(os.path.join(ROOT, "include", "gfpp_radnerf.h")).read()
     declared = set(re.findall(r"^\} gfpp_(\w+);", text, flags=re.M))
     assert declared == set(mirrors), (declared, set(mirrors))

@@ -89,6 +89,7 @@ def test_late_trips_on_the_small_grid_render_the_same_frames(dev, precision):
     case = frame_case("may_torso", HW)
     model = build_model(case, dev, "fused")
     model.precision = precision
+    model.pipeline().lp_kernel = "trips"              # trip-launch calibration only exists on that path
     batch = _clip_batch(case["hp"], 5)
     mk = lambda **kw: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], ring=3,
                                    use_graph=True, render_kwargs=dict(case["hp"]), lanes=2, **kw)

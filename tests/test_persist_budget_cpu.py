@@ -1,0 +1,134 @@
+"""The arithmetic behind gfpp_head_frame_persist_lp / gfpp_head_frame_resolve (csrc/frame_head_lp.hip), restated in numpy and checked against a
+direct simulation of the reference's loop (renderer.py:354-384 + raymarching.cu:978-1022) on random rays:
+
+  * a ray composites its first min(c, e + 1, B) samples whatever way the loop cuts them into trips (c = occupied samples it owns, e = first sample
+    whose pre-sample transmittance is below T_thresh, B = sum of n_step over the trips that run);
+  * B and the n_alive sequence are functions of the histogram of m = min(c, e) alone (alive after the window ending at S  <=>  m >= S);
+  * the ownership tiles (32 rays, multiplicative permutation, slots b, b + G, ... per workgroup) cover every ray exactly once;
+  * a workgroup round never overflows its pool (8 x rw x n_step <= 1024 slots)."""
+import numpy as np
+import pytest
+
+
+def reference_loop(c, e, N, max_steps):
+    """renderer.py:354-384 on per-ray (c, e): returns (samples composited per ray, [n_alive per trip], B)."""
+    done = np.zeros(N, np.int64)
+    alive = np.arange(N)
+    step, trace = 0, []
+    while step < max_steps:
+        n_alive = alive.size
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        trace.append(n_alive)
+        keep = []
+        for r in alive:
+            s = 0
+            while s < n_step:
+                idx = step + s
+                if idx >= c[r]:                     # deltas == 0: no sample left
+                    break
+                done[r] = idx + 1                   # composited
+                if idx == e[r]:                     # pre-sample T < T_thresh: break after compositing, step not advanced
+                    break
+                s += 1
+            if s == n_step:
+                keep.append(r)
+        alive = np.array(keep, dtype=np.int64)
+        step += n_step
+    return done, trace, step, alive.size
+
+
+def budget_from_hist(hist, N, max_steps):
+    """k_head_budget_resolve / budget_from_hist restated."""
+    S, gone, alive, counters = 0, 0, N, []
+    while S < max_steps and alive > 0:
+        counters.append(alive)
+        n = max(min(N // alive, 8), 1)
+        gone += int(hist[S:S + n].sum())
+        S += n
+        alive = N - gone
+    counters.append(alive)
+    return S, counters
+
+
+@pytest.mark.parametrize("seed,max_steps,thin", [(0, 16, False), (1, 16, True), (2, 7, False), (3, 24, True), (4, 1, False), (5, 16, None)])
+def test_budget_and_alive_counts_follow_from_the_histogram(seed, max_steps, thin):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(200, 3000))
+    cap = max_steps + 7
+    c = rng.integers(0, cap + 1, N)
+    c[rng.random(N) < 0.5] = 0                                      # half the rays never meet an occupied cell
+    if thin is None:
+        c[:] = 0                                                     # empty bitfield
+    e = np.where(rng.random(N) < (0.1 if thin else 0.7), rng.integers(0, cap + 1, N), 10 ** 6)   # thin scenes rarely terminate by transmittance
+    done_ref, trace, B_ref, left = reference_loop(c, e, N, max_steps)
+    # the persistent launch: every ray runs to ITS end, whatever the local schedule
+    d = np.minimum(c, e + 1)
+    m = np.minimum(np.minimum(c, e), cap)
+    hist = np.bincount(m, minlength=32)
+    assert hist.sum() == N
+    B, counters = budget_from_hist(hist, N, max_steps)
+    assert B == B_ref
+    assert counters[:len(trace)] == trace and counters[len(trace)] == left
+    np.testing.assert_array_equal(np.minimum(d, B), done_ref)       # snapshot selection: min(d, B) samples
+    assert ((d > B) <= (B >= max_steps)).all() and (d <= cap).all()   # a snapshot index B - max_steps in [0, 6] exists whenever one is needed
+    assert (B - max_steps <= 6) or not (d > B).any()
+
+
+TILE = 8        # kPTile
+
+
+def _ownership(N, G):
+    """frame_head_lp.hip: tile slots [q0, q0 + my_tiles) per workgroup (consecutive), tile of slot q = (q * mult) % n_tiles."""
+    n_tiles = -(-N // TILE)
+    mult = next((m for m in (1237, 251, 61, 7) if n_tiles % m and n_tiles * m < 2 ** 32), 1)
+    G = min(G, n_tiles)
+    per_wg, extra = divmod(n_tiles, G)
+    b = np.arange(G)
+    my_tiles = per_wg + (b < extra)
+    q0 = b * per_wg + np.minimum(b, extra)
+    return n_tiles, mult, G, q0, my_tiles
+
+
+@pytest.mark.parametrize("N,G", [(512 * 512, 256), (256 * 256, 256), (37 * 37, 256), (1, 256), (64 * 64, 5), (640 * 640, 256), (1237 * 8, 256), (2048 * 2048, 256)])
+def test_ownership_tiles_cover_every_ray_once(N, G):
+    n_tiles, mult, G, q0, my_tiles = _ownership(N, G)
+    q = np.arange(n_tiles, dtype=np.uint64)
+    tiles = (q * np.uint64(mult)) % np.uint64(n_tiles)
+    assert np.array_equal(np.sort(tiles), np.arange(n_tiles, dtype=np.uint64))          # a permutation
+    assert int(q.max()) * mult < 2 ** 32                                                   # the kernel multiplies in 32 bits
+    assert my_tiles.sum() == n_tiles and q0[0] == 0 and np.array_equal(q0[1:], np.cumsum(my_tiles)[:-1])   # the slot ranges tile [0, n_tiles)
+    assert my_tiles.max() - my_tiles.min() <= 1
+
+
+@pytest.mark.parametrize("HW,bar", [(512, 1.12), (256, 1.2)])
+def test_workgroup_shares_are_balanced_on_the_bench_scene(oracle_mod, HW, bar):
+    """Occupied samples per workgroup share (an upper bound of its evaluations) on the bench frame: the busiest of the 256 workgroups stays within
+    12 % (512^2) / 20 % (256^2) of the mean.  (Slots strided by the grid size put every tile of a workgroup into one column block: 2.2 x the mean.)"""
+    from helpers import frame_case
+    case = frame_case("may_torso", HW)
+    hp, sd = case["hp"], case["sd"]
+    rays = oracle_mod.get_rays(case["pose"], case["intr"], HW, HW)
+    ro, rd = rays["rays_o"][0], rays["rays_d"][0]
+    N = HW * HW
+    nears, fars = oracle_mod.near_far_from_aabb(ro, rd, sd["aabb_infer"], 0.05)
+    _, _, deltas = oracle_mod.march_rays(N, 23, np.arange(N, dtype=np.int32), nears.copy(), ro, rd, float(hp["bound"]), sd["density_bitfield"], 1, 128, nears, fars,
+                                         -1, False, hp["dt_gamma"], hp["max_steps"])
+    c = (deltas[:N * 23, 0].reshape(N, 23) > 0).sum(1).astype(np.float64)
+    n_tiles, mult, G, q0, my_tiles = _ownership(N, 256)
+    per_tile = np.add.reduceat(np.pad(c, (0, n_tiles * TILE - N)), np.arange(0, n_tiles * TILE, TILE))
+    in_slot_order = per_tile[(np.arange(n_tiles, dtype=np.int64) * mult) % n_tiles]
+    share = np.array([in_slot_order[s:s + n].sum() for s, n in zip(q0, my_tiles)])
+    assert share.max() / share.mean() <= bar, share.max() / share.mean()
+    strided = np.array([in_slot_order[b::G].sum() for b in range(G)])
+    assert strided.max() / strided.mean() > 1.5                                            # what the consecutive slots avoid
+
+
+def test_round_geometry_never_overflows_the_pool():
+    for A in range(1, 1025):
+        rw = (A + 7) // 8
+        for cap in (1, 2, 4, 8):
+            n_step = max(1, min(128 // rw, cap, 8))
+            assert 8 * rw * n_step <= 1024 and rw <= 128
+            assert (8 * rw - 1) * n_step + n_step - 1 < 1024                               # the last slot index
