@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-grid-stage", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5, help="multi-GPU: all_gather the finished uint8 frames every this many frames, "
                                                                 "overlapped with the rendering of the next chunk")
-    ap.add_argument("--lanes", type=int, default=None, help="frames in flight per GPU (default: 3): consecutive frames alternate between this many streams, each with "
+    ap.add_argument("--lanes", type=int, default=None, help="frames in flight per GPU (default: 2 in the 16-bit modes since the head pass is ONE launch, 3 in fp32): consecutive frames alternate between this many streams, each with "
                                                          "its own workspace and hipGraph (weights / tables shared), so one frame's small prologue launches and "
                                                          "sparse late trips overlap the other's full-width launches; 1 = strictly one frame at a time")
     ap.add_argument("--gather", default="writer", choices=["writer", "all"],
@@ -543,11 +543,11 @@ def main():
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 
     # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
-    if rank == 0 and args.executor == "fused":
+    def head_roofline(model, hp, x, N, variant):
+        """HIP events around the head-pass launches of 5 frames issued back to back on the launch stream (production prologue before them)."""
         pipe = model.pipeline()
-        x = inputs[W]
         with torch.no_grad():
-            cond_feat = model.cal_cond_feat(x["cond"]) if args.variant != "may_torso_sr" else model.cal_cond_feat(x["cond"], eye_area_percent=x["eye"])
+            cond_feat = model.cal_cond_feat(x["cond"]) if variant != "may_torso_sr" else model.cal_cond_feat(x["cond"], eye_area_percent=x["eye"])
         reps = 5
         import ctypes
         from genefaceplusplus_amd._lib import call
@@ -597,7 +597,7 @@ def main():
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
             kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
                 else "k_head_trip_wp<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, workgroup sample pool)"
-            result["roofline"] = {"kernel": kname, "bound": "mfma",
+            return {"kernel": kname, "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         else:
@@ -608,7 +608,7 @@ def main():
             kname = "k_head_frame_persist" if persist else ("k_head_trip_lp" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" else "k_head_trip_pool")
             what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
                     else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
-            result["roofline"] = {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
+            return {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
                                   "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (algorithmic gather bytes vs the 8 TB/s HBM peak), not what "
                                                 "limits the kernel: the tables are L2 / Infinity-Cache resident (fabric traffic 0.17x the algorithmic bytes, `traffic`), "
                                                 "the counters show an issue / latency bound (VALU : MFMA = 15 : 1, ~half the wave-cycles waiting), see `limiter`",
@@ -619,6 +619,10 @@ def main():
                                          "what": "the same algorithmic gather stream against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves it"},
                                   "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP}, **common}
+
+
+    if rank == 0 and args.executor == "fused":
+        result["roofline"] = head_roofline(model, hp, inputs[W], N, args.variant)
 
     # ---- the other precision modes, briefly (same model, same inputs; graphs are kept per precision) -------------------------------
     if rank == 0 and world == 1 and not args.no_modes:
@@ -682,7 +686,7 @@ def main():
                 m_sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_sr.items()}, strict=True)
                 m_sr = m_sr.to(dev).eval()
                 m_sr.precision, m_sr.use_graph = args.precision, model.use_graph
-                n_s = 40
+                n_s = 120
                 fi_s = [syn.synthetic_frame_inputs(hp_sr, i) for i in range(n_s)]
                 batch_s = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(n_s)]).astype(np.float32),
                            "cond_wins": np.stack([f["cond"] for f in fi_s]), "lm68": np.stack([f["lm68"] for f in fi_s]),
@@ -704,6 +708,18 @@ def main():
                 modes["may_torso_sr"] = {"value": round(n_s / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_s, 4), "steps": n_s,
                                          "precision": args.precision,
                                          "workload": "256x256 rays + landmark-conditioned head-aware torso + StyleGAN2 super-resolution -> 512x512 frame"}
+                # the 256^2 geometry of the released checkpoint with its own roofline (the head pass carries a quarter of the 512^2 frame's samples)
+                try:
+                    pose_s = torch.from_numpy(batch_s["ngp_poses"][0]).to(dev)[None]
+                    rays_s = camera.get_rays(pose_s, syn.intrinsics_for(256, 256), 256, 256)
+                    x_s = {"rays_o": rays_s["rays_o"], "rays_d": rays_s["rays_d"], "cond": torch.from_numpy(fi_s[0]["cond"]).to(dev),
+                           "eye": torch.from_numpy(fi_s[0]["eye_area_percent"]).to(dev)}
+                    sr_cfg = {"baseline_config": "the released May checkpoint's class (RADNeRFTorsowithSR): 256x256 rays, landmark-conditioned head-aware torso, "
+                                                 "StyleGAN2 super-resolution to 512x512", "value": modes["may_torso_sr"]["value"], "unit": "frames/s",
+                              "frames_in_flight": cr_sr.lanes, "roofline": head_roofline(m_sr, hp_sr, x_s, 256 * 256, "may_torso_sr")}
+                    result.setdefault("configs", {})["may_torso_sr_256"] = sr_cfg
+                except Exception as exc:
+                    result.setdefault("configs", {})["may_torso_sr_256"] = {"error": str(exc)}
                 del cr_sr, m_sr
             except Exception as exc:
                 modes["may_torso_sr"] = {"value": None, "error": str(exc)}
@@ -734,7 +750,7 @@ def main():
 
     # ---- the other single-GPU BASELINE configurations ---------------------------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_configs and args.variant == "may_torso" and HW == 512:
-        cfgs = {}
+        cfgs = result.setdefault("configs", {})
         try:
             # configs[1]: "May head-NeRF full 512x512, 1 MI355X, fp32, single-frame latency": ONE frame in flight, the caller waits for it
             hp_h = may_hparams("may_head")

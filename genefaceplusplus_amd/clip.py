@@ -17,6 +17,7 @@ What changes against the reference's loop, and why:
 The per-frame device work is untouched by this file: it calls `model.render()` with exactly the arguments the reference passes.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -36,7 +37,8 @@ class ClipJob(ctypes.Structure):
 
 _lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
-_lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32])
+_lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                    ctypes.c_uint32])
 STRUCT_MIRRORS = {"clip_job": ClipJob}
 
 
@@ -80,7 +82,9 @@ class ClipRenderer:
         self.bg_img = None if bg_img is None else bg_img.to(dev).float().reshape(1, H * W, 3).contiguous()
         fused = getattr(model, "executor", "fused") == "fused"
         if lanes is None:
-            lanes = 3        # measured (round 2, after the trip kernel got faster): 512^2 frames 2 300 / 2 530 / 2 010 frames/s with 2 / 3 / 4 lanes
+            # measured, 512^2 frames: round 2 (one launch per trip) 2 300 / 2 530 / 2 010 frames/s with 2 / 3 / 4 lanes; round 3 (the head pass is ONE launch
+            # that holds every CU for ~0.29 ms) 2 535 / 2 956 / 2 769 / 2 693 with 1 / 2 / 3 / 4: a third frame's launch only gets in the way
+            lanes = 2 if getattr(model, "precision", "auto") != "fp32" else 3
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
@@ -212,10 +216,13 @@ class ClipRenderer:
             self._execs = (execs, streams)
         return self._execs
 
-    #: frames of a graph that draws from torch's generator (the SR stage's random noise) must be replayed by torch (it advances the generator's
-    #: offset before every launch); everything else is launched from C
+    #: (the SR stage's random noise is drawn inside its kernels since round 3: no graph of this renderer uses torch's generator, so every graph can be
+    #: launched from C -- torch's own replay() would only add the generator bookkeeping)
+    replay_mode = os.environ.get("GFPP_CLIP_REPLAY", "c")        # 'c' | 'python' (experiments)
+    max_ahead = int(os.environ.get("GFPP_CLIP_MAX_AHEAD", "0"))   # frames per lane the issuing thread may queue ahead of the GPU (0: no limit)
+
     def _replay_from_c(self):
-        return self.use_graph and not (self.with_sr and self.render_kwargs.get("sr_noise_mode", "random") == "random") and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
+        return self.replay_mode == "c" and self.use_graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
 
     def issue(self, count=None):
         """Issue the next `count` frames of the job (all that are left by default): frame k runs on lane k % lanes.  No host synchronisation."""
@@ -228,7 +235,7 @@ class ClipRenderer:
             execs, streams = self._exec_arrays()
             if self.lanes == 1:
                 streams[0] = torch.cuda.current_stream().cuda_stream
-            call("gfpp_graph_replay", execs, streams, self.lanes, first, count)
+            call("gfpp_graph_replay", execs, streams, self.lanes, first, count, int(self.max_ahead))
         else:
             inner, self.model.use_graph = self.model.use_graph, False
             try:
@@ -371,7 +378,15 @@ class ClipRenderer:
                 deliver(c - 1)
         deliver(len(bounds) - 1)
         self.join()
+        self.check()
         return collected
+
+    def check(self):
+        """After the frames of a job have completed: raise GfppError if any of them was rendered by a launch whose device-wide barrier timed out
+        (FramePipeline.check_barriers; only the trip-launch path has one).  render_to_host calls it before returning; callers of render_to_device /
+        start-issue-join call it once per clip, after their own synchronisation."""
+        if getattr(self.model, "executor", "fused") == "fused":
+            self.model.pipeline().check_barriers()
 
 
 class _NullContext:

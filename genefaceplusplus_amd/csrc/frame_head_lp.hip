@@ -142,6 +142,7 @@ struct LpTripArgs {
     float *snaps;                       // [N, 7, 5] ray state after max_steps .. max_steps + 6 composited samples
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
+    uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
 };
@@ -453,7 +454,7 @@ __device__ __forceinline__ uint32_t counter_load(const int32_t *p) {
 // delay it.  Release/acquire at agent scope write back and invalidate the per-XCD L2s, which is what makes one trip's ray state and
 // survivor list visible to whichever workgroup picks the ray up in the next trip.  The spin is bounded: on a timeout the barrier word
 // is poisoned (negative, so later barriers fall through and the host can see it, FramePipeline.trip_counters) instead of hanging the GPU.
-__device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target) {
+__device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target, uint32_t spin_limit) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -461,7 +462,7 @@ __device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target) {
         uint32_t spins = 0;
         while (counter_load(bar) < target) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) { __hip_atomic_store(bar, (int32_t)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > spin_limit) { __hip_atomic_store(bar, (int32_t)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(L
     if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + trip], (int)evaluated);   // evaluated samples of this trip
    }
     if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs, no barrier needed
-    if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
+    if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers, a.spin_limit);
   }
 }
 
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
             atomicMax(&a.phase_cycles[8 * trip + 7], longest);
         }
         if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs (every workgroup decides the same), no barrier needed
-        if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers);
+        if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers, a.spin_limit);
     }
 }
 
@@ -1342,6 +1343,8 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
              : (bf ? (slow ? launch_lp<2, __bf16, true> : launch_lp<2, __bf16, false>) : (slow ? launch_lp<2, _Float16, true> : launch_lp<2, _Float16, false>));
     a.alive[0] = ws->alive[0]; a.alive[1] = ws->alive[1];
     a.sync = ws->counters + 127;
+    a.spin_limit = 1u << 22;
+    if (const char *e = getenv("GFPP_BARRIER_SPINS")) { const long v = atol(e); if (v > 0) a.spin_limit = (uint32_t)v; }   // (tests force a timeout)
     // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
     const uint32_t want_separate = ws->separate_trips ? ws->separate_trips : lp_separate_trips();
     // a ray tile of a shared frame: the caller all-reduces the alive counts between trips, so every trip is a launch of its own
@@ -1427,6 +1430,7 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
     for (const uint32_t m : {1237u, 251u, 61u, 7u})
         if (a.n_tiles % m != 0u && (unsigned long long)a.n_tiles * m < (1ull << 32)) { a.tile_mult = m; break; }
     a.step_caps = persist_step_caps();
+    a.spin_limit = 0;
     uint32_t grid = (uint32_t)lp_cu_count();
     if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
     if (grid > a.n_tiles) grid = a.n_tiles;

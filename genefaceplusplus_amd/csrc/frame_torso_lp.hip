@@ -30,7 +30,8 @@ constexpr int kTlDef1 = kTlDef0 + 8;         // 4 x 2  64 -> 64
 constexpr int kTlCan0 = kTlDef1 + 8;         // 6 x 1  [grid 32 | freq 42 | pad 6 | head-aware 16] -> 32
 constexpr int kTlCan1 = kTlCan0 + 6;         // 2 x 1  32 -> 32
 constexpr int kTlFrags = kTlCan1 + 2;        // 28 fragments-of-64-lanes
-constexpr int kTlSkinnyWords = 2 * 2 * 16 + 2 * 4 * 8;   // def2 [2 halves][2 rows][32 values] + can2 [2][4][16], 16-bit pairs
+constexpr int kTlSkinnyVecs = 2 * 2 * 4 + 2 * 4 * 2;      // operand vectors of 8 values: def2 [2 halves][2 rows][4] + can2 [2][4][2]
+constexpr int kTlSkinnyDef = 0, kTlSkinnyCan = 2 * 2 * 4;
 
 struct TorsoLpArgs {
     const float *bg_coords, *density_grid, *cond_in, *code, *state /* [N,8] ray records of the head pass, march_device.h::kRayRec */, *nears, *fars, *bg_color;
@@ -40,15 +41,16 @@ struct TorsoLpArgs {
     const gfpp_grid_level *levels;
     const float *def_w0_c, *can_w0_c;                      // fp32 [64][const_dim], [32][const_dim]: folded in the prologue
     const float *ha_b0, *ha_b1, *ha_b2;                    // fp32 biases of the head-aware encoder
-    const uint4 *w16;                                      // kTlFrags * 64 fragments
-    const uint32_t *skinny16;                              // kTlSkinnyWords
+    const void *w16;                                       // kTlFrags * 64 fragments (operand vectors of 8 values: f16 / bf16 / f32)
+    const void *skinny16;                                  // kTlSkinnyVecs operand vectors
     float *out_image, *out_depth, *torso_alpha, *torso_bg, *deform;
     uint8_t *mask_out;
 };
 
+template <typename H>
 struct TorsoLpShared {
-    uint4 w[kTlFrags * 64];            // 28 672 B
-    uint32_t skinny[kTlSkinnyWords];   //    512 B
+    typename LpTraits<H>::vec w[kTlFrags * 64];            // 28 672 B (16-bit operands) / 57 344 B (exact fp32)
+    typename LpTraits<H>::vec skinny[kTlSkinnyVecs];       //    512 B / 1 024 B
     float consts[kTlMaxConst];
     float bdef[64], bcan[32], bha0[32], bha1[32], bha2[32];
     gfpp_grid_level lv[16];
@@ -113,7 +115,7 @@ __device__ __forceinline__ void tl_level2(const float (&u)[2], const float *__re
 template <typename H>
 __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     typedef typename LpTraits<H>::vec vec;
-    __shared__ TorsoLpShared sh;
+    __shared__ TorsoLpShared<H> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
 
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
     if (block_has_work) {
         // ---- prologue: weights -> LDS, per-frame constant columns folded into biases (same arithmetic as frame_torso.hip) ----------
-        for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = a.w16[i];
-        for (int i = tid; i < kTlSkinnyWords; i += kTlThreads) sh.skinny[i] = a.skinny16[i];
+        for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = reinterpret_cast<const vec *>(a.w16)[i];
+        for (int i = tid; i < kTlSkinnyVecs; i += kTlThreads) sh.skinny[i] = reinterpret_cast<const vec *>(a.skinny16)[i];
         if (tid < 16 * 8) reinterpret_cast<uint32_t *>(&sh.lv[0])[tid] = reinterpret_cast<const uint32_t *>(a.levels)[tid];
         if (tid < 32) {
             sh.bha0[tid] = (a.head_aware && tid < 16) ? a.ha_b0[tid] : 0.0f;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const vec *W = reinterpret_cast<const vec *>(sh.w);
+        const vec *W = sh.w;
 
         for (uint32_t first = 0; first < n_m; first += 32) {
             const uint32_t c = first + (uint32_t)j;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
                     for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
                 mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef1 * 64, bh, lane);
                 act_pack<H, 2, 1>(acc2, bh);
-                skinny_dot<2, 4, H>(sh.skinny, 2, bh, hi, dxy);
+                skinny_dot<2, 4, H>(sh.skinny + kTlSkinnyDef, 2, bh, hi, dxy);
             }
 
             // 2-D tiled grid at the displaced, clamped coordinate; half-wave h encodes the levels h, h+2, ...
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
                 for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
                 mfma_layer_lds<H, 2, 1>(acc1, W + kTlCan1 * 64, bh, lane);
                 act_pack<H, 1, 1>(acc1, bh);
-                skinny_dot<4, 2, H>(sh.skinny + 2 * 2 * 16, 4, bh, hi, o4);
+                skinny_dot<4, 2, H>(sh.skinny + kTlSkinnyCan, 4, bh, hi, o4);
             }
             if (valid && hi == 0) {
                 float *r = &sh.res[wave][0][0];
@@ -322,8 +324,8 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
         set_error("gfpp_torso_frame_lp: null argument");
         return GFPP_EINVAL;
     }
-    if (!m->lp_weights || !m->lp_skinny || (m->lp_dtype != GFPP_F16 && m->lp_dtype != GFPP_BF16)) {
-        set_error("gfpp_torso_frame_lp: the model carries no 16-bit weight image (lp_weights / lp_skinny / lp_dtype)");
+    if (!m->lp_weights || !m->lp_skinny || (m->lp_dtype != GFPP_F16 && m->lp_dtype != GFPP_BF16 && m->lp_dtype != GFPP_F32)) {
+        set_error("gfpp_torso_frame_lp: the model carries no MFMA weight image (lp_weights / lp_skinny / lp_dtype)");
         return GFPP_EINVAL;
     }
     if (m->grid.D != 2 || m->grid.L != 16 || m->grid.dtype != GFPP_F32 || m->grid.gridtype != 1 || m->grid.interp != 0 || m->grid.align_corners ||
@@ -347,10 +349,11 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     a.table = (const float *)m->grid.table; a.levels = m->grid.levels;
     a.def_w0_c = m->def_w0_c; a.can_w0_c = m->can_w0_c;
     a.ha_b0 = m->ha_b0; a.ha_b1 = m->ha_b1; a.ha_b2 = m->ha_b2;
-    a.w16 = (const uint4 *)m->lp_weights; a.skinny16 = (const uint32_t *)m->lp_skinny;
+    a.w16 = m->lp_weights; a.skinny16 = m->lp_skinny;
     a.out_image = out_image; a.out_depth = out_depth; a.torso_alpha = torso_alpha; a.torso_bg = torso_bg; a.deform = deform; a.mask_out = mask;
     const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
+    else if (m->lp_dtype == GFPP_F32) hipLaunchKernelGGL(k_torso_lp<float>, grid, block, 0, (hipStream_t)stream, a);   // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
     else hipLaunchKernelGGL(k_torso_lp<_Float16>, grid, block, 0, (hipStream_t)stream, a);
     return check_launch("gfpp_torso_frame_lp");
 }

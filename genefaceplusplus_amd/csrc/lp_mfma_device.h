@@ -44,6 +44,23 @@ struct LpTraits<__bf16> {
     }
 };
 
+// Exact-fp32 variant of the same fragment layout (the torso's fp32 mode): a "16-wide" step is eight v_mfma_f32_32x32x2_f32 -- an fp32 fma chain,
+// no rounding of operands -- instruction e taking element e of both fragments (its K pair is (h = 0, h = 1) of that element).
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <>
+struct LpTraits<float> {
+    typedef f32x8 vec;
+    static constexpr bool kPackedMax = false;
+    typedef float pair __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ v16f mfma(vec a, vec b, v16f c) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return fmaf(a[1], b[1], fmaf(a[0], b[0], c)); }
+    static __device__ __forceinline__ vec relu(vec t) { return __builtin_elementwise_max(t, (vec)0.0f); }
+};
+
 // acc[t] += W[32 t.., 16 s..] * b[s] for NS steps; A operands come from the LDS-resident weight image, kAhead steps ahead of
 // their use (the reads of all wavefronts of the workgroup queue up in the LDS; one step = T MFMAs does not cover the latency).
 // The sched_barriers pin the order: read-ahead first, then this step's MFMAs.
@@ -115,20 +132,20 @@ __device__ __forceinline__ float half_wave_sum(float t) {
 // hi * rows_per_half + c.  (Operand pairs are taken with shufflevector: bit-casting vector ELEMENTS to pairs is miscompiled by
 // ROCm 7.2's clang -- every element collapses to element 0.)
 template <int C, int NV, typename H>
-__device__ __forceinline__ void skinny_dot(const uint32_t *__restrict__ wrow, int rows_per_half, const typename LpTraits<H>::vec (&b)[NV], int hi,
+__device__ __forceinline__ void skinny_dot(const void *__restrict__ wrow, int rows_per_half, const typename LpTraits<H>::vec (&b)[NV], int hi,
                                            float (&out)[C]) {
     typedef typename LpTraits<H>::vec vec;
     // The weights of a row are NV 16-byte LDS reads (two distinct addresses per wavefront).  All reads of a row are issued together and the
     // next row's are in flight while this row's dot products run (the sched_barriers pin that order: left alone, the compiler issues
     // read - wait - 4 dot2 - read - wait ..., i.e. NV x C exposed LDS round trips per block).
     vec w[2][NV];
-    const vec *p0 = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half) * 4 * NV);
+    const vec *p0 = reinterpret_cast<const vec *>(wrow) + (hi * rows_per_half) * NV;   // (a row = NV operand vectors: 4 NV words of 16-bit pairs)
 #pragma unroll
     for (int s = 0; s < NV; ++s) w[0][s] = p0[s];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         if (c + 1 < C) {
-            const vec *p = reinterpret_cast<const vec *>(wrow + (hi * rows_per_half + c + 1) * 4 * NV);
+            const vec *p = reinterpret_cast<const vec *>(wrow) + (hi * rows_per_half + c + 1) * NV;
 #pragma unroll
             for (int s = 0; s < NV; ++s) w[(c + 1) & 1][s] = p[s];
         }

@@ -207,14 +207,26 @@ GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *
     return check_launch("gfpp_clip_store_u8");
 }
 
-GFPP_API int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count) {
-    GFPP_REQUIRE_EARLY(execs && streams && lanes > 0 && lanes <= 8, "gfpp_graph_replay");
-    for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t lane = (first_lane + k) % lanes;
+GFPP_API int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count, uint32_t max_ahead) {
+    GFPP_REQUIRE_EARLY(execs && streams && lanes > 0 && lanes <= 8 && max_ahead <= 16, "gfpp_graph_replay");
+    // max_ahead > 0: at most that many frames of a lane are queued ahead of the GPU (the issuing thread waits on the lane's frame max_ahead back)
+    hipEvent_t ev[8][16];
+    if (max_ahead)
+        for (uint32_t l = 0; l < lanes; ++l)
+            for (uint32_t d = 0; d < max_ahead; ++d)
+                if (hipEventCreateWithFlags(&ev[l][d], hipEventDisableTiming) != hipSuccess) { set_error("gfpp_graph_replay: cannot create events"); return GFPP_EINVAL; }
+    int rc = 0;
+    for (uint32_t k = 0; k < count && rc == 0; ++k) {
+        const uint32_t lane = (first_lane + k) % lanes, turn = k / lanes;
+        if (max_ahead && turn >= max_ahead) (void)hipEventSynchronize(ev[lane][turn % max_ahead]);
         const hipError_t err = hipGraphLaunch((hipGraphExec_t)execs[lane], (hipStream_t)streams[lane]);
-        if (err != hipSuccess) { set_error("gfpp_graph_replay: hipGraphLaunch failed at frame %u (%s)", k, hipGetErrorString(err)); return (int)err; }
+        if (err != hipSuccess) { set_error("gfpp_graph_replay: hipGraphLaunch failed at frame %u (%s)", k, hipGetErrorString(err)); rc = (int)err; break; }
+        if (max_ahead) (void)hipEventRecord(ev[lane][turn % max_ahead], (hipStream_t)streams[lane]);
     }
-    return 0;
+    if (max_ahead)
+        for (uint32_t l = 0; l < lanes; ++l)
+            for (uint32_t d = 0; d < max_ahead; ++d) (void)hipEventDestroy(ev[l][d]);
+    return rc;
 }
 
 GFPP_API int gfpp_abi_version(void) { return GFPP_ABI_VERSION; }

@@ -31,6 +31,33 @@ constexpr int kSrThreads = 256;
 constexpr int kSrPatch = 16;            // output patch side
 constexpr int kSrHalo = kSrPatch + 2;   // 3x3 convolution
 
+// ---- noise_mode 'random' inside the kernels: counter-based Philox4x32-10 (Salmon et al., the generator family torch.randn uses on the GPU) -------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+struct SrRng {
+    const unsigned long long *state;   // [0] = frame counter (null: no in-kernel noise)
+    unsigned long long seed;
+    uint32_t layer;
+};
+
+// one unit normal per (pixel, layer, frame): Box-Muller on two of the four Philox words
+__device__ __forceinline__ float sr_randn(const SrRng &g, unsigned long long frame, uint32_t pixel) {
+    const uint4 r = philox4x32_10(make_uint4(pixel, g.layer, (uint32_t)frame, (uint32_t)(frame >> 32)), make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+    const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float u2 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
+}
+
 enum SrEpilogue { kSrPlain = 0, kSrRgbAdd = 1, kSrUpPhases = 2, kSrFinal = 3 };
 
 struct SrConvArgs {
@@ -48,6 +75,9 @@ struct SrConvArgs {
     const float *img_in;      // kSrRgbAdd: [H][W][3] fp32 (the NeRF image);  kSrFinal: [H/2][W/2][3] fp32 (img256)
     float *img_out;           // kSrRgbAdd: [H][W][3];  kSrFinal: [H][W][3] fp32 (the 512^2 result)
     float fir[4];             // kSrFinal: 1-D taps of the separable resample filter x up (= [1,3,3,1]/8 * 2)
+    SrRng rng;                // noise == null and rng.state != null: unit normals drawn here
+    unsigned long long *rng_tick;   // kSrFinal: the last launch of a frame advances the frame counter ([0] counter, [1] ticket)
+    uint32_t clamp01;         // kSrFinal: clamp the image to [0, 1]
 };
 
 __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
@@ -177,6 +207,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     // the channel: both are fetched BEFORE the 2 x NT x 4 store loop (noise: at most 4 loads per lane; bias: LDS).  Inside the loop a
     // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
     constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
+    const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
     float nzv[2][NPH];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -188,7 +219,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
                 const int phase = ((int)pass * NT * 32 + 64 * ph) >> 6;
                 at = (size_t)(2 * Y + (phase >> 1)) * (2 * a.W) + 2 * X + (phase & 1);
             }
-            nzv[u][ph] = a.noise ? a.noise[at] * a.noise_strength : 0.0f;
+            nzv[u][ph] = a.noise ? a.noise[at] * a.noise_strength : (a.rng.state ? sr_randn(a.rng, frame_ctr, (uint32_t)at) * a.noise_strength : 0.0f);
         }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -268,7 +299,23 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float t = fminf(fmaxf(rgb[k] + s_rgb[NT * 32 * 3 + k], -a.clamp), a.clamp);
-                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = base[k] + t;
+                    float o = base[k] + t;
+                    if (EPI == kSrFinal && a.clamp01) o = fminf(fmaxf(o, 0.0f), 1.0f);
+                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = o;
+                }
+            }
+        }
+    }
+    if constexpr (EPI == kSrFinal) {
+        // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
+        if (a.rng_tick) {
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+                if (atomicAdd(&a.rng_tick[1], 1ull) == total - 1ull) {
+                    a.rng_tick[1] = 0ull;
+                    __threadfence();
+                    atomicAdd(&a.rng_tick[0], 1ull);
                 }
             }
         }
@@ -285,6 +332,7 @@ struct SrFirstArgs {
     float act_gain, clamp;
     _Float16 *y;           // [H][W][128]
     uint32_t H, W;
+    SrRng rng;
 };
 
 __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
@@ -356,7 +404,8 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int Y = y0 + prow + 2 * u, X = x0 + pcol;
-        const float nz = a.noise ? a.noise[(size_t)Y * a.W + X] * a.noise_strength : 0.0f;
+        const float nz = a.noise ? a.noise[(size_t)Y * a.W + X] * a.noise_strength
+                                 : (a.rng.state ? sr_randn(a.rng, a.rng.state[0], (uint32_t)(Y * a.W + X)) * a.noise_strength : 0.0f);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -385,8 +434,10 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t R = 256;
     const float gain = 1.4142135623730951f, clamp = m->conv_clamp;
+    const bool draw = !noise && ws->rng_state;                      // noise_mode 'random' inside the kernels
+    auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
     {
-        SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R};
+        SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
         hipLaunchKernelGGL(k_sr_first, dim3(R / kSrPatch, R / kSrPatch), dim3(kSrThreads), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv0)");
         if (rc) return rc;
@@ -396,6 +447,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x0; a.w = (const uint4 *)m->w_b0c1; a.noise = noise ? noise[1] : nullptr; a.noise_strength = m->noise_strength[1];
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
+        a.rng = rng_of(1);
         hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
         if (rc) return rc;
@@ -404,6 +456,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         SrConvArgs a{};
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
+        a.rng = rng_of(2);
         hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(kSrThreads), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
@@ -414,6 +467,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[3]; a.act_gain = gain; a.clamp = clamp; a.y = nullptr; a.H = 2 * R; a.W = 2 * R;
         a.w_rgb = m->rgb1_w; a.b_rgb = m->rgb1_b; a.img_in = ws->img256; a.img_out = rgb_out;
         for (int k = 0; k < 4; ++k) a.fir[k] = m->fir[k];
+        a.rng = rng_of(3);
+        a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
+        a.clamp01 = ws->clamp01;
         hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;

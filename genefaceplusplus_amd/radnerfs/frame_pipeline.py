@@ -418,6 +418,14 @@ class FramePipeline:
         """'fp32' (exact-fp32 MFMA) | 'fp16' | 'bf16' (16-bit MFMA operands, fp32 accumulation; weights repacked on first use)."""
         if precision == "fp32":
             self.precision = "fp32"
+            if self.torso is not None and self.fp32_torso == "mfma":
+                # the torso MLPs on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 = an fp32 fma chain): the same fragment image as the 16-bit modes, in fp32
+                if "torso_fp32" not in self._lp_images:
+                    w, sk = torso_lp_images(model, torch.float32)
+                    self._lp_images["torso_fp32"] = (w.to(self.device), sk.to(self.device))
+                self.torso.lp_weights = self._lp_images["torso_fp32"][0].data_ptr()
+                self.torso.lp_skinny = self._lp_images["torso_fp32"][1].data_ptr()
+                self.torso.lp_dtype = 0                     # GFPP_F32
             return
         if precision not in LP_DTYPES:
             raise GfppError(f"precision must be 'fp32', 'fp16' or 'bf16', got {precision!r}")
@@ -606,6 +614,10 @@ class FramePipeline:
     #: kernel that marches inside the trip (gfpp_head_frame_march); same bits per sample
     fp32_kernel = "wave"
 
+    #: exact-fp32 mode, torso pass: 'mfma' = the MFMA kernel with fp32 fragments (gfpp_torso_frame_lp, lp_dtype GFPP_F32; round 3), 'valu' = one
+    #: thread per pixel on the vector ALU (gfpp_torso_frame, 170 us per 512^2 frame; the A/B partner)
+    fp32_torso = os.environ.get("GFPP_FP32_TORSO", "mfma")
+
     #: slab test + state reset + pre-march as one launch (gfpp_head_frame_begin_premarch); False = the two separate launches (tests compare them)
     fuse_begin = os.environ.get("GFPP_FUSE_BEGIN", "1") != "0"
 
@@ -789,7 +801,8 @@ class FramePipeline:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
                "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
-        call("gfpp_torso_frame" if self.precision == "fp32" else "gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws),
+        valu = self.precision == "fp32" and (self.fp32_torso != "mfma" or not self.torso.lp_weights or self.torso.lp_dtype != 0)
+        call("gfpp_torso_frame" if valu else "gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws),
              bg_coords.data_ptr(), cond_in.data_ptr(),
              code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
              out["depth"].data_ptr(), out["torso_alpha"].data_ptr(), out["torso_bg"].data_ptr(), out["deform_dense"].data_ptr(),
@@ -818,6 +831,18 @@ class FramePipeline:
             ws.sample_t, ws.sample_cnt, ws.sample_stride = None, None, 0
             t.pop("phase_cycles", None)
         return t.get("phase_cycles")
+
+    def check_barriers(self):
+        """Raise if a device-wide barrier of a multi-trip launch (the trip-launch path of the 16-bit modes) timed out in any frame rendered since the
+        last check: the kernel then poisons counters[127] (negative) instead of hanging the GPU, later barriers of that launch fall through and the
+        frame may lack trips -- it must not be delivered.  One 4-byte read per workspace; synchronises."""
+        bad = []
+        for (n, lane), (ws, t) in self._ws.items():
+            if int(t["counters"][127].item()) < 0:
+                bad.append((n, lane))
+        if bad:
+            raise GfppError(f"a device-wide barrier of the multi-trip launch timed out (workspaces (rays, lane) = {bad}): the frames rendered there are "
+                            f"incomplete.  Other work held compute units for too long; render with lp_kernel='persist' (no barrier) or separate_trips >= max_steps")
 
     def budget(self, N):
         """The persistent 16-bit launch's own record of the last frame: histogram of the rays' end points [32], evaluated samples, workgroup rounds

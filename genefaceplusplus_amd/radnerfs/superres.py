@@ -29,7 +29,7 @@ class SrModel(ctypes.Structure):
 
 
 class SrWs(ctypes.Structure):
-    _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p)]
+    _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p), ("rng_state", c_p), ("rng_seed", ctypes.c_uint64), ("clamp01", ctypes.c_uint32)]
 
 
 _lib.register("gfpp_sr_forward", [ctypes.POINTER(SrModel), ctypes.POINTER(SrWs), c_p, c_p, c_p, c_p])
@@ -243,8 +243,19 @@ class Superresolution(nn.Module):
             ws = SrWs()
             for k, v in bufs.items():
                 setattr(ws, k, v.data_ptr())
+            # noise_mode 'random' is drawn inside the kernels: frame counter + ticket word of this lane, key = torch's seed mixed with the lane
+            bufs["rng_state"] = torch.zeros(2, dtype=torch.int64, device=dev)
+            bufs["rng_seed"] = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(self.lane) + 1)) & 0xFFFFFFFFFFFFFFFF
             ent = P["ws"][self.lane] = (ws, bufs)
-        return ent[0]
+        return ent
+
+    def reseed(self, seed):
+        """Restart the in-kernel noise of every lane from `seed` (frame counter 0): the same seed gives the same frames."""
+        if self._packed is not None:
+            for lane, (ws, bufs) in self._packed["ws"].items():
+                bufs["rng_state"].zero_()
+                bufs["rng_seed"] = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(lane) + 1)) & 0xFFFFFFFFFFFFFFFF
+        self._reseed = int(seed)
 
     # -- training: the same network in autograd-visible torch ops (the convolutions go to MIOpen) ----------------------------------------
     def _forward_autograd(self, rgb, noise_mode):
@@ -273,9 +284,10 @@ class Superresolution(nn.Module):
         return up + self.block1.torgb.forward_autograd(x, c)
 
     # -- forward ------------------------------------------------------------------------------------------------------------------
-    def forward(self, rgb, noise_mode="random", **block_kwargs):
+    def forward(self, rgb, noise_mode="random", clamp01=False, **block_kwargs):
         """rgb [1,3,256,256] in [0,1] -> [1,3,512,512] fp32 (radnerf_sr.py:30-43).  noise_mode: 'random' (the reference's default: a fresh
-        unit normal field per layer, scaled by the learned noise_strength), 'const' (the stored noise_const buffers) or 'none'."""
+        unit normal field per layer, scaled by the learned noise_strength), 'const' (the stored noise_const buffers) or 'none'.
+        clamp01 (not a reference argument): clamp the result to [0, 1] inside the last kernel -- what the callers do next (radnerf_torso_sr.py:221,231)."""
         assert noise_mode in ("random", "const", "none")
         if rgb.dim() != 4 or rgb.shape[0] != 1 or rgb.shape[1] != 3:
             raise GfppError(f"Superresolution: expected rgb [1,3,H,W], got {tuple(rgb.shape)}")
@@ -287,22 +299,27 @@ class Superresolution(nn.Module):
         if rgb.shape[-1] != self.input_resolution or rgb.shape[-2] != self.input_resolution:
             raise GfppError("Superresolution: input must be 256x256 (or smaller, then it is interpolated up like in the reference)")
         if torch.is_grad_enabled() and (rgb.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            return self._forward_autograd(rgb.float(), noise_mode)
+            out = self._forward_autograd(rgb.float(), noise_mode)
+            return out.clamp(0, 1) if clamp01 else out
         P = self._pack()
         x = rgb.detach().float().permute(0, 2, 3, 1).contiguous()               # NHWC view of the NeRF image: no copy when it came from render()
         layers = (self.block0.conv0, self.block0.conv1, self.block1.conv0, self.block1.conv1)
         if noise_mode == "const":
             noises = [l.noise_const.detach().float().contiguous() for l in layers]
-        elif noise_mode == "random":
-            # one generator launch for the four layers' noise fields (655 k unit normals per frame) instead of four; like the reference's
-            # per-layer torch.randn calls the values are fresh per frame and per layer, their position in the generator stream is not the same
-            sizes = [l.resolution * l.resolution for l in layers]
-            flat = torch.randn(sum(sizes), device=x.device)
-            noises = [c.view(l.resolution, l.resolution) for c, l in zip(flat.split(sizes), layers)]
         else:
+            # 'random': the reference draws a fresh unit-normal field per layer and frame with torch.randn (networks_stylegan2.py:329-331); here the
+            # kernels draw it themselves (Philox4x32-10 keyed by torch's seed, counter = pixel / layer / frame) -- no generator launch, no 2.6 MB of
+            # noise written and read back, and nothing in a captured graph that torch would have to re-seed per replay
             noises = None
         arr = (c_p * 4)(*[n.data_ptr() for n in noises]) if noises is not None else None
+        ws, bufs = self._workspace(P)
+        if getattr(self, "_reseed", None) is not None and bufs.get("seeded") != self._reseed:
+            bufs["rng_state"].zero_()
+            bufs["rng_seed"] = (self._reseed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(self.lane) + 1)) & 0xFFFFFFFFFFFFFFFF
+            bufs["seeded"] = self._reseed
+        ws.rng_state = bufs["rng_state"].data_ptr() if noise_mode == "random" else None
+        ws.rng_seed = bufs["rng_seed"]
+        ws.clamp01 = 1 if clamp01 else 0
         out = torch.empty(512, 512, 3, dtype=torch.float32, device=x.device)
-        call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(self._workspace(P)), x.data_ptr(), arr, out.data_ptr(),
-             torch.cuda.current_stream().cuda_stream)
+        call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(ws), x.data_ptr(), arr, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return out.permute(2, 0, 1).unsqueeze(0)                                # [1,3,512,512] view

@@ -292,9 +292,9 @@ class RADNeRFTorsowithSR(_TorsoBase):
 
         def superresolve(o):
             if self.sr_net.ready:
-                o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
+                o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise, clamp01=True)
                 if upscale_torso:
-                    o["sr_torso_rgb"] = self.sr_net(o["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise).clamp(0, 1)
+                    o["sr_torso_rgb"] = self.sr_net(o["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise, clamp01=True)
 
         out = self._render_common(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, max_steps, T_thresh, lm68,
                                   eye_area_percent, True, post=superresolve, post_key=("sr", sr_noise, bool(upscale_torso)),
@@ -343,5 +343,5 @@ class RADNeRFwithSR(RADNeRF):
         res["rgb_map"] = rgb
         if self.sr_net.ready:
             # the reference always renders with the layers' default noise ('random', radnerf_sr.py:30-43); `sr_noise_mode` is our test hook
-            res["sr_rgb_map"] = self.sr_net(rgb.clone(), noise_mode=kwargs.get("sr_noise_mode", "random")).clamp(0, 1)
+            res["sr_rgb_map"] = self.sr_net(rgb.clone(), noise_mode=kwargs.get("sr_noise_mode", "random"), clamp01=True)
         return res

@@ -166,8 +166,9 @@ int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, u
 int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
 
 /* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
- * (first_lane + k) % lanes on that lane's stream.  execs: [lanes] hipGraphExec_t, streams: [lanes] hipStream_t (host arrays). */
-int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count);
+ * (first_lane + k) % lanes on that lane's stream.  execs: [lanes] hipGraphExec_t, streams: [lanes] hipStream_t (host arrays).
+ * max_ahead: 0 = queue everything at once; d > 0 = the issuing thread keeps at most d frames per lane queued ahead of the GPU. */
+int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count, uint32_t max_ahead);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section B -- fused frame pipeline (no native counterpart in the reference; replaces the Python loop of
@@ -584,10 +585,18 @@ typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
     void *x1;      /* [256][256][128] f16 */
     void *x2;      /* [512][512][64]  f16 */
     float *img256; /* [256][256][3]   f32 */
+    /* noise_mode 'random' generated inside the kernels (networks_stylegan2.py:329-331 draws a fresh unit-normal field per layer and frame with
+     * torch.randn): rng_state != NULL and noise == NULL -> every output pixel of every layer gets normal(Philox4x32-10(key = rng_seed,
+     * counter = (pixel, layer, frame))), Box-Muller; frame = rng_state[0], which the last launch of the call increments (rng_state[1] is its ticket
+     * word; both zero-initialised by the caller, one pair per stream that runs this workspace). */
+    uint64_t *rng_state; /* [2] u64, or NULL */
+    uint64_t rng_seed;
+    uint32_t clamp01;    /* 1: rgb_out = clamp(result, 0, 1) (the caller's `.clamp(0, 1)` of radnerf_torso_sr.py:221,231 folded in) */
 } gfpp_sr_ws;
 
-/* replaces Superresolution.forward (radnerf_sr.py:30-43).  rgb_in [256][256][3] f32 (NHWC, values in [0,1]) -> rgb_out [512][512][3] f32.  noise: NULL (noise_mode 'none') or 4 device pointers to
- * the per-layer noise fields [256^2], [256^2], [512^2], [512^2] f32 (noise_const, or fresh unit normals for noise_mode 'random'). */
+/* replaces Superresolution.forward (radnerf_sr.py:30-43).  rgb_in [256][256][3] f32 (NHWC, values in [0,1]) -> rgb_out [512][512][3] f32.  noise: 4 device pointers to
+ * the per-layer noise fields [256^2], [256^2], [512^2], [512^2] f32 (noise_const, or caller-drawn unit normals), or NULL: noise_mode 'none', or -- with
+ * ws->rng_state set -- noise_mode 'random' drawn inside the kernels. */
 int gfpp_sr_forward(const gfpp_sr_model *model, const gfpp_sr_ws *ws, const float *rgb_in, const float *const noise[4], float *rgb_out,
                     gfpp_stream_t stream);
 

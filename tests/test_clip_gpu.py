@@ -119,3 +119,30 @@ def test_late_trips_on_the_small_grid_render_the_same_frames(dev, precision):
         pipe.lane, pipe.frames_in_flight = lane, 2
         pipe.workspace(HW * HW)[0].full_grid_trips = 0
     pipe.lane, pipe.frames_in_flight = 0, 1
+
+
+def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
+    """The multi-trip launch of the trip-launch path poisons its barrier word instead of hanging when a workgroup waits too long; a frame rendered
+    that way may lack trips.  Force the timeout (spin bound 1) and see the clip renderer refuse the clip."""
+    from genefaceplusplus_amd._lib import GfppError
+    from genefaceplusplus_amd.clip import ClipRenderer
+    HW = 96
+    case = frame_case("may_torso", HW, sigma_gain=0.05)           # a thin field: the loop needs 7 trips, the multi-trip launch passes barriers
+    model = build_model(case, dev, "fused")
+    model.precision = "fp16"
+    pipe = model.pipeline()
+    pipe.lp_kernel, pipe.separate_trips = "trips", 1              # trips 1.. in ONE launch
+    batch = _clip_batch(case["hp"], 3)
+    cr = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], use_graph=False, render_kwargs=dict(case["hp"]),
+                      lanes=1)
+    clip = cr.prepare(batch, dev)
+    cr.render_to_host(clip)                                       # healthy: no error
+    monkeypatch.setenv("GFPP_BARRIER_SPINS", "1")
+    with pytest.raises(GfppError, match="barrier"):
+        cr.render_to_host(clip)
+    monkeypatch.delenv("GFPP_BARRIER_SPINS")
+    cr.render_to_host(clip)                                       # the next frame resets the word (gfpp_head_frame_begin_premarch)
+    pipe.lp_kernel, pipe.separate_trips = "persist", None
+    cr2 = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], use_graph=True, render_kwargs=dict(case["hp"]),
+                       lanes=2)
+    cr2.render_to_host(cr2.prepare(batch, dev))                   # the production path has no barrier to time out

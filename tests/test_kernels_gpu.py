@@ -327,3 +327,45 @@ def test_empty_inputs_are_no_ops(dev):
     assert SHEncoder(degree=4)(z3).shape == (0, 16)
     assert FreqEncoder(input_dim=2, degree=10)(torch.zeros(0, 2, device=dev)).shape == (0, 42)
     torch.cuda.synchronize()
+
+
+def test_superresolution_random_noise_is_drawn_in_the_kernels(dev):
+    """noise_mode 'random' (the reference's default: a fresh unit-normal field per layer and frame, networks_stylegan2.py:329-331) without a generator
+    launch: Philox4x32-10 inside the SR kernels, keyed by the seed, counted by (pixel, layer, frame).  What must hold: a frame differs from the next
+    and from the noise-free one; the perturbation is what `noise_strength * N(0, 1)` through the rest of the net gives with the oracle's own normals
+    (same first two moments); the same seed reproduces the same frames; clamp01 is the caller's clamp."""
+    from oracle import sr_oracle
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    net = Superresolution(channels=3)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    net = net.to(dev).eval()
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.random((1, 3, 256, 256)).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        net.reseed(1234)
+        a0 = net(x, noise_mode="random").cpu().numpy()
+        a1 = net(x, noise_mode="random").cpu().numpy()
+        none = net(x, noise_mode="none").cpu().numpy()
+        net.reseed(1234)
+        b0 = net(x, noise_mode="random").cpu().numpy()
+        b1 = net(x, noise_mode="random").cpu().numpy()
+        net.reseed(99)
+        c0 = net(x, noise_mode="random").cpu().numpy()
+        clamped = net(x, noise_mode="none", clamp01=True).cpu().numpy()
+    np.testing.assert_array_equal(a0, b0)
+    np.testing.assert_array_equal(a1, b1)
+    assert not np.array_equal(a0, a1) and not np.array_equal(a0, c0)
+    np.testing.assert_array_equal(clamped, np.clip(none, 0.0, 1.0))
+    # moments of the perturbation against the oracle run with numpy normals of the same law (4 independent fields)
+    ref_none = sr_oracle.superresolution(x.cpu().numpy(), sd, prefix="", noise_mode="none")
+    torch.manual_seed(3)
+    ref_rand = sr_oracle.superresolution(x.cpu().numpy(), sd, prefix="", noise_mode="random")
+    d_ref, d_got = (ref_rand - ref_none).reshape(-1), (a0 - none).reshape(-1)
+    print("perturbation std: oracle", float(d_ref.std()), "kernels", float(d_got.std()), "means", float(d_ref.mean()), float(d_got.mean()))
+    assert abs(d_got.std() / d_ref.std() - 1.0) <= 0.05
+    assert abs(d_got.mean() - d_ref.mean()) <= 0.05 * d_ref.std()
+    # the two frames' perturbations are uncorrelated
+    d1 = (a1 - none).reshape(-1)
+    assert abs(np.corrcoef(d_got, d1)[0, 1]) <= 0.02

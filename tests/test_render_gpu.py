@@ -181,6 +181,28 @@ def test_persistent_launch_equals_trip_launches(dev, oracle_mod, variant, HW, pr
     assert 0.7 * outs["trips"]["_samples"] <= outs["persist"]["_samples"] <= 1.5 * outs["trips"]["_samples"] + 64
 
 
+@pytest.mark.parametrize("variant,HW", [("may_torso", 128), ("may_torso_sr", 256), ("may_torso", 37)])
+def test_fp32_torso_on_mfma_matches_the_valu_kernel(dev, oracle_mod, variant, HW):
+    """Exact-fp32 mode, torso pass: k_torso_lp<float> (fp32 fragments through v_mfma_f32_32x32x2_f32, an fp32 fma chain) against the one-thread-per-pixel
+    kernel k_torso: the same fp32 arithmetic in another summation order -- 1e-5 apart, both within the fp32 bars of the oracle."""
+    outs = {}
+    case = frame_case(variant, HW)
+    ref = oracle_render(oracle_mod, case)
+    for kind in ("mfma", "valu"):
+        model = build_model(case, dev, "fused")
+        model.precision = "fp32"
+        model.use_graph = False
+        if hasattr(model, "sr_net"):
+            model.sr_net.ready = False
+        model.pipeline().fp32_torso = kind
+        res = product_render(model, case, dev, "oracle", oracle_mod)
+        compare_frames(res, ref, variant, HW)
+        outs[kind] = {k: v.detach().float().cpu().numpy().copy() for k, v in res.items() if torch.is_tensor(v)}
+    assert float(np.abs(outs["mfma"]["torso_alpha_map"]).max()) > 0.1   # the torso is in the picture
+    for k in ("rgb_map", "torso_alpha_map", "torso_rgb_map"):
+        assert float(np.abs(outs["mfma"][k] - outs["valu"][k]).max()) <= 2e-5, k
+
+
 def test_persistent_launch_under_graph_replay_and_step_caps(dev, oracle_mod, monkeypatch):
     """Graph replay of the one-launch frame == eager, and the frame does not depend on the local schedule."""
     case = frame_case("may_torso", 128)

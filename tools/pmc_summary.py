@@ -42,7 +42,7 @@ def main(dirs):
                 tot[names[k]][c] += v
         for n, cs in tot.items():
             print(n, {c: round(v, 1) for c, v in cs.items()})
-        trips = [k for k in last if "k_head_trip" in names[k]]
+        trips = [k for k in last if "k_head_trip" in names[k] or "k_head_frame_persist" in names[k]]
         for c in counters:
             print("  per trip", c, [round(disp[k].get(c, 0.0), 1) for k in trips[:8]])
 

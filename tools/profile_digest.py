@@ -47,17 +47,20 @@ def main(tag, precision, bench_args=None):
                    f"{int(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.1f} |")
     d = json.loads(bench_line)
     rf = d.get("roofline", {})
-    trip = [r for r in rows if "k_head_trip" in r["Name"]]
+    is_head = lambda n: "k_head_trip" in n or "k_head_frame_persist" in n
+    persist = any("k_head_frame_persist" in r["Name"] for r in rows)
+    trip = [r for r in rows if is_head(r["Name"])]
     if trip:
         calls = sum(int(r["Calls"]) for r in trip)
-        per_frame = 16 if precision == "fp32" else 6      # launches per frame of the roofline section (one frame at a time): fp32 = one per trip; 16-bit = 5 + 1 multi-trip
+        # launches per frame of the roofline section (one frame at a time): fp32 = one per trip; 16-bit = ONE persistent launch (round 3; 5 + 1 multi-trip before)
+        per_frame = 16 if precision == "fp32" else (1 if persist else 6)
         tot_ms = sum(int(r["TotalDurationNs"]) for r in trip) / 1e6
         out += ["", f"Trip launches in this trace: {calls} dispatches, {tot_ms:.3f} ms in total.  The timed loop keeps several frames in flight (one stream per lane), so a launch there "
                     "shares the GPU with the other frame's kernels and its duration is not a property of the kernel alone; the roofline is therefore quoted on the launches of "
                     "bench.py's roofline section, which renders one frame at a time after the timed loop:"]
         tpath = os.path.join(src, f"{tag}_stats", "bench_kernel_trace.csv")
         if os.path.exists(tpath):
-            tr = [r for r in csv.DictReader(open(tpath)) if "k_head_trip" in r["Kernel_Name"]]
+            tr = [r for r in csv.DictReader(open(tpath)) if is_head(r["Kernel_Name"])]
             tr.sort(key=lambda r: int(r["Start_Timestamp"]))
             last = tr[-5 * per_frame:]
             dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
@@ -83,7 +86,7 @@ def main(tag, precision, bench_args=None):
     head = [f"# rocprofv3 --pmc passes -- {tag}", "",
             f"Each counter group in its own run (`rocprofv3 --pmc <group> --kernel-trace -- python tools/profile_frame.py may_torso 512 3 {precision}`), summed per kernel over the",
             ("dispatches of the LAST rendered frame (16 trip launches, 6 of them non-empty);" if precision == "fp32" else
-             "dispatches of the LAST rendered frame (trip launches: one per trip for the first five trips, then one multi-trip launch for the rest);"),
+             "dispatches of the LAST rendered frame (head pass: ONE persistent launch per frame since round 3; before: one launch per trip for the first five trips + one multi-trip launch);"),
             "`per trip` lists those launches in order.",
             "Units as rocprofv3 reports them: FETCH_SIZE / WRITE_SIZE in KiB of fabric-side (L2 <-> Infinity Cache / HBM) traffic -- on gfx950 a wide coalesced read",
             "is under-reported by 2x and other access shapes are uncalibrated (MI355X_MICROARCH.md, HBM section), so read them as lower bounds and compare runs, not absolutes;",
@@ -92,7 +95,7 @@ def main(tag, precision, bench_args=None):
     open(os.path.join(dst, f"{tag}_pmc.md"), "w").write("\n".join(head + lines + ["```"]) + "\n")
 
     def grab(counter):
-        m = re.search(r"k_head_trip\S* \{[^}]*'" + counter + r"': ([0-9.]+)", pmc)
+        m = re.search(r"(?:k_head_trip|k_head_frame_persist)\S* \{[^}]*'" + counter + r"': ([0-9.]+)", pmc)
         return float(m.group(1)) if m else None
     fetch, write = grab("FETCH_SIZE"), grab("WRITE_SIZE")
     hit, miss = grab("TCC_HIT_sum"), grab("TCC_MISS_sum")
@@ -106,6 +109,7 @@ def main(tag, precision, bench_args=None):
     traffic = {"source": f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, summed over the trip launches of one frame)",
                "bytes_per_launch": int((fetch_b + write_b) / nonempty) if fetch_b and write_b else None,
                "nonempty_launches_per_frame": nonempty,
+               "bytes_per_frame": int(fetch_b + write_b) if fetch_b and write_b else None,
                "fetch_MB_per_frame": round(fetch_b / 1e6, 1) if fetch_b else None, "write_MB_per_frame": round(write_b / 1e6, 1) if write_b else None,
                "fetch_MB_per_frame_uncorrected": round(fetch * 1024 / 1e6, 1) if fetch else None,
                "l2_hit_rate": round(hit / (hit + miss), 4) if hit and miss else None,
