@@ -142,6 +142,7 @@ struct LpTripArgs {
     float *snaps;                       // [N, 7, 5] ray state after max_steps .. max_steps + 6 composited samples
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
+    uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 8 128 cycles late
     uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
@@ -985,7 +986,11 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         __syncthreads();
         lap(1);
 
-        // phase 2: the pooled 32-sample blocks, dealt out round-robin
+        // phase 2: the pooled 32-sample blocks, dealt out round-robin.  The two wavefronts of a SIMD (w and w + 4) leave the barrier together and would
+        // walk the block's phases in step -- both gathering, then both on the matrix pipe; the second one starts a fraction of a block later so that
+        // one's gathers run under the other's MFMA layers (it never has more blocks than the first, so the round does not get longer)
+        if (wave >= 4)
+            for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
         for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
             evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
         __syncthreads();
@@ -1431,6 +1436,8 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
         if (a.n_tiles % m != 0u && (unsigned long long)a.n_tiles * m < (1ull << 32)) { a.tile_mult = m; break; }
     a.step_caps = persist_step_caps();
     a.spin_limit = 0;
+    a.stagger = 0;
+    if (const char *e = getenv("GFPP_PERSIST_STAGGER")) { const int v = atoi(e); if (v > 0 && v < 64) a.stagger = (uint32_t)v; }
     uint32_t grid = (uint32_t)lp_cu_count();
     if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
     if (grid > a.n_tiles) grid = a.n_tiles;

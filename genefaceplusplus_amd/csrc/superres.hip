@@ -15,6 +15,8 @@
 // that the 16 pixels of a row hit distinct banks); each wavefront owns 4 rows = 64 pixels = two 32-column MFMA tiles x NT row tiles
 // of output channels.  The weights of one tap (CIN/16 steps x NT fragments, pre-packed in fragment order) are double-buffered
 // through LDS: the next tap's fragments are in flight (global -> registers) while the current tap's MFMAs run.
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "gfpp_common.h"
@@ -87,17 +89,21 @@ __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
 
 // One tap's weight fragments (PER_THREAD x 256 x 16 B, already in [step][tile][lane] order) from global memory straight into LDS: the LDS address
 // of a direct load is wave-uniform base + lane x 16, which is exactly the fragment layout.
-template <int PER_THREAD>
+template <int PER_THREAD, int THREADS>
 __device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint4 *dst, int tid, int lane) {
 #pragma unroll
     for (int q = 0; q < PER_THREAD; ++q) {
-        const int i = q * kSrThreads + tid;
+        const int i = q * THREADS + tid;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i), (__attribute__((address_space(3))) void *)(dst + (i - lane)), 16, 0, 0);
     }
 }
 
-template <int CIN, int NT, int EPI>
-__global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
+// NU = 32-column MFMA tiles per wavefront: 2 (round 1-2) = 4 wavefronts of 64 pixels, one per SIMD; 1 = 8 wavefronts of 32 pixels, two per SIMD --
+// a weight fragment then feeds one MFMA instead of two (1.25 KB of LDS operands per MFMA instead of 0.75: still below the LDS's 128 B/clk), but the
+// second wavefront of a SIMD runs under the first one's LDS latency, tap barriers and epilogue stores.
+template <int CIN, int NT, int EPI, int NU>
+__global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
+    constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
     constexpr int PS = CIN + 8;                  // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
     constexpr int STEPS = CIN / 16;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
         constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CIN / 8);
         constexpr int HALO_ITERS = (HALO_CHUNKS + kSrThreads - 1) / kSrThreads;
         uint4 hv[HALO_ITERS];
-        sr_stage_tap<PER_THREAD>(wg, wbuf[0], tid, lane);
+        sr_stage_tap<PER_THREAD, kSrThreads>(wg, wbuf[0], tid, lane);
 #pragma unroll
         for (int q = 0; q < HALO_ITERS; ++q) {
             const int i = q * kSrThreads + tid;
@@ -155,37 +161,37 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     }
     __syncthreads();
 
-    v16f acc[2][NT];
+    v16f acc[NU][NT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.0f;
 
-    // this lane's two pixels (one per column tile): rows 4 wave + 2 u + (j >> 4), column j & 15 of the patch
-    const int prow = 4 * wave + (j >> 4), pcol = j & 15;
+    // this lane's NU pixels (one per column tile): rows 2 NU wave + 2 u + (j >> 4), column j & 15 of the patch
+    const int prow = 2 * NU * wave + (j >> 4), pcol = j & 15;
     int cur = 0;
     for (int tap = 0; tap < ((GFPP_SR_ABLATE & 1) ? 0 : 9); ++tap) {
         // the next tap's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
         // cost half of the tap loop), into the buffer the previous tap's MFMAs released at the last barrier; they land while this tap computes
-        if (tap + 1 < 9 && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD>(wg + (size_t)(tap + 1) * TAPFRAGS, wbuf[cur ^ 1], tid, lane);
+        if (tap + 1 < 9 && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(wg + (size_t)(tap + 1) * TAPFRAGS, wbuf[cur ^ 1], tid, lane);
         const int dy = tap / 3, dx = tap % 3;
         const _Float16 *b0 = &patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi];
         const _Float16 *b1 = b0 + 2 * kSrHalo * PS;
         const vec *wl = reinterpret_cast<const vec *>(wbuf[cur]) + lane;
         // operands of step s + 1 are read while the 2 NT MFMAs of step s run (one wavefront per SIMD here: nobody else hides the LDS latency);
         // the sched_barriers pin that order, as in lp_mfma_device.h::mfma_layer_lds
-        vec Bq[2][2], Aq[2][NT];
+        vec Bq[2][NU], Aq[2][NT];
         Bq[0][0] = *reinterpret_cast<const vec *>(b0);
-        Bq[0][1] = *reinterpret_cast<const vec *>(b1);
+        if constexpr (NU == 2) Bq[0][1] = *reinterpret_cast<const vec *>(b1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) Aq[0][t] = wl[t * 64];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             if (s + 1 < STEPS) {
                 Bq[(s + 1) & 1][0] = *reinterpret_cast<const vec *>(b0 + 16 * (s + 1));
-                Bq[(s + 1) & 1][1] = *reinterpret_cast<const vec *>(b1 + 16 * (s + 1));
+                if constexpr (NU == 2) Bq[(s + 1) & 1][1] = *reinterpret_cast<const vec *>(b1 + 16 * (s + 1));
 #pragma unroll
                 for (int t = 0; t < NT; ++t) Aq[(s + 1) & 1][t] = wl[((s + 1) * NT + t) * 64];
             }
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[0][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][0], acc[0][t]);
-                acc[1][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][1], acc[1][t]);
+                if constexpr (NU == 2) acc[1][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][1], acc[1][t]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -208,9 +214,9 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
     // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
     constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
     const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
-    float nzv[2][NPH];
+    float nzv[NU][NPH];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             const int Y = y0 + prow + 2 * u, X = x0 + pcol;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(kSrThreads, 1) void k_sr_conv3(SrConvArgs a) {
             nzv[u][ph] = a.noise ? a.noise[at] * a.noise_strength : (a.rng.state ? sr_randn(a.rng, frame_ctr, (uint32_t)at) * a.noise_strength : 0.0f);
         }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int Y = y0 + prow + 2 * u, X = x0 + pcol;          // position at the patch-grid (input) resolution
         float rgb[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -435,6 +441,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     const uint32_t R = 256;
     const float gain = 1.4142135623730951f, clamp = m->conv_clamp;
     const bool draw = !noise && ws->rng_state;                      // noise_mode 'random' inside the kernels
+    int nu = 1;                                                     // column tiles per wavefront of the 3x3 convolutions (GFPP_SR_TILES=2: the round-2 shape, A/B runs)
+    if (const char *e = getenv("GFPP_SR_TILES")) nu = atoi(e) == 2 ? 2 : 1;
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
     {
         SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
@@ -448,7 +456,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
         a.rng = rng_of(1);
-        hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
+        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
         if (rc) return rc;
     }
@@ -457,7 +466,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
-        hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(kSrThreads), 0, st, a);
+        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
     }
@@ -470,7 +480,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(kSrThreads), 0, st, a);
+        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;
     }
