@@ -32,7 +32,7 @@ class ClipJob(ctypes.Structure):
     """gfpp_clip_job (include/gfpp_radnerf.h): the device-resident record through which a frame's graph finds its inputs and its output slot."""
     _fields_ = [("packed", ctypes.c_void_p), ("order", ctypes.c_void_p), ("out", ctypes.c_void_p), ("frame_bytes", ctypes.c_uint64),
                 ("row_floats", ctypes.c_uint32), ("n", ctypes.c_uint32), ("lanes", ctypes.c_uint32), ("ring_frames", ctypes.c_uint32),
-                ("cursor", ctypes.c_uint32 * 8)]
+                ("cursor", ctypes.c_uint32 * 8), ("ticket", ctypes.c_uint32 * 8)]
 
 
 _lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
@@ -130,7 +130,17 @@ class ClipRenderer:
         kw = dict(self.render_kwargs)
         kw.update(index=0, staged=False, bg_color=self.bg_img, lm68=lm68, perturb=False, force_all_rays=False, T_thresh=self.T_thresh,
                   eye_area_percent=eye)
-        res = self.model.render(L["rays_o"], L["rays_d"], cond, self.bg_coords, pose6, **kw)
+        pipe = self.model.pipeline() if getattr(self.model, "executor", "fused") == "fused" else None
+        if pipe is not None and not self.with_sr:
+            pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane), False       # the torso kernel stores the uint8 frame itself when it can
+        try:
+            res = self.model.render(L["rays_o"], L["rays_d"], cond, self.bg_coords, pose6, **kw)
+        finally:
+            stored = pipe is not None and pipe.clip_job_consumed
+            if pipe is not None:
+                pipe.clip_job, pipe.clip_job_consumed = None, False
+        if stored:
+            return {}
         if self.with_sr:
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1)        # [1,3,h,w] view of NHWC memory
         else:

@@ -953,13 +953,21 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
                 const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
                 const uint32_t base = idx * n_step;
-                for (uint32_t s = 0; s < cnt; ++s) {
-                    // the same expressions as march_one_ray (raymarching.cu:873-882) evaluated at the stored t
-                    const float t0 = ts[s];
-                    pool.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
-                    pool.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
-                    pool.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
-                    pool.t0[base + s] = t0;
+                // all sample times of the take in ONE memory round trip: eight unconditional loads from clamped indices (used + 7 < sample_stride),
+                // issued together with the ray's origin / direction -- a loop of load-then-store iterations costs a round trip per sample
+                float tv[8];
+#pragma unroll
+                for (uint32_t s = 0; s < 8u; ++s) tv[s] = ts[s < cnt ? s : 0u];
+#pragma unroll
+                for (uint32_t s = 0; s < 8u; ++s) {
+                    if (s < cnt) {
+                        // the same expressions as march_one_ray (raymarching.cu:873-882) evaluated at the stored t
+                        const float t0 = tv[s];
+                        pool.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
+                        pool.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
+                        pool.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
+                        pool.t0[base + s] = t0;
+                    }
                 }
             }
             if (in_tile) pool.cnt[idx] = (uint8_t)(has_ray ? cnt : kNoRay);
@@ -1065,23 +1073,6 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         for (int k = 0; k < 4; ++k) atomicAdd(&a.budget[kBudgetCycles + k], (int)(cyc[k] >> 10));
         atomicMax(&a.budget[kBudgetCycles + 4], (int)((cyc[0] + cyc[1] + cyc[2] + cyc[3]) >> 10));
     }
-}
-
-// renderer.py:359-364,384 replayed on the histogram: alive rays at the start of every trip and the step budget.  Every thread that calls this
-// computes the same numbers from <= max_steps + 8 cached loads.
-__device__ __forceinline__ uint32_t budget_from_hist(const int32_t *__restrict__ hist, uint32_t N_global, uint32_t max_steps, int32_t *counters_out) {
-    uint32_t S = 0, gone = 0, alive = N_global, trip = 0;
-    while (S < max_steps && alive > 0u) {
-        if (counters_out) counters_out[trip] = (int32_t)alive;
-        uint32_t n = N_global / alive;
-        n = n < 1u ? 1u : (n > 8u ? 8u : n);
-        for (uint32_t j = S; j < S + n; ++j) gone += (uint32_t)hist[j];     // rays whose m lies inside this window are dead after it
-        S += n;
-        alive = N_global - gone;
-        ++trip;
-    }
-    if (counters_out) counters_out[trip] = (int32_t)alive;   // what the last trip appended for a next one (0 when the loop ended for lack of rays)
-    return S;
 }
 
 __global__ __launch_bounds__(256) void k_head_budget_resolve(float *__restrict__ state, const float *__restrict__ snaps, const int32_t *__restrict__ hist,
@@ -1447,7 +1438,7 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
              : (bf ? (slow ? launch_persist<2, __bf16, true> : launch_persist<2, __bf16, false>) : (slow ? launch_persist<2, _Float16, true> : launch_persist<2, _Float16, false>));
     launch(grid, (hipStream_t)stream, a);
     const int rc = check_launch("gfpp_head_frame_persist_lp");
-    if (rc || ws->gcounters) return rc;          // a ray tile of a shared frame: the caller sums the histograms of all tiles first
+    if (rc || ws->gcounters || ws->defer_resolve) return rc;   // a ray tile of a shared frame: the caller sums the histograms of all tiles first; defer_resolve: the consumer kernel resolves
     return gfpp_head_frame_resolve(ws, max_steps, stream);
 }
 

@@ -14,6 +14,7 @@
 
 #include "grid_device.h"
 #include "lp_mfma_device.h"
+#include "march_device.h"
 #include "sh_device.h"
 
 namespace gfpp {
@@ -45,6 +46,9 @@ struct TorsoLpArgs {
     const void *skinny16;                                  // kTlSkinnyVecs operand vectors
     float *out_image, *out_depth, *torso_alpha, *torso_bg, *deform;
     uint8_t *mask_out;
+    BudgetView bv;            // hist != null: the head pass was the persistent launch with the resolve deferred to this kernel
+    gfpp_clip_job *job;       // != null: also store the frame as uint8 into the clip job's slot of lane `lane` and advance its cursor
+    uint32_t lane;
 };
 
 template <typename H>
@@ -122,15 +126,20 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     // ---- this thread's pixel: occupancy test first (most workgroups of a frame have no torso pixel and skip the weights) ----------
     const uint32_t n = blockIdx.x * kTlThreads + tid;
     const bool in_frame = n < a.N;
-    float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f;
+    float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f, hdepth = 0.0f;
     bool masked = false;
+    // the step budget of the head pass (renderer.py:359-364,384 replayed on the histogram) when its resolve step was left to this kernel
+    __shared__ uint32_t s_budget;
+    if (tid == 0) s_budget = a.bv.hist ? budget_from_hist(a.bv.hist, a.bv.N_global, a.bv.max_steps, nullptr) : 0u;
     if (in_frame) {
         cx = a.bg_coords[2ull * n]; cy = a.bg_coords[2ull * n + 1];
         masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
-        hr = a.state[8ull * n + 2]; hg = a.state[8ull * n + 3]; hb = a.state[8ull * n + 4];
-        wsum = a.state[8ull * n];
     }
     const bool block_has_work = __syncthreads_or(masked ? 1 : 0) != 0;
+    if (in_frame) {
+        const RayAccum head = ray_state_final(a.state, a.bv, s_budget, n);
+        hr = head.r; hg = head.g; hb = head.b; wsum = head.wsum; hdepth = head.depth;
+    }
 
     float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
     if (block_has_work) {
@@ -294,23 +303,55 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
             alpha = r[lane]; tr = r[64 + lane]; tg = r[128 + lane]; tb = r[192 + lane]; ddx = r[256 + lane]; ddy = r[320 + lane];
         }
     }
-    if (!in_frame) return;
-
-    // ---- torso over background, head over torso (radnerf_torso.py:186-197) ---------------------------------------------------------
-    const float T = 1.0f - wsum;
-    const float tcol[3] = {tr, tg, tb}, hcol[3] = {hr, hg, hb};
+    uint32_t packed = 0;                // this pixel's uint8 r | g << 8 | b << 16 (clip job only)
+    if (in_frame) {
+        // ---- torso over background, head over torso (radnerf_torso.py:186-197) -----------------------------------------------------
+        const float T = 1.0f - wsum;
+        const float tcol[3] = {tr, tg, tb}, hcol[3] = {hr, hg, hb};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float bg = a.bg_color ? a.bg_color[3ull * n + c] : a.bg_scalar;
-        const float tbg = tcol[c] * alpha + bg * (1.0f - alpha);
-        a.torso_bg[3ull * n + c] = tbg;
-        a.out_image[3ull * n + c] = clampf(hcol[c] + T * tbg, 0.0f, 1.0f);
+        for (int c = 0; c < 3; ++c) {
+            const float bg = a.bg_color ? a.bg_color[3ull * n + c] : a.bg_scalar;
+            const float tbg = tcol[c] * alpha + bg * (1.0f - alpha);
+            const float v = clampf(hcol[c] + T * tbg, 0.0f, 1.0f);
+            a.torso_bg[3ull * n + c] = tbg;
+            a.out_image[3ull * n + c] = v;
+            packed |= (uint32_t)(uint8_t)clampf(v * 255.0f, 0.0f, 255.0f) << (8 * c);   // gfpp_rgb_to_u8's conversion (genefacepp_infer.py:468)
+        }
+        a.torso_alpha[n] = alpha;
+        a.deform[2ull * n] = ddx;
+        a.deform[2ull * n + 1] = ddy;
+        a.mask_out[n] = masked ? 1 : 0;
+        a.out_depth[n] = fmaxf(hdepth - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
     }
-    a.torso_alpha[n] = alpha;
-    a.deform[2ull * n] = ddx;
-    a.deform[2ull * n + 1] = ddy;
-    a.mask_out[n] = masked ? 1 : 0;
-    a.out_depth[n] = fmaxf(a.state[8ull * n + 1] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+    if (a.job) {
+        // the uint8 frame, fused: four consecutive pixels hold 12 bytes = three dwords, assembled inside the lane quad and written as dwords (a wavefront
+        // writes 192 contiguous bytes with ONE store instruction; per-pixel byte stores took 45 us per 512^2 frame, the whole torso pass takes 30)
+        const int q0 = lane & ~3, ql = lane & 3;
+        const uint32_t w0 = (uint32_t)__shfl((int)packed, q0), w1 = (uint32_t)__shfl((int)packed, q0 + 1);
+        const uint32_t w2 = (uint32_t)__shfl((int)packed, q0 + 2), w3 = (uint32_t)__shfl((int)packed, q0 + 3);
+        const uint32_t pos = a.job->cursor[a.lane];
+        if (in_frame && pos < a.job->n) {
+            uint8_t *frame = a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes;
+            const uint32_t nq = n & ~3u;
+            if (nq + 3u < a.N && (a.job->frame_bytes & 3ull) == 0ull) {     // (odd frame sizes: byte stores keep every access aligned)
+                const uint32_t d = ql == 0 ? (w0 | (w1 << 24)) : (ql == 1 ? ((w1 >> 8) | (w2 << 16)) : ((w2 >> 16) | (w3 << 8)));
+                if (ql < 3) *reinterpret_cast<uint32_t *>(frame + 3ull * nq + 4u * (uint32_t)ql) = d;
+            } else {
+                frame[3ull * n] = (uint8_t)packed; frame[3ull * n + 1] = (uint8_t)(packed >> 8); frame[3ull * n + 2] = (uint8_t)(packed >> 16);
+            }
+        }
+    }
+    if (a.job) {
+        // the lane's cursor moves on when every workgroup has read it: the last one to get here advances it (as k_clip_store_u8 does)
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t pos = a.job->cursor[a.lane];
+            if (atomicAdd(&a.job->ticket[a.lane], 1u) == gridDim.x - 1u) {
+                a.job->ticket[a.lane] = 0u;
+                a.job->cursor[a.lane] = pos + a.job->lanes;
+            }
+        }
+    }
 }
 
 }  // namespace gfpp
@@ -351,6 +392,13 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     a.ha_b0 = m->ha_b0; a.ha_b1 = m->ha_b1; a.ha_b2 = m->ha_b2;
     a.w16 = m->lp_weights; a.skinny16 = m->lp_skinny;
     a.out_image = out_image; a.out_depth = out_depth; a.torso_alpha = torso_alpha; a.torso_bg = torso_bg; a.deform = deform; a.mask_out = mask;
+    a.bv = BudgetView{nullptr, nullptr, 0u, 0u};
+    if (ws->defer_resolve) {
+        if (!ws->snapshots || !ws->counters || ws->resolve_max_steps == 0 || ws->resolve_max_steps > 24u) { set_error("gfpp_torso_frame_lp: defer_resolve needs snapshots, counters and resolve_max_steps"); return GFPP_EINVAL; }
+        a.bv = BudgetView{ws->gcounters ? ws->gcounters : ws->counters + 128, ws->snapshots, ws->gcounters ? ws->N_global : ws->N, ws->resolve_max_steps};
+    }
+    a.job = ws->clip_job; a.lane = ws->clip_lane;
+    if (a.job && a.lane >= 8) { set_error("gfpp_torso_frame_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
     const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
     else if (m->lp_dtype == GFPP_F32) hipLaunchKernelGGL(k_torso_lp<float>, grid, block, 0, (hipStream_t)stream, a);   // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)

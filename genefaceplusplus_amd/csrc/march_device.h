@@ -163,4 +163,45 @@ __device__ __forceinline__ bool composite_sample(RayAccum &a, float sigma, float
     return T < T_thresh;
 }
 
+
+// renderer.py:359-364,384 replayed on the histogram: alive rays at the start of every trip and the step budget.  Every thread that calls this
+// computes the same numbers from <= max_steps + 8 cached loads.
+__device__ __forceinline__ uint32_t budget_from_hist(const int32_t *__restrict__ hist, uint32_t N_global, uint32_t max_steps, int32_t *counters_out) {
+    uint32_t S = 0, gone = 0, alive = N_global, trip = 0;
+    while (S < max_steps && alive > 0u) {
+        if (counters_out) counters_out[trip] = (int32_t)alive;
+        uint32_t n = N_global / alive;
+        n = n < 1u ? 1u : (n > 8u ? 8u : n);
+        for (uint32_t j = S; j < S + n; ++j) gone += (uint32_t)hist[j];     // rays whose m lies inside this window are dead after it
+        S += n;
+        alive = N_global - gone;
+        ++trip;
+    }
+    if (counters_out) counters_out[trip] = (int32_t)alive;   // what the last trip appended for a next one (0 when the loop ended for lack of rays)
+    return S;
+}
+
+
+// What a consumer of the ray records needs to finish the persistent launch's job on the fly (gfpp_frame_ws.defer_resolve): the budget histogram and
+// the snapshots.  hist == nullptr: the records are final already.
+struct BudgetView {
+    const int32_t *hist;     // [32] rays by end point (frame-wide)
+    const float *snaps;      // [N, 7, 5]
+    uint32_t N_global, max_steps;
+};
+
+// The final {weights_sum, depth, r, g, b} of ray n: its record, or -- if it composited more samples than the step budget B allows -- the snapshot
+// after B samples (k_head_budget_resolve does the same in place).
+__device__ __forceinline__ RayAccum ray_state_final(const float *__restrict__ state, const BudgetView &bv, uint32_t B, uint32_t n) {
+    RayAccum acc = ray_state_load(state, n);
+    if (bv.hist) {
+        const uint32_t done = __float_as_uint(state[(size_t)kRayRec * n + 7]);
+        if (done > B && B >= bv.max_steps && done <= bv.max_steps + 7u) {
+            const float *sp = bv.snaps + ((size_t)n * 7u + (B - bv.max_steps)) * 5u;
+            acc = RayAccum{sp[0], sp[1], sp[2], sp[3], sp[4]};
+        }
+    }
+    return acc;
+}
+
 }  // namespace gfpp

@@ -184,10 +184,13 @@ __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restr
             for (size_t k = i; k < n; ++k) out[k] = (uint8_t)clampf(rgb[k] * 255.0f, 0.0f, 255.0f);
         }
     }
+    // the cursor moves on when every workgroup of the launch has read it: the last one to get here advances it
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&job->ticket[lane], 1u) == gridDim.x - 1u) {
+        job->ticket[lane] = 0u;
+        job->cursor[lane] = pos + job->lanes;
+    }
 }
-
-// the cursor moves on only when every block of the store kernel has read it: a second, one-thread launch in the same stream
-__global__ void k_clip_advance(gfpp_clip_job *__restrict__ job, uint32_t lane) { job->cursor[lane] += job->lanes; }
 
 }  // namespace gfpp
 
@@ -203,7 +206,6 @@ GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *
     GFPP_REQUIRE_EARLY(job && rgb && lane < 8 && n_values > 0 && ((uintptr_t)rgb & 15u) == 0 && (n_values & 3u) == 0, "gfpp_clip_store_u8");
     const uint64_t threads = (n_values + 3) / 4;
     hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, job, lane, rgb, (size_t)n_values);
-    hipLaunchKernelGGL(k_clip_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, job, lane);
     return check_launch("gfpp_clip_store_u8");
 }
 

@@ -43,7 +43,7 @@ class FrameWs(ctypes.Structure):
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
-                ("snapshots", c_p)]
+                ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32)]
 
 
 class CondModel(ctypes.Structure):
@@ -575,6 +575,7 @@ class FramePipeline:
             ws.gcounters, ws.N_global, ws.trip_first, ws.trip_count = None, 0, 0, 0
             ws.full_grid_trips = 0
             ws.snapshots = None
+            ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane = 0, 0, None, 0
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
         if self.frames_in_flight <= 1:
@@ -638,7 +639,16 @@ class FramePipeline:
             raise GfppError(f"{name} must be on the GPU")
         return t.detach().float().contiguous()
 
-    def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=None):
+    #: (device pointer of a gfpp_clip_job, lane) while a clip renderer issues / captures a frame: the torso kernel of the 16-bit modes then stores the
+    #: uint8 frame itself and advances the job's cursor (sets clip_job_consumed); None otherwise
+    clip_job = None
+    clip_job_consumed = False
+    #: resolve-in-consumer and uint8-store-in-torso (GFPP_FUSE_TAIL: "0" none, "1" both, "resolve" / "store" one of them).  Measured same-box (round 3,
+    #: 512^2 bf16, two frames in flight): none 2 860-2 906 frames/s, resolve only 2 830-2 883 (neutral: the 6 us launch it saves is hidden by the other
+    #: frame in flight), store fused 2 640-2 660 (the torso kernel itself gets 45 us longer) -- so the default keeps the two small launches
+    fuse_tail = os.environ.get("GFPP_FUSE_TAIL", "0")
+
+    def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=None, defer_resolve=False):
         """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace.
 
         shard = (process group, rays of the whole frame): `rays_o/rays_d` are ONE TILE of a frame that several GPUs render together.  The
@@ -697,11 +707,17 @@ class FramePipeline:
             main.wait_stream(side)                      # join
         trips = "gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march")
         persist = lp and self.lp_kernel == "persist" and int(max_steps) <= 24 and N <= (1 << 22)
+        ws.defer_resolve, ws.resolve_max_steps = 0, 0
+        t["deferred"] = 0
         if persist:
             trips = "gfpp_head_frame_persist_lp"
             if "snapshots" not in t:
                 t["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=self.device)
             ws.snapshots = t["snapshots"].data_ptr()
+            if defer_resolve and shard is None and self.fuse_tail in ("1", "resolve"):
+                # the consumer of the ray records (the 16-bit torso kernel) picks budget and snapshot per ray itself: one launch less on the frame's critical path
+                ws.defer_resolve, ws.resolve_max_steps = 1, int(max_steps)
+                t["deferred"] = int(max_steps)
         if shard is None:
             call(trips, ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps), float(T_thresh), st)
             return ws, t
@@ -782,7 +798,7 @@ class FramePipeline:
         deform_dense [N,2], torso_mask [N] u8, deform=None)."""
         if self.torso is None:
             raise GfppError("this model has no torso networks")
-        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=shard)
+        ws, t = self.head_pass(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=shard, defer_resolve=self.precision != "fp32")
         N = ws.N
         dev = self.device
         bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
@@ -802,6 +818,10 @@ class FramePipeline:
         out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
                "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
         valu = self.precision == "fp32" and (self.fp32_torso != "mfma" or not self.torso.lp_weights or self.torso.lp_dtype != 0)
+        ws.clip_job, ws.clip_lane = None, 0
+        if self.clip_job is not None and not valu and self.fuse_tail in ("1", "store"):
+            ws.clip_job, ws.clip_lane = int(self.clip_job[0]), int(self.clip_job[1])
+            self.clip_job_consumed = True
         call("gfpp_torso_frame" if valu else "gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws),
              bg_coords.data_ptr(), cond_in.data_ptr(),
              code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
@@ -857,5 +877,9 @@ class FramePipeline:
         """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises.  After the persistent 16-bit
         launch the alive counts are the ones gfpp_head_frame_resolve reconstructed (what the trip launches would have left), and the samples of the
         whole frame are reported under trip 0 (a workgroup's local trips are not the reference's)."""
-        c = self.workspace(N)[1]["counters"].cpu().numpy()
+        ws, t = self.workspace(N)
+        if t.get("deferred"):
+            # the frame's consumer resolved budget and snapshots on the fly; the reconstructed alive counts are written by the resolve entry (idempotent)
+            call("gfpp_head_frame_resolve", ctypes.byref(ws), int(t["deferred"]), torch.cuda.current_stream().cuda_stream)
+        c = t["counters"].cpu().numpy()
         return c[:64], c[64:127]

@@ -155,14 +155,16 @@ typedef struct gfpp_clip_job {
     uint32_t lanes;           /* frames in flight: lane l renders the positions l, l + lanes, ... */
     uint32_t ring_frames;     /* positions wrap around in `out` (= n: no wrap) */
     uint32_t cursor[8];       /* per lane: position of the lane's next frame (host: cursor[l] = l) */
+    uint32_t ticket[8];       /* per lane: workgroups of the storing launch that are done (host: 0); the last one advances the cursor */
 } gfpp_clip_job;
 
 /* job (DEVICE pointer) -> static_in [row_floats] f32 (device); replaces the per-frame indexing `cond_inp[i], poses[i], lm68s[i]`
  * of inference/genefacepp_infer.py:461-463 */
 int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
 
-/* the conversion of gfpp_rgb_to_u8 (inference/genefacepp_infer.py:468) written to the job's output slot of this lane's frame, then
- * cursor[lane] += lanes.  rgb [n_values] f32 16-byte aligned; n_values must equal the job's frame_bytes. */
+/* the conversion of gfpp_rgb_to_u8 (inference/genefacepp_infer.py:468) written to the job's output slot of this lane's frame; the launch's last
+ * workgroup then advances cursor[lane] by `lanes`.  rgb [n_values] f32 16-byte aligned; n_values must equal the job's frame_bytes.
+ * (gfpp_torso_frame_lp does the same itself when ws->clip_job is set: no separate launch on the frame's critical path.) */
 int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
 
 /* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
@@ -353,6 +355,13 @@ typedef struct gfpp_frame_ws {
                                * trip that does have work is rendered by the small grid, just more slowly. */
     float *snapshots;      /* gfpp_head_frame_persist_lp only: [N, 7, 5] f32 -- {weights_sum, depth, r, g, b} of a ray after max_steps .. max_steps + 6
                             * composited samples (only rays that get that far write it; gfpp_head_frame_resolve reads it) */
+    uint32_t defer_resolve;   /* 1: gfpp_head_frame_persist_lp issues no resolve launch; the consumers of the ray records (gfpp_torso_frame_lp,
+                               * gfpp_head_frame_finish) pick budget and snapshot per ray on the fly (they read counters[128..] / gcounters and
+                               * `snapshots`, with `resolve_max_steps`).  counters[k] then stay unset until gfpp_head_frame_resolve is called. */
+    uint32_t resolve_max_steps; /* max_steps of the head pass, for the consumers' on-the-fly resolve */
+    gfpp_clip_job *clip_job;  /* NULL, or (DEVICE pointer) the clip job this frame belongs to: gfpp_torso_frame_lp then also writes the frame as uint8
+                               * into the job's output slot of lane `clip_lane` and advances that lane's cursor (= gfpp_clip_store_u8 fused) */
+    uint32_t clip_lane;
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state
