@@ -1366,12 +1366,14 @@ static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
     hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
 }
 
-// upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8,8,8,8" overrides, experiments): the shape of the
-// reference's own schedule (1, 2, 2, 2, 4, 8 for the bench scene) -- a larger first take only evaluates samples behind a ray's termination
+// upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8" overrides, experiments).  The take is
+// min(128 / rays per wavefront, cap): at 512^2 a workgroup holds ~440 occupied rays and the pool limits it to 2 whatever the cap; the cap matters for
+// small shares (256^2: ~110 rays per workgroup), where every round costs a whole block time however few blocks it has -- 4,4,4,8 needs 4 rounds
+// instead of 5 there (head pass 0.133 -> 0.122 ms, 1 % more samples evaluated behind rays' ends); 8,8 evaluates 11 % more for nothing
 static uint32_t persist_step_caps() {
     static uint32_t caps = 0;
     if (caps == 0) {
-        uint32_t v[8] = {2, 2, 2, 4, 8, 8, 8, 8};
+        uint32_t v[8] = {4, 4, 4, 8, 8, 8, 8, 8};
         if (const char *e = getenv("GFPP_PERSIST_CAPS")) {
             int k = 0;
             for (const char *p = e; *p && k < 8; ++k) {

@@ -101,17 +101,33 @@ __device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint
 // NU = 32-column MFMA tiles per wavefront: 2 (round 1-2) = 4 wavefronts of 64 pixels, one per SIMD; 1 = 8 wavefronts of 32 pixels, two per SIMD --
 // a weight fragment then feeds one MFMA instead of two (1.25 KB of LDS operands per MFMA instead of 0.75: still below the LDS's 128 B/clk), but the
 // second wavefront of a SIMD runs under the first one's LDS latency, tap barriers and epilogue stores.
-template <int CIN, int NT, int EPI, int NU>
-__global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
+// KS = how many slices the input channels are cut into (1 or 2).  With KS = 2 a 128-channel layer keeps only a 64-channel half of its halo patch
+// (46 KB) and 16 KB weight chunks in LDS: 80 KB per workgroup, so TWO workgroups share a CU -- one's halo load, tap barriers and epilogue stores run
+// under the other's MFMAs (with one 154 KB workgroup per CU those phases were exposed on every CU at the same time).  The accumulators run over both
+// halves (18 chunk iterations instead of 9 taps); nothing else changes.
+template <int CIN, int NT, int EPI, int NU, int KS>
+__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * KS) void k_sr_conv3(SrConvArgs a) {   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
     constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
-    constexpr int PS = CIN + 8;                  // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
-    constexpr int STEPS = CIN / 16;
-    constexpr int TAPFRAGS = STEPS * NT * 64;    // 16-byte fragments of one tap
-    constexpr int PER_THREAD = TAPFRAGS / kSrThreads;
-    static_assert(TAPFRAGS % kSrThreads == 0, "tap weights must split evenly over the workgroup");
-    __shared__ __attribute__((aligned(16))) _Float16 patch[kSrHalo * kSrHalo * PS];
-    __shared__ uint4 wbuf[2][TAPFRAGS];
+    constexpr int CINH = CIN / KS;               // channels of one K slice
+    constexpr int PS = CINH + 8;                 // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
+    constexpr int STEPS = CIN / 16, STEPS_H = CINH / 16;
+    constexpr int TAPFRAGS = STEPS * NT * 64;    // 16-byte fragments of one tap (all channels)
+    constexpr int CHUNKFRAGS = STEPS_H * NT * 64;   // ... of one (tap, K slice) chunk: what is staged through LDS at a time
+    constexpr int PER_THREAD = CHUNKFRAGS / kSrThreads;
+    static_assert(CHUNKFRAGS % kSrThreads == 0, "chunk weights must split evenly over the workgroup");
+    static_assert(NU == 1 || KS == 1, "K slices are built for the 8-wavefront shape");
+    // halo patch | two weight-chunk buffers; after the last chunk the same memory stages the f16 output of the workgroup (a row of 128 halves + 16 B
+    // of padding per input-grid pixel), so that it leaves as whole 256-byte rows instead of 8-byte pieces
+    constexpr int PATCH_BYTES = kSrHalo * kSrHalo * PS * 2, WBUF_BYTES = 2 * CHUNKFRAGS * 16;
+    constexpr int SROW = NT * 32 + 8;            // staging row in halves
+    constexpr int STAGE_BYTES = (EPI != kSrFinal) ? kSrPatch * kSrPatch * SROW * 2 : 0;
+    constexpr int LDS_BYTES = PATCH_BYTES + WBUF_BYTES > STAGE_BYTES ? PATCH_BYTES + WBUF_BYTES : STAGE_BYTES;
+    static_assert(PATCH_BYTES % 16 == 0, "weight buffers must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    _Float16 *patch = reinterpret_cast<_Float16 *>(lds_raw);
+    uint4(*wbuf)[CHUNKFRAGS] = reinterpret_cast<uint4(*)[CHUNKFRAGS]>(lds_raw + PATCH_BYTES);
+    _Float16 *stage = reinterpret_cast<_Float16 *>(lds_raw);
     __shared__ float s_rgb[(EPI == kSrRgbAdd || EPI == kSrFinal) ? NT * 32 * 3 + 4 : 1];
     __shared__ __attribute__((aligned(16))) float s_bias[NT * 32];   // this pass's output-channel biases (UpPhases: the 64 channels, twice)
 
@@ -120,37 +136,40 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
     const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
     const uint32_t pass = blockIdx.z;
     const uint4 *wg = a.w + (size_t)pass * 9 * TAPFRAGS;
+    auto chunk_src = [&](int it) { return wg + (size_t)((it % 9) * STEPS + (it / 9) * STEPS_H) * NT * 64; };   // iteration it = slice * 9 + tap
 
-    // ---- first tap's weights and the input halo -> LDS (zero padding outside the image) ---------------------------------------------------------
+    // ---- the input halo of one K slice -> LDS (zero padding outside the image) ------------------------------------------------------------------
     // All loads are issued before the first LDS store: the addresses are clamped into the image and the zero padding is a select on the loaded
     // value, so there is no branch around a load (a conditional load makes the compiler wait vmcnt(0) per element: 20 serial memory round
     // trips per thread, ~20 us of the 44 us this kernel took in round 1).
-    {
-        constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CIN / 8);
+    auto load_patch = [&](int kh) {
+        constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CINH / 8);
         constexpr int HALO_ITERS = (HALO_CHUNKS + kSrThreads - 1) / kSrThreads;
         uint4 hv[HALO_ITERS];
-        sr_stage_tap<PER_THREAD, kSrThreads>(wg, wbuf[0], tid, lane);
 #pragma unroll
         for (int q = 0; q < HALO_ITERS; ++q) {
             const int i = q * kSrThreads + tid;
             const int ic = i < HALO_CHUNKS ? i : HALO_CHUNKS - 1;
-            const int pp = ic / (CIN / 8), c8 = ic % (CIN / 8);
+            const int pp = ic / (CINH / 8), c8 = ic % (CINH / 8);
             int py = y0 - 1 + pp / kSrHalo, px = x0 - 1 + pp % kSrHalo;
             py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
             px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
-            hv[q] = (GFPP_SR_ABLATE & 4) ? make_uint4(py, px, c8, 1) : *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + c8 * 8);
+            hv[q] = (GFPP_SR_ABLATE & 4) ? make_uint4(py, px, c8, 1)
+                                         : *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + kh * CINH + c8 * 8);
         }
 #pragma unroll
         for (int q = 0; q < HALO_ITERS; ++q) {
             const int i = q * kSrThreads + tid;
             if (i < HALO_CHUNKS) {
-                const int pp = i / (CIN / 8), c8 = i % (CIN / 8);
+                const int pp = i / (CINH / 8), c8 = i % (CINH / 8);
                 const int py = y0 - 1 + pp / kSrHalo, px = x0 - 1 + pp % kSrHalo;
                 const bool in = py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W;
                 *reinterpret_cast<uint4 *>(&patch[pp * PS + c8 * 8]) = in ? hv[q] : make_uint4(0, 0, 0, 0);
             }
         }
-    }
+    };
+    sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(0), wbuf[0], tid, lane);
+    load_patch(0);
     for (int i = tid; i < NT * 32; i += kSrThreads) {
         const int ng = (int)blockIdx.z * NT * 32 + i;
         s_bias[i] = a.bias[EPI == kSrUpPhases ? (ng & 63) : ng];
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
         for (int i = tid; i < NT * 32 * 3; i += kSrThreads) s_rgb[i] = a.w_rgb[i];
         if (tid < 3) s_rgb[NT * 32 * 3 + tid] = a.b_rgb[tid];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     v16f acc[NU][NT];
@@ -172,24 +192,31 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
     // this lane's NU pixels (one per column tile): rows 2 NU wave + 2 u + (j >> 4), column j & 15 of the patch
     const int prow = 2 * NU * wave + (j >> 4), pcol = j & 15;
     int cur = 0;
-    for (int tap = 0; tap < ((GFPP_SR_ABLATE & 1) ? 0 : 9); ++tap) {
-        // the next tap's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
-        // cost half of the tap loop), into the buffer the previous tap's MFMAs released at the last barrier; they land while this tap computes
-        if (tap + 1 < 9 && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(wg + (size_t)(tap + 1) * TAPFRAGS, wbuf[cur ^ 1], tid, lane);
+    constexpr int ITERS = 9 * KS;
+    for (int it = 0; it < ((GFPP_SR_ABLATE & 1) ? 0 : ITERS); ++it) {
+        const int tap = it % 9;
+        if (KS > 1 && it > 0 && tap == 0) {
+            // next K slice: every wavefront is done with the old half patch (barrier at the end of the last iteration); its first weight chunk is
+            // already in wbuf[cur]
+            load_patch(it / 9);
+            __syncthreads();
+        }
+        // the next chunk's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
+        // cost half of the tap loop), into the buffer the previous chunk's MFMAs released at the last barrier; they land while this one computes
+        if (it + 1 < ITERS && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[cur ^ 1], tid, lane);
         const int dy = tap / 3, dx = tap % 3;
         const _Float16 *b0 = &patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi];
         const _Float16 *b1 = b0 + 2 * kSrHalo * PS;
         const vec *wl = reinterpret_cast<const vec *>(wbuf[cur]) + lane;
-        // operands of step s + 1 are read while the 2 NT MFMAs of step s run (one wavefront per SIMD here: nobody else hides the LDS latency);
-        // the sched_barriers pin that order, as in lp_mfma_device.h::mfma_layer_lds
+        // operands of step s + 1 are read while the NU x NT MFMAs of step s run; the sched_barriers pin that order, as in lp_mfma_device.h::mfma_layer_lds
         vec Bq[2][NU], Aq[2][NT];
         Bq[0][0] = *reinterpret_cast<const vec *>(b0);
         if constexpr (NU == 2) Bq[0][1] = *reinterpret_cast<const vec *>(b1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) Aq[0][t] = wl[t * 64];
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            if (s + 1 < STEPS) {
+        for (int s = 0; s < STEPS_H; ++s) {
+            if (s + 1 < STEPS_H) {
                 Bq[(s + 1) & 1][0] = *reinterpret_cast<const vec *>(b0 + 16 * (s + 1));
                 if constexpr (NU == 2) Bq[(s + 1) & 1][1] = *reinterpret_cast<const vec *>(b1 + 16 * (s + 1));
 #pragma unroll
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the next tap has landed in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the next chunk has landed in LDS
         __syncthreads();
         cur ^= 1;
     }
@@ -252,11 +279,13 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
                 for (int e = 0; e < 4; ++e) v[e] = sr_act(acc[u][t][4 * q + e] + nz + bv[e], a.act_gain, a.clamp);
 
                 if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
+                    // into the wavefront's own rows of the staging area (every wavefront is past the last chunk's barrier: patch and weight buffers are free)
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                    *reinterpret_cast<h4 *>(a.y + ((size_t)oy * OW + ox) * OC + oc) = o;
+                    *reinterpret_cast<h4 *>(stage + ((wave * NU + u) * 32 + j) * SROW + n0) = o;
+                    (void)oy; (void)ox; (void)oc; (void)OW; (void)OC;
                 }
                 if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
                     // the next stage sees the f16-rounded activation in the reference too (x stays fp16 through ToRGB)
@@ -312,6 +341,23 @@ __global__ __launch_bounds__(512 / NU, 1) void k_sr_conv3(SrConvArgs a) {
             }
         }
     }
+    if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
+        // the wavefront's 32 NU pixels leave as rows: 16 lanes x 16 B = the 256 contiguous bytes of one input-grid pixel (plain layers: its 128 channels;
+        // up-sampling layer: the two output pixels (2Y + pass, 2X) and (2Y + pass, 2X + 1) x 64 channels, adjacent in memory), four pixels per store
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        static_assert(NT == 4, "a staged row is 128 halves = 16 lanes x 16 B");
+#pragma unroll
+        for (int r = 0; r < 8 * NU; ++r) {
+            const int pl = r * 4 + (lane >> 4), chunk = lane & 15;          // pixel of the wavefront, 16-byte chunk of its row
+            const int uu = pl >> 5, jj = pl & 31;
+            const int Y = y0 + 2 * NU * wave + 2 * uu + (jj >> 4), X = x0 + (jj & 15);
+            const uint4 row = *reinterpret_cast<const uint4 *>(stage + (wave * NU * 32 + pl) * SROW + chunk * 8);
+            const size_t base = EPI == kSrUpPhases ? ((size_t)(2 * Y + (int)pass) * (2 * a.W) + 2 * X) * 64 : ((size_t)Y * a.W + X) * 128;
+            *reinterpret_cast<uint4 *>(a.y + base + chunk * 8) = row;
+        }
+    }
     if constexpr (EPI == kSrFinal) {
         // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
         if (a.rng_tick) {
@@ -346,6 +392,8 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
     __shared__ float patch[kSrHalo * kSrHalo * 3];
     __shared__ uint4 wl[2 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float s_bias[128];
+    constexpr int SROW = 128 + 8;                                   // staging row in halves (see k_sr_conv3)
+    __shared__ __attribute__((aligned(16))) _Float16 stage[kSrPatch * kSrPatch * SROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
@@ -421,8 +469,20 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_first(SrFirstArgs a) {
                 h4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (_Float16)sr_act(acc[u][t][4 * q + e] + nz + s_bias[n0 + e], a.act_gain, a.clamp);
-                *reinterpret_cast<h4 *>(a.y + ((size_t)Y * a.W + X) * 128 + n0) = o;
+                *reinterpret_cast<h4 *>(stage + ((wave * 2 + u) * 32 + j) * SROW + n0) = o;
             }
+    }
+    // whole 256-byte pixel rows leave the workgroup (16 lanes x 16 B per pixel, four pixels per store) instead of 8-byte pieces
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pl = r * 4 + (lane >> 4), chunk = lane & 15;
+        const int uu = pl >> 5, jj = pl & 31;
+        const int Y = y0 + 4 * wave + 2 * uu + (jj >> 4), X = x0 + (jj & 15);
+        const uint4 row = *reinterpret_cast<const uint4 *>(stage + (wave * 64 + pl) * SROW + chunk * 8);
+        *reinterpret_cast<uint4 *>(a.y + ((size_t)Y * a.W + X) * 128 + chunk * 8) = row;
     }
 }
 
@@ -443,6 +503,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     const bool draw = !noise && ws->rng_state;                      // noise_mode 'random' inside the kernels
     int nu = 1;                                                     // column tiles per wavefront of the 3x3 convolutions (GFPP_SR_TILES=2: the round-2 shape, A/B runs)
     if (const char *e = getenv("GFPP_SR_TILES")) nu = atoi(e) == 2 ? 2 : 1;
+    int ks = 2;                                                     // K slices of the 128-channel layers (GFPP_SR_KSLICES=1: whole halo patch in LDS, one workgroup per CU)
+    if (const char *e = getenv("GFPP_SR_KSLICES")) ks = atoi(e) == 1 ? 1 : 2;
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
     {
         SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
@@ -456,8 +518,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
         a.rng = rng_of(1);
-        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
+        if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+        else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
         if (rc) return rc;
     }
@@ -466,8 +529,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
-        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
+        if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
+        else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
     }
@@ -480,8 +544,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
+        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;
     }
