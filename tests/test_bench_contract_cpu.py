@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(HERE, "..", "profiles", "r02_bench_final.json")))
+    d = json.load(open(os.path.join(HERE, "..", "profiles", "r03_bench_final.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -16,6 +16,9 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_per_frame"] == 1 and "limiter" in r and r["l2"]["peak"] > r["peak"]      # one persistent launch; the level that serves the stream is labelled
+    assert d["config"]["host_issue_ms_per_frame"] <= 0.05                          # the frame loop is issued from C
+    assert "roofline" in d["configs"]["may_torso_sr_256"]                          # the released checkpoint's own configuration carries its own roofline
     assert d["dtype"] == "bf16" and "bf16" not in d["modes"]                       # BASELINE configs[2] literally is the headline
     assert d["modes"]["long_run"]["frames"] >= 2000 and d["modes"]["long_run"]["block_std"] >= 0
     assert d["configs"]["may_head_fp32_latency"]["frames"] >= 200 and d["configs"]["may_head_fp32_latency"]["latency_ms_p99"] >= d["configs"]["may_head_fp32_latency"]["latency_ms_p50"]
