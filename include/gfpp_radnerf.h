@@ -355,9 +355,9 @@ typedef struct gfpp_frame_ws {
                                * trip that does have work is rendered by the small grid, just more slowly. */
     float *snapshots;      /* gfpp_head_frame_persist_lp only: [N, 7, 5] f32 -- {weights_sum, depth, r, g, b} of a ray after max_steps .. max_steps + 6
                             * composited samples (only rays that get that far write it; gfpp_head_frame_resolve reads it) */
-    uint32_t defer_resolve;   /* 1: gfpp_head_frame_persist_lp issues no resolve launch; the consumers of the ray records (gfpp_torso_frame_lp,
-                               * gfpp_head_frame_finish) pick budget and snapshot per ray on the fly (they read counters[128..] / gcounters and
-                               * `snapshots`, with `resolve_max_steps`).  counters[k] then stay unset until gfpp_head_frame_resolve is called. */
+    uint32_t defer_resolve;   /* 1: gfpp_head_frame_persist_lp issues no resolve launch; the consumer of the ray records, gfpp_torso_frame_lp
+                               * (16-bit / MFMA torso kernel only; gfpp_head_frame_finish and gfpp_torso_frame do NOT resolve), picks budget and
+                               * snapshot per ray on the fly (it reads counters[128..] / gcounters and `snapshots`, with `resolve_max_steps`).  counters[k] then stay unset until gfpp_head_frame_resolve is called. */
     uint32_t resolve_max_steps; /* max_steps of the head pass, for the consumers' on-the-fly resolve */
     gfpp_clip_job *clip_job;  /* NULL, or (DEVICE pointer) the clip job this frame belongs to: gfpp_torso_frame_lp then also writes the frame as uint8
                                * into the job's output slot of lane `clip_lane` and advances that lane's cursor (= gfpp_clip_store_u8 fused) */
