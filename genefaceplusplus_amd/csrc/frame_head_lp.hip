@@ -1108,7 +1108,34 @@ struct PremarchArgs {
     float min_near, aabb[6];
     float *nears_out, *fars_out, *state;
     int32_t *counters;
+    // conservative bounds of the occupied cells (gfpp_head_model.occ_aabb; occ_valid = 0: unknown)
+    float occ[6];
+    uint32_t occ_valid;
 };
+
+// Where the marcher may stop: beyond the point where the ray leaves the bounds of the occupied cells no cell is occupied, so the loop of
+// march_one_ray would only skip empty cells until `far` and emit nothing more -- the emitted samples (and their t, a chain of fp32 additions from
+// `near` on: the walk BEFORE the bounds cannot be skipped, and skipping only the bitfield reads there measured slower, a divergent branch per
+// cell) are the same bits.  A ray that misses the bounds has no sample at all (-1).
+__device__ __forceinline__ float march_far_limit(float ox, float oy, float oz, float dx, float dy, float dz, const PremarchArgs &p, float far) {
+    if (!p.occ_valid) return far;
+    const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    float tn = -FLT_MAX, tf = FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (fabsf(d[k]) < 1e-12f) {
+            if (o[k] < p.occ[k] || o[k] > p.occ[3 + k]) return -1.0f;
+        } else {
+            const float rd = 1.0f / d[k];
+            float t1 = (p.occ[k] - o[k]) * rd, t2 = (p.occ[3 + k] - o[k]) * rd;
+            if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
+            tn = fmaxf(tn, t1);
+            tf = fminf(tf, t2);
+        }
+    }
+    if (tn > tf) return -1.0f;
+    return fminf(far, tf);
+}
 
 __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
@@ -1116,8 +1143,8 @@ __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
     const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
     float t = p.nears[n];
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = march_one_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, p.fars[n], p.max_samples, p.bitfield, p.mp,
-                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+    p.sample_cnt[n] = march_one_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, march_far_limit(o[0], o[1], o[2], d[0], d[1], d[2], p, p.fars[n]), p.max_samples,
+                                    p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }
 
 // k_frame_begin (frame_head.hip) and k_premarch in one pass: the slab test's near is the marcher's start, so the rays are read once and one
@@ -1135,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, rb.far, p.max_samples, p.bitfield, p.mp,
+    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }
 
@@ -1279,6 +1306,14 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
     return 0;
 }
 
+static void premarch_occupancy(PremarchArgs &p, const gfpp_head_model *model) {
+    const char *e = getenv("GFPP_OCC_CLIP");          // A/B switch (0 = off), read at every issue (a captured graph keeps what it was captured with)
+    const uint32_t mode = e && atoi(e) == 0 ? 0u : 1u;
+    p.occ_valid = 0u;
+    for (int i = 0; i < 6; ++i) p.occ[i] = model->occ_aabb[i];
+    if (model->occ_aabb[3] > model->occ_aabb[0] && model->occ_aabb[4] > model->occ_aabb[1] && model->occ_aabb[5] > model->occ_aabb[2]) p.occ_valid = mode;
+}
+
 GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                       float dt_gamma, uint32_t max_steps, gfpp_stream_t stream) {
     const int bad = lp_check_common("gfpp_head_frame_premarch", model, ws, rays_o, rays_d, max_steps);
@@ -1291,6 +1326,7 @@ GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_f
     p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
     p.min_near = 0.0f; p.nears_out = nullptr; p.fars_out = nullptr; p.state = nullptr; p.counters = nullptr;
     for (int i = 0; i < 6; ++i) p.aabb[i] = 0.0f;
+    premarch_occupancy(p, model);
     hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gfpp_head_frame_premarch");
 }
@@ -1309,6 +1345,7 @@ GFPP_API int gfpp_head_frame_begin_premarch(const gfpp_head_model *model, const 
     p.min_near = model->min_near;
     for (int i = 0; i < 6; ++i) p.aabb[i] = model->aabb[i];
     p.nears_out = ws->nears; p.fars_out = ws->fars; p.state = ws->ray_state; p.counters = ws->counters;
+    premarch_occupancy(p, model);
     hipLaunchKernelGGL(k_begin_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gfpp_head_frame_begin_premarch");
 }

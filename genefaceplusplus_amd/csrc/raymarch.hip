@@ -261,6 +261,66 @@ GFPP_API int gfpp_near_far_from_aabb(const float *rays_o, const float *rays_d, c
     return check_launch("gfpp_near_far_from_aabb");
 }
 
+// ---- bounds of the occupied cells ---------------------------------------------------------------------------------------------------------
+// One workgroup walks the bitfield (2 Mbit for one cascade of 128^3: 64 K words), every set bit widens per-thread bounds by the world extent of
+// its cell; LDS reduction; thread 0 writes lo xyz, hi xyz widened by one cell of the coarsest occupied level.  Build-time work (once per bitfield).
+__global__ __launch_bounds__(1024) void k_occupancy_bounds(const uint32_t *__restrict__ words, uint32_t n_words, uint32_t H, uint32_t log2_H3, float bound, float *__restrict__ out6) {
+    __shared__ float s_lo[3][1024], s_hi[3][1024];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    float margin = 0.0f;
+    for (uint32_t w = threadIdx.x; w < n_words; w += 1024u) {
+        uint32_t bits = words[w];
+        while (bits) {
+            const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            const uint32_t cell = w * 32u + b, level = cell >> log2_H3, code = cell & ((1u << log2_H3) - 1u);
+            const float mip_bound = fminf(scalbnf(1.0f, (int)level), bound), cw = 2.0f * mip_bound / (float)H;
+            const uint32_t n[3] = {compact3(code), compact3(code >> 1), compact3(code >> 2)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // positions are clamped into the first / last cell of an axis (voxel_of): those cells reach to the scene bound
+                const float a = n[k] == 0u ? -bound : fmaf((float)n[k], cw, -mip_bound), z = n[k] + 1u >= H ? bound : fmaf((float)(n[k] + 1u), cw, -mip_bound);
+                lo[k] = fminf(lo[k], a);
+                hi[k] = fmaxf(hi[k], z);
+            }
+            margin = fmaxf(margin, cw);
+        }
+    }
+    __shared__ float s_margin[1024];
+    for (int k = 0; k < 3; ++k) { s_lo[k][threadIdx.x] = lo[k]; s_hi[k][threadIdx.x] = hi[k]; }
+    s_margin[threadIdx.x] = margin;
+    __syncthreads();
+    for (uint32_t stride = 512u; stride > 0u; stride >>= 1) {
+        if (threadIdx.x < stride) {
+            for (int k = 0; k < 3; ++k) {
+                s_lo[k][threadIdx.x] = fminf(s_lo[k][threadIdx.x], s_lo[k][threadIdx.x + stride]);
+                s_hi[k][threadIdx.x] = fmaxf(s_hi[k][threadIdx.x], s_hi[k][threadIdx.x + stride]);
+            }
+            s_margin[threadIdx.x] = fmaxf(s_margin[threadIdx.x], s_margin[threadIdx.x + stride]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const bool any = s_hi[k][0] >= s_lo[k][0];
+        out6[k] = any ? s_lo[k][0] - s_margin[0] : 1.0f;          // empty bitfield: lo > hi
+        out6[3 + k] = any ? s_hi[k][0] + s_margin[0] : -1.0f;
+    }
+}
+
+GFPP_API int gfpp_occupancy_bounds(const uint8_t *bitfield, uint32_t cascade, uint32_t grid_size, float bound, float *out6, gfpp_stream_t stream) {
+    GFPP_REQUIRE(bitfield && out6, "gfpp_occupancy_bounds");
+    uint32_t log2_H = 0;
+    while ((1u << log2_H) < grid_size) ++log2_H;
+    if ((1u << log2_H) != grid_size || grid_size < 4u || grid_size > 256u || cascade == 0u || cascade > 8u || !(bound > 0.0f)) {
+        set_error("gfpp_occupancy_bounds: grid_size must be a power of two in 4..256, cascade in 1..8, bound > 0");
+        return GFPP_EINVAL;
+    }
+    const uint32_t n_words = cascade * grid_size * grid_size * grid_size / 32u;
+    hipLaunchKernelGGL(k_occupancy_bounds, dim3(1), dim3(1024), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t *>(bitfield), n_words, grid_size, 3u * log2_H, bound, out6);
+    return check_launch("gfpp_occupancy_bounds");
+}
+
 GFPP_API int gfpp_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, gfpp_stream_t stream) {
     if (N == 0) return 0;
     GFPP_REQUIRE(coords && indices, "gfpp_morton3D");

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 4
+#define GFPP_ABI_VERSION 5
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -59,6 +59,12 @@ unsigned gfpp_struct_size(const char *name);
  * A ray missing the box gets near = far = FLT_MAX; near is clamped up to min_near. */
 int gfpp_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
                             float *nears, float *fars, gfpp_stream_t stream);
+
+/* Conservative bounds of the occupied cells of a density bitfield -> out6 (device, 6 floats: lo xyz, hi xyz; lo > hi when no bit is set): every
+ * set bit (bit layout of kernel_packbits, raymarching.cu:268-300; cell = level * H^3 + Morton code, raymarching.cu:56-88) contributes the world extent
+ * its cell has in kernel_march_rays' position -> cell mapping (raymarching.cu:880-894; the first / last cell of an axis reaches to the scene bound,
+ * positions are clamped into them), the result is widened by one cell.  For gfpp_head_model.occ_aabb; bitfield must be 4-byte aligned. */
+int gfpp_occupancy_bounds(const uint8_t *bitfield, uint32_t cascade, uint32_t grid_size, float bound, float *out6, gfpp_stream_t stream);
 
 /* replaces morton3D / morton3D_invert (raymarching.h:9-10; raymarching.cu:214-241).
  * coords [N,3] i32 <-> indices [N] i32; x -> bit 0, y -> bit 1, z -> bit 2 of each 3-bit group. */
@@ -304,6 +310,11 @@ typedef struct gfpp_head_model {
      * so that a row is a sequence of packed dot products against the operand registers of the preceding layer (1 792 B) */
     const void *lp_skinny;
     int32_t lp_dtype;
+    /* (ABI 5) conservative world-space bounds of the occupied cells of density_bitfield, lo xyz | hi xyz (gfpp_occupancy_bounds).  The pre-march
+     * kernels stop a ray where it leaves these bounds -- kernel_march_rays (raymarching.cu:828-940) would only skip empty cells from there to `far`
+     * -- and give a ray that misses them no sample; the sample times are the bits of the full march.  hi <= lo on an axis (e.g. all zero): unknown,
+     * every ray is marched to `far`. */
+    float occ_aabb[6];
 } gfpp_head_model;
 
 /* per-frame device workspace (caller-allocated, reusable across frames) */

@@ -376,3 +376,46 @@ def test_superresolution_random_noise_is_drawn_in_the_kernels(dev):
     c_got, c_ref = float(np.corrcoef(d_got, d1)[0, 1]), float(np.corrcoef(d_ref, d_ref2)[0, 1])
     print("correlation of two frames' perturbations: kernels", c_got, "oracle", c_ref)
     assert abs(c_got - c_ref) <= 0.03
+
+
+def test_occupancy_bounds_enclose_exactly_the_set_cells(dev):
+    """gfpp_occupancy_bounds against a numpy walk over the set bits (Morton order, raymarching.cu:56-88; two cascades), plus the empty bitfield."""
+    import ctypes
+    from genefaceplusplus_amd import _lib
+    from genefaceplusplus_amd.radnerfs import frame_pipeline  # noqa: F401  (registers the entry)
+    H, C, bound = 64, 2, 2.0
+    rng = np.random.default_rng(3)
+    cells = np.zeros((C, H, H, H), bool)                      # [level][x][y][z]
+    cells[0, 20:41, 25:33, 0:7] = rng.random((21, 8, 7)) < 0.3
+    cells[0, 20, 25, 3] = cells[0, 40, 32, 6] = True
+    cells[1, 30:35, 31:34, 60:64] = True
+    def spread(v):
+        v = v.astype(np.uint64)
+        out = np.zeros_like(v)
+        for b in range(10):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+    lv, x, y, z = np.nonzero(cells)
+    idx = lv.astype(np.uint64) * np.uint64(H ** 3) + (spread(x) | (spread(y) << np.uint64(1)) | (spread(z) << np.uint64(2)))
+    bits = np.zeros(C * H ** 3, np.uint8)
+    bits[idx.astype(np.int64)] = 1
+    packed = np.packbits(bits, bitorder="little")
+    lo, hi, margin = np.full(3, np.inf), np.full(3, -np.inf), 0.0
+    for l in range(C):
+        sel = lv == l
+        if not sel.any():
+            continue
+        mb = min(2.0 ** l, bound)
+        cw = 2.0 * mb / H
+        for k, n in enumerate((x[sel], y[sel], z[sel])):
+            lo[k] = min(lo[k], -bound if n.min() == 0 else n.min() * cw - mb)
+            hi[k] = max(hi[k], bound if n.max() == H - 1 else (n.max() + 1) * cw - mb)
+        margin = max(margin, cw)
+    out = torch.empty(6, dtype=torch.float32, device=dev)
+    field = torch.from_numpy(packed).to(dev)
+    _lib.call("gfpp_occupancy_bounds", field.data_ptr(), C, H, bound, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_allclose(out.cpu().numpy(), np.concatenate([lo - margin, hi + margin]), rtol=0, atol=1e-6)
+    field.zero_()
+    _lib.call("gfpp_occupancy_bounds", field.data_ptr(), C, H, bound, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    o = out.cpu().numpy()
+    assert np.all(o[:3] > o[3:])

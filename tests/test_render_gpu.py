@@ -340,6 +340,34 @@ def test_empty_and_full_occupancy(dev, oracle_mod, precision):
             assert (err > (2e-4 if precision == "fp32" else 2e-2)).mean() <= 5e-4, float(err.max())
 
 
+@pytest.mark.parametrize("variant,HW,over", [("may_torso", 256, None), ("may_head", 96, {"bound": 2}), ("may_head", 64, {"min_near": 0.6})])
+def test_premarch_stops_at_the_occupancy_bounds_with_the_same_samples(dev, oracle_mod, monkeypatch, variant, HW, over):
+    """gfpp_head_model.occ_aabb: the pre-march ends a ray where it leaves the bounds of the occupied cells and skips rays that miss them.  The samples
+    -- count and every t, a chain of fp32 additions that starts at `near` -- are the bits of the march to `far` (GFPP_OCC_CLIP=0), and so is the frame."""
+    got = {}
+    for clip in ("0", "1"):
+        monkeypatch.setenv("GFPP_OCC_CLIP", clip)
+        case = frame_case(variant, HW, hp_over=over)
+        model = build_model(case, dev, "fused")
+        model.precision = "fp16"
+        model.use_graph = False
+        r = product_render(model, case, dev, "oracle", oracle_mod)
+        torch.cuda.synchronize()
+        pipe = model.pipeline()
+        occ = np.array(list(pipe.head.occ_aabb))
+        assert np.all(occ[3:] > occ[:3]) and np.all(np.abs(occ) <= float(case["hp"]["bound"]) * 1.1 + 1e-6)
+        t = pipe.workspace(HW * HW)[1]
+        cnt = t["sample_cnt"].cpu().numpy().astype(np.int64)
+        ts = t["sample_t"].cpu().numpy()
+        valid = np.arange(ts.shape[1])[None, :] < cnt[:, None]
+        got[clip] = (cnt, np.where(valid, ts, 0.0), {k: v.detach().float().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)})
+    assert got["1"][0].sum() > 0 and (got["1"][0] == 0).mean() > 0.05              # rays with and without samples
+    np.testing.assert_array_equal(got["0"][0], got["1"][0])
+    np.testing.assert_array_equal(got["0"][1], got["1"][1])
+    for k in got["0"][2]:
+        np.testing.assert_array_equal(got["0"][2][k], got["1"][2][k], err_msg=k)
+
+
 def test_full_size_frame_matches_oracle(dev, oracle_mod):
     """BASELINE.json's full size: 512 x 512 = 262 144 rays, head + torso, every precision mode against one oracle render."""
     case = frame_case("may_torso", 512)
