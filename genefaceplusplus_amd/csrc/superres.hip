@@ -80,6 +80,13 @@ struct SrConvArgs {
     SrRng rng;                // noise == null and rng.state != null: unit normals drawn here
     unsigned long long *rng_tick;   // kSrFinal: the last launch of a frame advances the frame counter ([0] counter, [1] ticket)
     uint32_t clamp01;         // kSrFinal: clamp the image to [0, 1]
+    // FIRST (block 0's first convolution computed into the halo patch instead of being read from x): its operands
+    const float *first_rgb;   // [H][W][3] fp32, the NeRF image
+    const uint4 *first_w;     // [2 steps][4 tiles][64] fragments (SrFirstArgs.w)
+    const float *first_bias;  // [128]
+    const float *first_noise; // [H][W] or null
+    float first_noise_strength;
+    SrRng first_rng;
 };
 
 __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
@@ -105,8 +112,11 @@ __device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint
 // (46 KB) and 16 KB weight chunks in LDS: 80 KB per workgroup, so TWO workgroups share a CU -- one's halo load, tap barriers and epilogue stores run
 // under the other's MFMAs (with one 154 KB workgroup per CU those phases were exposed on every CU at the same time).  The accumulators run over both
 // halves (18 chunk iterations instead of 9 taps); nothing else changes.
-template <int CIN, int NT, int EPI, int NU, int KS>
-__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * KS) void k_sr_conv3(SrConvArgs a) {   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
+// FIRST: the layer's input is not read from memory but computed in place -- block 0's first convolution (3 -> 128, K = 27; k_sr_first) evaluated
+// for the 18 x 18 halo pixels of the patch, straight into the LDS patch: one launch, a 16.8 MB activation write and its 1.27x re-read less per frame.
+// Same fragments, same MFMA order, same epilogue as k_sr_first: the values in the patch are the bits k_sr_first would have stored.
+template <int CIN, int NT, int EPI, int NU, int KS, bool FIRST = false>
+__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) void k_sr_conv3(SrConvArgs a) {   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
     constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
     constexpr int CINH = CIN / KS;               // channels of one K slice
@@ -130,6 +140,10 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * KS) void k_sr_conv3(S
     _Float16 *stage = reinterpret_cast<_Float16 *>(lds_raw);
     __shared__ float s_rgb[(EPI == kSrRgbAdd || EPI == kSrFinal) ? NT * 32 * 3 + 4 : 1];
     __shared__ __attribute__((aligned(16))) float s_bias[NT * 32];   // this pass's output-channel biases (UpPhases: the 64 channels, twice)
+    constexpr int kInSide = kSrHalo + 2;                             // FIRST: the image patch under the halo's own 3 x 3 taps
+    __shared__ float s_in[FIRST ? kInSide * kInSide * 3 : 1];
+    __shared__ uint4 s_wf[FIRST ? 2 * 4 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) float s_fb[FIRST ? 128 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
@@ -168,8 +182,85 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * KS) void k_sr_conv3(S
             }
         }
     };
+    // FIRST: channels [kh CINH, (kh + 1) CINH) of the first convolution at the 324 halo pixels, 32 pixels per MFMA tile, tiles dealt out to the wavefronts
+    [[maybe_unused]] auto first_patch = [&](int kh) {
+        constexpr int HP = kSrHalo * kSrHalo, TILES = (HP + 31) / 32, TL = CINH / 32;
+        const unsigned long long fctr = a.first_rng.state ? a.first_rng.state[0] : 0ull;
+        for (int tile = wave; tile < TILES; tile += kSrThreads / 64) {
+            const int pp = tile * 32 + j, ppc = pp < HP ? pp : HP - 1;
+            const int hy = ppc / kSrHalo, hx = ppc % kSrHalo;
+            v16f facc[TL];
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) facc[t][r] = 0.0f;
+            const vec *Wf = reinterpret_cast<const vec *>(s_wf) + lane;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                vec B;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * s2 + 8 * hi + e;
+                    float v = 0.0f;
+                    if (k < 27) {
+                        const int tap = k / 3, c = k % 3;
+                        v = s_in[((hy + tap / 3) * kInSide + hx + tap % 3) * 3 + c];
+                    }
+                    B[e] = (_Float16)v;
+                }
+#pragma unroll
+                for (int t = 0; t < TL; ++t) facc[t] = LpTraits<_Float16>::mfma(Wf[(s2 * 4 + kh * TL + t) * 64], B, facc[t]);
+            }
+            const int Y = y0 - 1 + hy, X = x0 - 1 + hx;
+            const bool in = Y >= 0 && Y < (int)a.H && X >= 0 && X < (int)a.W;
+            const size_t at = in ? (size_t)Y * a.W + X : 0;
+            const float nz = a.first_noise ? a.first_noise[at] * a.first_noise_strength
+                                           : (a.first_rng.state ? sr_randn(a.first_rng, fctr, (uint32_t)at) * a.first_noise_strength : 0.0f);
+            if (pp < HP) {
+#pragma unroll
+                for (int t = 0; t < TL; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = 32 * t + 8 * q + 4 * hi, ng = kh * CINH + nl;
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = in ? (_Float16)sr_act(facc[t][4 * q + e] + nz + s_fb[ng + e], a.act_gain, a.clamp) : (_Float16)0.0f;   // zero padding of THIS layer's input
+                        *reinterpret_cast<h4 *>(&patch[pp * PS + nl]) = o;
+                    }
+            }
+        }
+    };
     sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(0), wbuf[0], tid, lane);
-    load_patch(0);
+    if constexpr (FIRST) {
+        for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) s_wf[i] = a.first_w[i];
+        if (tid < 128) s_fb[tid] = a.first_bias[tid];
+        constexpr int N = kInSide * kInSide * 3, IT = (N + kSrThreads - 1) / kSrThreads;
+        float hv[IT];
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * kSrThreads + tid, ic = i < N ? i : N - 1;
+            const int p = ic / 3, c = ic % 3;
+            int py = y0 - 2 + p / kInSide, px = x0 - 2 + p % kInSide;
+            py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
+            px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
+            hv[q] = a.first_rgb[((size_t)py * a.W + px) * 3 + c];
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * kSrThreads + tid;
+            if (i < N) {
+                const int p = i / 3;
+                const int py = y0 - 2 + p / kInSide, px = x0 - 2 + p % kInSide;
+                // the reference casts the block input to fp16 before the first convolution (superresolution.py:216)
+                s_in[i] = (py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W) ? (float)(_Float16)hv[q] : 0.0f;
+            }
+        }
+        __syncthreads();
+        first_patch(0);
+    } else {
+        load_patch(0);
+    }
     for (int i = tid; i < NT * 32; i += kSrThreads) {
         const int ng = (int)blockIdx.z * NT * 32 + i;
         s_bias[i] = a.bias[EPI == kSrUpPhases ? (ng & 63) : ng];
@@ -198,7 +289,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * KS) void k_sr_conv3(S
         if (KS > 1 && it > 0 && tap == 0) {
             // next K slice: every wavefront is done with the old half patch (barrier at the end of the last iteration); its first weight chunk is
             // already in wbuf[cur]
-            load_patch(it / 9);
+            if constexpr (FIRST) first_patch(it / 9); else load_patch(it / 9);
             __syncthreads();
         }
         // the next chunk's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
@@ -506,7 +597,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     int ks = 2;                                                     // K slices of the 128-channel layers (GFPP_SR_KSLICES=1: whole halo patch in LDS, one workgroup per CU)
     if (const char *e = getenv("GFPP_SR_KSLICES")) ks = atoi(e) == 1 ? 1 : 2;
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
-    {
+    bool fuse_first = nu == 1 && ks == 2;                           // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, A/B runs)
+    if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = fuse_first && atoi(e) != 0;
+    if (!fuse_first) {
         SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
         hipLaunchKernelGGL(k_sr_first, dim3(R / kSrPatch, R / kSrPatch), dim3(kSrThreads), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv0)");
@@ -518,7 +611,11 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
         a.rng = rng_of(1);
-        if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+        if (fuse_first) {
+            a.first_rgb = rgb_in; a.first_w = (const uint4 *)m->w_first; a.first_bias = m->bias[0];
+            a.first_noise = noise ? noise[0] : nullptr; a.first_noise_strength = m->noise_strength[0]; a.first_rng = rng_of(0);
+            hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2, true>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+        } else if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");

@@ -378,6 +378,29 @@ def test_superresolution_random_noise_is_drawn_in_the_kernels(dev):
     assert abs(c_got - c_ref) <= 0.03
 
 
+@pytest.mark.parametrize("noise_mode", ["const", "random", "none"])
+def test_superresolution_first_layer_inside_the_second_equals_its_own_launch(dev, monkeypatch, noise_mode):
+    """Block 0's first convolution computed into the halo patch of the second one (k_sr_conv3<..., FIRST>) against its own launch (k_sr_first,
+    GFPP_SR_FUSE_FIRST=0): same fragments, same MFMA order, same epilogue -- the 512^2 image bit for bit, image borders included."""
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.random((1, 3, 256, 256)).astype(np.float32)).to(dev)
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("GFPP_SR_FUSE_FIRST", fuse)
+        net = Superresolution(channels=3)
+        net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+        net = net.to(dev).eval()
+        with torch.no_grad():
+            net.reseed(77)
+            outs.append([net(x, noise_mode=noise_mode).cpu().numpy() for _ in range(2)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert (noise_mode == "random") == (not np.array_equal(outs[0][0], outs[0][1]))
+
+
 def test_occupancy_bounds_enclose_exactly_the_set_cells(dev):
     """gfpp_occupancy_bounds against a numpy walk over the set bits (Morton order, raymarching.cu:56-88; two cascades), plus the empty bitfield."""
     import ctypes
