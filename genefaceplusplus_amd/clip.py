@@ -52,13 +52,13 @@ class ClipRenderer:
     def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None,
                  calibrate_trips=True):
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
-        workspace and graph; weights and tables are shared), so one frame's prologue (slab test, pre-march, conditioning nets: small
-        launches that leave most CUs idle) and its late, sparse trips overlap the other frame's full-width launches.  None = 3
-        (round 2: +10 % over two lanes at 512^2, +12 % for the 256^2 frames of the super-resolution models; a fourth lane loses 13 %).
-        calibrate_trips: with several lanes every possible trip of the render loop is a launch of its own (gfpp_frame_ws.separate_trips); when a
-        lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given a small grid, because a launch that finds
-        nothing left still needs a whole CU per workgroup (+5 % frames/s at 512^2; results never depend on it, a later frame that needs more
-        trips is rendered by the small grid)."""
+        workspace and graph; weights and tables are shared), so one frame's prologue and epilogue (slab test + pre-march, conditioning nets, torso
+        pass, uint8 store) overlap the tail of the other frame's head pass.  None = 2 for the 16-bit modes (the head pass is one launch that holds
+        every CU: a third frame only queues behind it), 3 for the exact-fp32 mode (one launch per trip; numbers at the assignment below).
+        calibrate_trips (trip-launch paths only: fp32, lp_kernel='trips'): with several lanes every possible trip of the render loop is a launch of
+        its own (gfpp_frame_ws.separate_trips); when a lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given
+        a small grid, because a launch that finds nothing left still needs a whole CU per workgroup (results never depend on it, a later frame that
+        needs more trips is rendered by the small grid)."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")

@@ -87,12 +87,21 @@ def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):   # gridencoder.h:13
     if embeddings.dtype != torch.float32:
         # Under autocast the reference's grid.py:43-44 hands half tables / half grad / half dy_dx to the extension
-        # (egs_bases/radnerf/base.yaml:50 `amp: true`).  The C ABI accumulates table gradients in fp32 only: up-cast, run, and cast the
-        # results into the caller's tensors (more accurate than the reference's __half2 atomics, same interface).
+        # (egs/datasets/May/lm3d_radnerf.yaml:5 `amp: true`).
         ge32 = torch.zeros(grad_embeddings.shape, dtype=torch.float32, device=grad_embeddings.device)
         gi32 = torch.zeros(grad_inputs.shape, dtype=torch.float32, device=grad_inputs.device) if grad_inputs is not None else None
-        grid_encode_backward(grad.float(), inputs, embeddings.float(), offsets, ge32, B, D, C, L, S, H, dy_dx.float() if dy_dx is not None else None, gi32,
-                             gridtype, align_corners, interp)
+        if int(C) == 2 and grad.dtype == torch.float16:
+            # level_dim 2: the half grad goes into the kernels as it is (fp32 accumulation; gridencoder.cu:306-318 accumulates in half); the fp32
+            # result is cast into the caller's half tensors
+            rows = int(embeddings.shape[0])
+            copies = torch.empty(8, rows * 2, device=grad_embeddings.device, dtype=torch.float32)
+            dy32 = dy_dx.float().contiguous() if dy_dx is not None else None
+            call("gfpp_grid_encode_backward_f16", _p(grad.contiguous()), _p(inputs), _p(offsets), _p(ge32), rows, _p(copies), int(B), int(D), 2, int(L), float(S),
+                 int(H), _p(dy32), _p(gi32), int(gridtype), int(bool(align_corners)), int(interp), _st())
+        else:
+            # other level_dims: fp32 accumulation (more accurate than the reference's half atomics, same interface)
+            grid_encode_backward(grad.float(), inputs, embeddings.float(), offsets, ge32, B, D, C, L, S, H, dy_dx.float() if dy_dx is not None else None, gi32,
+                                 gridtype, align_corners, interp)
         grad_embeddings.add_(ge32.to(grad_embeddings.dtype))
         if grad_inputs is not None:
             grad_inputs.add_(gi32.to(grad_inputs.dtype))

@@ -116,7 +116,7 @@ __device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint
 // for the 18 x 18 halo pixels of the patch, straight into the LDS patch: one launch, a 16.8 MB activation write and its 1.27x re-read less per frame.
 // Same fragments, same MFMA order, same epilogue as k_sr_first: the values in the patch are the bits k_sr_first would have stored.
 template <int CIN, int NT, int EPI, int NU, int KS, bool FIRST = false>
-__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) void k_sr_conv3(SrConvArgs a) {   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
+__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) void k_sr_conv3(SrConvArgs a) {   // NU = 2, KS = 2: two 4-wavefront workgroups per CU   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
     constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
     constexpr int CINH = CIN / KS;               // channels of one K slice
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     constexpr int CHUNKFRAGS = STEPS_H * NT * 64;   // ... of one (tap, K slice) chunk: what is staged through LDS at a time
     constexpr int PER_THREAD = CHUNKFRAGS / kSrThreads;
     static_assert(CHUNKFRAGS % kSrThreads == 0, "chunk weights must split evenly over the workgroup");
-    static_assert(NU == 1 || KS == 1, "K slices are built for the 8-wavefront shape");
     // halo patch | two weight-chunk buffers; after the last chunk the same memory stages the f16 output of the workgroup (a row of 128 halves + 16 B
     // of padding per input-grid pixel), so that it leaves as whole 256-byte rows instead of 8-byte pieces
     constexpr int PATCH_BYTES = kSrHalo * kSrHalo * PS * 2, WBUF_BYTES = 2 * CHUNKFRAGS * 16;
@@ -597,6 +596,10 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     int ks = 2;                                                     // K slices of the 128-channel layers (GFPP_SR_KSLICES=1: whole halo patch in LDS, one workgroup per CU)
     if (const char *e = getenv("GFPP_SR_KSLICES")) ks = atoi(e) == 1 ? 1 : 2;
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
+    int nu_up = nu;                                                 // the up-sampling layer alone (GFPP_SR_TILES_UP)
+    if (const char *e = getenv("GFPP_SR_TILES_UP")) nu_up = atoi(e) == 2 ? 2 : 1;
+    int nu_fin = nu;
+    if (const char *e = getenv("GFPP_SR_TILES_FINAL")) nu_fin = atoi(e) == 2 ? 2 : 1;
     bool fuse_first = nu == 1 && ks == 2;                           // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, A/B runs)
     if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = fuse_first && atoi(e) != 0;
     if (!fuse_first) {
@@ -626,8 +629,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
-        if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
-        else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
+        if (nu_up == 2 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
+        else if (nu_up == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
+        else if (nu_up == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
@@ -641,7 +645,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
+        if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;

@@ -283,15 +283,15 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 constexpr uint32_t kLdsGradFloats = 32768;     // 128 KiB of the CU's 160 KiB
 constexpr uint32_t kLdsGradPoints = 8192;      // points per workgroup of the LDS kernel
 
-template <int D, int C>
-__device__ __forceinline__ void grid_backward_point(const float *__restrict__ grad, const float *__restrict__ inputs, uint32_t b, uint32_t B, uint32_t level, float scale,
+template <int D, int C, typename G>
+__device__ __forceinline__ void grid_backward_point(const G *__restrict__ grad, const float *__restrict__ inputs, uint32_t b, uint32_t B, uint32_t level, float scale,
                                                     uint32_t size, uint32_t res, uint32_t gridtype, bool align_corners, uint32_t interp, float *gg) {
     float pos[D], deriv[D];
     uint32_t pg[D];
     if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) return;
     float gc[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) gc[c] = grad[((size_t)level * B + b) * C + c];
+    for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c];
 #pragma unroll
     for (int idx = 0; idx < (1 << D); ++idx) {
         float w = 1.0f;
@@ -307,8 +307,8 @@ __device__ __forceinline__ void grid_backward_point(const float *__restrict__ gr
     }
 }
 
-template <int D, int C>
-__global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restrict__ grad, const float *__restrict__ inputs,
+template <int D, int C, typename G = float>
+__global__ __launch_bounds__(kTrBlock) void k_grid_backward(const G *__restrict__ grad, const float *__restrict__ inputs,
                                                            const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
                                                            TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t lds_floats,
                                                            float *__restrict__ xcd_copies, uint32_t total_floats) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward(const float *__restr
     const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
     if (size * C <= lds_floats) return;                        // owned by k_grid_backward_lds
     float *dst = xcd_copies ? xcd_copies + (size_t)xcc_id() * total_floats : grad_table;
-    grid_backward_point<D, C>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, dst + (size_t)off * C);
+    grid_backward_point<D, C, G>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, dst + (size_t)off * C);
 }
 
 // grad_table[i] += sum over the eight XCD copies
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_reduce_xcd(const float *__res
     if (s != 0.0f) grad_table[i] += s;
 }
 
-template <int D, int C>
-__global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
+template <int D, int C, typename G = float>
+__global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const G *__restrict__ grad, const float *__restrict__ inputs,
                                                                const int32_t *__restrict__ offsets, float *__restrict__ grad_table, uint32_t B, uint32_t L,
                                                                TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
                                                                float *__restrict__ xcd_copies, uint32_t total_floats) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const float *__r
     __syncthreads();
     const uint32_t first = blockIdx.x * kLdsGradPoints, last = first + kLdsGradPoints < B ? first + kLdsGradPoints : B;
     for (uint32_t b = first + threadIdx.x; b < last; b += kTrBlock)
-        grid_backward_point<D, C>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, acc);
+        grid_backward_point<D, C, G>(grad, inputs, b, B, level, lv.scale[level], size, res, gridtype, align_corners, interp, acc);
     __syncthreads();
     float *gg = (xcd_copies ? xcd_copies + (size_t)xcc_id() * total_floats : grad_table) + (size_t)off * C;
     for (uint32_t i = threadIdx.x; i < n; i += kTrBlock) {
@@ -360,8 +360,72 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const float *__r
     }
 }
 
+// ---- every level without device atomics: range passes -------------------------------------------------------------------------------------------------
+// The direct scatter above is bound by the device's atomic rate (measured 14.6 G float atomics/s with XCD-private copies: 4.6 ms for the 67 M atomics
+// of one May grid, 45 % of a training step).  Here a workgroup owns ONE range of <= kLdsGradFloats table values of one level and one eighth of the
+// points: it walks its points, recomputes the corners (cheap: ~200 instructions per point and level) and adds the ones that fall into its range into
+// LDS accumulators (ds_add_f32); the range then leaves as plain coalesced stores into the slice's private copy of the gradient (the `xcd_copies`
+// scratch: slice s owns copy s; k_grid_reduce_xcd sums the copies).  A 2^16-row level is four ranges, i.e. its corners are located four times --
+// ~20x cheaper than an atomic each.  grad: fp32 or half ([L, B, C]); accumulation fp32 either way.
+constexpr uint32_t kRgThreads = 1024;
+constexpr uint32_t kRgSlices = kXcds;          // point slices = gradient copies
+
+template <int D, int C, typename G>
+__global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                                                     uint32_t B, uint32_t L, TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
+                                                                     float *__restrict__ copies, uint32_t total_floats) {
+    extern __shared__ float acc[];
+    uint32_t item = blockIdx.x / kRgSlices;
+    const uint32_t slice = blockIdx.x % kRgSlices;
+    uint32_t level = 0, range = 0, off = 0, size = 0;
+    bool found = false;
+    for (; level < L; ++level) {                                   // (scalar loop: <= 32 levels)
+        off = (uint32_t)offsets[level];
+        size = (uint32_t)offsets[level + 1] - off;
+        const uint32_t n = size * C;
+        const uint32_t nr = (n + kLdsGradFloats - 1u) / kLdsGradFloats;   // (a level that fits the LDS is one range)
+        if (item < nr) { range = item; found = true; break; }
+        item -= nr;
+    }
+    if (!found) return;                                            // the grid is sized by an upper bound of the ranges
+    const uint32_t rows_per = kLdsGradFloats / C, row0 = range * rows_per;
+    const uint32_t nrows = size - row0 < rows_per ? size - row0 : rows_per, n = nrows * C;
+    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
+    const float scale = lv.scale[level];
+    const uint32_t res = lv.resolution[level];
+    for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
+        float pos[D], deriv[D];
+        uint32_t pg[D];
+        if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
+        float gc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c];
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); ++idx) {
+            float w = 1.0f;
+            uint32_t pl[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if ((idx & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+            }
+            const uint32_t r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;   // (wraps for rows below the range)
+            if (r < nrows) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) atomicAdd(&acc[r * C + c], w * gc[c]);
+            }
+        }
+    }
+    __syncthreads();
+    float *dst = copies + (size_t)slice * total_floats + (size_t)(off + row0) * C;
+    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) dst[i] = acc[i];
+}
+
 // input gradient from dy_dx (gridencoder.cu:342-368)
-__global__ __launch_bounds__(kTrBlock) void k_grid_input_backward(const float *__restrict__ grad, const float *__restrict__ dy_dx, float *__restrict__ grad_inputs,
+template <typename G>
+__global__ __launch_bounds__(kTrBlock) void k_grid_input_backward(const G *__restrict__ grad, const float *__restrict__ dy_dx, float *__restrict__ grad_inputs,
                                                                  uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     const uint32_t t = blockIdx.x * kTrBlock + threadIdx.x;
     if (t >= B * D) return;
@@ -369,7 +433,7 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_input_backward(const float *_
     const float *dd = dy_dx + (size_t)b * L * D * C;
     float r = 0.0f;
     for (uint32_t l = 0; l < L; ++l)
-        for (uint32_t c = 0; c < C; ++c) r = fmaf(grad[((size_t)l * B + b) * C + c], dd[(l * D + d) * C + c], r);
+        for (uint32_t c = 0; c < C; ++c) r = fmaf((float)grad[((size_t)l * B + b) * C + c], dd[(l * D + d) * C + c], r);
     grad_inputs[t] = r;
 }
 
@@ -511,30 +575,6 @@ GFPP_API int gfpp_sph_from_ray(const float *rays_o, const float *rays_d, float r
         else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2, 4 or 8 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; } \
     } while (0)
 
-// the LDS-privatised kernel: a workgroup per kLdsGradPoints points and level, 128 KiB of dynamic LDS (opt-in above the 64 KiB default)
-#define GFPP_LDS_ONE(KERNEL, DD, CC, ...)                                                                                              \
-    do {                                                                                                                                \
-        /* per call, not once per process: the attribute is per device and a process may train on several (it costs a table write) */   \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<DD, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                (int)(kLdsGradFloats * sizeof(float))) != hipSuccess) {                                                 \
-            (void)hipGetLastError();                                                                                                    \
-            lds_ok_ = false;                                                                                                            \
-        } else {                                                                                                                        \
-            hipLaunchKernelGGL((KERNEL<DD, CC>), dim3(div_up(B, kLdsGradPoints), L), dim3(kTrBlock), kLdsGradFloats * sizeof(float), st, __VA_ARGS__); \
-        }                                                                                                                               \
-    } while (0)
-#define GFPP_DISPATCH_LDS(KERNEL, ...)                                                                                                 \
-    do {                                                                                                                                \
-        if (D == 2 && C == 2) GFPP_LDS_ONE(KERNEL, 2, 2, __VA_ARGS__);                                                                  \
-        else if (D == 3 && C == 2) GFPP_LDS_ONE(KERNEL, 3, 2, __VA_ARGS__);                                                             \
-        else if (D == 2 && C == 1) GFPP_LDS_ONE(KERNEL, 2, 1, __VA_ARGS__);                                                             \
-        else if (D == 3 && C == 1) GFPP_LDS_ONE(KERNEL, 3, 1, __VA_ARGS__);                                                             \
-        else if (D == 2 && C == 4) GFPP_LDS_ONE(KERNEL, 2, 4, __VA_ARGS__);                                                             \
-        else if (D == 3 && C == 4) GFPP_LDS_ONE(KERNEL, 3, 4, __VA_ARGS__);                                                             \
-        else if (D == 2 && C == 8) GFPP_LDS_ONE(KERNEL, 2, 8, __VA_ARGS__);                                                             \
-        else if (D == 3 && C == 8) GFPP_LDS_ONE(KERNEL, 3, 8, __VA_ARGS__);                                                             \
-    } while (0)
-
 GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings, const int32_t *offsets, float *dy_dx, uint32_t B, uint32_t D, uint32_t C,
                                    uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
     if (B == 0) return 0;
@@ -546,9 +586,44 @@ GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings,
     return check_launch("gfpp_grid_encode_dydx");
 }
 
-static int grid_backward_impl(const char *who, const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
-                              float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs,
-                              uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+// One (D, C) instantiation of the three table-gradient kernels for grad type G
+template <int D, int C, typename G>
+static int grid_backward_launch(const char *who, const G *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, float *xcd_copies,
+                                uint32_t total_floats, uint32_t B, uint32_t L, const TrLevels &lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    // levels whose table fits kLdsGradFloats go through the LDS-privatised kernel (128 KiB of dynamic LDS); a device that cannot reserve that much
+    // (64 KiB parts) scatters every level directly instead (lds_floats = 0) -- slower, same result
+    const int lds_bytes = (int)(kLdsGradFloats * sizeof(float));
+    // per call, not once per process: the attribute is per device and a process may train on several (it costs a table write)
+    bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_backward_lds<D, C, G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    bool ranges = lds_ok && xcd_copies != nullptr;
+    if (ranges) {
+        const char *e = getenv("GFPP_GRID_BWD");                   // A/B: "scatter" = device atomics for the levels beyond the LDS (the round-2 path)
+        if (e && e[0] == 's') ranges = false;
+    }
+    if (ranges) ranges = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_backward_ranges<D, C, G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    if (!lds_ok) (void)hipGetLastError();
+    int rc = 0;
+    if (lds_ok && !ranges) {
+        hipLaunchKernelGGL((k_grid_backward_lds<D, C, G>), dim3(div_up(B, kLdsGradPoints), L), dim3(kTrBlock), (size_t)lds_bytes, st, grad, inputs, offsets,
+                           grad_embeddings, B, L, lv, gridtype, ac, interp, xcd_copies, total_floats);
+        rc = check_launch(who);
+        if (rc) return rc;
+    }
+    if (ranges) {
+        // sum over levels of ceil(size C / F) <= total / F + L: workgroups beyond the actual ranges return at once
+        const uint32_t items = total_floats / kLdsGradFloats + L;
+        hipLaunchKernelGGL((k_grid_backward_ranges<D, C, G>), dim3(items * kRgSlices), dim3(kRgThreads), (size_t)lds_bytes, st, grad, inputs, offsets, B, L, lv,
+                           gridtype, ac, interp, xcd_copies, total_floats);
+    } else {
+        hipLaunchKernelGGL((k_grid_backward<D, C, G>), dim3(div_up(B, kTrBlock), L), dim3(kTrBlock), 0, st, grad, inputs, offsets, grad_embeddings, B, L, lv,
+                           gridtype, ac, interp, lds_ok ? kLdsGradFloats : 0u, xcd_copies, total_floats);
+    }
+    return check_launch(who);
+}
+
+static int grid_backward_impl(const char *who, const void *grad, int grad_dtype, const float *inputs, const int32_t *offsets, float *grad_embeddings,
+                              uint32_t rows_total, float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                              float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
     if (B == 0) return 0;
     if (!grad || !inputs || !offsets || !grad_embeddings || gridtype > 1 || interp > 1 || ((dy_dx == nullptr) != (grad_inputs == nullptr))) {
         set_error("%s: bad arguments (dy_dx and grad_inputs go together)", who);
@@ -558,16 +633,28 @@ static int grid_backward_impl(const char *who, const float *grad, const float *i
     if (tr_levels(lv, L, S, H)) { set_error("%s: 1 <= L <= 32", who); return GFPP_EINVAL; }
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t total_floats = rows_total * C;
-    if (xcd_copies && hipMemsetAsync(xcd_copies, 0, (size_t)kXcds * total_floats * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear the XCD copies", who); return GFPP_EINVAL; }
-    // levels whose table fits kLdsGradFloats go through the LDS-privatised kernel (128 KiB of dynamic LDS); a device that cannot reserve that much
-    // (64 KiB parts) scatters every level directly instead (lds_floats = 0) -- slower, same result
-    bool lds_ok_ = true;
-    GFPP_DISPATCH_LDS(k_grid_backward_lds, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, xcd_copies, total_floats);
-    int rc = check_launch(who);
-    if (rc) return rc;
-    const uint32_t lds_floats = lds_ok_ ? kLdsGradFloats : 0u;
-    GFPP_DISPATCH_DC(k_grid_backward, grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, align_corners != 0, interp, lds_floats, xcd_copies, total_floats);
-    rc = check_launch(who);
+    if (xcd_copies && hipMemsetAsync(xcd_copies, 0, (size_t)kXcds * total_floats * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear the gradient copies", who); return GFPP_EINVAL; }
+    const bool ac = align_corners != 0;
+    int rc;
+    if (grad_dtype == GFPP_F16) {
+        const _Float16 *g = static_cast<const _Float16 *>(grad);
+        if (C != 2 || (D != 2 && D != 3)) { set_error("%s: half gradients are built for level_dim 2, input_dim 2 or 3 (got %u, %u)", who, C, D); return GFPP_EUNSUPPORTED; }
+        rc = D == 2 ? grid_backward_launch<2, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st)
+                    : grid_backward_launch<3, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st);
+    } else {
+        const float *g = static_cast<const float *>(grad);
+#define GFPP_BWD_ONE(DD, CC) rc = grid_backward_launch<DD, CC, float>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st)
+        if (D == 2 && C == 2) GFPP_BWD_ONE(2, 2);
+        else if (D == 3 && C == 2) GFPP_BWD_ONE(3, 2);
+        else if (D == 2 && C == 1) GFPP_BWD_ONE(2, 1);
+        else if (D == 3 && C == 1) GFPP_BWD_ONE(3, 1);
+        else if (D == 2 && C == 4) GFPP_BWD_ONE(2, 4);
+        else if (D == 3 && C == 4) GFPP_BWD_ONE(3, 4);
+        else if (D == 2 && C == 8) GFPP_BWD_ONE(2, 8);
+        else if (D == 3 && C == 8) GFPP_BWD_ONE(3, 8);
+        else { set_error("grid encoder (training): input_dim must be 2 or 3 and level_dim 1, 2, 4 or 8 (got %u, %u)", D, C); return GFPP_EUNSUPPORTED; }
+#undef GFPP_BWD_ONE
+    }
     if (rc) return rc;
     if (xcd_copies) {
         hipLaunchKernelGGL(k_grid_reduce_xcd, dim3(div_up(total_floats, kTrBlock)), dim3(kTrBlock), 0, st, xcd_copies, grad_embeddings, total_floats);
@@ -575,15 +662,24 @@ static int grid_backward_impl(const char *who, const float *grad, const float *i
         if (rc) return rc;
     }
     if (!dy_dx) return 0;
-    hipLaunchKernelGGL(k_grid_input_backward, dim3(div_up(B * D, kTrBlock)), dim3(kTrBlock), 0, st, grad, dy_dx, grad_inputs, B, D, C, L);
+    if (grad_dtype == GFPP_F16) hipLaunchKernelGGL(k_grid_input_backward<_Float16>, dim3(div_up(B * D, kTrBlock)), dim3(kTrBlock), 0, st, static_cast<const _Float16 *>(grad), dy_dx, grad_inputs, B, D, C, L);
+    else hipLaunchKernelGGL(k_grid_input_backward<float>, dim3(div_up(B * D, kTrBlock)), dim3(kTrBlock), 0, st, static_cast<const float *>(grad), dy_dx, grad_inputs, B, D, C, L);
     return check_launch(who);
+}
+
+GFPP_API int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
+                                           float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+    if (!xcd_copies || rows_total == 0) { set_error("gfpp_grid_encode_backward_f16: needs the [8, rows_total * C] fp32 scratch"); return GFPP_EINVAL; }
+    return grid_backward_impl("gfpp_grid_encode_backward_f16", grad, GFPP_F16, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx,
+                              grad_inputs, gridtype, align_corners, interp, stream);
 }
 
 GFPP_API int gfpp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, float *grad_embeddings, uint32_t B,
                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                                        int align_corners, uint32_t interp, gfpp_stream_t stream) {
     (void)embeddings;
-    return grid_backward_impl("gfpp_grid_encode_backward", grad, inputs, offsets, grad_embeddings, 0, nullptr, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+    return grid_backward_impl("gfpp_grid_encode_backward", grad, GFPP_F32, inputs, offsets, grad_embeddings, 0, nullptr, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
                               align_corners, interp, stream);
 }
 
@@ -591,7 +687,7 @@ GFPP_API int gfpp_grid_encode_backward_xcd(const float *grad, const float *input
                                            float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
                                            float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
     if (!xcd_copies || rows_total == 0) { set_error("gfpp_grid_encode_backward_xcd: needs the [8, rows_total * C] scratch"); return GFPP_EINVAL; }
-    return grid_backward_impl("gfpp_grid_encode_backward_xcd", grad, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx, grad_inputs,
+    return grid_backward_impl("gfpp_grid_encode_backward_xcd", grad, GFPP_F32, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx, grad_inputs,
                               gridtype, align_corners, interp, stream);
 }
 

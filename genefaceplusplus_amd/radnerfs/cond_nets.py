@@ -8,8 +8,13 @@ These nets see a [smo_win, 1, 204] window once per frame (~0.1 MFLOP): they stay
 per-sample MLPs (ambient / sigma / colour / torso) are evaluated by the fused HIP kernels, which read the weights out of
 the MLP containers below; ``MLP.forward`` (plain torch GEMMs) is kept for the stand-alone ``forward()/density()`` API.
 """
+import ctypes
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import _lib
 
 _SLOPE = 0.02
 # window length -> strides of the four k=3 convolutions (the table of cond_encoder.py:103-114, whose `== [5, 8]` branch
@@ -57,6 +62,42 @@ class AudioAttNet(nn.Module):
         return (w * x).sum(dim=0)
 
 
+_lib.register("gfpp_linear_weight_grad", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p])
+#: rows from which a training-mode Linear layer takes the split-M weight-gradient kernel (below, the BLAS call is fine)
+WGRAD_MIN_ROWS = 8192
+
+
+class _LinearNoBias(torch.autograd.Function):
+    """y = x W^T for the per-sample MLPs in training (cond_encoder.py:183-202).  Forward and the input gradient are plain GEMMs ([M, I] x [I, O]
+    shapes the BLAS handles well); the weight gradient dW = dY^T X -- an O x I output with a reduction over the step's ~3 x 10^5 samples, 27-46 % of a
+    training step through the BLAS heuristics -- is gfpp_linear_weight_grad.  Under autocast the operands are cast to half like F.linear's are."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        if torch.is_autocast_enabled():
+            x, w = x.to(torch.float16), weight.to(torch.float16)
+        else:
+            x, w = x.float(), weight.float()
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.to(x.dtype).contiguous()
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            M, O, I = x.shape[0], w.shape[0], w.shape[1]
+            gw = torch.empty(O, I, dtype=torch.float32, device=x.device)
+            partial = torch.empty(512, O, I, dtype=torch.float32, device=x.device)
+            _lib.call("gfpp_linear_weight_grad", gy.data_ptr(), x.data_ptr(), M, O, I, 1 if x.dtype == torch.float16 else 0, partial.data_ptr(), gw.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        return gx, gw
+
+
 class MLP(nn.Module):
     """num_layers bias-free Linear layers, ReLU between them."""
 
@@ -68,8 +109,11 @@ class MLP(nn.Module):
 
     def forward(self, x):
         last = self.num_layers - 1
+        # training batches (a step's samples x features): the layers' weight gradients through the split-M kernel
+        own = (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and max(l.out_features for l in self.net) <= 256
+               and max(l.in_features for l in self.net) <= 160 and x.dtype in (torch.float32, torch.float16))
         for i, layer in enumerate(self.net):
-            x = layer(x)
+            x = _LinearNoBias.apply(x, layer.weight) if own and layer.weight.requires_grad else layer(x)
             if i != last:
                 x = F.relu(x, inplace=True)
         return x

@@ -569,9 +569,33 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                               int align_corners, uint32_t interp, gfpp_stream_t stream);
 
-/* The same gradient (gridencoder.cu:247-368) with XCD-private accumulation (no reference counterpart: MI355X has eight L2s): `xcd_copies` is caller-provided scratch of
- * 8 x rows_total x C floats (cleared by the call); every workgroup scatters into the copy of the XCD it runs on, so a gradient line stays in one L2
- * instead of migrating between eight, and the copies are summed into grad_embeddings (+=) at the end.  rows_total = embeddings.shape[0]. */
+/* Weight gradient of a bias-free Linear layer over a training batch: grad_weight [O, I] fp32 = grad_out^T [O, M] x input [M, I] -- what autograd's
+ * backward of the reference's `MLP` layers (cond_encoder.py:183-202: nn.Linear(..., bias=False), used for ambient_net / sigma_net / color_net,
+ * radnerf.py:60-100) computes with a BLAS call per layer.  M = the samples of the step: the output is small and the reduction very long, so the M
+ * rows are cut into <= 512 slices, one workgroup each with the whole O x I output in MFMA accumulators (fp32 accumulation; dtype GFPP_F16: half
+ * operands as under `amp: true`, GFPP_F32: exact-fp32 MFMA), and the slices are summed.  partial: scratch [512, O, I] fp32.  O <= 256, I <= 160
+ * (GFPP_EUNSUPPORTED beyond: the caller keeps its BLAS call).  grad_weight is overwritten.  grad_out and input: 16-byte aligned, read as 16-byte vectors
+ * up to the vector that holds their last element (i.e. at most 15 bytes past the end: inside any allocator's granule). */
+int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
+                            gfpp_stream_t stream);
+
+/* grid_encode_backward with a HALF grad (gridencoder.h:13; gridencoder.cu:247-368 instantiated for at::Half -- what `amp: true`, the reference's training
+ * configuration egs/datasets/May/lm3d_radnerf.yaml:5, runs: grid.py:43-44 casts the table to half, so features and their gradient are half).  grad:
+ * [L,B,2] half.  Accumulation is fp32 (the reference adds __half2 atomics into a half gradient, gridencoder.cu:306-318, which autograd then casts to the
+ * fp32 parameter; here the fp32 gradient comes out directly): same kernels and scratch as gfpp_grid_encode_backward_xcd, which see below.  dy_dx (fp32,
+ * gfpp_grid_encode_dydx) and grad_inputs [B,D] fp32 go together.  level_dim 2 only (GFPP_EUNSUPPORTED otherwise; the reference forces fp32 for odd
+ * level_dim too). */
+int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
+                                  float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
+
+/* The same gradient (gridencoder.cu:247-368) without a device atomic per corner (no reference counterpart).  `xcd_copies` is caller-provided scratch of
+ * 8 x rows_total x C floats (cleared by the call): eight private copies of the table gradient that are summed into grad_embeddings (+=) at the end.
+ * Levels whose table fits 128 KiB of LDS: a workgroup per 8 192 points accumulates in LDS and adds the touched values into the copy of the XCD it runs
+ * on (MI355X has eight L2s: a line then stays in one of them).  Larger levels (since round 3): a workgroup owns one 32 768-value RANGE of a level's table
+ * and one eighth of the points; it recomputes the corners of its points, adds those that fall into its range into LDS accumulators and stores the range
+ * into the eighth's copy -- a 2^16-row level is located four times, which is ~20x cheaper than the 67 M device atomics of a May grid were (4.6 ms per
+ * call, 45 % of a training step in round 2).  rows_total = embeddings.shape[0]. */
 int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
                                   float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);

@@ -132,6 +132,79 @@ def test_grid_encoder_gradients(dev, oracle_mod, D, gridtype, interp):
     assert np.abs(delta - tv_ref).max() <= 2e-5 * np.abs(tv_ref).max() + 5e-7 * float(before.abs().max())
 
 
+@pytest.mark.parametrize("D,gridtype", [(3, "tiled"), (2, "tiled"), (3, "hash")])
+def test_grid_encoder_gradients_under_autocast_use_the_half_kernels(dev, oracle_mod, D, gridtype):
+    """The reference's training configuration (`amp: true`): under autocast the lookup runs on a half copy of the table and the table gradient is
+    accumulated with packed half atomics (grid.py:41-44, gridencoder.cu:306-318).  Here: half features out, a half grad in, fp32 accumulation and an fp32
+    parameter gradient out, equal to the oracle's fp32 gradient of the half-rounded problem up to summation order."""
+    from genefaceplusplus_amd.radnerfs.encoders import GridEncoder
+    rng = np.random.default_rng(16)
+    enc = GridEncoder(input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=14, desired_resolution=512, gridtype=gridtype).to(dev)
+    E = rng.standard_normal(tuple(enc.embeddings.shape)).astype(np.float16).astype(f32)      # a table that is exact in half
+    with torch.no_grad():
+        enc.embeddings.copy_(_t(E, dev))
+    B = 6000
+    x = rng.uniform(-1, 1, (B, D)).astype(f32)
+    off = enc.offsets.cpu().numpy()
+    xt = _t(x, dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = enc(xt, bound=1)
+    assert y.dtype == torch.float16
+    u = ((x + f32(1)) / f32(2)).astype(f32)
+    fwd = oracle_mod.grid_encode_levels(u, E, off, enc.per_level_scale, 16, gridtype, False, "linear")
+    ref_y = np.ascontiguousarray(fwd.transpose(1, 0, 2)).reshape(B, 32)
+    assert np.abs(y.detach().float().cpu().numpy() - ref_y).max() <= 4e-3 * np.abs(ref_y).max()        # the reference's own half-accumulation bar (ref_kernel_cases.py)
+    g = (rng.standard_normal((B, 32)) * 1e-2).astype(np.float16)
+    y.backward(torch.from_numpy(g).to(dev))
+    grad_lbc = np.ascontiguousarray(g.astype(f32).reshape(B, 16, 2).transpose(1, 0, 2))
+    dy = oracle_mod.grid_encode_dydx(u, E, off, enc.per_level_scale, 16, gridtype, False, "linear")
+    ge, gi = oracle_mod.grid_encode_backward(grad_lbc, u, E, off, enc.per_level_scale, 16, gridtype, False, "linear", dy_dx=dy)
+    got_e = enc.embeddings.grad
+    assert got_e.dtype == torch.float32
+    got_e = got_e.cpu().numpy()
+    scale = np.abs(ge).max()
+    err = np.abs(got_e - ge)
+    assert err.max() <= 2e-5 * scale + 1e-7, (float(err.max() / scale), float(err.mean() / scale))      # fp32 accumulation: the fp32 path's bar
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), 0.5 * gi, rtol=2e-3, atol=2e-3 * np.abs(gi).max())
+    # the fp32 path is untouched by autocast being off
+    enc.embeddings.grad = None
+    y32 = enc(_t(x, dev), bound=1)
+    assert y32.dtype == torch.float32
+    np.testing.assert_array_equal(y32.detach().cpu().numpy(), ref_y)
+
+
+@pytest.mark.parametrize("dims,M", [((96, 3, 128, 3), 10007), ((64, 129, 128, 3), 8192), ((148, 3, 128, 2), 33000)])
+@pytest.mark.parametrize("amp", [False, True])
+def test_mlp_weight_gradients_through_the_split_m_kernel(dev, dims, M, amp):
+    """gfpp_linear_weight_grad (dW = dY^T X with the step's samples as the reduction, split over workgroups, MFMA accumulators) inside the training-mode
+    MLP against the same MLP through torch's own Linear backward: the May layer shapes incl. the ragged ones (3, 129 outputs; 96, 148 inputs) and a row
+    count that is no multiple of the chunk.  fp32: exact-fp32 MFMA, another summation order; autocast: half operands, fp32 accumulation."""
+    from genefaceplusplus_amd.radnerfs import cond_nets
+    torch.manual_seed(3)
+    ref = cond_nets.MLP(*dims).to(dev)
+    own = cond_nets.MLP(*dims).to(dev)
+    own.load_state_dict(ref.state_dict())
+    x = torch.randn(M, dims[0], device=dev)
+    gy = torch.randn(M, dims[1], device=dev) * 1e-2
+    outs = {}
+    for name, net, rows in (("ref", ref, 1 << 30), ("own", own, 1024)):
+        cond_nets.WGRAD_MIN_ROWS = rows
+        try:
+            xin = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                y = net(xin)
+            y.backward(gy.to(y.dtype))
+        finally:
+            cond_nets.WGRAD_MIN_ROWS = 8192
+        outs[name] = (y.detach().float(), xin.grad.float(), [l.weight.grad.float() for l in net.net])
+    tol = 2e-2 if amp else 2e-5
+    for a, b in zip(outs["ref"][2], outs["own"][2]):
+        assert b.dtype == torch.float32 and torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-7, (float((a - b).abs().max()), float(a.abs().max()))
+    assert float((outs["ref"][0] - outs["own"][0]).abs().max()) <= tol * float(outs["ref"][0].abs().max())
+    assert float((outs["ref"][1] - outs["own"][1]).abs().max()) <= tol * float(outs["ref"][1].abs().max()) + 1e-7
+
+
 def test_dilation_and_sph(dev, oracle_mod):
     from genefaceplusplus_amd.radnerfs import raymarching as rm
     rng = np.random.default_rng(7)
@@ -268,6 +341,52 @@ def test_training_render_gradients_and_descent(dev, oracle_mod):
         opt.step()
         first = float(loss.detach()) if first is None else first
     assert float(loss_fn().detach()) < 0.9 * first
+
+
+def test_training_step_under_autocast_follows_the_fp32_step(dev, oracle_mod):
+    """One training-mode render + backward under torch.autocast(fp16) with a GradScaler (the reference's `amp: true` step, utils/commons/trainer.py): finite
+    gradients on every tensor, the loss within fp16 distance of the fp32 step's, the table gradients aligned with the fp32 ones, and Adam steps descend."""
+    orc = oracle_mod
+    case = _train_case(32)
+    HW = case["HW"]
+    r = orc.get_rays(case["pose"], case["intr"], HW, HW)
+    ro, rd = torch.from_numpy(r["rays_o"]).to(dev), torch.from_numpy(r["rays_d"]).to(dev)
+    torch.manual_seed(0)
+    target = torch.rand(1, HW * HW, 3, device=dev)
+    grads, losses = {}, {}
+    for amp in (False, True):
+        model = _train_model(case, dev)
+        scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=1024.0)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = _train_render(model, case, dev, ro, rd)
+            loss = ((out["rgb_map"].float() - target) ** 2).mean() + 1e-3 * out["ambient"].float().mean()
+        scaler.scale(loss).backward()
+        inv = 1.0 / (1024.0 if amp else 1.0)
+        grads[amp] = {n: p.grad.detach().float() * inv for n, p in model.named_parameters() if p.grad is not None}
+        losses[amp] = float(loss.detach())
+        for n, g in grads[amp].items():
+            assert torch.isfinite(g).all(), n
+    assert abs(losses[True] - losses[False]) <= 2e-2 * abs(losses[False])
+    for name in ("position_embedder.embeddings", "ambient_embedder.embeddings", "sigma_net.net.0.weight", "color_net.net.0.weight"):
+        a, b = grads[True][name].reshape(-1), grads[False][name].reshape(-1)
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        # (the fine levels of the tables hold single contributions of ~1e-7 x the loss scale: half rounding of those is what the cosine sees)
+        assert cos >= (0.95 if "embeddings" in name else 0.98), (name, cos)
+    model = _train_model(case, dev)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    scaler = torch.amp.GradScaler("cuda")
+    first = last = None
+    for it in range(12):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = _train_render(model, case, dev, ro, rd)
+            loss = ((out["rgb_map"].float() - target) ** 2).mean() + 1e-3 * out["ambient"].float().mean()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        first = float(loss.detach()) if first is None else first
+        last = float(loss.detach())
+    assert last < 0.9 * first
 
 
 def test_update_extra_state_and_mark_untrained(dev, oracle_mod):
