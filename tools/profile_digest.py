@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def demangle(name):
     if name.startswith("_Z"):
         try:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
+            name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
         except OSError:
             pass
     if name.startswith("_ZN4gfpp"):   # llvm-cxxfilt of ROCm 7.2 does not know the _Float16 / __bf16 manglings (DF16_, DF16b)

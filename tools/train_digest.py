@@ -14,11 +14,11 @@ tot = sum(int(r["TotalDurationNs"]) for r in rows)
 
 def name(n):
     if n.startswith("_Z"):
-        try:
-            n = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip() or n
+        try:        # (c++filt does not know the _Float16 mangling DF16_: hand it the IEEE-half code Dh)
+            n = subprocess.run(["c++filt", n.replace("DF16_", "Dh")], capture_output=True, text=True).stdout.strip() or n
         except OSError:
             pass
-    n = n.replace("DF16_", "_Float16")
+    n = n.replace("__fp16", "_Float16").replace("half", "_Float16") if "gfpp::" in n else n
     return n if len(n) < 100 else n[:97] + "..."
 
 
