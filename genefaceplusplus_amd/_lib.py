@@ -42,6 +42,7 @@ _SIGNATURES = {
     "gfpp_grid_encode_dydx": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_u32, c_p],
     "gfpp_grid_encode_backward": [c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
     "gfpp_grid_encode_backward_xcd": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
+    "gfpp_grid_encode_input_backward": [c_p, c_i, c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_u32, c_p],
     "gfpp_grid_encode_backward_f16": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
     "gfpp_grad_total_variation": [c_p, c_p, c_p, c_p, c_f, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_p],
     "gfpp_get_rays": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_p],

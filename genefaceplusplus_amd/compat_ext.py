@@ -94,7 +94,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
             # level_dim 2: the half grad goes into the kernels as it is (fp32 accumulation; gridencoder.cu:306-318 accumulates in half); the fp32
             # result is cast into the caller's half tensors
             rows = int(embeddings.shape[0])
-            copies = torch.empty(8, rows * 2, device=grad_embeddings.device, dtype=torch.float32)
+            copies = torch.empty(8 * rows * 2 + 64, device=grad_embeddings.device, dtype=torch.float32)
             dy32 = dy_dx.float().contiguous() if dy_dx is not None else None
             call("gfpp_grid_encode_backward_f16", _p(grad.contiguous()), _p(inputs), _p(offsets), _p(ge32), rows, _p(copies), int(B), int(D), 2, int(L), float(S),
                  int(H), _p(dy32), _p(gi32), int(gridtype), int(bool(align_corners)), int(interp), _st())
@@ -107,7 +107,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
             grad_inputs.add_(gi32.to(grad_inputs.dtype))
         return
     rows = int(embeddings.shape[0])
-    copies = torch.empty(8, rows * int(C), device=grad_embeddings.device, dtype=torch.float32)       # XCD-private accumulation, see gfpp_grid_encode_backward_xcd
+    copies = torch.empty(8 * rows * int(C) + 64, device=grad_embeddings.device, dtype=torch.float32)       # gradient copies + level maxima, see gfpp_grid_encode_backward_xcd
     call("gfpp_grid_encode_backward_xcd", _p(grad), _p(inputs), _p(offsets), _p(grad_embeddings), rows, _p(copies), int(B), int(D), int(C), int(L), float(S), int(H),
          _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st())
 

@@ -362,19 +362,48 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const G *__restr
 
 // ---- every level without device atomics: range passes -------------------------------------------------------------------------------------------------
 // The direct scatter above is bound by the device's atomic rate (measured 14.6 G float atomics/s with XCD-private copies: 4.6 ms for the 67 M atomics
-// of one May grid, 45 % of a training step).  Here a workgroup owns ONE range of <= kLdsGradFloats table values of one level and one eighth of the
-// points: it walks its points, recomputes the corners (cheap: ~200 instructions per point and level) and adds the ones that fall into its range into
-// LDS accumulators (ds_add_f32); the range then leaves as plain coalesced stores into the slice's private copy of the gradient (the `xcd_copies`
-// scratch: slice s owns copy s; k_grid_reduce_xcd sums the copies).  A 2^16-row level is four ranges, i.e. its corners are located four times --
-// ~20x cheaper than an atomic each.  grad: fp32 or half ([L, B, C]); accumulation fp32 either way.
+// of one May grid, 45 % of a training step).  Here a workgroup owns ONE range of a level's table and one eighth of the points: it walks its points,
+// recomputes the corners (cheap: ~200 instructions per point and level) and adds the ones that fall into its range into LDS accumulators; the range
+// then leaves as plain coalesced stores into the slice's private copy of the gradient (the `xcd_copies` scratch: slice s owns copy s;
+// k_grid_reduce_xcd sums the copies).  A 2^16-row level is eight ranges, i.e. its corners are located eight times -- still ~10x cheaper than an atomic
+// each.  grad: fp32 or half ([L, B, C]).
+//
+// The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 turned out to run at ~1 lane per 5 cycles on gfx950 (the range kernel took 877 us with float
+// LDS atomics, 167 us with the adds replaced by plain stores, 177 us with ds_add_u64), integer LDS atomics at full rate.  A level's values are scaled by
+// 2^(40 - e) with 2^e > max |grad| of that level (k_grid_grad_levelmax), so one contribution is below 2^40 and 4 M of them fit; what is kept of a
+// contribution reaches 40 bits below the level's largest gradient (fp32 keeps 24 bits below each value; the reference's half accumulators under amp 11,
+// and nothing below 6e-8).  A non-finite gradient anywhere in the level makes the whole level NaN, so that a GradScaler still sees the overflow.
+#ifndef GFPP_RG_ABLATE
+#define GFPP_RG_ABLATE 0
+#endif
 constexpr uint32_t kRgThreads = 1024;
 constexpr uint32_t kRgSlices = kXcds;          // point slices = gradient copies
+constexpr uint32_t kRgValues = kLdsGradFloats * sizeof(float) / sizeof(long long);   // accumulators of one range (16 384)
+
+// max |grad| per level as float bits (non-negative floats order like unsigned integers; NaN bit patterns are above +inf's): out[level], zeroed before
+template <typename G>
+__global__ __launch_bounds__(kTrBlock) void k_grid_grad_levelmax(const G *__restrict__ grad, uint32_t per_level, uint32_t *__restrict__ out) {
+    const uint32_t level = blockIdx.y;
+    const G *g = grad + (size_t)level * per_level;
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * kTrBlock + threadIdx.x; i < per_level; i += gridDim.x * kTrBlock) {
+        const uint32_t bits = __float_as_uint(fabsf((float)g[i]));
+        m = bits > m ? bits : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&out[level], m);
+}
 
 template <int D, int C, typename G>
 __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
                                                                      uint32_t B, uint32_t L, TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
-                                                                     float *__restrict__ copies, uint32_t total_floats) {
-    extern __shared__ float acc[];
+                                                                     float *__restrict__ copies, uint32_t total_floats, const uint32_t *__restrict__ levelmax) {
+    extern __shared__ long long rg_acc[];
+    long long *acc = rg_acc;
     uint32_t item = blockIdx.x / kRgSlices;
     const uint32_t slice = blockIdx.x % kRgSlices;
     uint32_t level = 0, range = 0, off = 0, size = 0;
@@ -382,45 +411,58 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     for (; level < L; ++level) {                                   // (scalar loop: <= 32 levels)
         off = (uint32_t)offsets[level];
         size = (uint32_t)offsets[level + 1] - off;
-        const uint32_t n = size * C;
-        const uint32_t nr = (n + kLdsGradFloats - 1u) / kLdsGradFloats;   // (a level that fits the LDS is one range)
+        const uint32_t nr = (size * C + kRgValues - 1u) / kRgValues;
         if (item < nr) { range = item; found = true; break; }
         item -= nr;
     }
     if (!found) return;                                            // the grid is sized by an upper bound of the ranges
-    const uint32_t rows_per = kLdsGradFloats / C, row0 = range * rows_per;
+    const uint32_t rows_per = kRgValues / C, row0 = range * rows_per;
     const uint32_t nrows = size - row0 < rows_per ? size - row0 : rows_per, n = nrows * C;
-    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) acc[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) acc[i] = 0ll;
     __syncthreads();
+    // fixed-point scale of this level: contributions |w g| <= max |g| < 2^e  ->  |w g| 2^(40 - e) < 2^40
+    const uint32_t maxbits = levelmax[level];
+    const bool finite = maxbits < 0x7F800000u;
+    const int e = maxbits ? (int)(maxbits >> 23) - 126 : 0;          // 2^e > max |g| (denormal maxima: e = -126, still an upper bound)
+    const float to_fixed_a = ldexpf(1.0f, 20 - (e > 100 ? 100 : e)), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
     const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
-    for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
-        float pos[D], deriv[D];
-        uint32_t pg[D];
-        if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
-        float gc[C];
+    if (finite) {
+        for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
+            float pos[D], deriv[D];
+            uint32_t pg[D];
+            if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
+            float gc[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c];
+            for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c] * to_fixed_a;
 #pragma unroll
-        for (int idx = 0; idx < (1 << D); ++idx) {
-            float w = 1.0f;
-            uint32_t pl[D];
+            for (int idx = 0; idx < (1 << D); ++idx) {
+                float w = to_fixed_b;
+                uint32_t pl[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if ((idx & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                else { w *= pos[d]; pl[d] = pg[d] + 1u; }
-            }
-            const uint32_t r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;   // (wraps for rows below the range)
-            if (r < nrows) {
+                for (int d = 0; d < D; ++d) {
+                    if ((idx & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+                }
+                const uint32_t r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;   // (wraps for rows below the range)
+                if (r < nrows) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) atomicAdd(&acc[r * C + c], w * gc[c]);
+                    for (int c = 0; c < C; ++c) {
+#if GFPP_RG_ABLATE == 1     // experiment builds (wrong results): plain LDS stores instead of atomics
+                        acc[r * C + c] = (long long)(w * gc[c]);
+#else
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[r * C + c]), (unsigned long long)__float2ll_rn(w * gc[c]));
+#endif
+                    }
+                }
             }
         }
     }
     __syncthreads();
     float *dst = copies + (size_t)slice * total_floats + (size_t)(off + row0) * C;
-    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) dst[i] = acc[i];
+    const float back_a = ldexpf(1.0f, (e > 100 ? 100 : e) - 20), back_b = 1.0f / 1048576.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) dst[i] = finite ? ((float)acc[i] * back_b) * back_a : __uint_as_float(0x7FC00000u);
 }
 
 // input gradient from dy_dx (gridencoder.cu:342-368)
@@ -435,6 +477,64 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_input_backward(const G *__res
     for (uint32_t l = 0; l < L; ++l)
         for (uint32_t c = 0; c < C; ++c) r = fmaf((float)grad[((size_t)l * B + b) * C + c], dd[(l * D + d) * C + c], r);
     grad_inputs[t] = r;
+}
+
+// The input gradient WITHOUT a materialised dy_dx (gridencoder.cu:198-243 + 342-368 in one pass): dL/dx[b, d] = sum over levels and channels of
+// grad[l, b, c] * d feature[l, b, c] / d x[d].  The reference writes dy_dx [B, L, D, C] in the forward pass (116 MB for a May step's ambient grid) and
+// reads it back here; the derivative along every axis is a pairing of the SAME 2^D corner values the forward pass interpolates, so one thread per point
+// walks the levels, gathers the corners once per level and keeps the D sums in registers.
+template <int D, int C, typename G>
+__global__ __launch_bounds__(kTrBlock) void k_grid_input_grad(const G *__restrict__ grad, const float *__restrict__ inputs, const float *__restrict__ table,
+                                                             const int32_t *__restrict__ offsets, float *__restrict__ grad_inputs, uint32_t B, uint32_t L, TrLevels lv,
+                                                             uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * kTrBlock + threadIdx.x;
+    if (b >= B) return;
+    float sum[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) sum[d] = 0.0f;
+    for (uint32_t level = 0; level < L; ++level) {
+        float pos[D], deriv[D];
+        uint32_t pg[D];
+        const float scale = lv.scale[level];
+        if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) break;   // out of range at one level = at every level
+        const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+        const float *grid = table + (size_t)off * C;
+        float v[1 << D][C];
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); ++idx) {
+            uint32_t pl[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) pl[d] = pg[d] + ((idx >> d) & 1u);
+            const uint32_t row = grid_row<D>(pl, gridtype, align_corners, size, res);
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[idx][c] = grid[(size_t)row * C + c];
+        }
+        float gc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c];
+#pragma unroll
+        for (int gd = 0; gd < D; ++gd) {
+            float rg[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) rg[c] = 0.0f;
+#pragma unroll
+            for (int idx = 0; idx < (1 << D); ++idx) {
+                if (idx & (1 << gd)) continue;                     // the pair (idx, idx | 1 << gd): left and right neighbour along gd
+                float w = scale;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (d == gd) continue;
+                    w *= (idx & (1 << d)) ? pos[d] : 1.0f - pos[d];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) rg[c] = fmaf(w * (v[idx | (1 << gd)][c] - v[idx][c]), deriv[gd], rg[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) sum[gd] = fmaf(gc[c], rg[c], sum[gd]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) grad_inputs[(size_t)b * D + d] = sum[d];
 }
 
 // total-variation gradient (gridencoder.cu:505-597)
@@ -610,10 +710,16 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
         if (rc) return rc;
     }
     if (ranges) {
-        // sum over levels of ceil(size C / F) <= total / F + L: workgroups beyond the actual ranges return at once
-        const uint32_t items = total_floats / kLdsGradFloats + L;
+        // per-level max |grad| -> the levels' fixed-point scales (kept behind the eight copies: the scratch has 64 spare words)
+        uint32_t *levelmax = reinterpret_cast<uint32_t *>(xcd_copies + (size_t)kXcds * total_floats);
+        if (hipMemsetAsync(levelmax, 0, 64 * sizeof(uint32_t), st) != hipSuccess) { set_error("%s: cannot clear the level maxima", who); return GFPP_EINVAL; }
+        hipLaunchKernelGGL((k_grid_grad_levelmax<G>), dim3(64, L), dim3(kTrBlock), 0, st, grad, B * (uint32_t)C, levelmax);
+        rc = check_launch(who);
+        if (rc) return rc;
+        // sum over levels of ceil(size C / V) <= total / V + L: workgroups beyond the actual ranges return at once
+        const uint32_t items = total_floats / kRgValues + L;
         hipLaunchKernelGGL((k_grid_backward_ranges<D, C, G>), dim3(items * kRgSlices), dim3(kRgThreads), (size_t)lds_bytes, st, grad, inputs, offsets, B, L, lv,
-                           gridtype, ac, interp, xcd_copies, total_floats);
+                           gridtype, ac, interp, xcd_copies, total_floats, levelmax);
     } else {
         hipLaunchKernelGGL((k_grid_backward<D, C, G>), dim3(div_up(B, kTrBlock), L), dim3(kTrBlock), 0, st, grad, inputs, offsets, grad_embeddings, B, L, lv,
                            gridtype, ac, interp, lds_ok ? kLdsGradFloats : 0u, xcd_copies, total_floats);
@@ -689,6 +795,31 @@ GFPP_API int gfpp_grid_encode_backward_xcd(const float *grad, const float *input
     if (!xcd_copies || rows_total == 0) { set_error("gfpp_grid_encode_backward_xcd: needs the [8, rows_total * C] scratch"); return GFPP_EINVAL; }
     return grid_backward_impl("gfpp_grid_encode_backward_xcd", grad, GFPP_F32, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx, grad_inputs,
                               gridtype, align_corners, interp, stream);
+}
+
+GFPP_API int gfpp_grid_encode_input_backward(const void *grad, int grad_dtype, const float *inputs, const float *embeddings, const int32_t *offsets,
+                                             float *grad_inputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                             int align_corners, uint32_t interp, gfpp_stream_t stream) {
+    const char *who = "gfpp_grid_encode_input_backward";
+    if (B == 0) return 0;
+    if (!grad || !inputs || !embeddings || !offsets || !grad_inputs || gridtype > 1 || interp > 1) { set_error("%s: bad arguments", who); return GFPP_EINVAL; }
+    if (grad_dtype != GFPP_F32 && grad_dtype != GFPP_F16) { set_error("%s: grad must be fp32 or half", who); return GFPP_EUNSUPPORTED; }
+    if (C != 2 || (D != 2 && D != 3)) { set_error("%s: built for level_dim 2, input_dim 2 or 3 (got %u, %u): use dy_dx + gfpp_grid_encode_backward", who, C, D); return GFPP_EUNSUPPORTED; }
+    TrLevels lv;
+    if (tr_levels(lv, L, S, H)) { set_error("%s: 1 <= L <= 32", who); return GFPP_EINVAL; }
+    const hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(div_up(B, kTrBlock)), block(kTrBlock);
+    const bool ac = align_corners != 0;
+    if (grad_dtype == GFPP_F16) {
+        const _Float16 *g = static_cast<const _Float16 *>(grad);
+        if (D == 2) hipLaunchKernelGGL((k_grid_input_grad<2, 2, _Float16>), grid, block, 0, st, g, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, interp);
+        else hipLaunchKernelGGL((k_grid_input_grad<3, 2, _Float16>), grid, block, 0, st, g, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, interp);
+    } else {
+        const float *g = static_cast<const float *>(grad);
+        if (D == 2) hipLaunchKernelGGL((k_grid_input_grad<2, 2, float>), grid, block, 0, st, g, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, interp);
+        else hipLaunchKernelGGL((k_grid_input_grad<3, 2, float>), grid, block, 0, st, g, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, interp);
+    }
+    return check_launch(who);
 }
 
 GFPP_API int gfpp_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t D,

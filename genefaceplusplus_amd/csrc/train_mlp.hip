@@ -93,26 +93,38 @@ __global__ __launch_bounds__(kWgThreads) void k_linear_wgrad(WgArgs a) {
         }
         const uint32_t shy = (uint32_t)((((size_t)m0 * a.O * sizeof(G)) & 15u) / sizeof(G)), shx = (uint32_t)((((size_t)m0 * a.I * sizeof(G)) & 15u) / sizeof(G));
         const uint32_t valid = a.M - m0 < (uint32_t)R ? a.M - m0 : (uint32_t)R;      // rows of this chunk that exist
+        // a fragment = this lane's column of the operand at 8 consecutive rows: unconditional LDS reads (a column beyond the matrix reads column 0 and
+        // is zeroed afterwards; rows beyond M exist only in the job's last chunk, which takes the per-element path)
+        auto fragment = [&](const G *sm, uint32_t shift, uint32_t C, uint32_t col, uint32_t row) {
+            const bool col_ok = col < C;
+            const G *p = sm + shift + row * C + (col_ok ? col : 0u);
+            vec f;
+            if (valid == (uint32_t)R) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = p[e * C];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = row + e < valid;
+                    const G v = p[ok ? e * C : 0u];
+                    f[e] = ok ? v : (G)0.0f;
+                }
+            }
+            if (!col_ok) f = (vec)(G)0.0f;
+            return f;
+        };
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const uint32_t row = (uint32_t)(16 * s + 8 * h);
             vec B[kWgMaxTI];
 #pragma unroll
-            for (int t = 0; t < kWgMaxTI; ++t) {
-                if ((uint32_t)t < a.TI) {
-                    const uint32_t col = 32u * t + (uint32_t)i;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) B[t][e] = (col < a.I && row + e < valid) ? sx[shx + (row + e) * a.I + col] : (G)0.0f;
-                }
-            }
+            for (int t = 0; t < kWgMaxTI; ++t)
+                if ((uint32_t)t < a.TI) B[t] = fragment(sx, shx, a.I, 32u * t + (uint32_t)i, row);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const uint32_t to = (uint32_t)wave + 4u * k;
                 if (to < a.TO) {                                   // wavefront-uniform
-                    const uint32_t col = 32u * to + (uint32_t)i;
-                    vec A;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) A[e] = (col < a.O && row + e < valid) ? sy[shy + (row + e) * a.O + col] : (G)0.0f;
+                    const vec A = fragment(sy, shy, a.O, 32u * to + (uint32_t)i, row);
 #pragma unroll
                     for (int t = 0; t < kWgMaxTI; ++t)
                         if ((uint32_t)t < a.TI) acc[k][t] = LpTraits<G>::mfma(A, B[t], acc[k][t]);

@@ -43,12 +43,13 @@ def grid_encode_raw(inputs01, embeddings, offsets, per_level_scale, base_resolut
 
 class _GridEncodeFn(torch.autograd.Function):
     """Differentiable lookup (reference: _grid_encode, grid.py:24-94): gradients w.r.t. the table always, w.r.t. the inputs when they
-    require grad (then the forward also produces dy_dx).
+    require grad.  The reference's forward then also writes dy_dx [B, L*D*C] for the backward pass; with level_dim 2 the derivative is recomputed
+    from the table there instead (gfpp_grid_encode_input_backward: the same 2^D corners, no 116 MB intermediate), other level_dims keep dy_dx.
 
     Under autocast with an even level_dim the reference casts the table to half for the call (grid.py:41-44) -- features, their gradient and the
     table gradient's accumulators are then half -- and that is the reference's training configuration (`amp: true`).  Same here (`half=True`): the
     half lookup kernel forward, a half grad into gfpp_grid_encode_backward_f16 backward; accumulation and the parameter's gradient are fp32 (more
-    accurate than the reference's half atomics, same interface), dy_dx stays fp32."""
+    accurate than the reference's half atomics, same interface), and so is the input gradient."""
 
     @staticmethod
     def forward(ctx, inputs01, embeddings, offsets, per_level_scale, base_resolution, gridtype_id, align_corners, interp_id):
@@ -61,38 +62,34 @@ class _GridEncodeFn(torch.autograd.Function):
         out = torch.empty(L, B, C, device=inputs01.device, dtype=torch.half if half else torch.float32)
         # decide from autograd's own bookkeeping: `inputs01` may be a fresh no-grad copy after the cast above (a non-fp32 or non-contiguous
         # input), whose requires_grad flag says nothing about the caller's tensor
-        dy_dx = torch.empty(B, L * D * C, device=inputs01.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        want_dx = bool(ctx.needs_input_grad[0])
+        # level_dim 2: the input gradient is recomputed from the table in the backward pass (gfpp_grid_encode_input_backward); otherwise dy_dx is kept
+        dy_dx = torch.empty(B, L * D * C, device=inputs01.device, dtype=torch.float32) if want_dx and C != 2 else None
         if half:
             call("gfpp_grid_encode_forward", inputs01.data_ptr(), emb.to(torch.half).data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S,
                  int(base_resolution), None, int(gridtype_id), int(bool(align_corners)), int(interp_id), 1, _stream())
-            if dy_dx is not None:
-                call("gfpp_grid_encode_dydx", inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), dy_dx.data_ptr(), B, D, C, L, S, int(base_resolution),
-                     int(gridtype_id), int(bool(align_corners)), int(interp_id), _stream())
         else:
             call("gfpp_grid_encode_forward", inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), out.data_ptr(), B, D, C, L, S, int(base_resolution),
                  dy_dx.data_ptr() if dy_dx is not None else None, int(gridtype_id), int(bool(align_corners)), int(interp_id), 0, _stream())
-        ctx.save_for_backward(inputs01, offsets, dy_dx)
-        ctx.dims = (B, D, C, L, S, int(base_resolution), int(gridtype_id), int(bool(align_corners)), int(interp_id), int(emb.shape[0]), half)
+        ctx.save_for_backward(inputs01, offsets, dy_dx, emb if want_dx and C == 2 else None)
+        ctx.dims = (B, D, C, L, S, int(base_resolution), int(gridtype_id), int(bool(align_corners)), int(interp_id), int(emb.shape[0]), half, want_dx)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        inputs01, offsets, dy_dx = ctx.saved_tensors
-        B, D, C, L, S, H, gridtype, ac, interp, rows, half = ctx.dims
+        inputs01, offsets, dy_dx, emb = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, ac, interp, rows, half, want_dx = ctx.dims
         grad_emb = torch.zeros(rows, C, device=grad.device, dtype=torch.float32)
-        grad_inputs = torch.zeros_like(inputs01) if dy_dx is not None else None
+        grad_inputs = torch.zeros_like(inputs01) if want_dx else None
         # eight scratch copies of the table gradient (gfpp_grid_encode_backward_xcd: LDS accumulation per level range, no device atomic per corner)
-        copies = torch.empty(8, rows * C, device=grad.device, dtype=torch.float32)
-        if half:
-            grad = grad.to(torch.half).contiguous()
-            call("gfpp_grid_encode_backward_f16", grad.data_ptr(), inputs01.data_ptr(), offsets.data_ptr(), grad_emb.data_ptr(), rows, copies.data_ptr(),
-                 B, D, C, L, S, H, dy_dx.data_ptr() if dy_dx is not None else None, grad_inputs.data_ptr() if grad_inputs is not None else None, gridtype, ac,
-                 interp, _stream())
-        else:
-            grad = grad.float().contiguous()
-            call("gfpp_grid_encode_backward_xcd", grad.data_ptr(), inputs01.data_ptr(), offsets.data_ptr(), grad_emb.data_ptr(), rows, copies.data_ptr(),
-                 B, D, C, L, S, H, dy_dx.data_ptr() if dy_dx is not None else None, grad_inputs.data_ptr() if grad_inputs is not None else None, gridtype, ac,
-                 interp, _stream())
+        copies = torch.empty(8 * rows * C + 64, device=grad.device, dtype=torch.float32)     # (+ 64 words: the levels' gradient maxima)
+        grad = grad.to(torch.half if half else torch.float32).contiguous()
+        call("gfpp_grid_encode_backward_f16" if half else "gfpp_grid_encode_backward_xcd", grad.data_ptr(), inputs01.data_ptr(), offsets.data_ptr(),
+             grad_emb.data_ptr(), rows, copies.data_ptr(), B, D, C, L, S, H, dy_dx.data_ptr() if dy_dx is not None else None,
+             grad_inputs.data_ptr() if dy_dx is not None else None, gridtype, ac, interp, _stream())
+        if want_dx and dy_dx is None:
+            call("gfpp_grid_encode_input_backward", grad.data_ptr(), 1 if half else 0, inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), grad_inputs.data_ptr(),
+                 B, D, C, L, S, H, gridtype, ac, interp, _stream())
         return grad_inputs, grad_emb, None, None, None, None, None, None
 
 

@@ -579,6 +579,14 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
 int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
                             gfpp_stream_t stream);
 
+/* The input gradient of the lookup without a materialised dy_dx (gridencoder.cu:198-243 kernel_grid's dy_dx branch + gridencoder.cu:342-368
+ * kernel_input_backward in one pass): grad [L,B,2] (fp32 or half, grad_dtype) -> grad_inputs [B,D] fp32, the derivative recomputed from the fp32 table.
+ * The reference keeps dy_dx [B, L*D*C] from the forward pass (116 MB per May step for the ambient grid); callers that hold one can still pass it to
+ * gfpp_grid_encode_backward.  level_dim 2, input_dim 2 or 3 (GFPP_EUNSUPPORTED otherwise). */
+int gfpp_grid_encode_input_backward(const void *grad, int grad_dtype, const float *inputs, const float *embeddings, const int32_t *offsets,
+                                    float *grad_inputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                    int align_corners, uint32_t interp, gfpp_stream_t stream);
+
 /* grid_encode_backward with a HALF grad (gridencoder.h:13; gridencoder.cu:247-368 instantiated for at::Half -- what `amp: true`, the reference's training
  * configuration egs/datasets/May/lm3d_radnerf.yaml:5, runs: grid.py:43-44 casts the table to half, so features and their gradient are half).  grad:
  * [L,B,2] half.  Accumulation is fp32 (the reference adds __half2 atomics into a half gradient, gridencoder.cu:306-318, which autograd then casts to the
@@ -590,12 +598,13 @@ int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const i
                                   float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
 
 /* The same gradient (gridencoder.cu:247-368) without a device atomic per corner (no reference counterpart).  `xcd_copies` is caller-provided scratch of
- * 8 x rows_total x C floats (cleared by the call): eight private copies of the table gradient that are summed into grad_embeddings (+=) at the end.
- * Levels whose table fits 128 KiB of LDS: a workgroup per 8 192 points accumulates in LDS and adds the touched values into the copy of the XCD it runs
- * on (MI355X has eight L2s: a line then stays in one of them).  Larger levels (since round 3): a workgroup owns one 32 768-value RANGE of a level's table
- * and one eighth of the points; it recomputes the corners of its points, adds those that fall into its range into LDS accumulators and stores the range
- * into the eighth's copy -- a 2^16-row level is located four times, which is ~20x cheaper than the 67 M device atomics of a May grid were (4.6 ms per
- * call, 45 % of a training step in round 2).  rows_total = embeddings.shape[0]. */
+ * 8 x rows_total x C + 64 floats (cleared by the call): eight private copies of the table gradient that are summed into grad_embeddings (+=) at the
+ * end, and the levels' gradient maxima behind them.  A workgroup owns one RANGE of 16 384 values of a level's table and one eighth of the points; it
+ * recomputes the corners of its points, adds those that fall into its range into LDS accumulators and stores the range into the eighth's copy -- a
+ * 2^16-row level is located eight times, which is ~10x cheaper than the 67 M device atomics of a May grid were (4.6 ms per call, 45 % of a training step
+ * in round 2).  The LDS accumulators are 64-bit fixed point scaled by the level's largest |grad| (float LDS atomics run ~50x slower than integer ones
+ * on gfx950): a contribution is kept down to 2^-40 of that maximum; a non-finite grad makes its level's gradient NaN.  GFPP_GRID_BWD=scatter selects the
+ * round-2 path (LDS-privatised coarse levels + XCD-private device atomics).  rows_total = embeddings.shape[0]. */
 int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
                                   float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
