@@ -54,6 +54,13 @@ def dispatch(name, *a):
                                           ctypes.c_int(ac), u32(interp)) == 0
         if dy_dx:
             L.orc_grid_input_backward(fp(grad), fp(dy_dx), fp(grad_inputs), u32(B), u32(D), u32(C), u32(Lv))
+    elif name == "gfpp_grid_encode_input_backward":    # the device recomputes the derivative from the table; the oracle takes its two reference steps
+        grad, grad_dtype, inputs, emb, offsets, grad_inputs, B, D, C, Lv, S, H, gridtype, ac, interp = a[:15]
+        assert grad_dtype == 0
+        dy_dx = np.zeros(int(B) * int(Lv) * int(D) * int(C), np.float32)
+        assert L.orc_grid_encode_dydx(fp(inputs), fp(emb), ip(offsets), dy_dx.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), u32(B), u32(D), u32(C), u32(Lv), cf(S),
+                                      u32(H), u32(gridtype), ctypes.c_int(ac), u32(interp)) == 0
+        L.orc_grid_input_backward(fp(grad), dy_dx.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), fp(grad_inputs), u32(B), u32(D), u32(C), u32(Lv))
     elif name == "gfpp_sh_encode_forward":
         assert not a[5]
         assert L.orc_sh_encode_forward(fp(a[0]), fp(a[1]), u32(a[2]), u32(a[4])) == 0
