@@ -119,9 +119,9 @@ class ClipRenderer:
         if self.with_sr:
             self.model.sr_net.lane = 0
 
-    def _frame(self, lane, pose, pose6, cond, lm68, eye):
+    def _frame(self, lane, pose, pose6, cond, lm68, eye, cond_feat=None):
         """One frame on the current stream: the job's next row of this lane -> the lane's static input -> rays -> model.render() -> uint8 into
-        the job's output slot (the views `pose` .. `eye` are views of the lane's static input)."""
+        the job's output slot (the views `pose` .. `eye` are views of the lane's static input; `cond_feat`: the frame's precomputed conditioning row)."""
         L = self._lane[lane]
         st = torch.cuda.current_stream().cuda_stream
         call("gfpp_clip_fetch", self._job_dev.data_ptr(), lane, L["static_in"].data_ptr(), int(L["static_in"].numel()), st)
@@ -133,9 +133,11 @@ class ClipRenderer:
         pipe = self.model.pipeline() if getattr(self.model, "executor", "fused") == "fused" else None
         if pipe is not None and not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane), False       # the torso kernel stores the uint8 frame itself when it can
+        self.model._clip_cond_feat = cond_feat
         try:
             res = self.model.render(L["rays_o"], L["rays_d"], cond, self.bg_coords, pose6, **kw)
         finally:
+            self.model._clip_cond_feat = None
             stored = pipe is not None and pipe.clip_job_consumed
             if pipe is not None:
                 pipe.clip_job, pipe.clip_job_consumed = None, False
@@ -205,6 +207,7 @@ class ClipRenderer:
         ring_frames = len(idx) if ring_frames is None else int(ring_frames)
         if out.shape[0] < min(ring_frames, max(len(idx), 1)):
             raise GfppError("ClipRenderer.start: out is smaller than the job's ring")
+        clip = self._with_cond_features(clip)
         self._ensure_graphs(clip)
         order = torch.tensor(idx if idx else [0], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
         job = ClipJob()
@@ -215,8 +218,33 @@ class ClipRenderer:
             job.cursor[l] = l
         self._upload_job(job)
         main = self._fork()
-        self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip}
+        self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip}       # (keeps the extended rows alive)
         return self
+
+    #: conditioning features of all frames in one launch at the start of a job instead of 16 dependent layers inside every frame (GFPP_CLIP_PRECOND=0: per frame)
+    precompute_cond = os.environ.get("GFPP_CLIP_PRECOND", "1") != "0"
+
+    def _with_cond_features(self, clip):
+        """The clip with one more field per row: the 256 per-frame constants the head pass gets from the frame's conditioning window (cal_cond_feat +
+        fold; RADNeRF.frame_consts_rows: two launches for the whole clip, the bits of the per-frame kernels).  Computed at every start() on the caller's
+        stream -- ~50 us, and the weights may have changed since the last job."""
+        fn = getattr(self.model, "frame_consts_rows", None)
+        if not self.precompute_cond or fn is None or clip["frames"] == 0:
+            return clip
+        at, cols = 0, {}
+        for (name, _shape), width in zip(clip["layout"], clip["strides"]):
+            cols[name] = at
+            at += width
+        with torch.no_grad():
+            feats = fn(clip["packed"], cols["cond"], cols["eye"], clip["frames"])
+        if feats is None:
+            return clip
+        width = feats.shape[1]
+        pad = (-width) % 4
+        if pad:
+            feats = torch.nn.functional.pad(feats, (0, pad))
+        return {"packed": torch.cat([clip["packed"], feats], dim=1).contiguous(), "layout": clip["layout"] + (("cond_feat", (width,)),),
+                "strides": clip["strides"] + (width + pad,), "frames": clip["frames"]}
 
     def _exec_arrays(self):
         if getattr(self, "_execs", None) is None:

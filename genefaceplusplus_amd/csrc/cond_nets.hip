@@ -101,8 +101,13 @@ __device__ void linear(const float *__restrict__ in, const float *__restrict__ w
     }
 }
 
+// (one workgroup per window: gfpp_cond_feat_batch launches `count` of them, the strides say where window / eye value / result of workgroup k are)
 __global__ __launch_bounds__(kCondThreads) void k_cond_feat(gfpp_cond_model m, const float *__restrict__ cond, const float *__restrict__ eye_area,
-                                                           float *__restrict__ cond_feat, uint32_t widest) {
+                                                           float *__restrict__ cond_feat, uint32_t widest, uint32_t cond_stride, uint32_t eye_stride,
+                                                           uint32_t out_stride) {
+    cond += (size_t)blockIdx.x * cond_stride;
+    if (eye_area) eye_area += (size_t)blockIdx.x * eye_stride;
+    cond_feat += (size_t)blockIdx.x * out_stride;
     __shared__ float lds[kCondLds];
     __shared__ float small[64];
     float *const buf0 = lds, *const buf1 = lds + widest;
@@ -200,7 +205,9 @@ __global__ __launch_bounds__(kCondThreads) void k_cond_feat(gfpp_cond_model m, c
 
 using namespace gfpp;
 
-GFPP_API int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, const float *eye_area, float *cond_feat, gfpp_stream_t stream) {
+GFPP_API int gfpp_cond_feat_batch(const gfpp_cond_model *model, const float *cond, uint32_t cond_stride, const float *eye_area, uint32_t eye_stride,
+                                  float *cond_feat, uint32_t out_stride, uint32_t count, gfpp_stream_t stream) {
+    if (count == 0) return 0;
     if (!model || !cond || !cond_feat) { set_error("gfpp_cond_feat: null argument"); return GFPP_EINVAL; }
     const gfpp_cond_model &m = *model;
     if (m.smo == 0 || m.t_win == 0 || m.c_in == 0 || m.dim_aud == 0 || m.dim_aud > 64) { set_error("gfpp_cond_feat: bad dimensions"); return GFPP_EINVAL; }
@@ -225,6 +232,10 @@ GFPP_API int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, con
         set_error("gfpp_cond_feat: missing weights");
         return GFPP_EINVAL;
     }
-    hipLaunchKernelGGL(k_cond_feat, dim3(1), dim3(kCondThreads), 0, (hipStream_t)stream, m, cond, eye_area, cond_feat, widest);
+    hipLaunchKernelGGL(k_cond_feat, dim3(count), dim3(kCondThreads), 0, (hipStream_t)stream, m, cond, eye_area, cond_feat, widest, cond_stride, eye_stride, out_stride);
     return check_launch("gfpp_cond_feat");
+}
+
+GFPP_API int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, const float *eye_area, float *cond_feat, gfpp_stream_t stream) {
+    return gfpp_cond_feat_batch(model, cond, 0, eye_area, 0, cond_feat, 0, 1, stream);
 }

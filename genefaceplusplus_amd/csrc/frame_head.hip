@@ -623,8 +623,11 @@ __global__ __launch_bounds__(kThreads) void k_frame_begin(const float *__restric
 // out[row] = sum_k W[row, k] * v[k] for 128 rows, written in bias-fragment order Bf[h][16*m+r] <- row 32*m+rr(r)+4*h.
 __global__ __launch_bounds__(128) void k_fold_constants(const float *__restrict__ w_cond, const float *__restrict__ cond, uint32_t cond_dim,
                                                        const float *__restrict__ w_ind, const float *__restrict__ ind, uint32_t ind_dim,
-                                                       float *__restrict__ frame_consts) {
+                                                       float *__restrict__ frame_consts, uint32_t cond_stride) {
     const int row = threadIdx.x;  // 0..127
+    // (blockIdx.y = frame of a batch: its conditioning row and its 256 constants; the individual code is the same for all)
+    cond += (size_t)blockIdx.y * cond_stride;
+    frame_consts += (size_t)blockIdx.y * 256u;
     const float *w = blockIdx.x == 0 ? w_cond : w_ind;
     const float *v = blockIdx.x == 0 ? cond : ind;
     const uint32_t K = blockIdx.x == 0 ? cond_dim : ind_dim;
@@ -716,9 +719,18 @@ GFPP_API int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_fram
 GFPP_API int gfpp_head_frame_fold(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *cond_feat, const float *ind_code,
                                   gfpp_stream_t stream) {
     if (!model || !ws || !cond_feat || !ws->frame_consts) { set_error("gfpp_head_frame_fold: null argument"); return GFPP_EINVAL; }
-    hipLaunchKernelGGL(k_fold_constants, dim3(2), dim3(128), 0, (hipStream_t)stream, model->amb_w0_cond, cond_feat, model->cond_dim, model->col_w0_ind,
-                       model->ind_dim ? ind_code : nullptr, model->ind_dim, ws->frame_consts);
+    hipLaunchKernelGGL(k_fold_constants, dim3(2, 1), dim3(128), 0, (hipStream_t)stream, model->amb_w0_cond, cond_feat, model->cond_dim, model->col_w0_ind,
+                       model->ind_dim ? ind_code : nullptr, model->ind_dim, ws->frame_consts, 0u);
     return check_launch("gfpp_head_frame_fold");
+}
+
+GFPP_API int gfpp_head_frame_fold_batch(const gfpp_head_model *model, const float *cond_feats, uint32_t cond_stride, const float *ind_code, float *frame_consts,
+                                        uint32_t count, gfpp_stream_t stream) {
+    if (count == 0) return 0;
+    if (!model || !cond_feats || !frame_consts || count > 65535u) { set_error("gfpp_head_frame_fold_batch: null argument, or more than 65 535 frames"); return GFPP_EINVAL; }
+    hipLaunchKernelGGL(k_fold_constants, dim3(2, count), dim3(128), 0, (hipStream_t)stream, model->amb_w0_cond, cond_feats, model->cond_dim, model->col_w0_ind,
+                       model->ind_dim ? ind_code : nullptr, model->ind_dim, frame_consts, cond_stride);
+    return check_launch("gfpp_head_frame_fold_batch");
 }
 
 GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,

@@ -66,6 +66,7 @@ class TorsoModel(ctypes.Structure):
 _lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p])
 _lib.register("gfpp_cond_feat", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p])
+_lib.register("gfpp_cond_feat_batch", [ctypes.POINTER(CondModel), c_p, c_u32, c_p, c_u32, c_p, c_u32, c_u32, c_p])
 _lib.register("gfpp_torso_frame_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_p])
 _lib.register("gfpp_occupancy_bounds", [c_p, c_u32, c_u32, c_f, c_p, c_p])
@@ -74,6 +75,7 @@ _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.
 _lib.register("gfpp_head_frame_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_march", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_fold", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p])
+_lib.register("gfpp_head_frame_fold_batch", [ctypes.POINTER(HeadModel), c_p, c_u32, c_p, c_p, c_u32, c_p])
 _lib.register("gfpp_head_frame_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
 _lib.register("gfpp_head_frame_begin_premarch", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_p])
 _lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
@@ -258,6 +260,14 @@ def shared_stream(device, role, lane=0):
     if st is None:
         st = _STREAMS[key] = torch.cuda.Stream(device=device)
     return st
+
+
+class FoldedConsts:
+    """A frame's 256 folded constants, computed ahead of the frame (FramePipeline.fold_rows): head_pass points the workspace at them instead of running
+    the conditioning networks and the fold."""
+
+    def __init__(self, consts):
+        self.consts = consts
 
 
 class GraphedFrame:
@@ -524,6 +534,34 @@ class FramePipeline:
              torch.cuda.current_stream().cuda_stream)
         return out
 
+    def cond_feat_rows(self, rows, cond_at, eye_at, count):
+        """cal_cond_feat for `count` frames whose driving signals are the rows of one packed matrix (`rows` [F, row_floats] f32 on the device; the window
+        starts at column `cond_at`, the eye value -- or None -- at column `eye_at`) in one launch -> [count, cond_out] (flattened [smo * dim] rows without
+        the attention net)."""
+        cm = self.cond
+        if rows.dtype != torch.float32 or not rows.is_contiguous() or rows.dim() != 2 or rows.shape[0] < count:
+            raise GfppError("cond_feat_rows: rows must be a contiguous float32 [F, row_floats] matrix")
+        width = cm.dim_aud if cm.with_att else cm.smo * cm.dim_aud
+        out = torch.empty(count, width, dtype=torch.float32, device=self.device)
+        stride = int(rows.shape[1])
+        use_eye = cm.blink_dim and eye_at is not None
+        call("gfpp_cond_feat_batch", ctypes.byref(cm), rows.data_ptr() + 4 * int(cond_at), stride, (rows.data_ptr() + 4 * int(eye_at)) if use_eye else None,
+             stride if use_eye else 0, out.data_ptr(), width, int(count), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def fold_rows(self, cond_feats, ind_code):
+        """gfpp_head_frame_fold for every row of cond_feats [F, >= cond_dim] (one launch) -> frame constants [F, 256]."""
+        if cond_feats.dtype != torch.float32 or not cond_feats.is_contiguous() or cond_feats.dim() != 2 or cond_feats.shape[1] < self.head.cond_dim:
+            raise GfppError("fold_rows: cond_feats must be a contiguous float32 [F, >= cond_dim] matrix")
+        F = int(cond_feats.shape[0])
+        out = torch.empty(F, 256, dtype=torch.float32, device=self.device)
+        ind = self._dev_f32(ind_code.reshape(-1), "ind_code") if ind_code is not None else None
+        for first in range(0, F, 65535):
+            n = min(65535, F - first)
+            call("gfpp_head_frame_fold_batch", ctypes.byref(self.head), cond_feats[first:].data_ptr(), int(cond_feats.shape[1]), ind.data_ptr() if ind is not None else None,
+                 out[first:].data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        return out
+
     def _build_torso(self, m):
         hp = m.hparams
         tm = TorsoModel()
@@ -691,6 +729,12 @@ class FramePipeline:
             call("gfpp_head_frame_fold", ctypes.byref(self.head), ctypes.byref(ws), cf.data_ptr(), ind_ptr, stream_ptr)
             return cf
 
+        ws.frame_consts = t["frame_consts"].data_ptr()
+        folded = isinstance(cond_feat, FoldedConsts)
+        if folded:
+            if cond_feat.consts.numel() != 256 or cond_feat.consts.dtype != torch.float32 or not cond_feat.consts.is_contiguous():
+                raise GfppError("FoldedConsts: 256 contiguous float32 values")
+            ws.frame_consts = cond_feat.consts.data_ptr()
         side = None
         if callable(cond_feat):
             side = self._side_stream.get(self.lane)
@@ -703,11 +747,11 @@ class FramePipeline:
             # slab test + state reset + pre-march in one launch (the rays are read once)
             call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),
                  int(max_steps), st)
-            if side is None:
+            if side is None and not folded:
                 fold(cond_feat, st)
         else:
             call("gfpp_head_frame_begin", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), None, None, st)
-            if side is None:
+            if side is None and not folded:
                 fold(cond_feat, st)
             if premarched:
                 call("gfpp_head_frame_premarch", ctypes.byref(self.head), ctypes.byref(ws), rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma),

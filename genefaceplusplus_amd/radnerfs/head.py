@@ -273,7 +273,11 @@ class NeRFRenderer(nn.Module):
         shard = kwargs.get("ray_shard")          # (process group, rays of the whole frame): this call renders one ray tile (frames.render_frame_tiled)
         if self.executor == "fused" and self._fused_ok(perturb, max_steps, cond_mask):
             def frame(rays_o, rays_d, cond, eye, bg_color):
-                cond_feat = lambda: self.cal_cond_feat(cond, eye_area_percent=eye)     # runs on the pipeline's side stream
+                # (a clip renderer that computed the conditioning of all frames up front hands the frame's constants in: clip.ClipRenderer, frame_consts_rows)
+                pre = self._clip_cond_feat
+                if pre is not None:
+                    from .frame_pipeline import FoldedConsts
+                cond_feat = FoldedConsts(pre) if pre is not None else (lambda: self.cal_cond_feat(cond, eye_area_percent=eye))     # runs on the pipeline's side stream
                 return self.pipeline().render_head(rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, bg_color, shard=shard)
             inputs = {"rays_o": rays_o, "rays_d": rays_d, "cond": cond, "eye": eye_area_percent, "bg_color": bg_color}
             if self.use_graph and not torch.is_grad_enabled() and shard is None:
@@ -349,6 +353,28 @@ class RADNeRF(NeRFRenderer):
         self.dropout = nn.Dropout(p=hparams["cond_dropout_rate"], inplace=False)
 
     # -- conditioning ---------------------------------------------------------------------------------------
+    #: whether this class's render() hands eye_area_percent to cal_cond_feat (RADNeRFTorso does not: radnerf_torso.py:106)
+    _render_passes_eye = True
+    #: set by clip.ClipRenderer around a frame: that frame's row of frame_consts_rows (256 folded constants)
+    _clip_cond_feat = None
+
+    def frame_consts_rows(self, rows, cond_at, eye_at, count, index=0):
+        """Everything a frame's head pass needs from its conditioning window, for `count` frames in two launches: cal_cond_feat (one workgroup per frame,
+        FramePipeline.cond_feat_rows -- with the eye value only where this class's render() passes it) and the fold of the result into the first
+        layers' per-frame constants (fold_rows) -> [count, 256] rows that render() takes as `_clip_cond_feat`; None when the fused kernels do not
+        serve this model.  Same kernels as inside a frame: the frame is bit-equal."""
+        from .frame_pipeline import supports
+        if self.executor != "fused" or self.training or not supports(self):
+            return None
+        pipe = self.pipeline()
+        if pipe.cond is None:
+            return None
+        use_eye = self._render_passes_eye and self.hparams.get("add_eye_blink_cond", False)
+        feats = pipe.cond_feat_rows(rows, cond_at, eye_at if use_eye else None, count)
+        if feats.shape[1] != pipe.head.cond_dim:
+            return None
+        return pipe.fold_rows(feats, self._individual_code(index))
+
     def cal_cond_feat(self, cond, eye_area_percent=None):
         """cond [smo_win, t_window, cond_in] -> cond_feat [cond_out] (radnerf.py:88-106)."""
         hp = self.hparams

@@ -175,6 +175,9 @@ class _TorsoBase(RADNeRF):
                 def cond_feat():                                                        # runs on the pipeline's side stream
                     with torch.no_grad():
                         return self.cal_cond_feat(cond, eye_area_percent=eye)
+                if self._clip_cond_feat is not None:                                    # the clip renderer's precomputed constants of this frame
+                    from .frame_pipeline import FoldedConsts
+                    cond_feat = FoldedConsts(self._clip_cond_feat)
                 o = self.pipeline().render_head_torso(rays_o, rays_d, cond_feat, ind_code, bg_coords, poses, torso_code, lm68, dt_gamma,
                                                       max_steps, T_thresh, bg_color, use_head_for_torso, shard=shard)
                 if post is not None:
@@ -199,6 +202,8 @@ class _TorsoBase(RADNeRF):
 
 
 class RADNeRFTorso(_TorsoBase):
+    _render_passes_eye = False        # radnerf_torso.py:106 calls cal_cond_feat(cond) without eye_area_percent
+
     """Pose-conditioned torso (non-SR configs, 512x512 rays)."""
 
     def __init__(self, hparams):

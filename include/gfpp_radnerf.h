@@ -258,6 +258,13 @@ typedef struct gfpp_cond_model {
  * eye_area_percent=None); cond_feat [dim_aud] f32 out ([smo, dim_aud] when with_att == 0). */
 int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, const float *eye_area, float *cond_feat, gfpp_stream_t stream);
 
+/* RADNeRF.cal_cond_feat (radnerf.py:88-106) for `count` windows in ONE launch, one workgroup per window (the same kernel as gfpp_cond_feat, so the
+ * same bits): window k at cond + k cond_stride, its eye value at eye_area + k eye_stride (eye_area NULL = 0 for all), its result at cond_feat +
+ * k out_stride (strides in floats).  The caller's frame loop computes it per frame (genefacepp_infer.py:461-463 -> render -> cal_cond_feat); a clip
+ * renderer that holds the driving signals of all frames takes the 16 dependent layers (~40 us on one CU) out of every frame this way. */
+int gfpp_cond_feat_batch(const gfpp_cond_model *model, const float *cond, uint32_t cond_stride, const float *eye_area, uint32_t eye_stride,
+                         float *cond_feat, uint32_t out_stride, uint32_t count, gfpp_stream_t stream);
+
 /* MLP weight packing for the MFMA kernels ("fragment order", fp32):
  *   a dense layer out[128] = W[128,K] x  is evaluated as a sequence of K/2 rank-2 updates with
  *   v_mfma_f32_32x32x2_f32; update `s` consumes the input pair (k0[s], k1[s]).  Packed array P[s/4][m][lane][s%4] =
@@ -387,6 +394,13 @@ int gfpp_head_frame_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws,
  * e.g. on a second stream next to the slab test and the pre-march, which do not depend on the conditioning networks. */
 int gfpp_head_frame_fold(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *cond_feat, const float *ind_code,
                          gfpp_stream_t stream);
+
+/* gfpp_head_frame_fold for `count` frames in one launch (same kernel, same bits): frame k's conditioning vector at cond_feats + k cond_stride (floats),
+ * its 256 constants at frame_consts + 256 k; then gfpp_frame_ws.frame_consts of a frame may point at its row.  What is folded: the conditioning
+ * columns of ambient_net's first layer and the individual-code columns of color_net's (radnerf.py:108-141: those inputs are the same for every sample of
+ * a frame).  For callers that hold the driving signals of a whole clip (with gfpp_cond_feat_batch). */
+int gfpp_head_frame_fold_batch(const gfpp_head_model *model, const float *cond_feats, uint32_t cond_stride, const float *ind_code, float *frame_consts,
+                               uint32_t count, gfpp_stream_t stream);
 
 /* Runs the whole march -> evaluate -> composite loop of renderer.py:354-384 (kernels raymarching.cu:827-929, :942-1029;
  * networks radnerf.py:108-141; encoders gridencoder.cu:87-196, shencoder.cu:28-68): `max_steps` fused trip launches, each of
