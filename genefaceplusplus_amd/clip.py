@@ -54,7 +54,8 @@ class ClipRenderer:
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
         workspace and graph; weights and tables are shared), so one frame's prologue and epilogue (slab test + pre-march, conditioning nets, torso
         pass, uint8 store) overlap the tail of the other frame's head pass.  None = 2 for the 16-bit modes (the head pass is one launch that holds
-        every CU: a third frame only queues behind it), 3 for the exact-fp32 mode (one launch per trip; numbers at the assignment below).
+        every CU: a third frame only queues behind it), 3 for the exact-fp32 mode (one launch per trip) and for the super-resolution models (numbers
+        at the assignment below).
         calibrate_trips (trip-launch paths only: fp32, lp_kernel='trips'): with several lanes every possible trip of the render loop is a launch of
         its own (gfpp_frame_ws.separate_trips); when a lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given
         a small grid, because a launch that finds nothing left still needs a whole CU per workgroup (results never depend on it, a later frame that
@@ -83,8 +84,10 @@ class ClipRenderer:
         fused = getattr(model, "executor", "fused") == "fused"
         if lanes is None:
             # measured, 512^2 frames: round 2 (one launch per trip) 2 300 / 2 530 / 2 010 frames/s with 2 / 3 / 4 lanes; round 3 (the head pass is ONE launch
-            # that holds every CU for ~0.29 ms) 2 535 / 2 956 / 2 769 / 2 693 with 1 / 2 / 3 / 4: a third frame's launch only gets in the way
-            lanes = 2 if getattr(model, "precision", "auto") != "fp32" else 3
+            # that holds every CU for ~0.29 ms) 2 535 / 2 956 / 2 769 / 2 693 with 1 / 2 / 3 / 4, and 2 980 / 2 995 with 2 / 3 once the conditioning left the
+            # frames: a third frame's launches only queue behind the head pass.  The super-resolution models (256^2 rays: a 0.12 ms head pass + four SR
+            # launches) do gain from a third frame: 3 860 -> 4 050 frames/s
+            lanes = 3 if (getattr(model, "precision", "auto") == "fp32" or self.with_sr) else 2
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
