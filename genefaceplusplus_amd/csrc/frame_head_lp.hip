@@ -185,10 +185,18 @@ struct LevelU {   // one level's descriptor in scalar registers
     uint32_t sy, sz, mask, offset;
 };
 
-template <int D, bool SMOOTH>
-__device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
-                                                   float (&out)[2]) {
+// (two halves: level_fast_issue puts the level's 2^(D-1) gathers in flight and keeps the fractions, level_fast_finish interpolates -- so that a caller
+// can issue the gathers of several levels before it consumes the first: left as one function, the compiler waits for a level's four gathers before it
+// even computes the next level's addresses, i.e. sixteen dependent memory round trips per block and grid instead of sixteen overlapped ones)
+template <int D>
+struct LevelGathers {
     float frac[D];
+    f32x4_a8 v[1 << (D - 1)];
+};
+
+template <int D, bool SMOOTH>
+__device__ __forceinline__ void level_fast_issue(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
+                                                 LevelGathers<D> &g) {
     uint32_t base[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -198,7 +206,7 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
         base[d] = (uint32_t)pos;
         float f = __builtin_amdgcn_fractf(pos);
         if constexpr (SMOOTH) f = f * f * fmaf(-2.0f, f, 3.0f);
-        frac[d] = f;
+        g.frac[d] = f;
     }
     // byte offsets in 32 bits against the wave-uniform table pointer (global_load with an SGPR base): one v_add_lshl_u32 per gather instead of a
     // 64-bit per-lane address; the padded tables are far below 4 GiB
@@ -207,37 +215,57 @@ __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const fl
     uint32_t z0 = 0, z1 = 0;
     if constexpr (D == 3) { z0 = __umul24(base[2], lv.sz); z1 = z0 + lv.sz; }
     constexpr int kPairs = 1 << (D - 1);
-    f32x4_a8 v[kPairs];
 #pragma unroll
     for (int pair = 0; pair < kPairs; ++pair) {
         uint32_t row = base[0] + ((pair & 1) ? y1 : y0);
         if constexpr (D == 3) row += (pair & 2) ? z1 : z0;   // sz == 0 (z dropped by the tiled index): the same rows again, an L1 hit
         row &= lv.mask;
 #if GFPP_ABLATE & 1
-        v[pair] = f32x4_a8{frac[0], __uint_as_float(row), frac[1], lv.scale};
+        g.v[pair] = f32x4_a8{g.frac[0], __uint_as_float(row), g.frac[1], lv.scale};
         (void)lt;
 #else
-        v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
+        g.v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
 #endif
     }
+}
+
+template <int D>
+__device__ __forceinline__ void level_fast_finish(const LevelGathers<D> &g, float (&out)[2]) {
     // corner weights and accumulation on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): (w0, w1) = ((1 - fx) * yf * zf, fx * yf * zf) with the
     // products in grid_level_lookup's order, so the (1 - fx, fx) * yf halves are shared by the two z planes -- 6 packed multiplies per 3-D level
     // instead of 16 scalar ones, same bits
+    constexpr int kPairs = 1 << (D - 1);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 wx = {1.0f - frac[0], frac[0]};
-    f32x2 wxy[2] = {wx * (1.0f - frac[1]), wx * frac[1]};
+    const f32x2 wx = {1.0f - g.frac[0], g.frac[0]};
+    f32x2 wxy[2] = {wx * (1.0f - g.frac[1]), wx * g.frac[1]};
     f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
     for (int pair = 0; pair < kPairs; ++pair) {
         f32x2 w = wxy[pair & 1];
-        if constexpr (D == 3) w = w * ((pair & 2) ? frac[2] : 1.0f - frac[2]);
-        const f32x2 c0 = {v[pair][0], v[pair][1]}, c1 = {v[pair][2], v[pair][3]};
+        if constexpr (D == 3) w = w * ((pair & 2) ? g.frac[2] : 1.0f - g.frac[2]);
+        const f32x2 c0 = {g.v[pair][0], g.v[pair][1]}, c1 = {g.v[pair][2], g.v[pair][3]};
         acc = __builtin_elementwise_fma(f32x2{w[0], w[0]}, c0, acc);
         acc = __builtin_elementwise_fma(f32x2{w[1], w[1]}, c1, acc);
     }
     out[0] = acc[0];
     out[1] = acc[1];
 }
+
+template <int D, bool SMOOTH>
+__device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
+                                                   float (&out)[2]) {
+    LevelGathers<D> g;
+    level_fast_issue<D, SMOOTH>(u, table, lv, align_corners, g);
+    level_fast_finish<D>(g, out);
+}
+
+// How many levels' gathers a lane keeps in flight (kLpLevelGroup x 2^(D-1) loads of 16 bytes = 16 VGPRs per 3-D level).  Measured (512^2 bf16, same box,
+// k-kcycles of `evaluate` / frames/s): 1 level 131.6 / 2 983, 2 levels 124.8 / 3 076, 4 levels 126.1 / 3 046, 8 levels (7 spilled registers) 123.9 / 2 993;
+// issuing the next group before the current one is interpolated (16 in flight, 240 VGPRs) 122.7 -- within the noise of 2 levels, which keeps 229 VGPRs
+#ifndef GFPP_LP_LEVEL_GROUP
+#define GFPP_LP_LEVEL_GROUP 2
+#endif
+constexpr int kLpLevelGroup = GFPP_LP_LEVEL_GROUP;
 
 // This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..:
 // the level descriptors sit in LDS and the lookup is straight-line code, so the gathers of several levels are in flight together.  Value k (= 8 s + e) of the lane is level 2 (k/2) + hi,
@@ -286,23 +314,24 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         }
         __builtin_amdgcn_sched_barrier(0);
         // the interpolation type is wave-uniform: one branch around two specialised bodies instead of a smoothstep polynomial + select per coordinate
-        if (smooth) {
+        auto levels = [&](auto smooth_tag) {
+            constexpr bool SM = decltype(smooth_tag)::value;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float o[2];
-                level_fast_uniform<D, true>(uc, g.table, lvs[i], ac, o);
-                f[2 * i] = o[0];
-                f[2 * i + 1] = o[1];
-            }
-        } else {
+            for (int i0 = 0; i0 < 8; i0 += kLpLevelGroup) {
+                LevelGathers<D> lg[kLpLevelGroup];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float o[2];
-                level_fast_uniform<D, false>(uc, g.table, lvs[i], ac, o);
-                f[2 * i] = o[0];
-                f[2 * i + 1] = o[1];
+                for (int k = 0; k < kLpLevelGroup; ++k) level_fast_issue<D, SM>(uc, g.table, lvs[i0 + k], ac, lg[k]);
+                __builtin_amdgcn_sched_barrier(0);             // the group's gathers are all in flight before the first one is consumed
+#pragma unroll
+                for (int k = 0; k < kLpLevelGroup; ++k) {
+                    float o[2];
+                    level_fast_finish<D>(lg[k], o);
+                    f[2 * (i0 + k)] = o[0];
+                    f[2 * (i0 + k) + 1] = o[1];
+                }
             }
-        }
+        };
+        if (smooth) levels(std::true_type{}); else levels(std::false_type{});
     }
     // out-of-range / padding samples get zero features (gridencoder.cu:110-135): selected on the 8 packed operand words, not on the 16 floats
     // (the hash / true-modulo path above already zeroed its own)
