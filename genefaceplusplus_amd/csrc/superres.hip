@@ -105,6 +105,26 @@ __device__ __forceinline__ void sr_stage_tap(const uint4 *__restrict__ src, uint
     }
 }
 
+// Operand reads of the tap loop as inline assembly.  The loop streams the next weight chunk into LDS with global_load_lds while it multiplies the current
+// one; the compiler cannot tell that the ds_read of the CURRENT buffer does not alias the DMA into the OTHER buffer and puts `s_waitcnt vmcnt(0)` in front
+// of every chunk's first operand read (visible in the ISA as `stage, wait, MFMAs`): the request for the next chunk was issued and then waited for before
+// any multiplying started -- no overlap at all, one exposed L2 -> LDS round trip per chunk (9-18 per workgroup).  A read the compiler does not see as an
+// LDS access cannot be given that wait; the counters are then ours to keep: sr_lds_wait ties the freshly read registers to an explicit lgkmcnt(0).
+__device__ __forceinline__ uint32_t sr_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void sr_lds_read128(f16x8 &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int NA, int NB2>
+__device__ __forceinline__ void sr_lds_wait(f16x8 (&a)[NA], f16x8 (&b)[NB2]) {
+    static_assert(NA == 4 || NA == 2, "row tiles per wavefront");
+    if constexpr (NA == 4 && NB2 == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0])::"memory");
+    else if constexpr (NA == 4 && NB2 == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory");
+    else if constexpr (NA == 2 && NB2 == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
+}
+
 // NU = 32-column MFMA tiles per wavefront: 2 (round 1-2) = 4 wavefronts of 64 pixels, one per SIMD; 1 = 8 wavefronts of 32 pixels, two per SIMD --
 // a weight fragment then feeds one MFMA instead of two (1.25 KB of LDS operands per MFMA instead of 0.75: still below the LDS's 128 B/clk), but the
 // second wavefront of a SIMD runs under the first one's LDS latency, tap barriers and epilogue stores.
@@ -295,30 +315,30 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
         // cost half of the tap loop), into the buffer the previous chunk's MFMAs released at the last barrier; they land while this one computes
         if (it + 1 < ITERS && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[cur ^ 1], tid, lane);
         const int dy = tap / 3, dx = tap % 3;
-        const _Float16 *b0 = &patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi];
-        const _Float16 *b1 = b0 + 2 * kSrHalo * PS;
-        const vec *wl = reinterpret_cast<const vec *>(wbuf[cur]) + lane;
-        // operands of step s + 1 are read while the NU x NT MFMAs of step s run; the sched_barriers pin that order, as in lp_mfma_device.h::mfma_layer_lds
+        const uint32_t b0 = sr_lds_addr(&patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi]);
+        const uint32_t b1 = b0 + 2u * kSrHalo * PS * 2u;
+        const uint32_t wl = sr_lds_addr(wbuf[cur]) + (uint32_t)lane * 16u;
+        // operands of step s + 1 are read while the NU x NT MFMAs of step s run (sr_lds_read128: see above)
         vec Bq[2][NU], Aq[2][NT];
-        Bq[0][0] = *reinterpret_cast<const vec *>(b0);
-        if constexpr (NU == 2) Bq[0][1] = *reinterpret_cast<const vec *>(b1);
+        sr_lds_read128(Bq[0][0], b0);
+        if constexpr (NU == 2) sr_lds_read128(Bq[0][1], b1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) Aq[0][t] = wl[t * 64];
+        for (int t = 0; t < NT; ++t) sr_lds_read128(Aq[0][t], wl + (uint32_t)t * 1024u);
+        sr_lds_wait<NT, NU>(Aq[0], Bq[0]);
 #pragma unroll
         for (int s = 0; s < STEPS_H; ++s) {
             if (s + 1 < STEPS_H) {
-                Bq[(s + 1) & 1][0] = *reinterpret_cast<const vec *>(b0 + 16 * (s + 1));
-                if constexpr (NU == 2) Bq[(s + 1) & 1][1] = *reinterpret_cast<const vec *>(b1 + 16 * (s + 1));
+                sr_lds_read128(Bq[(s + 1) & 1][0], b0 + 32u * (uint32_t)(s + 1));
+                if constexpr (NU == 2) sr_lds_read128(Bq[(s + 1) & 1][1], b1 + 32u * (uint32_t)(s + 1));
 #pragma unroll
-                for (int t = 0; t < NT; ++t) Aq[(s + 1) & 1][t] = wl[((s + 1) * NT + t) * 64];
+                for (int t = 0; t < NT; ++t) sr_lds_read128(Aq[(s + 1) & 1][t], wl + (uint32_t)((s + 1) * NT + t) * 1024u);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[0][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][0], acc[0][t]);
                 if constexpr (NU == 2) acc[1][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][1], acc[1][t]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < STEPS_H) sr_lds_wait<NT, NU>(Aq[(s + 1) & 1], Bq[(s + 1) & 1]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the next chunk has landed in LDS
         __syncthreads();

@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of the SR kernels' shape knobs (GPU box)
+# same-box A/B of two library builds on the SR stage (GPU box): tools/sr_ab.sh <lib A> <lib B>   (paths relative to genefaceplusplus_amd/)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-GFPP_SR_TILES_UP=2 GFPP_SR_TILES_FINAL=2 timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -m gpu -k "superresolution" 2>&1 | tail -2
-for rep in 1 2; do for up in 1 2; do for fin in 1 2; do echo -n "up=$up final=$fin "; GFPP_SR_TILES_UP=$up GFPP_SR_TILES_FINAL=$fin timeout 120 python tools/sr_bench.py 200 random 2>&1 | tail -1; done; done; done
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -m gpu -k "superresolution" 2>&1 | tail -2
+for rep in 1 2; do for lib in "$1" "$2"; do for m in const random; do echo -n "$lib "; GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$lib timeout 120 python tools/sr_bench.py 200 $m 2>&1 | tail -1; done; done; done
+bash tools/ab_lib.sh r03_srasm_ab "$1" "$2" --variant may_torso_sr --hw 256 --precision fp16
+cat gpurun_out/r03_srasm_ab.log | cut -c 1-120
