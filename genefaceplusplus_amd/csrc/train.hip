@@ -203,13 +203,18 @@ struct TrLevels {
 template <int D>
 __device__ __forceinline__ bool tr_locate(const float *__restrict__ in, float scale, bool align_corners, uint32_t interp, float (&pos)[D],
                                           float (&deriv)[D], uint32_t (&pg)[D]) {
+    // all coordinates first, then the range test without short-circuit: `a && b` on values that are loaded inside the expression compiles to a branch
+    // per coordinate with the load behind it -- D memory round trips in a row per point
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = in[d];
     bool inside = true;
 #pragma unroll
-    for (int d = 0; d < D; ++d) inside = inside && !(in[d] < 0.0f || in[d] > 1.0f);
+    for (int d = 0; d < D; ++d) inside = inside & !(x[d] < 0.0f || x[d] > 1.0f);
     if (!inside) return false;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        float p = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+        float p = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
         const float fl = floorf(p);
         pg[d] = (uint32_t)fl;
         p -= (float)pg[d];
@@ -432,10 +437,10 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
         for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
             float pos[D], deriv[D];
             uint32_t pg[D];
-            if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
             float gc[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c] * to_fixed_a;
+            for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c] * to_fixed_a;   // (in flight together with the coordinates)
+            if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
 #pragma unroll
             for (int idx = 0; idx < (1 << D); ++idx) {
                 float w = to_fixed_b;
