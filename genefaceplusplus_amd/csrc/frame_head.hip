@@ -747,8 +747,8 @@ GFPP_API int gfpp_head_frame_march(const gfpp_head_model *model, const gfpp_fram
     }
     TripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
-    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
-    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.pos = make_grid_dev(model->pos_grid);
+    a.amb = make_grid_dev(model->amb_grid);
     a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.bitfield = model->density_bitfield;
@@ -791,8 +791,8 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
     }
     TripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
-    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
-    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.pos = make_grid_dev(model->pos_grid);
+    a.amb = make_grid_dev(model->amb_grid);
     a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.bitfield = model->density_bitfield;
@@ -847,8 +847,8 @@ GFPP_API int gfpp_head_eval_samples(const gfpp_head_model *model, const gfpp_fra
     EvalArgs e{};
     TripArgs &a = e.t;
     a.mp = make_march_params(model->bound, 0.0f, 16, model->cascade, model->grid_size);
-    a.pos = GridDev{model->pos_grid.table, model->pos_grid.levels, model->pos_grid.gridtype, model->pos_grid.interp, model->pos_grid.align_corners};
-    a.amb = GridDev{model->amb_grid.table, model->amb_grid.levels, model->amb_grid.gridtype, model->amb_grid.interp, model->amb_grid.align_corners};
+    a.pos = make_grid_dev(model->pos_grid);
+    a.amb = make_grid_dev(model->amb_grid);
     a.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
                       (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
     a.frame_consts = ws->frame_consts;

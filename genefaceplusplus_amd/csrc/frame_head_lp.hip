@@ -175,82 +175,7 @@ __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTrait
     act_pack<H, 4, 1>(acc, b);
 }
 
-// ---- grid encoding, straight-line ---------------------------------------------------------------------------------------
-// One level of the lookup with the index arithmetic resolved on the host (gfpp_grid_levels_fill) and no branch: tables are the
-// per-level padded copy (row `size` repeats row 0), so the x+1 neighbour of the last row needs no wrap-around case, and a dropped
-// z coordinate (sz == 0) simply fetches the same rows again.  Same corner order, weight products and fma chain as
-// grid_level_lookup => bit-identical features.
-struct LevelU {   // one level's descriptor in scalar registers
-    float scale;
-    uint32_t sy, sz, mask, offset;
-};
-
-// (two halves: level_fast_issue puts the level's 2^(D-1) gathers in flight and keeps the fractions, level_fast_finish interpolates -- so that a caller
-// can issue the gathers of several levels before it consumes the first: left as one function, the compiler waits for a level's four gathers before it
-// even computes the next level's addresses, i.e. sixteen dependent memory round trips per block and grid instead of sixteen overlapped ones)
-template <int D>
-struct LevelGathers {
-    float frac[D];
-    f32x4_a8 v[1 << (D - 1)];
-};
-
-template <int D, bool SMOOTH>
-__device__ __forceinline__ void level_fast_issue(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
-                                                 LevelGathers<D> &g) {
-    uint32_t base[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        // pos >= 0 here (u is clamped to [0,1]): truncation IS floor, and v_fract_f32 returns pos - floor(pos) exactly (the subtraction is exact
-        // in fp32 and < 1) -- two instructions instead of floor + convert + subtract, same bits
-        const float pos = fmaf(u[d], lv.scale, align_corners ? 0.0f : 0.5f);
-        base[d] = (uint32_t)pos;
-        float f = __builtin_amdgcn_fractf(pos);
-        if constexpr (SMOOTH) f = f * f * fmaf(-2.0f, f, 3.0f);
-        g.frac[d] = f;
-    }
-    // byte offsets in 32 bits against the wave-uniform table pointer (global_load with an SGPR base): one v_add_lshl_u32 per gather instead of a
-    // 64-bit per-lane address; the padded tables are far below 4 GiB
-    const char *lt = reinterpret_cast<const char *>(table);
-    const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
-    uint32_t z0 = 0, z1 = 0;
-    if constexpr (D == 3) { z0 = __umul24(base[2], lv.sz); z1 = z0 + lv.sz; }
-    constexpr int kPairs = 1 << (D - 1);
-#pragma unroll
-    for (int pair = 0; pair < kPairs; ++pair) {
-        uint32_t row = base[0] + ((pair & 1) ? y1 : y0);
-        if constexpr (D == 3) row += (pair & 2) ? z1 : z0;   // sz == 0 (z dropped by the tiled index): the same rows again, an L1 hit
-        row &= lv.mask;
-#if GFPP_ABLATE & 1
-        g.v[pair] = f32x4_a8{g.frac[0], __uint_as_float(row), g.frac[1], lv.scale};
-        (void)lt;
-#else
-        g.v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
-#endif
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void level_fast_finish(const LevelGathers<D> &g, float (&out)[2]) {
-    // corner weights and accumulation on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): (w0, w1) = ((1 - fx) * yf * zf, fx * yf * zf) with the
-    // products in grid_level_lookup's order, so the (1 - fx, fx) * yf halves are shared by the two z planes -- 6 packed multiplies per 3-D level
-    // instead of 16 scalar ones, same bits
-    constexpr int kPairs = 1 << (D - 1);
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 wx = {1.0f - g.frac[0], g.frac[0]};
-    f32x2 wxy[2] = {wx * (1.0f - g.frac[1]), wx * g.frac[1]};
-    f32x2 acc = {0.0f, 0.0f};
-#pragma unroll
-    for (int pair = 0; pair < kPairs; ++pair) {
-        f32x2 w = wxy[pair & 1];
-        if constexpr (D == 3) w = w * ((pair & 2) ? g.frac[2] : 1.0f - g.frac[2]);
-        const f32x2 c0 = {g.v[pair][0], g.v[pair][1]}, c1 = {g.v[pair][2], g.v[pair][3]};
-        acc = __builtin_elementwise_fma(f32x2{w[0], w[0]}, c0, acc);
-        acc = __builtin_elementwise_fma(f32x2{w[1], w[1]}, c1, acc);
-    }
-    out[0] = acc[0];
-    out[1] = acc[1];
-}
-
+// (grid encoding, straight-line: LevelU / level_fast_issue / level_fast_finish live in grid_device.h, shared with the exact-fp32 kernels)
 template <int D, bool SMOOTH>
 __device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
                                                    float (&out)[2]) {

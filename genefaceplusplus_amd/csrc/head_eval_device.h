@@ -2,6 +2,8 @@
 // grid-encoder halves, fragment-order bias load, accumulator -> operand moves, skinny VALU output rows, wave scan.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 #include "grid_device.h"
@@ -22,7 +24,15 @@ struct GridDev {
     const void *table;
     const gfpp_grid_level *levels;
     uint32_t gridtype, interp, align_corners;
+    uint32_t fast;     // no level needs the hash / a true modulo and the table is the padded copy: the straight-line lookup (level_fast_issue / _finish)
 };
+
+inline GridDev make_grid_dev(const gfpp_grid_desc &d) {
+    uint32_t slow = 0;
+    if (d.levels_host)
+        for (uint32_t l = 0; l < d.L && l < 32; ++l) slow |= d.levels_host[l].flags & GFPP_LEVEL_SLOW;
+    return GridDev{d.table, d.levels, d.gridtype, d.interp, d.align_corners, (d.levels_host && !slow && d.row_padded) ? 1u : 0u};
+}
 
 __device__ __forceinline__ void load_bias(v16f (&acc)[4], const float *__restrict__ bias_frag, int hi) {
     const float4 *p = reinterpret_cast<const float4 *>(bias_frag + hi * 64);
@@ -75,8 +85,36 @@ __device__ __forceinline__ void encode_half(const float (&u)[D], const GridDev &
     if (!valid) return;
     bool inside = true;
 #pragma unroll
-    for (int d = 0; d < D; ++d) inside = inside && !(u[d] < 0.0f || u[d] > 1.0f);
+    for (int d = 0; d < D; ++d) inside = inside & !(u[d] < 0.0f || u[d] > 1.0f);
     if (!inside) return;
+    if (g.fast) {
+        // (wave-uniform) the straight-line lookup of the 16-bit kernels -- same corner order, weight products and fma chain as grid_level_lookup, so the
+        // same bits -- with the gathers of two levels in flight before the first is interpolated; the generic lookup below waits level by level
+        const float *table = reinterpret_cast<const float *>(g.table);
+        const bool ac = g.align_corners != 0;
+        auto levels = [&](auto smooth_tag) {
+            constexpr bool SM = decltype(smooth_tag)::value;
+#pragma unroll
+            for (int i0 = 0; i0 < 8; i0 += 2) {
+                LevelGathers<D> lg[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const gfpp_grid_level &d = g.levels[hi * 8 + i0 + k];
+                    level_fast_issue<D, SM>(u, table, LevelU{d.scale, d.sy, d.sz, d.mask, d.offset}, ac, lg[k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float o[2];
+                    level_fast_finish<D>(lg[k], o);
+                    f[2 * (i0 + k)] = o[0];
+                    f[2 * (i0 + k) + 1] = o[1];
+                }
+            }
+        };
+        if (g.interp == 1) levels(std::true_type{}); else levels(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const gfpp_grid_level lv = g.levels[hi * 8 + i];
