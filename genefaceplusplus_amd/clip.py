@@ -136,11 +136,12 @@ class ClipRenderer:
         pipe = self.model.pipeline() if getattr(self.model, "executor", "fused") == "fused" else None
         if pipe is not None and not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane), False       # the torso kernel stores the uint8 frame itself when it can
-        self.model._clip_cond_feat = cond_feat
+        target = getattr(self.model, "_orig_mod", self.model)     # (a torch.compile wrapper keeps attributes set on it to itself)
+        target._clip_cond_feat = cond_feat
         try:
             res = self.model.render(L["rays_o"], L["rays_d"], cond, self.bg_coords, pose6, **kw)
         finally:
-            self.model._clip_cond_feat = None
+            target._clip_cond_feat = None
             stored = pipe is not None and pipe.clip_job_consumed
             if pipe is not None:
                 pipe.clip_job, pipe.clip_job_consumed = None, False
