@@ -375,8 +375,8 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const G *__restr
 //
 // The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 turned out to run at ~1 lane per 5 cycles on gfx950 (the range kernel took 877 us with float
 // LDS atomics, 167 us with the adds replaced by plain stores, 177 us with ds_add_u64), integer LDS atomics at full rate.  A level's values are scaled by
-// 2^(40 - e) with 2^e > max |grad| of that level (k_grid_grad_levelmax), so one contribution is below 2^40 and 4 M of them fit; what is kept of a
-// contribution reaches 40 bits below the level's largest gradient (fp32 keeps 24 bits below each value; the reference's half accumulators under amp 11,
+// 2^(36 - e) with 2^e > max |grad| of that level (k_grid_grad_levelmax), so one contribution is below 2^36 and 2^27 of them fit (16 M points hitting
+// one entry with all eight corners); what is kept of a contribution reaches 36 bits below the level's largest gradient (fp32 keeps 24 bits below each value; the reference's half accumulators under amp 11,
 // and nothing below 6e-8).  A non-finite gradient anywhere in the level makes the whole level NaN, so that a GradScaler still sees the overflow.
 #ifndef GFPP_RG_ABLATE
 #define GFPP_RG_ABLATE 0
@@ -425,11 +425,11 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     const uint32_t nrows = size - row0 < rows_per ? size - row0 : rows_per, n = nrows * C;
     for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) acc[i] = 0ll;
     __syncthreads();
-    // fixed-point scale of this level: contributions |w g| <= max |g| < 2^e  ->  |w g| 2^(40 - e) < 2^40
+    // fixed-point scale of this level: contributions |w g| <= max |g| < 2^e  ->  |w g| 2^(36 - e) < 2^36
     const uint32_t maxbits = levelmax[level];
     const bool finite = maxbits < 0x7F800000u;
     const int e = maxbits ? (int)(maxbits >> 23) - 126 : 0;          // 2^e > max |g| (denormal maxima: e = -126, still an upper bound)
-    const float to_fixed_a = ldexpf(1.0f, 20 - (e > 100 ? 100 : e)), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
+    const float to_fixed_a = ldexpf(1.0f, 16 - (e > 100 ? 100 : e)), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
     const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     }
     __syncthreads();
     float *dst = copies + (size_t)slice * total_floats + (size_t)(off + row0) * C;
-    const float back_a = ldexpf(1.0f, (e > 100 ? 100 : e) - 20), back_b = 1.0f / 1048576.0f;
+    const float back_a = ldexpf(1.0f, (e > 100 ? 100 : e) - 16), back_b = 1.0f / 1048576.0f;
     for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) dst[i] = finite ? ((float)acc[i] * back_b) * back_a : __uint_as_float(0x7FC00000u);
 }
 

@@ -617,7 +617,7 @@ int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const i
  * recomputes the corners of its points, adds those that fall into its range into LDS accumulators and stores the range into the eighth's copy -- a
  * 2^16-row level is located eight times, which is ~10x cheaper than the 67 M device atomics of a May grid were (4.6 ms per call, 45 % of a training step
  * in round 2).  The LDS accumulators are 64-bit fixed point scaled by the level's largest |grad| (float LDS atomics run ~50x slower than integer ones
- * on gfx950): a contribution is kept down to 2^-40 of that maximum; a non-finite grad makes its level's gradient NaN.  GFPP_GRID_BWD=scatter selects the
+ * on gfx950): a contribution is kept down to 2^-36 of that maximum; a non-finite grad makes its level's gradient NaN.  GFPP_GRID_BWD=scatter selects the
  * round-2 path (LDS-privatised coarse levels + XCD-private device atomics).  rows_total = embeddings.shape[0]. */
 int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
