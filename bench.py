@@ -534,8 +534,10 @@ def main():
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
                              "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + ((" + RCCL " + ("gather to the writer rank" if args.gather == "writer" else "all_gather")
                                                                            + f" of uint8 frames every {chunk} frames, overlapped with rendering") if world > 1 else ""),
-                             "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: per frame ONE graph launch issued from C (gfpp_graph_replay); inside the graph: fetch the "
-                                           "frame's row of driving signals by a device-side cursor -> rays on device -> model.render() -> uint8 HWC into the output stack",
+                             "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: at the start of the timed job the conditioning networks and the constant fold of all its "
+                                           "frames (two launches, inside the timed region); then per frame ONE graph launch issued from C (gfpp_graph_replay); inside the "
+                                           "graph: fetch the frame's row of driving signals and folded constants by a device-side cursor -> rays on device -> model.render() "
+                                           "-> uint8 HWC into the output stack",
                              "frames_in_flight": cr.lanes, "host_issue_ms_per_frame": round(1e3 * t_issue / K, 4),
                              **({"gather_note": gather_note} if gather_note else {}),
                              **({"dist": dinfo} if dinfo else {}),
