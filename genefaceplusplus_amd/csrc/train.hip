@@ -428,8 +428,9 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     // fixed-point scale of this level: contributions |w g| <= max |g| < 2^e  ->  |w g| 2^(36 - e) < 2^36
     const uint32_t maxbits = levelmax[level];
     const bool finite = maxbits < 0x7F800000u;
-    const int e = maxbits ? (int)(maxbits >> 23) - 126 : 0;          // 2^e > max |g| (denormal maxima: e = -126, still an upper bound)
-    const float to_fixed_a = ldexpf(1.0f, 16 - (e > 100 ? 100 : e)), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
+    int e = maxbits ? (int)(maxbits >> 23) - 126 : 0;                // 2^e > max |g|
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);                       // (keeps both scale factors inside fp32's range; gradients below 2^-100 round to zero)
+    const float to_fixed_a = ldexpf(1.0f, 16 - e), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
     const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     }
     __syncthreads();
     float *dst = copies + (size_t)slice * total_floats + (size_t)(off + row0) * C;
-    const float back_a = ldexpf(1.0f, (e > 100 ? 100 : e) - 16), back_b = 1.0f / 1048576.0f;
+    const float back_a = ldexpf(1.0f, e - 16), back_b = 1.0f / 1048576.0f;
     for (uint32_t i = threadIdx.x; i < n; i += kRgThreads) dst[i] = finite ? ((float)acc[i] * back_b) * back_a : __uint_as_float(0x7FC00000u);
 }
 
