@@ -211,6 +211,10 @@ class ClipRenderer:
         ring_frames = len(idx) if ring_frames is None else int(ring_frames)
         if out.shape[0] < min(ring_frames, max(len(idx), 1)):
             raise GfppError("ClipRenderer.start: out is smaller than the job's ring")
+        if self._job is not None and self._job["issued"]:
+            # frames of the previous job may still be running on the lanes (a caller that never joined): the new job record, its rows and its
+            # output ring must not reach the device before they are done.  A stream-level wait, no host synchronisation
+            self._join(torch.cuda.current_stream())
         clip = self._with_cond_features(clip)
         self._ensure_graphs(clip)
         order = torch.tensor(idx if idx else [0], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)

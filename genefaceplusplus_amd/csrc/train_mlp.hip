@@ -177,11 +177,9 @@ GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, ui
     a.TO = div_up(O, 32); a.TI = div_up(I, 32);
     if (a.TO > (uint32_t)kWgMaxTO || a.TI > (uint32_t)kWgMaxTI) { set_error("%s: built for out_features <= 256 and in_features <= 160 (got %u, %u)", who, O, I); return GFPP_EUNSUPPORTED; }
     const uint32_t R = dtype == GFPP_F16 ? (uint32_t)WgCfg<_Float16>::rows : (uint32_t)WgCfg<float>::rows;
-    const size_t esz = dtype == GFPP_F16 ? 2 : 4;
     a.n_chunks = div_up(M, R);
     a.chunks_per_wg = div_up(a.n_chunks, kWgMaxSlices);
     const uint32_t slices = div_up(a.n_chunks, a.chunks_per_wg);
-    (void)esz;
     const hipStream_t st = (hipStream_t)stream;
     if (((uintptr_t)grad_out | (uintptr_t)input) & 15u) { set_error("%s: grad_out and input must be 16-byte aligned", who); return GFPP_EINVAL; }
     if (hipMemsetAsync(grad_weight, 0, (size_t)O * I * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear grad_weight", who); return GFPP_EINVAL; }

@@ -91,6 +91,11 @@ class _LinearNoBias(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             M, O, I = x.shape[0], w.shape[0], w.shape[1]
+            # the kernel reads 16-byte vectors: a contiguous VIEW into a larger buffer (rows sliced off a batch) may start anywhere
+            if x.data_ptr() % 16:
+                x = x.clone()
+            if gy.data_ptr() % 16:
+                gy = gy.clone()
             gw = torch.empty(O, I, dtype=torch.float32, device=x.device)
             partial = torch.empty(512, O, I, dtype=torch.float32, device=x.device)
             _lib.call("gfpp_linear_weight_grad", gy.data_ptr(), x.data_ptr(), M, O, I, 1 if x.dtype == torch.float16 else 0, partial.data_ptr(), gw.data_ptr(),
