@@ -32,6 +32,11 @@
 #ifndef GFPP_ABLATE
 #define GFPP_ABLATE 0
 #endif
+// Experiment build (tools/ab_lib.sh; not validated on the GPU yet, hence off): the three skinny output layers (3 + 1 + 3 rows) as MFMA chains on a 16-row
+// tile gathered from the skinny image instead of 224 packed dot products per block on the VALU -- see skinny_mfma below.
+#ifndef GFPP_LP_SKINNY_MFMA
+#define GFPP_LP_SKINNY_MFMA 0
+#endif
 #if GFPP_ABLATE & 4
 #define GFPP_TANH(x) (x)
 #define GFPP_EXP(x) (x)
@@ -58,6 +63,12 @@ constexpr int kLpSteps = 31;
 constexpr int kLpWeightChunks = kLpSteps * 4 * 64;   // 16-byte chunks: [step][tile m][lane]
 constexpr int kSkinnyRows = 7;   // ambient_net.2 (3, padded), sigma_net.2 row 0, color_net.1 (3): rows 0-2, 3, 4-6
 constexpr int kSkinnyWords = 2 * kSkinnyRows * 32;   // [half][row][32 pairs of 16-bit weights]
+#if GFPP_LP_SKINNY_MFMA
+constexpr int kSkinnyPitch = 9;                       // 16-byte chunks per (half, row) in LDS: 8 steps + 1 of padding (rows 128 B apart would all start in the same banks)
+constexpr int kSkinnyLds = 2 * kSkinnyRows * kSkinnyPitch * 4;
+#else
+constexpr int kSkinnyLds = kSkinnyWords;
+#endif
 
 struct LpWaveTile {
     float px[kLpSlots], py[kLpSlots], pz[kLpSlots];   // sample position; after evaluation: sigma, r, g of the slot
@@ -102,7 +113,7 @@ struct LpPoolP {
 
 struct LpShared {
     uint4 w[kLpWeightChunks];      // 126 976 B
-    uint32_t skinny[kSkinnyWords]; //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
+    uint32_t skinny[kSkinnyLds];   //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
     gfpp_grid_level lv[2][16];     //   1 024 B  level descriptors of the position / ambient grid
     float bias[256];               //   1 024 B
     union {
@@ -281,6 +292,43 @@ __device__ __forceinline__ void skinny_rows(const uint32_t *__restrict__ wrow, c
     skinny_dot<C, 8, H>(wrow, kSkinnyRows, b, hi, out);
 }
 
+#if GFPP_LP_SKINNY_MFMA
+// The skinny layers on the matrix pipe.  A row of the skinny image is already an A operand: its chunk s holds the weights of the eight activations
+// lane-half h supplies in step s.  One 32-row tile is gathered from the image with a per-lane row map,
+//     tile row  0 1 2 3 | 4 5 6 7 | 8 9 10 11 | 12 13 14 15 | 16..31 = rows 0..15 again (never read)
+//     image row 0 1 2 3 | 0 1 2 3 | 4 5  6  6 |  4  5  6  6
+// so that after eight steps lane (j, h) holds in acc[0..2] the three ambient rows, in acc[3] the density row and in acc[4..6] the three colour rows of
+// sample j, in BOTH half-waves (tile rows r and r + 4 are the same image row: no exchange between the halves).  All three layers use the same tile -- each
+// multiplies it with its own activations and reads its own rows; the other rows' products are finite and ignored.  8 MFMAs + 8 LDS reads per layer instead of
+// 32 dot products + 8 LDS reads per ROW.  Same operands, fp32 accumulation in another order.
+__device__ __forceinline__ uint32_t skinny_tile_chunk(int lane) {
+    const uint32_t i = (uint32_t)lane & 15u, h = (uint32_t)lane >> 5;
+    const uint32_t low = i & 3u, row = (i & 8u) ? 4u + (low < 2u ? low : 2u) : low;
+    static_assert(kSkinnyRows == 7 && kSkinnyPitch == 9, "shift-and-add forms below");
+    const uint32_t q = (h << 3) - h + row;          // (half, row)
+    return (q << 3) + q;
+}
+template <typename H>
+__device__ __forceinline__ void skinny_mfma(const uint32_t *__restrict__ image, const typename LpTraits<H>::vec (&b)[8], int lane, v16f &acc) {
+    typedef typename LpTraits<H>::vec vec;
+    const vec *p = reinterpret_cast<const vec *>(image) + skinny_tile_chunk(lane);
+    vec a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a[s] = p[s];
+    // two independent chains (even / odd steps): a dependent MFMA waits for its predecessor's last pass
+    v16f even, odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) even[r] = odd[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+        even = LpTraits<H>::mfma(a[s], b[s], even);
+        odd = LpTraits<H>::mfma(a[s + 1], b[s + 1], odd);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = even[r] + odd[r];
+}
+#endif
+
 // ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves
 template <int AMB_D, typename H>
 __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi, float (&amb)[AMB_D]) {
@@ -292,7 +340,14 @@ __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename
     zero_acc(acc);
     mfma_steps<H, 8>(acc, sh.w, kStepAmb1, bh, lane);
     relu_pack<H>(acc, bh);
+#if GFPP_LP_SKINNY_MFMA
+    v16f sk;
+    skinny_mfma<H>(sh.skinny, bh, lane, sk);
+#pragma unroll
+    for (int d = 0; d < AMB_D; ++d) amb[d] = sk[d];
+#else
     skinny_rows<AMB_D, H>(sh.skinny, bh, hi, amb);
+#endif
 }
 
 // sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
@@ -314,7 +369,15 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     mfma_steps<H, 8>(acc, sh.w, kStepSig1, bh, lane);
     relu_pack<H>(acc, bh);   // the hidden state feeds both the density row and the (merged) colour layer
     float logit[1];
+#if GFPP_LP_SKINNY_MFMA
+    {
+        v16f sk;
+        skinny_mfma<H>(sh.skinny, bh, lane, sk);
+        logit[0] = sk[3];
+    }
+#else
     skinny_rows<1, H>(sh.skinny + 3 * 32, bh, hi, logit);
+#endif
     const float sigma = a.density_scale * GFPP_EXP(logit[0]);
     {
         vec bcol[9];
@@ -330,7 +393,15 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     }
     relu_pack<H>(acc, bh);
     float rgb[3];
+#if GFPP_LP_SKINNY_MFMA
+    {
+        v16f sk;
+        skinny_mfma<H>(sh.skinny, bh, lane, sk);
+        rgb[0] = sk[4]; rgb[1] = sk[5]; rgb[2] = sk[6];
+    }
+#else
     skinny_rows<3, H>(sh.skinny + 4 * 32, bh, hi, rgb);
+#endif
 #if GFPP_ABLATE & 64
     if (!commit) asm volatile("" :: "v"(sigma), "v"(rgb[0]), "v"(rgb[1]), "v"(rgb[2]));   // the uncommitted pass must not be optimised away
 #endif
@@ -432,7 +503,11 @@ __device__ __forceinline__ void lp_fill_shared(LpShared &sh, const LpTripArgs &a
     for (int i = tid; i < kLpWeightChunks; i += kLpThreads)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w16 + i),
                                          (__attribute__((address_space(3))) void *)(&sh.w[i - lane]), 16, 0, 0);
+#if GFPP_LP_SKINNY_MFMA
+    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[(i >> 5) * (4 * kSkinnyPitch) + (i & 31)] = a.skinny16[i];
+#else
     for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
+#endif
     for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
     for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
         const int which = k >> 7, w = k & 127;

@@ -112,6 +112,41 @@ def test_16bit_weight_image_reproduces_the_head_mlps():
     np.testing.assert_allclose(rgb, rgb_ref, rtol=1e-8, atol=1e-8)
 
 
+def _skinny_tile_row(i):
+    """skinny_tile_chunk (frame_head_lp.hip, experiment build GFPP_LP_SKINNY_MFMA): image row that lane row i of the gathered 32-row tile reads."""
+    i &= 15
+    low = i & 3
+    return 4 + min(low, 2) if i & 8 else low
+
+
+def test_skinny_rows_as_one_gathered_mfma_tile():
+    """The experiment build runs the skinny layers as MFMA chains: every lane takes its A operand from the skinny image through a row map, all three
+    layers use the same tile, and each reads its rows from accumulator registers 0..6 -- in BOTH half-waves.  Emulated with the kernels' lane layout."""
+    m = _model()
+    rng = np.random.default_rng(5)
+    K = fp.lp_skinny_image(m, torch.float64).numpy()            # [2, 7, 64]
+    A2, S2row, C1 = m.ambient_net.net[2].weight.detach().numpy(), m.sigma_net.net[2].weight.detach().numpy()[0], m.color_net.net[1].weight.detach().numpy()
+    dense = np.concatenate([np.concatenate([A2, np.zeros((3 - A2.shape[0], 128))]), S2row[None], C1])      # the 7 image rows, dense
+    x = rng.standard_normal((128, 32))                          # activations of 32 samples
+    cols = fp.lp_cols_act()
+    B = _encoder_operands(x, cols)                              # what relu_pack leaves in the lanes
+    tile = np.zeros((8, 1, 64, 8))
+    for s in range(8):
+        for lane in range(64):
+            tile[s, 0, lane] = K[lane >> 5, _skinny_tile_row(lane & 31), 8 * s:8 * s + 8]
+    acc = np.zeros((1, 64, 16))
+    for s in range(8):                                          # (_mfma16 over one row tile)
+        A = tile[s, 0].reshape(2, 32, 8)
+        X = B[s].reshape(2, 32, 8)
+        D = np.einsum("hre,hje->rj", A, X)
+        for lane in range(64):
+            for r in range(16):
+                acc[0, lane, r] += D[_row(r, lane >> 5), lane & 31]
+    want = dense @ x                                            # [7, 32]
+    for lane in range(64):
+        np.testing.assert_allclose(acc[0, lane, :7], want[:, lane & 31], rtol=1e-10, atol=1e-10)
+
+
 def test_column_tables_are_permutations_held_by_the_right_half_wave():
     act = fp.lp_cols_act()
     flat = sorted(c for s in act for h in s for c in h)
