@@ -789,12 +789,19 @@ def main():
 
     # ---- HBM-side traffic of the trip launches: from the committed rocprofv3 --pmc pass of this same workload ---------------------------
     if rank == 0 and "roofline" in result:
-        tfile = None
-        for rnd in ("r03", "r02", "r01"):
-            cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.precision}.json")
-            if os.path.exists(cand):
-                tfile = cand
-                break
+        tfile, tnote = None, ""
+        # the committed counter passes are of the headline workload (may_torso, 512 x 512); any other workload has none and says so.  The two 16-bit
+        # modes run the same kernel template over the same tables, so the newest pass of either stands for both (labelled)
+        same_traffic = {"bf16": ("bf16", "fp16"), "fp16": ("fp16", "bf16")}.get(args.precision, (args.precision,))
+        if args.variant == "may_torso" and HW == 512:
+            for rnd in ("r03", "r02", "r01"):
+                for prec in same_traffic:
+                    cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{prec}.json")
+                    if tfile is None and os.path.exists(cand):
+                        tfile = cand
+                        tnote = "" if prec == args.precision else f"; measured in {prec} -- the same kernel template and tables as {args.precision}"
+        else:
+            result["roofline"]["traffic_source"] = "no counter pass committed for this workload (profiles/*_pmc_traffic_* are of may_torso at 512 x 512)"
         if tfile is not None:
             try:
                 detail = json.load(open(tfile))
@@ -803,7 +810,7 @@ def main():
                 # the committed pass counted per FRAME where available (the launch structure changed in round 3: one launch per frame)
                 per_frame = detail.get("bytes_per_frame") or (detail.get("bytes_per_launch") or 0) * (detail.get("launches_per_frame") or detail.get("nonempty_launches_per_frame") or 1)
                 result["roofline"]["traffic"] = int(per_frame / nl) if per_frame else detail.get("bytes_per_launch")
-                result["roofline"]["traffic_source"] = "committed rocprofv3 --pmc pass of this workload: " + os.path.relpath(tfile, ROOT) + " (not measured in this run)"
+                result["roofline"]["traffic_source"] = "committed rocprofv3 --pmc pass of this workload: " + os.path.relpath(tfile, ROOT) + " (not measured in this run" + tnote + ")"
                 result["roofline"]["algorithmic_bytes_per_launch"] = int(result["roofline"]["samples_per_frame"] * GATHER_BYTES_PER_SAMPLE
                                                                          / max(nl, 1))
                 result["roofline"]["traffic_detail"] = detail
