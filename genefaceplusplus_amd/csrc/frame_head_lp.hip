@@ -37,6 +37,12 @@
 #ifndef GFPP_LP_SKINNY_MFMA
 #define GFPP_LP_SKINNY_MFMA 0
 #endif
+// Experiment build (not validated on the GPU yet, hence off): the ray direction of a block's samples is requested 1 = before sigma_net's layers, 2 = before
+// the block's first grid lookup, instead of right in front of the SH basis -- in the production ISA that global_load is followed by `s_waitcnt vmcnt(0)`,
+// one exposed L2 round trip per block; the sched_barriers of the MFMA layers keep an earlier request where it is put.  Same values, same arithmetic.
+#ifndef GFPP_LP_EARLY_DIR
+#define GFPP_LP_EARLY_DIR 0
+#endif
 #if GFPP_ABLATE & 4
 #define GFPP_TANH(x) (x)
 #define GFPP_EXP(x) (x)
@@ -354,13 +360,26 @@ __device__ __forceinline__ void ambient_block(const LpShared &sh, const typename
 template <typename H, typename Tile>
 __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, Tile &wt, const typename LpTraits<H>::vec (&bpos)[2],
                                                const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi,
-                                               bool commit = true) {
+                                               bool commit = true, const float *dir_early = nullptr) {
     typedef typename LpTraits<H>::vec vec;
     const bool valid = c < n_valid;
     const uint32_t slot = valid ? wt.order[c] : 0u;
     const uint32_t ray_local = slot / n_step;
     v16f acc[4];
     vec bh[8];
+#if GFPP_LP_EARLY_DIR == 1
+    float dir3[3];
+    {
+        const float *dp = a.rays_d + 3ull * wt.ray[ray_local];
+        dir3[0] = dp[0]; dir3[1] = dp[1]; dir3[2] = dp[2];
+    }
+    const float *dir = dir3;
+    (void)dir_early;
+#elif GFPP_LP_EARLY_DIR == 2
+    const float *dir = dir_early;
+#else
+    (void)dir_early;
+#endif
     zero_acc(acc);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0, bpos, lane);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0 + 2, bamb, lane);
@@ -382,7 +401,9 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     {
         vec bcol[9];
         float shv[16];
+#if !GFPP_LP_EARLY_DIR
         const float *dir = a.rays_d + 3ull * wt.ray[ray_local];
+#endif
         sh_basis4(dir[0], dir[1], dir[2], shv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bcol[0][e] = (H)(hi ? shv[8 + e] : shv[e]);
@@ -443,6 +464,13 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
 #endif
 
     vec bpos[2], bamb[2];
+#if GFPP_LP_EARLY_DIR == 2
+    float dir3[3];
+    {
+        const float *dp = a.rays_d + 3ull * wt.ray[slot / n_step];
+        dir3[0] = dp[0]; dir3[1] = dp[1]; dir3[2] = dp[2];
+    }
+#endif
     {
         float u3[3];
         const float b2 = 2.0f * a.mp.bound;
@@ -465,7 +493,11 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
     lap(2);
+#if GFPP_LP_EARLY_DIR == 2
+    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi, commit, dir3);
+#else
     radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi, commit);
+#endif
     lap(3);
 }
 
