@@ -1223,6 +1223,13 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
+#if GFPP_MARCH_LEAN
+    if (p.mp.C == 1u && p.mp.H <= 256u) {       // every shipped model: one cascade, 128 cells per axis
+        p.sample_cnt[n] = march_one_ray<true>(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
+                                              [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+        return;
+    }
+#endif
     p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }

@@ -2,13 +2,14 @@
 # One gpurun call for the experiment builds of the head pass that were written without GPU time at the end of round 3:
 #   (here)   tools/build_variant.sh earlydir frame_head_lp.hip -DGFPP_LP_EARLY_DIR=2
 #            tools/build_variant.sh skmfma frame_head_lp.hip -DGFPP_LP_SKINNY_MFMA=1
-#            tools/build_variant.sh skmfma_earlydir frame_head_lp.hip -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
-#   (box)    tools/variants_ab.sh <tag> [lib names ...]        default: the three above
+#            tools/build_variant.sh lean frame_head_lp.hip -DGFPP_MARCH_LEAN=1
+#            tools/build_variant.sh all3 frame_head_lp.hip -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
+#   (box)    tools/variants_ab.sh <tag> [lib names ...]        default: the four above
 # Per variant: the parity tests that exercise the 16-bit head kernels (per-sample outputs vs the reference's forward, frames vs the oracle, persistent launch vs
 # trip launches), then the same-box A/B against the production library on the headline bench and on the 256^2 SR variant.  Results: gpurun_out/<tag>.log
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
-libs=${*:-"earlydir skmfma skmfma_earlydir"}
+libs=${*:-"earlydir skmfma lean all3"}
 out=gpurun_out/$tag.log
 for l in $libs; do
   echo "== parity on lib_$l.so" >> $out
