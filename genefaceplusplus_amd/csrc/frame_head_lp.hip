@@ -43,6 +43,12 @@
 #ifndef GFPP_LP_EARLY_DIR
 #define GFPP_LP_EARLY_DIR 0
 #endif
+// Experiment build (not validated on the GPU yet, hence off): the two hash-grid tables as 16-bit corner-block tables (grid_device.h: one 16-byte gather per
+// z plane of a level instead of two -- 32 gathers from <= 25 cache lines per sample and grid instead of 64 from 64 -- packed dot products instead of fp32 fma
+// pairs).  The library then ONLY accepts grids with gfpp_grid_desc.row_padded == 2 (frame_pipeline.py builds them under GFPP_LP_BLOCK_TABLE=1).
+#ifndef GFPP_LP_BLOCK_TABLE
+#define GFPP_LP_BLOCK_TABLE 0
+#endif
 #if GFPP_ABLATE & 4
 #define GFPP_TANH(x) (x)
 #define GFPP_EXP(x) (x)
@@ -260,14 +266,24 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
             constexpr bool SM = decltype(smooth_tag)::value;
 #pragma unroll
             for (int i0 = 0; i0 < 8; i0 += kLpLevelGroup) {
+#if GFPP_LP_BLOCK_TABLE
+                BlockGathers<D> lg[kLpLevelGroup];
+#pragma unroll
+                for (int k = 0; k < kLpLevelGroup; ++k) level_block_issue<D, SM>(uc, g.table, lvs[i0 + k], ac, lg[k]);
+#else
                 LevelGathers<D> lg[kLpLevelGroup];
 #pragma unroll
                 for (int k = 0; k < kLpLevelGroup; ++k) level_fast_issue<D, SM>(uc, g.table, lvs[i0 + k], ac, lg[k]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);             // the group's gathers are all in flight before the first one is consumed
 #pragma unroll
                 for (int k = 0; k < kLpLevelGroup; ++k) {
                     float o[2];
+#if GFPP_LP_BLOCK_TABLE
+                    level_block_finish<D>(lg[k], o);
+#else
                     level_fast_finish<D>(lg[k], o);
+#endif
                     f[2 * (i0 + k)] = o[0];
                     f[2 * (i0 + k) + 1] = o[1];
                 }
@@ -1302,7 +1318,11 @@ static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
 }
 
 static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {
+#if GFPP_LP_BLOCK_TABLE
+    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F16 && g.row_padded == 2;
+#else
     return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
+#endif
 }
 
 // How many trips get a launch of their own before the multi-trip launch takes over (GFPP_LP_SEPARATE_TRIPS overrides, for experiments).
@@ -1363,6 +1383,9 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
         g.levels = gd.levels;
         for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
         if (!g.any_slow && !gd.row_padded) { set_error("%s: tables must be the per-level padded copy (row_padded)", who); return GFPP_EINVAL; }
+#if GFPP_LP_BLOCK_TABLE
+        if (g.any_slow) { set_error("%s: corner-block tables (this experiment build) need levels without hash / true modulo", who); return GFPP_EUNSUPPORTED; }
+#endif
         g.table = (const float *)gd.table;
         g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
     }

@@ -267,4 +267,75 @@ __device__ __forceinline__ void level_fast_finish(const LevelGathers<D> &g, floa
 }
 
 
+// ---- corner-block tables (experiment build GFPP_LP_BLOCK_TABLE of frame_head_lp.hip; not validated on the GPU yet) ----------------------------------------
+// The straight-line lookup above fetches a level's 2^D corners with 2^(D-1) gathers of 16 bytes from 2^(D-1) different cache lines (rows r and r + 1 are
+// adjacent, the y and z neighbours are whole strides away) -- 64 gathers from 64 lines per sample and 16-level 3-D grid, and the vector L1's tag rate is what a
+// lane-divergent gather costs.  A corner-block table trades memory for that: row r of a level holds, in 16-bit floats, BOTH channels of the FOUR corners
+// (r, r + 1, r + sy, r + sy + 1) of the x-y cell that starts at r (index arithmetic is linear modulo the level size, so the neighbours are functions of r
+// alone) -- 16 bytes, 16-byte aligned: one gather per z plane.  A 3-D level is 2 gathers from 2 lines (1 line where the tiled index drops z: the same row
+// twice), a 2-D level is 1.  The reference's own autocast path reads a half table too (grid.py:43-47); the table is 2 x the fp32 one (16 B instead of 8 B per row).
+// Row layout (8 halves): c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1): a dword is one channel's x pair, the operand
+// of a packed dot product with the pair of corner weights (v_dot2_f32_f16: 16-bit products, fp32 accumulation).
+typedef _Float16 gfpp_h2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+
+template <int D>
+struct BlockGathers {
+    float frac[D];
+    u32x4_a16 v[D == 3 ? 2 : 1];
+};
+
+template <int D, bool SMOOTH>
+__device__ __forceinline__ void level_block_issue(const float (&u)[D], const void *__restrict__ table, const LevelU &lv, bool align_corners,
+                                                  BlockGathers<D> &g) {
+    uint32_t base[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float pos = fmaf(u[d], lv.scale, align_corners ? 0.0f : 0.5f);
+        base[d] = (uint32_t)pos;
+        float f = __builtin_amdgcn_fractf(pos);
+        if constexpr (SMOOTH) f = f * f * fmaf(-2.0f, f, 3.0f);
+        g.frac[d] = f;
+    }
+    const char *lt = reinterpret_cast<const char *>(table);
+    uint32_t row = base[0] + __umul24(base[1], lv.sy);
+    if constexpr (D == 3) row += __umul24(base[2], lv.sz);
+    row &= lv.mask;
+    g.v[0] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row + lv.offset) << 4));
+    if constexpr (D == 3) {
+        const uint32_t row1 = (row + lv.sz) & lv.mask;          // sz == 0 (z dropped by the tiled index): the same row again, an L1 hit
+        g.v[1] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row1 + lv.offset) << 4));
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void level_block_finish(const BlockGathers<D> &g, float (&out)[2]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 wx = {1.0f - g.frac[0], g.frac[0]};
+    const f32x2 wy[2] = {wx * (1.0f - g.frac[1]), wx * g.frac[1]};
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+    for (int z = 0; z < (D == 3 ? 2 : 1); ++z) {
+        // (pairs taken with shufflevector from the whole row: bit-casting single vector ELEMENTS to pairs is miscompiled by ROCm 7.2's clang -- every
+        // element collapses to element 0, see skinny_dot)
+        const h8 row = __builtin_bit_cast(h8, g.v[z]);
+        const gfpp_h2 c0y0 = __builtin_shufflevector(row, row, 0, 1), c1y0 = __builtin_shufflevector(row, row, 2, 3);
+        const gfpp_h2 c0y1 = __builtin_shufflevector(row, row, 4, 5), c1y1 = __builtin_shufflevector(row, row, 6, 7);
+        f32x2 w0 = wy[0], w1 = wy[1];
+        if constexpr (D == 3) {
+            const float fz = z ? g.frac[2] : 1.0f - g.frac[2];
+            w0 = w0 * fz;
+            w1 = w1 * fz;
+        }
+        const gfpp_h2 h0 = __builtin_convertvector(w0, gfpp_h2), h1 = __builtin_convertvector(w1, gfpp_h2);
+        o0 = __builtin_amdgcn_fdot2(c0y0, h0, o0, false);
+        o1 = __builtin_amdgcn_fdot2(c1y0, h0, o1, false);
+        o0 = __builtin_amdgcn_fdot2(c0y1, h1, o0, false);
+        o1 = __builtin_amdgcn_fdot2(c1y1, h1, o1, false);
+    }
+    out[0] = o0;
+    out[1] = o1;
+}
+
 }  // namespace gfpp

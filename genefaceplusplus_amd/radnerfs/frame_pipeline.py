@@ -238,6 +238,23 @@ def lp_skinny_image(model, dtype):
     return img.permute(2, 0, 1, 3).reshape(2, 7, 64).to(dtype).contiguous()
 
 
+def corner_block_table(emb, offsets, levels):
+    """The 16-bit corner-block copy of a 2-channel grid table (csrc/grid_device.h, experiment build GFPP_LP_BLOCK_TABLE): row r of level l holds both
+    channels of the four corners (r, r + 1, r + sy, r + sy + 1) of the x-y cell that starts at r -- index arithmetic modulo the level size, the neighbours
+    gfpp_grid_levels_fill's `sy` / `mask` give -- as 8 halves: c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1).
+    emb [rows, 2] float tensor, offsets [L+1] ints (unpadded), levels: sequence of objects with sy / mask / size.  Returns [rows, 8] float16."""
+    parts = []
+    for l, lv in enumerate(levels):
+        T = emb[int(offsets[l]):int(offsets[l + 1])].float()
+        size, sy, mask = int(lv.size), int(lv.sy), int(lv.mask)
+        assert T.shape == (size, 2)
+        r = torch.arange(size, device=T.device, dtype=torch.int64)
+        wrap = (lambda k: k & mask) if mask != 0xFFFFFFFF else (lambda k: k % size)      # (no power of two: valid cells never leave the level, the rest is never read)
+        i00, i10, i01, i11 = r, wrap(r + 1), wrap(r + sy), wrap(r + sy + 1)
+        parts.append(torch.stack([T[i00, 0], T[i10, 0], T[i00, 1], T[i10, 1], T[i01, 0], T[i11, 0], T[i01, 1], T[i11, 1]], dim=1).to(torch.float16))
+    return torch.cat(parts, dim=0).contiguous()
+
+
 def supports(model):
     """The MFMA kernels are specialised for the shipped architecture family (hidden 128, 3/3/2 layers, 16x2 grids)."""
     hp = model.hparams
@@ -394,6 +411,25 @@ class FramePipeline:
         d.gridtype, d.interp, d.align_corners = enc.gridtype_id, enc.interp_id, int(enc.align_corners)
         return d
 
+    def _grid_desc_block(self, enc):
+        """Experiment (GFPP_LP_BLOCK_TABLE=1 + a library built with -DGFPP_LP_BLOCK_TABLE=1): the grid as a 16-bit corner-block table, row_padded = 2."""
+        L = enc.num_levels
+        off = np.ascontiguousarray(enc.offsets.cpu().numpy().astype(np.int32))
+        lv = (GridLevel * L)()
+        call("gfpp_grid_levels_fill", int(enc.input_dim), L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id),
+             int(enc.align_corners), off.ctypes.data, 0, lv)
+        levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
+        d = GridDesc()
+        d.table = self._hold(corner_block_table(enc.embeddings.detach(), off, lv))
+        self._keep.append(lv)
+        d.levels_host = ctypes.addressof(lv)
+        d.row_padded = 2
+        d.levels = self._hold(levels)
+        d.dtype = 1                       # GFPP_F16
+        d.D, d.L = enc.input_dim, L
+        d.gridtype, d.interp, d.align_corners = enc.gridtype_id, enc.interp_id, int(enc.align_corners)
+        return d
+
     def _build_head(self, m):
         hm = HeadModel()
         aabb = m.aabb_infer.detach().cpu().numpy().astype(np.float32)
@@ -437,6 +473,8 @@ class FramePipeline:
         """'fp32' (exact-fp32 MFMA) | 'fp16' | 'bf16' (16-bit MFMA operands, fp32 accumulation; weights repacked on first use)."""
         if precision == "fp32":
             self.precision = "fp32"
+            if "plain_grids" in self._lp_images:            # (experiment GFPP_LP_BLOCK_TABLE: the fp32 kernels read the plain tables)
+                self.head.pos_grid, self.head.amb_grid = self._lp_images["plain_grids"]
             if self.torso is not None and self.fp32_torso == "mfma":
                 # the torso MLPs on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 = an fp32 fma chain): the same fragment image as the 16-bit modes, in fp32
                 if "torso_fp32" not in self._lp_images:
@@ -453,6 +491,12 @@ class FramePipeline:
             self._lp_images[precision] = (lp_weight_image(model, dt).to(self.device), lp_skinny_image(model, dt).to(self.device))
         self.head.lp_weights = self._lp_images[precision][0].data_ptr()
         self.head.lp_skinny = self._lp_images[precision][1].data_ptr()
+        if os.environ.get("GFPP_LP_BLOCK_TABLE", "0") == "1":
+            # experiment: the 16-bit head kernels of a -DGFPP_LP_BLOCK_TABLE=1 library read corner-block tables (the fp32 kernels cannot: 16-bit modes only)
+            if "block_grids" not in self._lp_images:
+                self._lp_images["plain_grids"] = (GridDesc.from_buffer_copy(self.head.pos_grid), GridDesc.from_buffer_copy(self.head.amb_grid))
+                self._lp_images["block_grids"] = (self._grid_desc_block(model.position_embedder), self._grid_desc_block(model.ambient_embedder))
+            self.head.pos_grid, self.head.amb_grid = self._lp_images["block_grids"]
         if self.torso is not None:
             key = "torso_" + precision
             if key not in self._lp_images:

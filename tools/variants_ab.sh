@@ -4,16 +4,19 @@
 #            tools/build_variant.sh skmfma frame_head_lp.hip -DGFPP_LP_SKINNY_MFMA=1
 #            tools/build_variant.sh lean frame_head_lp.hip -DGFPP_MARCH_LEAN=1
 #            tools/build_variant.sh all3 frame_head_lp.hip -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
-#   (box)    tools/variants_ab.sh <tag> [lib names ...]        default: the four above
+#            tools/build_variant.sh blk frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1          (names with "blk" / "all4" run with GFPP_LP_BLOCK_TABLE=1: corner-block tables)
+#            tools/build_variant.sh all4 frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1 -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
+#   (box)    tools/variants_ab.sh <tag> [lib names ...]        default: the six above
 # Per variant: the parity tests that exercise the 16-bit head kernels (per-sample outputs vs the reference's forward, frames vs the oracle, persistent launch vs
 # trip launches), then the same-box A/B against the production library on the headline bench and on the 256^2 SR variant.  Results: gpurun_out/<tag>.log
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
-libs=${*:-"earlydir skmfma lean all3"}
+libs=${*:-"earlydir skmfma lean all3 blk all4"}
+block_env() { case "$1" in *blk*|*all4*) echo 1;; *) echo 0;; esac; }
 out=gpurun_out/$tag.log
 for l in $libs; do
   echo "== parity on lib_$l.so" >> $out
-  GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/lib_$l.so timeout 900 python -m pytest tests/test_samples_gpu.py tests/test_render_gpu.py -m gpu -x -q 2>&1 | tail -3 >> $out
+  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/lib_$l.so timeout 900 python -m pytest tests/test_samples_gpu.py tests/test_render_gpu.py -m gpu -q 2>&1 | tail -12 >> $out
 done
 line() {
 python -c "
@@ -22,8 +25,8 @@ d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']
 print('$1', '$2', d['value'], d['ms_per_step'], 'head pass', r['avg_launch_ms'], 'frac', r['frac'], r.get('workgroup_kcycles'))"
 }
 for rep in 1 2 3; do for l in libgfpp_radnerf.so $(for x in $libs; do echo lib_$x.so; done); do
-  GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l 512 >> $out
+  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l 512 >> $out
 done; done
 for rep in 1 2; do for l in libgfpp_radnerf.so $(for x in $libs; do echo lib_$x.so; done); do
-  GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --variant may_torso_sr --hw 256 --precision fp16 --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l sr256 >> $out
+  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --variant may_torso_sr --hw 256 --precision fp16 --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l sr256 >> $out
 done; done
