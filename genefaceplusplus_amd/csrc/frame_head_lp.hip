@@ -45,7 +45,8 @@
 #endif
 // Experiment build (not validated on the GPU yet, hence off): the two hash-grid tables as 16-bit corner-block tables (grid_device.h: one 16-byte gather per
 // z plane of a level instead of two -- 32 gathers from <= 25 cache lines per sample and grid instead of 64 from 64 -- packed dot products instead of fp32 fma
-// pairs).  The library then ONLY accepts grids with gfpp_grid_desc.row_padded == 2 (frame_pipeline.py builds them under GFPP_LP_BLOCK_TABLE=1).
+// pairs).  = 2: x-y-z blocks (32-byte rows) for the levels that keep z -- one cache line per level.  The library then ONLY accepts grids with
+// gfpp_grid_desc.row_padded == 1 + GFPP_LP_BLOCK_TABLE (frame_pipeline.py builds them under the environment variable of the same name and value).
 #ifndef GFPP_LP_BLOCK_TABLE
 #define GFPP_LP_BLOCK_TABLE 0
 #endif
@@ -1319,7 +1320,7 @@ static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
 
 static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {
 #if GFPP_LP_BLOCK_TABLE
-    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F16 && g.row_padded == 2;
+    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F16 && g.row_padded == 1u + GFPP_LP_BLOCK_TABLE;
 #else
     return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
 #endif

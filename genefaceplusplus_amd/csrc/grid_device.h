@@ -195,6 +195,9 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
 // per-level padded copy (row `size` repeats row 0), so the x+1 neighbour of the last row needs no wrap-around case, and a dropped
 // z coordinate (sz == 0) simply fetches the same rows again.  Same corner order, weight products and fma chain as
 // grid_level_lookup => bit-identical features.
+#ifndef GFPP_LP_BLOCK_TABLE
+#define GFPP_LP_BLOCK_TABLE 0     // experiment builds of frame_head_lp.hip: 1 = x-y corner blocks, 2 = x-y-z corner blocks where a level keeps z (below)
+#endif
 struct LevelU {   // one level's descriptor in scalar registers
     float scale;
     uint32_t sy, sz, mask, offset;
@@ -301,11 +304,20 @@ __device__ __forceinline__ void level_block_issue(const float (&u)[D], const voi
     uint32_t row = base[0] + __umul24(base[1], lv.sy);
     if constexpr (D == 3) row += __umul24(base[2], lv.sz);
     row &= lv.mask;
+#if GFPP_LP_BLOCK_TABLE == 2
+    // x-y-z blocks: a level that keeps z has 32-byte rows -- the x-y block of the cell and, right behind it, the block of its z neighbour (row r + sz):
+    // ONE cache line per level; a level whose index drops z (sz == 0) keeps 16-byte rows and is read twice.  `offset` counts 16-byte units here
+    const uint32_t sh = D == 3 ? (lv.sz < 1u ? lv.sz : 1u) : 0u;
+    const uint32_t at = (lv.offset + (row << sh)) << 4;
+    g.v[0] = *reinterpret_cast<const u32x4_a16 *>(lt + at);
+    if constexpr (D == 3) g.v[1] = *reinterpret_cast<const u32x4_a16 *>(lt + at + (sh << 4));
+#else
     g.v[0] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row + lv.offset) << 4));
     if constexpr (D == 3) {
         const uint32_t row1 = (row + lv.sz) & lv.mask;          // sz == 0 (z dropped by the tiled index): the same row again, an L1 hit
         g.v[1] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row1 + lv.offset) << 4));
     }
+#endif
 }
 
 template <int D>

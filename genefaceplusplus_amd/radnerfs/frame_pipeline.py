@@ -238,6 +238,27 @@ def lp_skinny_image(model, dtype):
     return img.permute(2, 0, 1, 3).reshape(2, 7, 64).to(dtype).contiguous()
 
 
+def corner_block_table_xyz(emb, offsets, levels):
+    """(experiment build GFPP_LP_BLOCK_TABLE=2) x-y-z corner blocks: a level that keeps z (sz != 0) gets 32-byte rows -- the x-y block of row r followed by the
+    x-y block of row r + sz -- so that all eight corners of a cell sit in one cache line; levels whose index drops z keep the 16-byte rows.  Returns the table
+    as [n, 8] float16 (n 16-byte units) and the start of every level in those units."""
+    xy = corner_block_table(emb, offsets, levels)
+    parts, starts, at = [], [], 0
+    for l, lv in enumerate(levels):
+        B = xy[int(offsets[l]):int(offsets[l + 1])]
+        size, sz, mask = int(lv.size), int(lv.sz), int(lv.mask)
+        starts.append(at)
+        if sz == 0:
+            parts.append(B)
+            at += size
+        else:
+            r = torch.arange(size, device=B.device, dtype=torch.int64)
+            up = (r + sz) & mask if mask != 0xFFFFFFFF else (r + sz) % size
+            parts.append(torch.stack([B, B[up]], dim=1).reshape(2 * size, 8))
+            at += 2 * size
+    return torch.cat(parts, dim=0).contiguous(), starts
+
+
 def corner_block_table(emb, offsets, levels):
     """The 16-bit corner-block copy of a 2-channel grid table (csrc/grid_device.h, experiment build GFPP_LP_BLOCK_TABLE): row r of level l holds both
     channels of the four corners (r, r + 1, r + sy, r + sy + 1) of the x-y cell that starts at r -- index arithmetic modulo the level size, the neighbours
@@ -420,10 +441,18 @@ class FramePipeline:
              int(enc.align_corners), off.ctypes.data, 0, lv)
         levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
         d = GridDesc()
-        d.table = self._hold(corner_block_table(enc.embeddings.detach(), off, lv))
+        mode = int(os.environ.get("GFPP_LP_BLOCK_TABLE", "1"))
+        if mode == 2:
+            table, starts = corner_block_table_xyz(enc.embeddings.detach(), off, lv)
+            for l in range(L):
+                lv[l].offset = starts[l]                    # in 16-byte units
+            levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
+        else:
+            table = corner_block_table(enc.embeddings.detach(), off, lv)
+        d.table = self._hold(table)
         self._keep.append(lv)
         d.levels_host = ctypes.addressof(lv)
-        d.row_padded = 2
+        d.row_padded = 1 + mode
         d.levels = self._hold(levels)
         d.dtype = 1                       # GFPP_F16
         d.D, d.L = enc.input_dim, L
@@ -491,7 +520,7 @@ class FramePipeline:
             self._lp_images[precision] = (lp_weight_image(model, dt).to(self.device), lp_skinny_image(model, dt).to(self.device))
         self.head.lp_weights = self._lp_images[precision][0].data_ptr()
         self.head.lp_skinny = self._lp_images[precision][1].data_ptr()
-        if os.environ.get("GFPP_LP_BLOCK_TABLE", "0") == "1":
+        if os.environ.get("GFPP_LP_BLOCK_TABLE", "0") in ("1", "2"):
             # experiment: the 16-bit head kernels of a -DGFPP_LP_BLOCK_TABLE=1 library read corner-block tables (the fp32 kernels cannot: 16-bit modes only)
             if "block_grids" not in self._lp_images:
                 self._lp_images["plain_grids"] = (GridDesc.from_buffer_copy(self.head.pos_grid), GridDesc.from_buffer_copy(self.head.amb_grid))
