@@ -6,14 +6,15 @@
 #            tools/build_variant.sh all3 frame_head_lp.hip -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
 #            tools/build_variant.sh blk frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1          (names with "blk" / "all4" run with GFPP_LP_BLOCK_TABLE=1: corner-block tables)
 #            tools/build_variant.sh blk2 frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=2         (x-y-z blocks: one cache line per level; runs with GFPP_LP_BLOCK_TABLE=2)
-#            tools/build_variant.sh all4 frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1 -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
-#   (box)    tools/variants_ab.sh <tag> bench|parity [lib names ...]        default: the seven above
+#            tools/build_variant.sh blk_g8 frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1 -DGFPP_LP_LEVEL_GROUP=8     (all eight levels of a lane in flight: 237 VGPRs, no scratch)
+#            tools/build_variant.sh all4 frame_head_lp.hip -DGFPP_LP_BLOCK_TABLE=1 -DGFPP_LP_LEVEL_GROUP=8 -DGFPP_MARCH_LEAN=1 -DGFPP_LP_EARLY_DIR=2 -DGFPP_LP_SKINNY_MFMA=1
+#   (box)    tools/variants_ab.sh <tag> bench|parity [lib names ...]        default: the eight above
 #            bench: ~25 s per library and repetition (2 x 512^2 + 1 x 256^2 SR); parity: ~4 min per library -- run it for the winners only
 # Per variant: the parity tests that exercise the 16-bit head kernels (per-sample outputs vs the reference's forward, frames vs the oracle, persistent launch vs
 # trip launches), then the same-box A/B against the production library on the headline bench and on the 256^2 SR variant.  Results: gpurun_out/<tag>.log
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; what=$2; shift 2
-libs=${*:-"earlydir skmfma lean all3 blk blk2 all4"}
+libs=${*:-"earlydir skmfma lean all3 blk blk2 blk_g8 all4"}
 block_env() { case "$1" in *blk2*) echo 2;; *blk*|*all4*) echo 1;; *) echo 0;; esac; }
 out=gpurun_out/$tag.log
 if [ "$what" = parity ]; then
