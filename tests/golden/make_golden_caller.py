@@ -10,7 +10,10 @@ drop-in classes behind the same import paths).  The script asserts what the CPU 
   * RADNeRFTorso, 512x512 rays, 2 frames: the two passes deliver the SAME BYTES;
   * RADNeRFTorsowithSR (256x256 rays + super-resolution -> 512x512, `sr_rgb_map`), 2 frames: <= 1 LSB apart on <= 0.1 % of the values (the
     SR stage runs as fp32 torch ops in two formulations of the same network on the CPU; its kernels are GPU-tested against oracle/sr_oracle.py).
-Recorded per model: sha256 of the reference pass's frames, every 4th pixel of them, the loader's report (class, torch.compile wrapper)."""
+Recorded per model: sha256 of the reference pass's frames, every 4th pixel of them, the loader's report (class, torch.compile wrapper).
+
+Round 4: a second set `<variant>.fast.*` -- 8 frames (indices 0..7: eight poses, cond windows, individual-code rows) with the CLI's `--fast`
+(`raymarching_end_threshold` 0.05, genefacepp_infer.py:566,591-592), same assertions.  `--only fast` regenerates that set and keeps the rest of the file."""
 import hashlib
 import os
 import subprocess
@@ -25,26 +28,37 @@ FRAMES = 2
 SUB = 4
 
 
-def run(mode, variant, work):
-    out = os.path.join(work, f"{variant}_{mode}.npz")
-    r = subprocess.run([sys.executable, os.path.join(TESTS, "ref_caller.py"), "--mode", mode, "--variant", variant, "--frames", str(FRAMES), "--work", work,
-                        "--out", out], capture_output=True, text=True)
+SETS = {"": (FRAMES, 0.01), ".fast": (8, 0.05)}          # key infix -> (frames, raymarching_end_threshold)
+
+
+def run(mode, variant, work, frames=FRAMES, thresh=0.01):
+    out = os.path.join(work, f"{variant}_{mode}_{frames}.npz")
+    r = subprocess.run([sys.executable, os.path.join(TESTS, "ref_caller.py"), "--mode", mode, "--variant", variant, "--frames", str(frames), "--thresh", str(thresh),
+                        "--work", work, "--out", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = np.load(out)
     return d["frames"], str(d["info"][0])
 
 
 def main():
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    path = os.path.join(HERE, "caller_golden.npz")
     out = {"sub": np.array([SUB], np.int32)}
+    if only is not None:
+        out = dict(np.load(path))
+    sets = {k: v for k, v in SETS.items() if only is None or k == "." + only}
     with tempfile.TemporaryDirectory() as work:
-        for variant in ("may_torso", "may_torso_sr"):
-            ref, ref_info = run("reference", variant, work)
-            got, got_info = run("product", variant, work)
+        for infix, variant in [(i, v) for i in sets for v in ("may_torso", "may_torso_sr")]:
+            frames, thresh = sets[infix]
+            ref, ref_info = run("reference", variant, work, frames, thresh)
+            got, got_info = run("product", variant, work, frames, thresh)
+            variant_key = variant
+            variant = variant + infix
             diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
             print(variant, "reference:", ref_info)
             print(variant, "product:  ", got_info)
             print(variant, "values that differ:", int((diff != 0).sum()), "of", diff.size, "max", int(diff.max()))
-            if variant == "may_torso":
+            if variant_key == "may_torso":
                 assert np.array_equal(ref, got), "the drop-in does not deliver the reference's bytes"
             else:
                 assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
@@ -53,7 +67,7 @@ def main():
             out[f"{variant}.sub"] = ref[:, ::SUB, ::SUB].copy()
             out[f"{variant}.mean"] = ref.astype(np.float64).mean(axis=(1, 2))
             out[f"{variant}.product_differs"] = np.array([int((diff != 0).sum()), int(diff.max())])
-    np.savez_compressed(os.path.join(HERE, "caller_golden.npz"), **out)
+    np.savez_compressed(path, **out)
     print("wrote caller_golden.npz")
 
 

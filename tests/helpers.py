@@ -22,6 +22,55 @@ def frame_case(variant, HW, frame_idx=0, hp_over=None, **sd_kw):
             "bg_color": np.full((1, HW * HW, 3), 0.5, np.float32), "T_thresh": 0.01}
 
 
+def nonconvex_occupancy(case, kind, seed=7):
+    """Replace the scene's convex ellipsoid by an occupancy with HOLES along the rays (occupied -> empty -> occupied), the shape a trained
+    checkpoint's bitfield has after update_extra_state (renderer.py:202-284: min(mean_density, density_thresh) on a dilated, decayed probe).
+      'speckle': the kernel-level cases' grid (tests/ref_kernel_cases.py:42-54: an ellipsoid + 2 % random cells, random densities), every cascade;
+      'shell'  : a hollow ellipsoid shell with a detached blob in front of it and one behind (rays meet 2-3 separate occupied runs).
+    Returns the case with density_grid / density_bitfield replaced (arrays copied, nothing else touched)."""
+    import math
+    from ref_kernel_cases import make_density, morton3D_np, packbits_np
+    hp = case["hp"]
+    H = int(hp["grid_size"])
+    C = 1 + math.ceil(math.log2(hp["bound"]))
+    if kind == "speckle":
+        grid = make_density(C, H, seed)
+    elif kind == "shell":
+        ii, jj, kk = np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing="ij")
+        m = morton3D_np(ii.ravel(), jj.ravel(), kk.ravel())
+        grid = np.zeros((C, H ** 3), np.float32)
+        for c in range(C):
+            b = float(min(2 ** c, hp["bound"]))
+            x, y, z = (((a.ravel() + 0.5) / H * 2 - 1) * b for a in (ii, jj, kk))
+            r_out = (x / 0.42) ** 2 + (y / 0.30) ** 2 + (z / 0.46) ** 2
+            r_in = (x / 0.30) ** 2 + (y / 0.17) ** 2 + (z / 0.34) ** 2
+            blob_front = (x - 0.05) ** 2 + (y - 0.42) ** 2 + (z + 0.08) ** 2 < 0.06 ** 2          # towards the camera (+y)
+            blob_back = (x + 0.10) ** 2 + (y + 0.40) ** 2 + (z - 0.05) ** 2 < 0.08 ** 2
+            grid[c, m] = np.where(((r_out <= 1.0) & (r_in > 1.0)) | blob_front | blob_back, 20.0, 0.0).astype(np.float32)
+    else:
+        raise ValueError(kind)
+    case = dict(case)
+    case["sd"] = dict(case["sd"])
+    case["sd"]["density_grid"] = grid
+    case["sd"]["density_bitfield"] = packbits_np(grid, hp["density_thresh"])
+    return case
+
+
+def pose_at(distance=4.0, yaw_deg=0.0, shift=(0.0, 0.0, 0.0), away=False):
+    """ngp cam2world [1,4,4]: the bench camera (on +y, looking at the origin along -y) moved around -- closer / inside the AABB, turned about z,
+    translated sideways (part of the frame misses the box), or turned away from it (every ray misses: the NaN-depth convention)."""
+    import math
+    base = np.array([[-1, 0, 0, 0], [0, 0, -1, distance], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+    if away:
+        base[:3, :3] = base[:3, :3] @ np.diag([-1.0, 1.0, -1.0])       # half a turn about the camera's own y axis: view direction +y, away from the box
+    th = math.radians(yaw_deg)
+    c, s = math.cos(th), math.sin(th)
+    rz = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    pose = rz @ base
+    pose[:3, 3] += np.asarray(shift, np.float64)
+    return pose.astype(np.float32)[None]
+
+
 def oracle_render(orc, case, trace=None):
     hp, sd, HW = case["hp"], case["sd"], case["HW"]
     rays = orc.get_rays(case["pose"], case["intr"], HW, HW)
@@ -80,6 +129,9 @@ def compare_frames(res, ref, variant, HW, rgb_tol=2e-4, depth_tol=1e-3, frac=5e-
     derr = np.abs(d[ok] - dref[ok])
     stats["depth_frac_over"] = float((derr > depth_tol).mean())
     assert stats["depth_frac_over"] <= frac, stats
+    # rays that miss the box: near = far = FLT_MAX and the reference's (depth - near).clamp(0) / (far - near) is 0 / 0 (renderer.py:396)
+    stats["depth_nan"] = int(np.isnan(dref).sum())
+    assert np.array_equal(np.isnan(d), np.isnan(dref)), ("NaN pattern of depth_map", int(np.isnan(d).sum()), stats["depth_nan"])
     if "torso_alpha_map" in ref:
         ta = res["torso_alpha_map"].float().cpu().numpy().reshape(-1)
         taerr = np.abs(ta - ref["torso_alpha_map"].reshape(-1))

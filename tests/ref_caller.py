@@ -139,7 +139,7 @@ def prepare(mode, data_dir):
     os.chdir(REF)
 
 
-def run(mode, variant, n_frames, work):
+def run(mode, variant, n_frames, work, thresh=0.01):
     from dataset_fixture import write_synthetic_dataset
     sys.path.insert(0, REPO)
     from genefaceplusplus_amd import synthetic as syn
@@ -189,7 +189,8 @@ def run(mode, variant, n_frames, work):
     batch["bg_img"] = ds.bg_img.reshape([1, -1, 3]).cuda()
     batch["bg_coords"] = ds.bg_coords.cuda()
     shell.wav16k_name = os.path.join(work, "none_16k.wav")
-    inp = {"low_memory_usage": False, "raymarching_end_threshold": 0.01, "debug": False, "out_name": os.path.join(work, f"{variant}_{mode}.mp4")}
+    inp = {"low_memory_usage": False, "raymarching_end_threshold": thresh,    # 0.05 = the CLI's --fast (genefacepp_infer.py:591-592)
+            "debug": False, "out_name": os.path.join(work, f"{variant}_{mode}.mp4")}
     os.system = lambda cmd: 0                                     # ffmpeg mux + rm of the temporaries
     import random
     random.seed(0)
@@ -206,10 +207,11 @@ def main():
     ap.add_argument("--mode", required=True, choices=["reference", "product"])
     ap.add_argument("--variant", required=True, choices=["may_torso", "may_torso_sr", "may_head"])
     ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--thresh", type=float, default=0.01, help="raymarching_end_threshold; --fast sets 0.05 (genefacepp_infer.py:566,591-592)")
     ap.add_argument("--work", required=True)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    frames, info = run(a.mode, a.variant, a.frames, a.work)
+    frames, info = run(a.mode, a.variant, a.frames, a.work, a.thresh)
     np.savez_compressed(a.out, frames=frames, info=np.array([repr(info)]))
     print("REFCALLER", a.mode, a.variant, frames.shape, info)
 

@@ -76,6 +76,49 @@ def test_budget_and_alive_counts_follow_from_the_histogram(seed, max_steps, thin
     assert (B - max_steps <= 6) or not (d > B).any()
 
 
+@pytest.mark.parametrize("kind,HW,max_steps", [("shell", 48, 16), ("speckle", 48, 16), ("speckle", 40, 7), ("shell", 33, 24)])
+def test_budget_on_rays_with_holes(oracle_mod, kind, HW, max_steps):
+    """The same identity on the ray population of a NON-CONVEX occupancy (rays that go occupied -> empty -> occupied, tests/helpers.nonconvex_occupancy):
+    c = the occupied samples the reference's own marcher finds along each ray -- in as many separate runs as the ray crosses -- and e from a field whose
+    opacity differs per run (a thin first run, an opaque second one: the ray survives the hole and ends inside the second run).  Holes change nothing in
+    the arithmetic -- a trip takes the ray's next n_step OCCUPIED samples wherever they lie (raymarching.cu:878-927) -- and this pins that."""
+    from helpers import frame_case, nonconvex_occupancy
+    case = nonconvex_occupancy(frame_case("may_torso", HW), kind)
+    hp, sd = case["hp"], case["sd"]
+    rays = oracle_mod.get_rays(case["pose"], case["intr"], HW, HW)
+    ro, rd = rays["rays_o"][0], rays["rays_d"][0]
+    N = HW * HW
+    cap = max_steps + 7
+    nears, fars = oracle_mod.near_far_from_aabb(ro, rd, sd["aabb_infer"], 0.05)
+    _, _, deltas = oracle_mod.march_rays(N, cap, np.arange(N, dtype=np.int32), nears.copy(), ro, rd, float(hp["bound"]), sd["density_bitfield"], 1, 128, nears, fars,
+                                         -1, False, hp["dt_gamma"], 1024)
+    d = deltas[:N * cap].reshape(N, cap, 2)
+    occupied = d[:, :, 0] > 0
+    c = occupied.sum(1)
+    # a run starts where the step from the previous sample's end exceeds its own dt (the marcher skipped empty cells in between)
+    t_end, dt = d[:, :, 1], d[:, :, 0]
+    new_run = np.zeros_like(occupied)
+    new_run[:, 1:] = occupied[:, 1:] & ((t_end[:, 1:] - t_end[:, :-1]) > 1.5 * dt[:, 1:])
+    run_id = np.cumsum(new_run, axis=1)
+    assert (run_id.max(axis=1) >= 1).mean() > 0.2                       # a good share of the rays has at least one hole
+    rng = np.random.default_rng(HW)
+    # opacity per run: first run thin (alpha 0.05), later runs opaque (alpha 0.5..0.9); e = first sample whose PRE-sample transmittance < T_thresh
+    alpha = np.where(run_id == 0, 0.05, rng.uniform(0.5, 0.9, size=(N, 1))) * occupied
+    T_pre = np.concatenate([np.ones((N, 1)), np.cumprod(1 - alpha, axis=1)[:, :-1]], axis=1)
+    below = (T_pre < 0.01) & occupied
+    e = np.where(below.any(1), below.argmax(1), 10 ** 6)
+    ended_in_later_run = (e < 10 ** 6) & (run_id[np.arange(N), np.minimum(e, cap - 1)] >= 1)
+    assert ended_in_later_run.sum() > 0
+    done_ref, trace, B_ref, left = reference_loop(c, e, N, max_steps)
+    dd = np.minimum(c, e + 1)
+    m = np.minimum(np.minimum(c, e), cap)
+    hist = np.bincount(m, minlength=32)
+    B, counters = budget_from_hist(hist, N, max_steps)
+    assert B == B_ref and counters[:len(trace)] == trace and counters[len(trace)] == left
+    np.testing.assert_array_equal(np.minimum(dd, B), done_ref)
+    assert len(trace) >= 4                                               # a real multi-trip schedule
+
+
 TILE = 8        # kPTile
 
 

@@ -20,10 +20,10 @@ def _golden():
     return np.load(os.path.join(HERE, "golden", "caller_golden.npz"))
 
 
-def _run(mode, variant, frames, work):
+def _run(mode, variant, frames, work, thresh=0.01):
     out = os.path.join(work, f"{variant}_{mode}.npz")
-    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_caller.py"), "--mode", mode, "--variant", variant, "--frames", str(frames), "--work", str(work),
-                        "--out", out], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_caller.py"), "--mode", mode, "--variant", variant, "--frames", str(frames), "--thresh", str(thresh),
+                        "--work", str(work), "--out", out], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = np.load(out)
     return d["frames"], str(d["info"][0])
@@ -50,6 +50,19 @@ def test_reference_caller_on_the_dropin_torso_sr(tmp_path):
     assert "RADNeRFTorsowithSR" in info and "'with_sr': True" in info
     diff = np.abs(frames[:, ::4, ::4].astype(np.int32) - g["may_torso_sr.sub"][:1].astype(np.int32))
     assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3, (int(diff.max()), float((diff != 0).mean()))
+
+
+@needs_reference
+def test_reference_caller_fast_threshold_eight_frames(tmp_path):
+    """The CLI's `--fast` (raymarching_end_threshold 0.05, genefacepp_infer.py:566,591-592): the fixture holds 8 frames of the reference's caller over the
+    reference's classes (the generator asserted byte equality of the drop-in on all 8; tests/test_ref_caller_gpu.py renders all 8 on the real kernels);
+    here all 8 through the drop-in again -- every frame has its own pose, conditioning window and individual-code row -- byte for byte."""
+    g = _golden()
+    assert g["may_torso.fast.sub"].shape[0] == 8 and list(g["may_torso.fast.product_differs"]) == [0, 0]
+    assert not np.array_equal(g["may_torso.fast.sub"][:2], g["may_torso.sub"])                              # the threshold changed the picture
+    frames, info = _run("product", "may_torso", 8, tmp_path, thresh=0.05)
+    np.testing.assert_array_equal(frames[:, ::4, ::4], g["may_torso.fast.sub"])
+    assert hashlib.sha256(np.ascontiguousarray(frames).tobytes()).hexdigest() == str(g["may_torso.fast.sha256"][0])
 
 
 def test_checkpoint_writer_layout(tmp_path):

@@ -66,6 +66,31 @@ def test_caller_sequence_torso_512_under_torch_compile(tmp_path):
     np.testing.assert_array_equal(cs.forward_secc2video(plain, hparams, batch, 0.01, autocast=False), f32)
 
 
+def test_caller_sequence_fast_threshold_eight_frames(tmp_path):
+    """`--fast` (raymarching_end_threshold 0.05, genefacepp_infer.py:566,591-592), 8 frames (eight poses, conditioning windows and individual-code rows) against the
+    frames the reference's own caller produced with the reference's own classes (tests/golden/make_golden_caller.py --only fast)."""
+    from genefaceplusplus_amd.radnerfs import camera
+    g = np.load(os.path.join(HERE, "golden", "caller_golden.npz"))
+    want = g["may_torso.fast.sub"]
+    assert want.shape[0] == 8
+    cs, model, hparams, ds, dev = _setup(tmp_path, "may_torso")
+    batch = cs.make_batch(ds, hparams, 8, dev, camera.get_rays, camera.convert_poses)
+    f32 = cs.forward_secc2video(model, hparams, batch, 0.05, autocast=False)
+    d = np.abs(f32[:, ::4, ::4].astype(np.int32) - want.astype(np.int32))
+    per_frame = [float((x > 1).mean()) for x in d]
+    stats = {"differ": float((d != 0).mean()), "over_1": float((d > 1).mean()), "max": int(d.max()), "psnr": _psnr(f32[:, ::4, ::4], want), "over_1_per_frame": per_frame}
+    print("--fast, fp32 vs the reference caller's 8 frames", stats)
+    assert stats["over_1"] <= 5e-4 and max(per_frame) <= 1e-3 and stats["differ"] <= 2e-2 and stats["psnr"] >= 60, stats
+    f16 = cs.forward_secc2video(model, hparams, batch, 0.05, autocast=True)
+    p16 = [_psnr(a, b) for a, b in zip(f16[:, ::4, ::4], want)]
+    print("--fast, autocast per-frame PSNR", p16)
+    assert min(p16) >= 45, p16
+    # and the default threshold renders another picture with the same graph key family (T_thresh is part of the captured frame's key)
+    f16_default = cs.forward_secc2video(model, hparams, batch, 0.01, autocast=True)
+    assert not np.array_equal(f16_default, f16)
+    np.testing.assert_array_equal(cs.forward_secc2video(model, hparams, batch, 0.05, autocast=True), f16)
+
+
 def test_caller_sequence_torso_sr_under_torch_compile(tmp_path):
     from genefaceplusplus_amd.radnerfs import camera
     g = np.load(os.path.join(HERE, "golden", "caller_golden.npz"))

@@ -20,7 +20,7 @@ out=gpurun_out/$tag.log
 if [ "$what" = parity ]; then
   for l in $libs; do
     echo "== parity on lib_$l.so" >> $out
-    GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/lib_$l.so timeout 900 python -m pytest tests/test_samples_gpu.py tests/test_render_gpu.py -m gpu -q 2>&1 | tail -12 >> $out
+    GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/build/variants/lib_$l.so timeout 900 python -m pytest tests/test_samples_gpu.py tests/test_render_gpu.py -m gpu -q 2>&1 | tail -12 >> $out
   done
   exit 0
 fi
@@ -30,10 +30,11 @@ import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']
 print('$1', '$2', d['value'], d['ms_per_step'], 'head pass', r['avg_launch_ms'], 'frac', r['frac'], r.get('workgroup_kcycles'))"
 }
+libpath() { case "$1" in libgfpp_radnerf.so) echo $GRAFT_REPO_ROOT/genefaceplusplus_amd/$1;; *) echo $GRAFT_REPO_ROOT/build/variants/$1;; esac; }
 all="libgfpp_radnerf.so $(for x in $libs; do echo lib_$x.so; done)"
-for rep in 1 2; do for l in $all; do
-  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l 512 >> $out
+for rep in $(seq 1 ${REPS:-2}); do for l in $all; do
+  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$(libpath $l) timeout 300 python bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l 512 >> $out
 done; done
 for l in $all; do
-  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$GRAFT_REPO_ROOT/genefaceplusplus_amd/$l timeout 300 python bench.py --variant may_torso_sr --hw 256 --precision fp16 --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l sr256 >> $out
+  GFPP_LP_BLOCK_TABLE=$(block_env $l) GFPP_LIB_PATH=$(libpath $l) timeout 300 python bench.py --variant may_torso_sr --hw 256 --precision fp16 --steps 200 --warmup 8 --no-cpu-baseline --no-modes --no-configs --no-grid-stage 2>/dev/null | line $l sr256 >> $out
 done
