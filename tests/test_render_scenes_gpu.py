@@ -71,7 +71,11 @@ def check_all_modes(dev, orc, case, tag, frac16=5e-4, psnr16=45.0, alive16_rel=2
     got_step = [max(min(N // a, 8), 1) for a in got_alive if a > 0]
     print(tag, "fp32", stats, "trips", trace)
     assert got_step == n_step_ref, (got_step, n_step_ref)                       # the step budget of every ray follows from this sequence
-    assert got_alive == n_alive_ref, (got_alive, n_alive_ref)                   # the reference's own loop, trip for trip
+    # ... and the reference's own alive counts, trip for trip -- up to the rays whose transmittance crosses T_thresh within the fp32 summation order of the
+    # MLP layers (SURVEY 8c allows 0.05 % of the pixels for them; measured: at most 1 ray of 262 144 ends one trip earlier or later)
+    worst = max(abs(a - b) for a, b in zip(got_alive, n_alive_ref))
+    print(tag, "fp32 n_alive: largest difference to the reference's loop", worst, "rays")
+    assert worst <= max(2, int(2e-5 * N)), (got_alive, n_alive_ref)
 
     for precision in precisions:
         outs = {}
