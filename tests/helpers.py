@@ -127,7 +127,7 @@ def compare_frames(res, ref, variant, HW, rgb_tol=2e-4, depth_tol=1e-3, frac=5e-
     dref = ref["depth_map"].reshape(-1)
     ok = np.isfinite(dref)
     derr = np.abs(d[ok] - dref[ok])
-    stats["depth_frac_over"] = float((derr > depth_tol).mean())
+    stats["depth_frac_over"] = float((derr > depth_tol).mean()) if derr.size else 0.0      # (every ray may miss the box: no finite depth at all)
     assert stats["depth_frac_over"] <= frac, stats
     # rays that miss the box: near = far = FLT_MAX and the reference's (depth - near).clamp(0) / (far - near) is 0 / 0 (renderer.py:396)
     stats["depth_nan"] = int(np.isnan(dref).sum())
