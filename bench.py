@@ -607,7 +607,7 @@ def main():
             # HBM peak (the north star's yardstick for the hash-grid stage) and the MFMA fraction beside it
             gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
             tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
-            kname = "k_head_frame_persist" if persist else ("k_head_trip_lp" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" else "k_head_trip_pool")
+            kname = "k_head_frame_persist" if persist else "k_head_trip_pool"
             what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
                     else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
             return {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",

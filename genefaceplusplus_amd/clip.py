@@ -403,6 +403,8 @@ class ClipRenderer:
         def deliver(c):
             lo, hi = bounds[c]
             B["copied"][c & 1].synchronize()
+            if self._barriers_possible():
+                self.check()                     # BEFORE the chunk reaches the sink: a frame of it may lack trips (sticky word, FramePipeline.check_barriers)
             host = B["host"][c & 1].numpy()
             for k in range(lo, hi):
                 sink(idx[k], host[k - lo])
@@ -426,6 +428,13 @@ class ClipRenderer:
         self.join()
         self.check()
         return collected
+
+    def _barriers_possible(self):
+        """Only the trip-launch path of the 16-bit modes has device-wide barriers (lp_kernel='trips', or max_steps > 24 / more than 2^22 rays)."""
+        if getattr(self.model, "executor", "fused") != "fused":
+            return False
+        pipe = self.model.pipeline()
+        return pipe.precision != "fp32" and (pipe.lp_kernel != "persist" or int(self.render_kwargs.get("max_steps", 16)) > 24 or self.rays_per_frame > (1 << 22))
 
     def check(self):
         """After the frames of a job have completed: raise GfppError if any of them was rendered by a launch whose device-wide barrier timed out

@@ -23,40 +23,9 @@
 #include "head_eval_device.h"
 #include "lp_mfma_device.h"
 
-#ifndef GFPP_LP_LDS_LEVELS
-#define GFPP_LP_LDS_LEVELS 1   // level descriptors: 0 = scalar loads + per-lane select, 1 = per-lane LDS reads
-#endif
-// Experiment builds only (tools/eval_bench.py; results are WRONG with any bit set): what a block's time is made of.
-//   1 = table gathers replaced by register values, 2 = wide MFMA layers (and their LDS reads) skipped, 4 = skinny rows + transcendentals skipped
-//   64 = (k_head_trip_pool) every block evaluated twice, results right: trip time minus the normal build's = the evaluation's share of a trip
-#ifndef GFPP_ABLATE
-#define GFPP_ABLATE 0
-#endif
-// Experiment build (tools/ab_lib.sh; not validated on the GPU yet, hence off): the three skinny output layers (3 + 1 + 3 rows) as MFMA chains on a 16-row
-// tile gathered from the skinny image instead of 224 packed dot products per block on the VALU -- see skinny_mfma below.
-#ifndef GFPP_LP_SKINNY_MFMA
-#define GFPP_LP_SKINNY_MFMA 0
-#endif
-// Experiment build (not validated on the GPU yet, hence off): the ray direction of a block's samples is requested 1 = before sigma_net's layers, 2 = before
-// the block's first grid lookup, instead of right in front of the SH basis -- in the production ISA that global_load is followed by `s_waitcnt vmcnt(0)`,
-// one exposed L2 round trip per block; the sched_barriers of the MFMA layers keep an earlier request where it is put.  Same values, same arithmetic.
-#ifndef GFPP_LP_EARLY_DIR
-#define GFPP_LP_EARLY_DIR 0
-#endif
-// Experiment build (not validated on the GPU yet, hence off): the two hash-grid tables as 16-bit corner-block tables (grid_device.h: one 16-byte gather per
-// z plane of a level instead of two -- 32 gathers from <= 25 cache lines per sample and grid instead of 64 from 64 -- packed dot products instead of fp32 fma
-// pairs).  = 2: x-y-z blocks (32-byte rows) for the levels that keep z -- one cache line per level.  The library then ONLY accepts grids with
-// gfpp_grid_desc.row_padded == 1 + GFPP_LP_BLOCK_TABLE (frame_pipeline.py builds them under the environment variable of the same name and value).
-#ifndef GFPP_LP_BLOCK_TABLE
-#define GFPP_LP_BLOCK_TABLE 0
-#endif
-#if GFPP_ABLATE & 4
-#define GFPP_TANH(x) (x)
-#define GFPP_EXP(x) (x)
-#else
-#define GFPP_TANH(x) tanhf(x)
-#define GFPP_EXP(x) expf(x)
-#endif
+// Round 4 (measured on the GPU, then adopted; the A/B numbers are in docs/LAB_NOTEBOOK.md): the two hash grids are read as 16-bit CORNER-BLOCK tables
+// (grid_device.h: one 16-byte gather per z plane of a level, all eight levels of a lane in flight), the three skinny output layers run as MFMA chains on one
+// gathered tile (skinny_mfma), and a block's ray directions are requested before its first grid lookup.  Head pass 0.290 -> 0.240 ms at 512^2.
 
 namespace gfpp {
 
@@ -76,18 +45,15 @@ constexpr int kLpSteps = 31;
 constexpr int kLpWeightChunks = kLpSteps * 4 * 64;   // 16-byte chunks: [step][tile m][lane]
 constexpr int kSkinnyRows = 7;   // ambient_net.2 (3, padded), sigma_net.2 row 0, color_net.1 (3): rows 0-2, 3, 4-6
 constexpr int kSkinnyWords = 2 * kSkinnyRows * 32;   // [half][row][32 pairs of 16-bit weights]
-#if GFPP_LP_SKINNY_MFMA
 constexpr int kSkinnyPitch = 9;                       // 16-byte chunks per (half, row) in LDS: 8 steps + 1 of padding (rows 128 B apart would all start in the same banks)
 constexpr int kSkinnyLds = 2 * kSkinnyRows * kSkinnyPitch * 4;
-#else
-constexpr int kSkinnyLds = kSkinnyWords;
-#endif
 
 struct LpWaveTile {
     float px[kLpSlots], py[kLpSlots], pz[kLpSlots];   // sample position; after evaluation: sigma, r, g of the slot
     float cb[kLpSlots], dt[kLpSlots], tend[kLpSlots]; // b of the slot; step length; t after the sample
     uint32_t ray[kLpRays];                            // ray id by local ray (direction is re-read from rays_d for the SH basis)
     uint8_t order[kLpSlots];                          // compact index -> slot
+    __device__ __forceinline__ uint32_t ray_of(uint32_t local) const { return ray[local]; }
 };
 
 // The sample pool of one workgroup round (k_head_trip_pool): the eight wavefront tiles side by side, compacted TOGETHER, so that the
@@ -103,6 +69,7 @@ struct LpPool {
     uint32_t wave_valid[kLpWaves];   // occupied samples per wavefront tile
     uint32_t wave_surv[kLpWaves];    // surviving rays per wavefront tile
     uint32_t out_base;               // where the workgroup's survivors go in the next trip's list
+    __device__ __forceinline__ uint32_t ray_of(uint32_t local) const { return ray[local]; }
 };
 
 // The pool of the persistent launch (k_head_frame_persist): the workgroup's alive list lives here too, dt / t_end are recomputed from t0 when
@@ -122,6 +89,7 @@ struct LpPoolP {
     uint32_t wave_valid[kLpWaves], wave_surv[kLpWaves];
     uint32_t tile_cnt[kPTilesPerStep];   // ingest: occupied rays | empty rays << 16 of each candidate tile
     uint32_t hist[32];               // rays by the sample index their compositing ends at
+    __device__ __forceinline__ uint32_t ray_of(uint32_t local) const { return ray[local]; }
 };
 
 struct LpShared {
@@ -139,7 +107,7 @@ static_assert(sizeof(LpShared) <= 163840, "one workgroup per CU: everything must
 
 struct LpGrid {
     const gfpp_grid_level *levels;   // [16] device memory, read with scalar loads
-    const float *table;
+    const void *table;               // fast levels only: the 16-bit corner-block copy; otherwise (any_slow, SLOW instantiations) the fp32 table
     uint32_t gridtype, interp, align_corners, any_slow;
 };
 
@@ -158,6 +126,7 @@ struct LpTripArgs {
     const int32_t *gcounters;     // frame-wide alive counts per trip (== counters unless this launch renders one ray tile of a frame shared between GPUs)
     uint32_t N_global;            // rays of the whole frame (== N on one GPU)
     int32_t *sync;                // barrier word of multi-trip launches (counters[127], zeroed by k_frame_begin)
+    int32_t *timeouts;            // optional sticky word (gfpp_frame_ws.timeouts): +1 per barrier that timed out, reset by nobody but the host
     const float *frame_consts;
     float T_thresh, density_scale;
     uint32_t N, trip, trip_end, max_steps;   // this launch runs the trips [trip, trip_end)
@@ -169,28 +138,11 @@ struct LpTripArgs {
     uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 8 128 cycles late
     uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
-    unsigned long long *phase_cycles;   // optional [trips][8]: cycles summed over wavefronts: copy, gather samples, evaluate, composite | evaluate split: pos enc, amb MLP, amb enc, sigma+colour
+    unsigned long long *phase_cycles;   // optional [trips][8] (k_head_trip_pool<PROF>): cycles summed over wavefronts by phase, see there
 };
 
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
-#if GFPP_ABLATE & 2
-    for (int s = 0; s < NS; ++s) acc[s & 3][s & 15] += (float)b[s][0];
-    return;
-#endif
-#if GFPP_ABLATE & 8      // MFMAs kept, A operands from registers instead of the LDS stream
-    for (int s = 0; s < NS; ++s)
-        for (int t = 0; t < 4; ++t) acc[t] = LpTraits<H>::mfma(b[(s + t) % NS], b[s], acc[t]);
-    return;
-#endif
-#if GFPP_ABLATE & 16     // LDS stream kept, MFMAs replaced by one VALU op per fragment
-    {
-        const typename LpTraits<H>::vec *p = reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256 + lane;
-        for (int s = 0; s < NS; ++s)
-            for (int t = 0; t < 4; ++t) acc[t][s & 15] += (float)p[(s * 4 + t) * 64][t] * (float)b[s][0];
-        return;
-    }
-#endif
     mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);
 }
 
@@ -199,26 +151,13 @@ __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTrait
     act_pack<H, 4, 1>(acc, b);
 }
 
-// (grid encoding, straight-line: LevelU / level_fast_issue / level_fast_finish live in grid_device.h, shared with the exact-fp32 kernels)
-template <int D, bool SMOOTH>
-__device__ __forceinline__ void level_fast_uniform(const float (&u)[D], const float *__restrict__ table, const LevelU &lv, bool align_corners,
-                                                   float (&out)[2]) {
-    LevelGathers<D> g;
-    level_fast_issue<D, SMOOTH>(u, table, lv, align_corners, g);
-    level_fast_finish<D>(g, out);
-}
-
-// How many levels' gathers a lane keeps in flight (kLpLevelGroup x 2^(D-1) loads of 16 bytes = 16 VGPRs per 3-D level).  Measured (512^2 bf16, same box,
-// k-kcycles of `evaluate` / frames/s): 1 level 131.6 / 2 983, 2 levels 124.8 / 3 076, 4 levels 126.1 / 3 046, 8 levels (7 spilled registers) 123.9 / 2 993;
-// issuing the next group before the current one is interpolated (16 in flight, 240 VGPRs) 122.7 -- within the noise of 2 levels, which keeps 229 VGPRs
-#ifndef GFPP_LP_LEVEL_GROUP
-#define GFPP_LP_LEVEL_GROUP 2
-#endif
-constexpr int kLpLevelGroup = GFPP_LP_LEVEL_GROUP;
-
-// This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..:
-// the level descriptors sit in LDS and the lookup is straight-line code, so the gathers of several levels are in flight together.  Value k (= 8 s + e) of the lane is level 2 (k/2) + hi,
-// channel k % 2.
+// This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..; value k (= 8 s + e) of the
+// lane is level 2 (k/2) + hi, channel k % 2.
+//   SLOW = false (every level's index is linear modulo a power of two or provably in range -- the tiled grids of every shipped model): the table is the 16-bit
+//     CORNER-BLOCK copy (grid_device.h: level_block_issue / level_block_finish) and the lookup is straight-line code.  The gathers of ALL eight levels of the
+//     lane are issued before the first is interpolated -- two memory round trips per block and grid.  Measured at 512^2 bf16 (head pass, same box): fp32
+//     tables with two levels in flight 0.290 ms, block tables 0.263, with eight levels in flight 0.249 (with fp32 tables eight levels spill 7 registers).
+//   SLOW = true (hash-addressed or true-modulo levels present): the generic lookup on the fp32 table, level by level.
 template <int D, typename H, bool SLOW>
 __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, const gfpp_grid_level *lvl, int hi, bool valid,
                                                typename LpTraits<H>::vec (&b)[2]) {
@@ -234,10 +173,9 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
     if constexpr (SLOW) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // hash-addressed (or true-modulo) levels present: the generic lookup (separate kernel instantiation)
             float o[2];
             const gfpp_grid_level lv = g.levels[2 * i + hi];
-            grid_level_lookup<D, 2, float>(uc, g.table, lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
+            grid_level_lookup<D, 2, float>(uc, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
             f[2 * i] = ok ? o[0] : 0.0f;
             f[2 * i + 1] = ok ? o[1] : 0.0f;
         }
@@ -247,53 +185,29 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         LevelU lvs[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-#if GFPP_LP_LDS_LEVELS
             const gfpp_grid_level &d = lvl[2 * i + hi];
             lvs[i] = LevelU{d.scale, d.sy, d.sz, d.mask, d.offset};
-#else
-            // both descriptors of the iteration with one scalar load (uniform address, constant address space), selected per lane
-            typedef const __attribute__((address_space(4))) gfpp_grid_level *LevelsK;
-            const LevelsK lk = (LevelsK)lvl;
-            lvs[i].scale = hi ? lk[2 * i + 1].scale : lk[2 * i].scale;
-            lvs[i].sy = hi ? lk[2 * i + 1].sy : lk[2 * i].sy;
-            lvs[i].sz = hi ? lk[2 * i + 1].sz : lk[2 * i].sz;
-            lvs[i].mask = hi ? lk[2 * i + 1].mask : lk[2 * i].mask;
-            lvs[i].offset = hi ? lk[2 * i + 1].offset : lk[2 * i].offset;
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         // the interpolation type is wave-uniform: one branch around two specialised bodies instead of a smoothstep polynomial + select per coordinate
         auto levels = [&](auto smooth_tag) {
             constexpr bool SM = decltype(smooth_tag)::value;
+            BlockGathers<D> lg[8];
 #pragma unroll
-            for (int i0 = 0; i0 < 8; i0 += kLpLevelGroup) {
-#if GFPP_LP_BLOCK_TABLE
-                BlockGathers<D> lg[kLpLevelGroup];
+            for (int k = 0; k < 8; ++k) level_block_issue<D, SM>(uc, g.table, lvs[k], ac, lg[k]);
+            __builtin_amdgcn_sched_barrier(0);             // all of the lane's gathers are in flight before the first one is consumed
 #pragma unroll
-                for (int k = 0; k < kLpLevelGroup; ++k) level_block_issue<D, SM>(uc, g.table, lvs[i0 + k], ac, lg[k]);
-#else
-                LevelGathers<D> lg[kLpLevelGroup];
-#pragma unroll
-                for (int k = 0; k < kLpLevelGroup; ++k) level_fast_issue<D, SM>(uc, g.table, lvs[i0 + k], ac, lg[k]);
-#endif
-                __builtin_amdgcn_sched_barrier(0);             // the group's gathers are all in flight before the first one is consumed
-#pragma unroll
-                for (int k = 0; k < kLpLevelGroup; ++k) {
-                    float o[2];
-#if GFPP_LP_BLOCK_TABLE
-                    level_block_finish<D>(lg[k], o);
-#else
-                    level_fast_finish<D>(lg[k], o);
-#endif
-                    f[2 * (i0 + k)] = o[0];
-                    f[2 * (i0 + k) + 1] = o[1];
-                }
+            for (int k = 0; k < 8; ++k) {
+                float o[2];
+                level_block_finish<D>(lg[k], o);
+                f[2 * k] = o[0];
+                f[2 * k + 1] = o[1];
             }
         };
         if (smooth) levels(std::true_type{}); else levels(std::false_type{});
     }
     // out-of-range / padding samples get zero features (gridencoder.cu:110-135): selected on the 8 packed operand words, not on the 16 floats
-    // (the hash / true-modulo path above already zeroed its own)
+    // (the generic path above already zeroed its own)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -306,24 +220,15 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
     }
 }
 
-template <int C, typename H>
-__device__ __forceinline__ void skinny_rows(const uint32_t *__restrict__ wrow, const typename LpTraits<H>::vec (&b)[8], int hi, float (&out)[C]) {
-#if GFPP_ABLATE & 4
-    for (int c = 0; c < C; ++c) out[c] = (float)b[c][0];
-    return;
-#endif
-    skinny_dot<C, 8, H>(wrow, kSkinnyRows, b, hi, out);
-}
-
-#if GFPP_LP_SKINNY_MFMA
-// The skinny layers on the matrix pipe.  A row of the skinny image is already an A operand: its chunk s holds the weights of the eight activations
-// lane-half h supplies in step s.  One 32-row tile is gathered from the image with a per-lane row map,
+// The skinny layers (ambient_net.2: 3 rows, sigma_net.2 row 0, color_net.1: 3 rows) on the matrix pipe.  A row of the skinny image is already an A operand: its
+// chunk s holds the weights of the eight activations lane-half h supplies in step s.  One 32-row tile is gathered from the image with a per-lane row map,
 //     tile row  0 1 2 3 | 4 5 6 7 | 8 9 10 11 | 12 13 14 15 | 16..31 = rows 0..15 again (never read)
 //     image row 0 1 2 3 | 0 1 2 3 | 4 5  6  6 |  4  5  6  6
 // so that after eight steps lane (j, h) holds in acc[0..2] the three ambient rows, in acc[3] the density row and in acc[4..6] the three colour rows of
 // sample j, in BOTH half-waves (tile rows r and r + 4 are the same image row: no exchange between the halves).  All three layers use the same tile -- each
-// multiplies it with its own activations and reads its own rows; the other rows' products are finite and ignored.  8 MFMAs + 8 LDS reads per layer instead of
-// 32 dot products + 8 LDS reads per ROW.  Same operands, fp32 accumulation in another order.
+// multiplies it with its own activations and reads its own rows; the other rows' products are finite and ignored.  8 MFMAs + 8 LDS reads per layer; as packed
+// dot products on the VALU (round 3) a layer was 32 v_dot2c + 8 LDS reads per ROW: 224 v_dot2c per block, head pass 0.290 -> 0.282 ms without them.
+// The row map and register indices are pinned by the CPU lane emulation in tests/test_packing_cpu.py.
 __device__ __forceinline__ uint32_t skinny_tile_chunk(int lane) {
     const uint32_t i = (uint32_t)lane & 15u, h = (uint32_t)lane >> 5;
     const uint32_t low = i & 3u, row = (i & 8u) ? 4u + (low < 2u ? low : 2u) : low;
@@ -350,53 +255,37 @@ __device__ __forceinline__ void skinny_mfma(const uint32_t *__restrict__ image, 
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = even[r] + odd[r];
 }
-#endif
 
 // ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves
 template <int AMB_D, typename H>
-__device__ __forceinline__ void ambient_block(const LpShared &sh, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi, float (&amb)[AMB_D]) {
+__device__ __forceinline__ void ambient_block(const LpShared &sh, const float *__restrict__ bias, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi,
+                                              float (&amb)[AMB_D]) {
     v16f acc[4];
     typename LpTraits<H>::vec bh[8];
-    load_bias(acc, sh.bias, hi);
+    load_bias(acc, bias, hi);
     mfma_steps<H, 2>(acc, sh.w, kStepAmb0, bpos, lane);
     relu_pack<H>(acc, bh);
     zero_acc(acc);
     mfma_steps<H, 8>(acc, sh.w, kStepAmb1, bh, lane);
     relu_pack<H>(acc, bh);
-#if GFPP_LP_SKINNY_MFMA
     v16f sk;
     skinny_mfma<H>(sh.skinny, bh, lane, sk);
 #pragma unroll
     for (int d = 0; d < AMB_D; ++d) amb[d] = sk[d];
-#else
-    skinny_rows<AMB_D, H>(sh.skinny, bh, hi, amb);
-#endif
 }
 
-// sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples
+// sigma_net + colour net on one 32-sample block; results go to the slots of the block's samples.  `bias`: the sample's frame constants (LDS);
+// `dir`: the direction of the sample's ray (requested by the caller before the block's first grid lookup: in front of the SH basis the load was one exposed L2
+// round trip per block, the MFMA layers' sched_barriers keep it wherever it is put)
 template <typename H, typename Tile>
-__device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, Tile &wt, const typename LpTraits<H>::vec (&bpos)[2],
-                                               const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid, uint32_t n_step, int lane, int hi,
-                                               bool commit = true, const float *dir_early = nullptr) {
+__device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShared &sh, Tile &wt, const float *__restrict__ bias,
+                                               const typename LpTraits<H>::vec (&bpos)[2], const typename LpTraits<H>::vec (&bamb)[2], uint32_t c, uint32_t n_valid,
+                                               int lane, int hi, const float (&dir)[3]) {
     typedef typename LpTraits<H>::vec vec;
     const bool valid = c < n_valid;
     const uint32_t slot = valid ? wt.order[c] : 0u;
-    const uint32_t ray_local = slot / n_step;
     v16f acc[4];
     vec bh[8];
-#if GFPP_LP_EARLY_DIR == 1
-    float dir3[3];
-    {
-        const float *dp = a.rays_d + 3ull * wt.ray[ray_local];
-        dir3[0] = dp[0]; dir3[1] = dp[1]; dir3[2] = dp[2];
-    }
-    const float *dir = dir3;
-    (void)dir_early;
-#elif GFPP_LP_EARLY_DIR == 2
-    const float *dir = dir_early;
-#else
-    (void)dir_early;
-#endif
     zero_acc(acc);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0, bpos, lane);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0 + 2, bamb, lane);
@@ -404,66 +293,43 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     zero_acc(acc);
     mfma_steps<H, 8>(acc, sh.w, kStepSig1, bh, lane);
     relu_pack<H>(acc, bh);   // the hidden state feeds both the density row and the (merged) colour layer
-    float logit[1];
-#if GFPP_LP_SKINNY_MFMA
+    float logit;
     {
         v16f sk;
         skinny_mfma<H>(sh.skinny, bh, lane, sk);
-        logit[0] = sk[3];
+        logit = sk[3];
     }
-#else
-    skinny_rows<1, H>(sh.skinny + 3 * 32, bh, hi, logit);
-#endif
-    const float sigma = a.density_scale * GFPP_EXP(logit[0]);
+    const float sigma = a.density_scale * expf(logit);
     {
         vec bcol[9];
         float shv[16];
-#if !GFPP_LP_EARLY_DIR
-        const float *dir = a.rays_d + 3ull * wt.ray[ray_local];
-#endif
         sh_basis4(dir[0], dir[1], dir[2], shv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bcol[0][e] = (H)(hi ? shv[8 + e] : shv[e]);
 #pragma unroll
         for (int s = 0; s < 8; ++s) bcol[1 + s] = bh[s];
-        load_bias(acc, sh.bias + 128, hi);
+        load_bias(acc, bias + 128, hi);
         mfma_steps<H, 9>(acc, sh.w, kStepCol, bcol, lane);
     }
     relu_pack<H>(acc, bh);
     float rgb[3];
-#if GFPP_LP_SKINNY_MFMA
     {
         v16f sk;
         skinny_mfma<H>(sh.skinny, bh, lane, sk);
         rgb[0] = sk[4]; rgb[1] = sk[5]; rgb[2] = sk[6];
     }
-#else
-    skinny_rows<3, H>(sh.skinny + 4 * 32, bh, hi, rgb);
-#endif
-#if GFPP_ABLATE & 64
-    if (!commit) asm volatile("" :: "v"(sigma), "v"(rgb[0]), "v"(rgb[1]), "v"(rgb[2]));   // the uncommitted pass must not be optimised away
-#endif
-    if (valid && hi == 0 && commit) {
+    if (valid && hi == 0) {
         wt.px[slot] = sigma;
-        wt.py[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[0]));
-        wt.pz[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[1]));
-        wt.cb[slot] = 1.0f / (1.0f + GFPP_EXP(-rgb[2]));
+        wt.py[slot] = 1.0f / (1.0f + expf(-rgb[0]));
+        wt.pz[slot] = 1.0f / (1.0f + expf(-rgb[1]));
+        wt.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
     }
 }
 
-// RADNeRF.forward for the 32 occupied samples [first, first+32) of a tile (one wavefront's LpWaveTile or the workgroup's LpPool).
-template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool PROF = false, typename Tile>
+// RADNeRF.forward for the 32 occupied samples [first, first+32) of a tile (one wavefront's LpWaveTile or a workgroup's pool).
+template <int AMB_D, typename H, bool SLOW, bool DBG = false, typename Tile>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, Tile &wt, uint32_t first, uint32_t n_valid,
-                                                  uint32_t n_step, int lane_in, unsigned long long (&sub)[4], bool commit = true) {
-    constexpr bool prof = PROF;      // the phase counters are a separate kernel instantiation: no registers, scratch or s_memtime in the production kernel
-    unsigned long long tm = prof ? __builtin_readcyclecounter() : 0ull;
-    auto lap = [&](int k) {
-        if (prof) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            sub[k] += now - tm;
-            tm = now;
-        }
-    };
+                                                  uint32_t n_step, int lane_in) {
     typedef typename LpTraits<H>::vec vec;
     int lane = lane_in;
     // launder the lane id: keeps tile-loop-invariant per-lane LDS addresses from being hoisted out of the tile loop and spilled
@@ -473,21 +339,16 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
     const bool valid = c < n_valid;
     const uint32_t slot = valid ? wt.order[c] : 0u;
     // the descriptor tables are addressed through the laundered lane id too (hoisting 32 descriptors out of the tile loop would spill)
-#if GFPP_LP_LDS_LEVELS
     const gfpp_grid_level *lv_pos = &sh.lv[0][0] + (lane & 0), *lv_amb = &sh.lv[1][0] + (lane & 0);
-#else
-    const gfpp_grid_level *lv_pos = a.pos.levels, *lv_amb = a.amb.levels;
-    asm volatile("" : "+s"(lv_pos), "+s"(lv_amb));
-#endif
+    const uint32_t ray = wt.ray_of(slot / n_step);
+    const float *bias = sh.bias;        // (one frame per launch: the frame's constants)
 
     vec bpos[2], bamb[2];
-#if GFPP_LP_EARLY_DIR == 2
-    float dir3[3];
+    float dir[3];
     {
-        const float *dp = a.rays_d + 3ull * wt.ray[slot / n_step];
-        dir3[0] = dp[0]; dir3[1] = dp[1]; dir3[2] = dp[2];
+        const float *dp = a.rays_d + 3ull * ray;
+        dir[0] = dp[0]; dir[1] = dp[1]; dir[2] = dp[2];
     }
-#endif
     {
         float u3[3];
         const float b2 = 2.0f * a.mp.bound;
@@ -496,26 +357,18 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
         encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
     }
-    lap(0);
     {
         float amb[AMB_D], ua[AMB_D];
-        ambient_block<AMB_D, H>(sh, bpos, lane, hi, amb);
-        lap(1);
+        ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) {
-            const float th = GFPP_TANH(amb[d]);
+            const float th = tanhf(amb[d]);
             if constexpr (DBG) { if (a.dbg_ambient && valid && hi == 0) a.dbg_ambient[(size_t)c * AMB_D + d] = th; }
             ua[d] = (th + 1.0f) / 2.0f;
         }
         encode_half_lp<AMB_D, H, SLOW>(ua, a.amb, lv_amb, hi, valid, bamb);
     }
-    lap(2);
-#if GFPP_LP_EARLY_DIR == 2
-    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi, commit, dir3);
-#else
-    radiance_block<H>(a, sh, wt, bpos, bamb, c, n_valid, n_step, lane, hi, commit);
-#endif
-    lap(3);
+    radiance_block<H>(a, sh, wt, bias, bpos, bamb, c, n_valid, lane, hi, dir);
 }
 
 // Counters are written by other workgroups (atomics at the device's coherence point) while this kernel runs when it covers several
@@ -529,7 +382,7 @@ __device__ __forceinline__ uint32_t counter_load(const int32_t *p) {
 // delay it.  Release/acquire at agent scope write back and invalidate the per-XCD L2s, which is what makes one trip's ray state and
 // survivor list visible to whichever workgroup picks the ray up in the next trip.  The spin is bounded: on a timeout the barrier word
 // is poisoned (negative, so later barriers fall through and the host can see it, FramePipeline.trip_counters) instead of hanging the GPU.
-__device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target, uint32_t spin_limit) {
+__device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target, uint32_t spin_limit, int32_t *timeouts) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -537,7 +390,11 @@ __device__ __forceinline__ void grid_barrier(int32_t *bar, uint32_t target, uint
         uint32_t spins = 0;
         while (counter_load(bar) < target) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > spin_limit) { __hip_atomic_store(bar, (int32_t)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > spin_limit) {
+                __hip_atomic_store(bar, (int32_t)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (timeouts) __hip_atomic_fetch_add(timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // survives the next frame's counter reset
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -552,11 +409,7 @@ __device__ __forceinline__ void lp_fill_shared(LpShared &sh, const LpTripArgs &a
     for (int i = tid; i < kLpWeightChunks; i += kLpThreads)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w16 + i),
                                          (__attribute__((address_space(3))) void *)(&sh.w[i - lane]), 16, 0, 0);
-#if GFPP_LP_SKINNY_MFMA
-    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[(i >> 5) * (4 * kSkinnyPitch) + (i & 31)] = a.skinny16[i];
-#else
-    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[i] = a.skinny16[i];
-#endif
+    for (int i = tid; i < kSkinnyWords; i += kLpThreads) sh.skinny[(i >> 5) * (4 * kSkinnyPitch) + (i & 31)] = a.skinny16[i];   // rows padded to kSkinnyPitch chunks
     for (int i = tid; i < 256; i += kLpThreads) sh.bias[i] = a.frame_consts[i];
     for (int k = tid; k < 256; k += kLpThreads) {   // 2 x 16 descriptors x 8 dwords
         const int which = k >> 7, w = k & 127;
@@ -567,159 +420,9 @@ __device__ __forceinline__ void lp_fill_shared(LpShared &sh, const LpTripArgs &a
 // One launch runs the trips [a.trip, a.trip_end) (renderer.py:352-384: one loop iteration each).  The host issues the first few trips as
 // separate launches (no barrier needed: the stream orders them) and the rest -- which most frames never reach -- as ONE launch that
 // finds its first counter at zero and returns, instead of ten empty launches.
-template <int AMB_D, typename H, bool SLOW, bool PROF = false>
-__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_lp(LpTripArgs a) {
-    __shared__ LpShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t waves_total = gridDim.x * kLpWaves;
-    constexpr bool prof = PROF;
-    bool weights_resident = false;
-    uint32_t barriers = 0;
-    // ---- loop state up to the first trip of this launch (renderer.py:354-384) ------------------------------------------------------
-    uint32_t step_before = 0;
-    for (uint32_t k = 0; k < a.trip; ++k) {
-        const uint32_t na = counter_load(a.gcounters + k);
-        if (na == 0) return;
-        uint32_t ns = a.N_global / na;
-        ns = ns < 1u ? 1u : (ns > 8u ? 8u : ns);
-        step_before += ns;
-    }
-  for (uint32_t trip = a.trip; trip < a.trip_end; ++trip) {
-    // the sample budget follows the FRAME-wide alive count (renderer.py:364); the work list is this launch's own
-    const uint32_t n_alive_frame = counter_load(a.gcounters + trip);
-    if (n_alive_frame == 0 || step_before >= a.max_steps) return;   // the same decision in every workgroup (and on every GPU of a shared frame)
-    uint32_t n_step = a.N_global / n_alive_frame;
-    n_step = n_step < 1u ? 1u : (n_step > 8u ? 8u : n_step);
-    step_before += n_step;
-    const uint32_t n_alive = a.gcounters == a.counters ? n_alive_frame : counter_load(a.counters + trip);
-    if (n_alive == 0) return;                                       // (tile mode: every trip is its own launch) nothing left in this tile
-    const int32_t *alive_in = a.alive[trip & 1];
-    int32_t *alive_out = a.alive[(trip + 1) & 1];
-
-    // Rays per wavefront tile: at most 64 (128 sample slots).  A wavefront works through its tiles' 32-sample blocks one after the other,
-    // so the launch lasts (tiles per wavefront) x (blocks per tile + per-tile overhead) block times: take the largest tile that minimises that --
-    // few large tiles would leave most wavefronts idle behind a 4-block critical path (small frames, late trips), many small ones only
-    // add per-tile overhead.
-    uint32_t rays_per_tile = (uint32_t)kLpSlots / n_step < (uint32_t)kLpRays ? (uint32_t)kLpSlots / n_step : (uint32_t)kLpRays;
-    {
-        uint32_t best = 0xFFFFFFFFu, best_rpt = rays_per_tile;
-        for (uint32_t rpt = rays_per_tile; rpt * n_step >= 32u || rpt == rays_per_tile; rpt >>= 1) {
-            const uint32_t tiles = (n_alive + rpt - 1) / rpt;
-            // cost in fifths of a block time: every tile also pays for fetching its rays' state and compositing (~0.6 block, measured)
-            const uint32_t crit = ((tiles + waves_total - 1) / waves_total) * (5u * ((rpt * n_step + 31u) / 32u) + 3u);
-            if (crit < best) { best = crit; best_rpt = rpt; }
-            if (rpt == 1u) break;
-        }
-        rays_per_tile = best_rpt;
-    }
-    const uint32_t n_tiles = (n_alive + rays_per_tile - 1) / rays_per_tile;
-   if ((uint32_t)blockIdx.x * kLpWaves < n_tiles) {   // else: no tile for any wavefront of this workgroup in this trip
-
-    unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull, cyc[4] = {0ull, 0ull, 0ull, 0ull};
-    auto lap = [&](int phase) {
-        if (prof) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            cyc[phase] += now - t_mark;
-            t_mark = now;
-        }
-    };
-    // ---- weights, skinny rows and folded biases -> LDS (once per launch) ------------------------------------------
-    if (!weights_resident) {
-        lp_fill_shared(sh, a, tid, lane);
-        __syncthreads();
-        weights_resident = true;
-    }
-    lap(0);
-
-    LpWaveTile &wt = sh.tile[wave];
-    const uint32_t gw = blockIdx.x * kLpWaves + wave, nw = gridDim.x * kLpWaves;
-    uint32_t evaluated = 0;
-    unsigned long long sub[4] = {0ull, 0ull, 0ull, 0ull};   // profiling: position encode, ambient MLP, ambient encode, sigma + colour
-    for (uint32_t tile = gw; tile < n_tiles; tile += nw) {
-        // ---- phase 1: this trip's samples of every ray (one lane per ray), from the frame's pre-marched list -----------------
-        const uint32_t n = tile * rays_per_tile + lane;
-        const bool has_ray = (uint32_t)lane < rays_per_tile && n < n_alive;
-        // every ray that is still alive took the full n_step samples in each earlier trip (a shorter take declares it dead), so its cursor into the
-        // pre-marched list is the loop's cumulative step count -- no per-ray cursor to fetch behind the alive-list load
-        uint32_t ray = 0, cnt = 0;
-        const uint32_t used = step_before - n_step;
-        if (has_ray) {
-            ray = trip == 0 ? n : (uint32_t)alive_in[n];
-            const uint32_t avail = a.sample_cnt[ray] - used;
-            cnt = avail < n_step ? avail : n_step;
-            wt.ray[lane] = ray;
-            if (cnt) {
-                const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
-                const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
-                const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
-                const uint32_t base = lane * n_step;
-                for (uint32_t s = 0; s < cnt; ++s) {
-                    // the same expressions as march_one_ray (raymarching.cu:873-882, 905-913) evaluated at the stored t
-                    const float t0 = ts[s];
-                    const float dt = clampf(t0 * a.mp.dt_gamma, a.mp.dt_min, a.mp.dt_max);
-                    wt.px[base + s] = clampf(fmaf(t0, dx, ox), -a.mp.bound, a.mp.bound);
-                    wt.py[base + s] = clampf(fmaf(t0, dy, oy), -a.mp.bound, a.mp.bound);
-                    wt.pz[base + s] = clampf(fmaf(t0, dz, oz), -a.mp.bound, a.mp.bound);
-                    wt.dt[base + s] = dt;
-                    wt.tend[base + s] = t0 + dt;
-                }
-            }
-        }
-        // compaction of the occupied samples inside the wavefront
-        const uint32_t incl = wave_inclusive_scan(cnt, lane);
-        const uint32_t n_valid = (uint32_t)__shfl((int)incl, 63);
-        {
-            const uint32_t pos = incl - cnt;
-            for (uint32_t s = 0; s < cnt; ++s) wt.order[pos + s] = (uint8_t)(lane * n_step + s);
-        }
-        wave_sync();
-        lap(1);
-
-        // ---- phase 2: evaluate the radiance field on the occupied samples, 32 per pass --------------------------------
-        for (uint32_t first = 0; first < n_valid; first += 32) evaluate_block_lp<AMB_D, H, SLOW, false, PROF>(a, sh, wt, first, n_valid, n_step, lane, sub);
-        evaluated += n_valid;
-        wave_sync();
-        lap(2);
-
-        // ---- phase 3: composite, ray state update, survivor compaction -------------------------------------------------
-        bool survives = false;
-        if (has_ray) {
-            RayAccum acc = ray_state_load(a.state, ray);
-            const uint32_t base = lane * n_step;
-            uint32_t s = 0;
-            for (; s < cnt; ++s) {
-                const uint32_t k = base + s;
-                if (composite_sample(acc, wt.px[k], wt.dt[k], wt.tend[k], wt.py[k], wt.pz[k], wt.cb[k], a.T_thresh)) break;
-            }
-            // the reference declares the ray dead when it stops before n_step samples (terminated, or ran out of samples)
-            survives = (s == n_step);
-            ray_state_store(a.state, ray, acc, __uint_as_float(survives ? used + n_step : used));   // (cursor kept in the record for inspection; nobody reads it)
-        }
-        const unsigned long long ballot = __ballot(survives);
-        const uint32_t total = (uint32_t)__popcll(ballot);
-        uint32_t out_base = 0;
-        if (lane == 0 && total) out_base = (uint32_t)atomicAdd(&a.counters[trip + 1], (int)total);
-        out_base = (uint32_t)__shfl((int)out_base, 0);
-        if (survives) alive_out[out_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (int32_t)ray;
-        wave_sync();
-        lap(3);
-    }
-    if (prof && lane == 0)
-        for (int ph = 0; ph < 4; ++ph) {
-            atomicAdd(&a.phase_cycles[8 * trip + ph], cyc[ph]);
-            atomicAdd(&a.phase_cycles[8 * trip + 4 + ph], sub[ph]);
-        }
-    if (lane == 0 && evaluated) atomicAdd(&a.counters[64 + trip], (int)evaluated);   // evaluated samples of this trip
-   }
-    if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs, no barrier needed
-    if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers, a.spin_limit);
-  }
-}
-
-// The same trips with the samples of a whole workgroup pooled (the production kernel; k_head_trip_lp above is kept as the A/B partner,
-// GFPP_TRIP_POOL=0).  Why: a wavefront of k_head_trip_lp owns its tile's blocks, a tile holds 0..4
-// blocks, and the workgroup keeps its CU until its slowest wavefront is done -- at 512x512 a trip carries ~2.4 blocks per wavefront on
-// average but lasts 4 block times.  Here every workgroup takes an equal share of the alive rays (wavefront tiles dealt out through a
+// The samples of a whole workgroup are pooled (rounds 1-3 also kept a kernel with one tile per wavefront, k_head_trip_lp: a tile holds 0..4 blocks and the
+// workgroup keeps its CU until its slowest wavefront is done -- at 512x512 a trip carried ~2.4 blocks per wavefront on average but lasted 4 block
+// times; removed in round 4).  Every workgroup takes an equal share of the alive rays (wavefront tiles dealt out through a
 // multiplicative permutation, so that in trip 0 no workgroup gets only the empty image border), compacts the occupied samples of all
 // eight tiles into one list -- every block but the last is full -- and deals the blocks out to its wavefronts round-robin: a round lasts
 // ceil(blocks / 8) block times.  Per sample nothing changes (same evaluate_block_lp, same compositing order along a ray).
@@ -763,7 +466,6 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
         const uint32_t n_tiles = (n_alive + rw - 1) / rw;
         const uint32_t mult = n_tiles % 1237u ? 1237u : 1u;   // q -> q * mult mod n_tiles is a permutation of the tiles (1237 is prime)
         LpPool &pool = sh.pool;
-        unsigned long long sub4[4] = {0ull, 0ull, 0ull, 0ull};
         unsigned long long t_mark = 0ull, cyc[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, longest = 0ull;
         auto lap = [&](int phase) {
             if (prof) {
@@ -845,10 +547,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
 
             // ---- phase 2: the pooled blocks, dealt out round-robin -----------------------------------------------------------------
             for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves) {
-#if GFPP_ABLATE & 64
-                evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4, false);   // every block twice: the difference to the normal build is the evaluation's share of a trip
-#endif
-                evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
+                evaluate_block_lp<AMB_D, H, SLOW>(a, sh, pool, first, total, n_step, lane);
                 if (prof) cyc[6] += 1ull;
             }
             lap(2);
@@ -916,7 +615,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
             atomicMax(&a.phase_cycles[8 * trip + 7], longest);
         }
         if (step_before >= a.max_steps) return;   // the step budget is used up: no later trip runs (every workgroup decides the same), no barrier needed
-        if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers, a.spin_limit);
+        if (trip + 1 < a.trip_end) grid_barrier(a.sync, gridDim.x * ++barriers, a.spin_limit, a.timeouts);
     }
 }
 
@@ -945,7 +644,6 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     if (tid < 32) pool.hist[tid] = 0u;
     const uint32_t cap = a.max_steps + 7u;                        // a ray can never composite more samples than that (k_premarch stores no more)
     uint32_t j_next = 0, A = 0, evaluated = 0, round = 0;
-    unsigned long long sub4[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long t_mark = __builtin_readcyclecounter(), cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
     auto lap = [&](int k) {
         const unsigned long long now = __builtin_readcyclecounter();
@@ -1078,7 +776,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         if (wave >= 4)
             for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
         for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
-            evaluate_block_lp<AMB_D, H, SLOW, false, false>(a, sh, pool, first, total, n_step, lane, sub4);
+            evaluate_block_lp<AMB_D, H, SLOW>(a, sh, pool, first, total, n_step, lane);
         __syncthreads();
         lap(2);
 
@@ -1240,13 +938,6 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-#if GFPP_MARCH_LEAN
-    if (p.mp.C == 1u && p.mp.H <= 256u) {       // every shipped model: one cascade, 128 cells per axis
-        p.sample_cnt[n] = march_one_ray<true>(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
-                                              [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
-        return;
-    }
-#endif
     p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
 }
@@ -1269,7 +960,6 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_eval_lp(L
     lp_fill_shared(sh, e.t, tid, lane);
     __syncthreads();
     LpWaveTile &wt = sh.tile[wave];
-    unsigned long long sub[4] = {0ull, 0ull, 0ull, 0ull};
     if ((uint32_t)wave >= e.waves) return;
     // experiment order (waves < 8): wave w of the workgroup sits on SIMD w % 4, so waves 0..3 are one per SIMD
     for (uint32_t base = (blockIdx.x * e.waves + wave) * 32u; base < e.M; base += gridDim.x * e.waves * 32u) {
@@ -1286,7 +976,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_eval_lp(L
         LpTripArgs a = e.t;
         a.dbg_ambient = e.ambient ? e.ambient + (size_t)base * AMB_D : nullptr;
         const uint32_t n_valid = e.M - base < 32u ? e.M - base : 32u;
-        evaluate_block_lp<AMB_D, H, SLOW, true>(a, sh, wt, 0, n_valid, 1, lane, sub);
+        evaluate_block_lp<AMB_D, H, SLOW, true>(a, sh, wt, 0, n_valid, 1, lane);
         wave_sync();
         if (lane < 32 && ok) {
             e.sigma[idx] = wt.px[j];
@@ -1303,27 +993,19 @@ static void launch_eval_lp(uint32_t grid, hipStream_t st, const LpEvalArgs &e) {
     hipLaunchKernelGGL((k_head_eval_lp<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, e);
 }
 
-// GFPP_TRIP_POOL=0 selects the per-wavefront-tile kernel (A/B runs)
-static bool lp_pool_enabled() {
-    const char *e = getenv("GFPP_TRIP_POOL");   // read at every issue (a captured graph keeps what it was captured with)
-    return e ? atoi(e) != 0 : true;
-}
-
 template <int AMB_D, typename H, bool SLOW>
 static void launch_lp(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
-    if (lp_pool_enabled()) {
-        if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
-    } else if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
-    else hipLaunchKernelGGL((k_head_trip_lp<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    if (a.phase_cycles) hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_head_trip_pool<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
 }
 
 static bool lp_grid_ok(const gfpp_grid_desc &g, uint32_t D) {
-#if GFPP_LP_BLOCK_TABLE
-    return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F16 && g.row_padded == 1u + GFPP_LP_BLOCK_TABLE;
-#else
     return g.table && g.levels && g.D == D && g.L == 16 && g.gridtype <= 1 && g.interp <= 1 && g.dtype == GFPP_F32;
-#endif
+}
+// the 16-bit corner-block copy of a grid (gfpp_head_model.pos_grid_blk / amb_grid_blk): same level structure, 16-byte rows of 8 halves
+static bool lp_block_grid_ok(const gfpp_grid_desc &b, const gfpp_grid_desc &g) {
+    return b.table && b.levels && b.D == g.D && b.L == 16 && b.gridtype == g.gridtype && b.interp == g.interp && b.align_corners == g.align_corners &&
+           b.dtype == GFPP_F16 && b.row_padded == 2u;
 }
 
 // How many trips get a launch of their own before the multi-trip launch takes over (GFPP_LP_SEPARATE_TRIPS overrides, for experiments).
@@ -1377,17 +1059,27 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
         return GFPP_EUNSUPPORTED;
     }
     if (!model->pos_grid.levels_host || !model->amb_grid.levels_host) { set_error("%s: grid descriptors carry no host level table (levels_host)", who); return GFPP_EINVAL; }
+    uint32_t any_slow = 0;
     for (int which = 0; which < 2; ++which) {
         const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
+        for (int l = 0; l < 16; ++l) any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
+    }
+    for (int which = 0; which < 2; ++which) {
+        const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid, &gb = which ? model->amb_grid_blk : model->pos_grid_blk;
         LpGrid &g = which ? a.amb : a.pos;
-        g.any_slow = 0;
-        g.levels = gd.levels;
-        for (int l = 0; l < 16; ++l) g.any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
-        if (!g.any_slow && !gd.row_padded) { set_error("%s: tables must be the per-level padded copy (row_padded)", who); return GFPP_EINVAL; }
-#if GFPP_LP_BLOCK_TABLE
-        if (g.any_slow) { set_error("%s: corner-block tables (this experiment build) need levels without hash / true modulo", who); return GFPP_EUNSUPPORTED; }
-#endif
-        g.table = (const float *)gd.table;
+        g.any_slow = any_slow;            // one kernel instantiation serves both grids: a slow level in either sends both through the generic lookup
+        if (any_slow) {
+            g.levels = gd.levels;
+            g.table = gd.table;
+        } else {
+            if (!lp_block_grid_ok(gb, gd)) {
+                set_error("%s: the model carries no 16-bit corner-block copy of its %s table (gfpp_head_model.%s_grid_blk: f16, row_padded 2)", who,
+                          which ? "ambient" : "position", which ? "amb" : "pos");
+                return GFPP_EINVAL;
+            }
+            g.levels = gb.levels;
+            g.table = gb.table;
+        }
         g.gridtype = gd.gridtype; g.interp = gd.interp; g.align_corners = gd.align_corners;
     }
     a.w16 = (const uint4 *)model->lp_weights;
@@ -1468,6 +1160,7 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
              : (bf ? (slow ? launch_lp<2, __bf16, true> : launch_lp<2, __bf16, false>) : (slow ? launch_lp<2, _Float16, true> : launch_lp<2, _Float16, false>));
     a.alive[0] = ws->alive[0]; a.alive[1] = ws->alive[1];
     a.sync = ws->counters + 127;
+    a.timeouts = ws->timeouts;
     a.spin_limit = 1u << 22;
     if (const char *e = getenv("GFPP_BARRIER_SPINS")) { const long v = atol(e); if (v > 0) a.spin_limit = (uint32_t)v; }   // (tests force a timeout)
     // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
@@ -1544,7 +1237,7 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
     a.state = ws->ray_state;
     a.alive[0] = a.alive[1] = nullptr;
-    a.counters = ws->counters; a.gcounters = ws->counters; a.N_global = ws->N; a.sync = nullptr;
+    a.counters = ws->counters; a.gcounters = ws->counters; a.N_global = ws->N; a.sync = nullptr; a.timeouts = nullptr;
     a.frame_consts = ws->frame_consts;
     a.T_thresh = T_thresh; a.density_scale = model->density_scale;
     a.N = ws->N; a.max_steps = max_steps; a.trip = 0; a.trip_end = 0;

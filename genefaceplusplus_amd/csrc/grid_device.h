@@ -195,9 +195,6 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
 // per-level padded copy (row `size` repeats row 0), so the x+1 neighbour of the last row needs no wrap-around case, and a dropped
 // z coordinate (sz == 0) simply fetches the same rows again.  Same corner order, weight products and fma chain as
 // grid_level_lookup => bit-identical features.
-#ifndef GFPP_LP_BLOCK_TABLE
-#define GFPP_LP_BLOCK_TABLE 0     // experiment builds of frame_head_lp.hip: 1 = x-y corner blocks, 2 = x-y-z corner blocks where a level keeps z (below)
-#endif
 struct LevelU {   // one level's descriptor in scalar registers
     float scale;
     uint32_t sy, sz, mask, offset;
@@ -238,12 +235,7 @@ __device__ __forceinline__ void level_fast_issue(const float (&u)[D], const floa
         uint32_t row = base[0] + ((pair & 1) ? y1 : y0);
         if constexpr (D == 3) row += (pair & 2) ? z1 : z0;   // sz == 0 (z dropped by the tiled index): the same rows again, an L1 hit
         row &= lv.mask;
-#if defined(GFPP_ABLATE) && (GFPP_ABLATE & 1)
-        g.v[pair] = f32x4_a8{g.frac[0], __uint_as_float(row), g.frac[1], lv.scale};
-        (void)lt;
-#else
         g.v[pair] = *reinterpret_cast<const f32x4_a8 *>(lt + ((row + lv.offset) << 3));
-#endif
     }
 }
 
@@ -270,7 +262,7 @@ __device__ __forceinline__ void level_fast_finish(const LevelGathers<D> &g, floa
 }
 
 
-// ---- corner-block tables (experiment build GFPP_LP_BLOCK_TABLE of frame_head_lp.hip; not validated on the GPU yet) ----------------------------------------
+// ---- corner-block tables (the 16-bit head kernels of frame_head_lp.hip since round 4; gfpp_head_model.pos_grid_blk / amb_grid_blk) ------------------------
 // The straight-line lookup above fetches a level's 2^D corners with 2^(D-1) gathers of 16 bytes from 2^(D-1) different cache lines (rows r and r + 1 are
 // adjacent, the y and z neighbours are whole strides away) -- 64 gathers from 64 lines per sample and 16-level 3-D grid, and the vector L1's tag rate is what a
 // lane-divergent gather costs.  A corner-block table trades memory for that: row r of a level holds, in 16-bit floats, BOTH channels of the FOUR corners
@@ -304,20 +296,13 @@ __device__ __forceinline__ void level_block_issue(const float (&u)[D], const voi
     uint32_t row = base[0] + __umul24(base[1], lv.sy);
     if constexpr (D == 3) row += __umul24(base[2], lv.sz);
     row &= lv.mask;
-#if GFPP_LP_BLOCK_TABLE == 2
-    // x-y-z blocks: a level that keeps z has 32-byte rows -- the x-y block of the cell and, right behind it, the block of its z neighbour (row r + sz):
-    // ONE cache line per level; a level whose index drops z (sz == 0) keeps 16-byte rows and is read twice.  `offset` counts 16-byte units here
-    const uint32_t sh = D == 3 ? (lv.sz < 1u ? lv.sz : 1u) : 0u;
-    const uint32_t at = (lv.offset + (row << sh)) << 4;
-    g.v[0] = *reinterpret_cast<const u32x4_a16 *>(lt + at);
-    if constexpr (D == 3) g.v[1] = *reinterpret_cast<const u32x4_a16 *>(lt + at + (sh << 4));
-#else
+    // (measured alternative, dropped: 32-byte x-y-z rows for the levels that keep z -- one cache line per level, tables 3 x the fp32 bytes: head pass 0.256 ms
+    // against 0.263 for these rows, the same frames/s)
     g.v[0] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row + lv.offset) << 4));
     if constexpr (D == 3) {
         const uint32_t row1 = (row + lv.sz) & lv.mask;          // sz == 0 (z dropped by the tiled index): the same row again, an L1 hit
         g.v[1] = *reinterpret_cast<const u32x4_a16 *>(lt + ((row1 + lv.offset) << 4));
     }
-#endif
 }
 
 template <int D>

@@ -9,16 +9,6 @@
 
 #include "gfpp_common.h"
 
-// Experiment build (not validated on the GPU yet, hence off): fewer instructions per bitfield probe of the marcher, same bits --
-//   * 1 / mip_bound without the IEEE division sequence (11 instructions, some quarter rate): the shell bound is a power of two (exact reciprocal by
-//     exponent arithmetic) or the scene bound (its correctly rounded reciprocal comes from the host);
-//   * one cascade (every shipped model): the cell index is the Morton code itself, no float round trip;
-//   * grids of <= 256 cells per axis: the 10-bit spread's first stage is the identity, and the shifts of y / z are spelled so that the compiler does not
-//     fold them into quarter-rate 32-bit multiplies (v_mul_lo_u32 x 10, x 20 in the production ISA).
-#ifndef GFPP_MARCH_LEAN
-#define GFPP_MARCH_LEAN 0
-#endif
-
 namespace gfpp {
 
 struct RayBox {
@@ -54,9 +44,6 @@ struct MarchParams {
     uint32_t C, H;
     float half_H;       // 0.5 H
     uint32_t H_pow2;    // H is a power of two: the voxel coordinate's fp64 product is an exact scaling, done in fp32 (same bits)
-#if GFPP_MARCH_LEAN
-    float rbound;       // 1 / bound, correctly rounded (host division)
-#endif
 };
 
 __host__ __device__ inline MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
@@ -74,9 +61,6 @@ __host__ __device__ inline MarchParams make_march_params(float bound, float dt_g
     p.H = H;
     p.half_H = 0.5f * (float)H;
     p.H_pow2 = (H & (H - 1u)) == 0u && H >= 2u ? 1u : 0u;
-#if GFPP_MARCH_LEAN
-    p.rbound = 1.0f / bound;
-#endif
     return p;
 }
 
@@ -114,8 +98,9 @@ struct Sample {
 
 // Advance one ray from t, emitting up to n_step occupied samples through `emit(step, Sample)`.
 // Returns the number of samples emitted; `t` is left at the position after the last emitted sample (or >= far).
-// ONE_SMALL_SHELL (experiment build GFPP_MARCH_LEAN only): the caller has checked p.C == 1 and p.H <= 256.
-template <bool ONE_SMALL_SHELL = false, typename Emit>
+// (Measured and dropped in round 4: a probe without the IEEE division, the 32-bit multiplies of the Morton spread and the float round trip of the cell
+// index -- 164 -> 125 instructions per probe, same bits -- left the frame rate where it was: the pre-march runs under the other frame's head pass.)
+template <typename Emit>
 __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, float dx, float dy, float dz, float &t, float far,
                                                   uint32_t n_step, const uint8_t *__restrict__ bitfield, const MarchParams &p,
                                                   Emit &&emit) {
@@ -126,24 +111,12 @@ __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, 
         const float y = clampf(fmaf(t, dy, oy), -p.bound, p.bound);
         const float z = clampf(fmaf(t, dz, oz), -p.bound, p.bound);
         const float dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
-#if GFPP_MARCH_LEAN
-        const int level = ONE_SMALL_SHELL ? 0 : cascade_of(x, y, z, dt, p);
-        const float shell = scalbnf(1.0f, level);
-        const float mip_bound = fminf(shell, p.bound);
-        const float mip_rbound = shell <= p.bound ? scalbnf(1.0f, -level) : p.rbound;     // (1 / 2^level is exact; 1 / bound: the host's division)
-        const int nx = voxel_of(x, mip_rbound, p), ny = voxel_of(y, mip_rbound, p), nz = voxel_of(z, mip_rbound, p);
-        // the reference forms the cell index in fp32 (exact below 2^24); with one cascade the level is 0 and the index is the Morton code itself
-        const uint32_t cell = ONE_SMALL_SHELL ? morton3_8((uint32_t)nx, (uint32_t)ny, (uint32_t)nz)
-                                              : (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-#else
-        static_assert(!ONE_SMALL_SHELL, "GFPP_MARCH_LEAN builds only");
         const int level = cascade_of(x, y, z, dt, p);
         const float mip_bound = fminf(scalbnf(1.0f, level), p.bound);
         const float mip_rbound = 1.0f / mip_bound;
         const int nx = voxel_of(x, mip_rbound, p), ny = voxel_of(y, mip_rbound, p), nz = voxel_of(z, mip_rbound, p);
         // the reference forms this index in fp32 (exact below 2^24)
         const uint32_t cell = (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-#endif
         const bool occupied = (bitfield[cell >> 3] >> (cell & 7u)) & 1u;
         if (occupied) {
             const float t0 = t;

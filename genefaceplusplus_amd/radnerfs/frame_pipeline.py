@@ -35,7 +35,8 @@ class HeadModel(ctypes.Structure):
                 ("amb_w0", c_p), ("amb_w0_cond", c_p), ("amb_w1", c_p), ("amb_w2", c_p),
                 ("sig_w0", c_p), ("sig_w1", c_p), ("sig_w2_geo", c_p), ("sig_w2_sig", c_p),
                 ("col_w0", c_p), ("col_w0_ind", c_p), ("col_w1", c_p), ("cond_dim", c_u32), ("ind_dim", c_u32),
-                ("lp_weights", c_p), ("lp_skinny", c_p), ("lp_dtype", ctypes.c_int32), ("occ_aabb", c_f * 6)]
+                ("lp_weights", c_p), ("lp_skinny", c_p), ("lp_dtype", ctypes.c_int32), ("occ_aabb", c_f * 6),
+                ("pos_grid_blk", GridDesc), ("amb_grid_blk", GridDesc)]
 
 
 class FrameWs(ctypes.Structure):
@@ -43,7 +44,8 @@ class FrameWs(ctypes.Structure):
                 ("alive", c_p * 2), ("counters", c_p), ("frame_consts", c_p), ("sample_t", c_p), ("sample_cnt", c_p),
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
-                ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32)]
+                ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32),
+                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("timeouts", c_p)]
 
 
 class CondModel(ctypes.Structure):
@@ -238,29 +240,9 @@ def lp_skinny_image(model, dtype):
     return img.permute(2, 0, 1, 3).reshape(2, 7, 64).to(dtype).contiguous()
 
 
-def corner_block_table_xyz(emb, offsets, levels):
-    """(experiment build GFPP_LP_BLOCK_TABLE=2) x-y-z corner blocks: a level that keeps z (sz != 0) gets 32-byte rows -- the x-y block of row r followed by the
-    x-y block of row r + sz -- so that all eight corners of a cell sit in one cache line; levels whose index drops z keep the 16-byte rows.  Returns the table
-    as [n, 8] float16 (n 16-byte units) and the start of every level in those units."""
-    xy = corner_block_table(emb, offsets, levels)
-    parts, starts, at = [], [], 0
-    for l, lv in enumerate(levels):
-        B = xy[int(offsets[l]):int(offsets[l + 1])]
-        size, sz, mask = int(lv.size), int(lv.sz), int(lv.mask)
-        starts.append(at)
-        if sz == 0:
-            parts.append(B)
-            at += size
-        else:
-            r = torch.arange(size, device=B.device, dtype=torch.int64)
-            up = (r + sz) & mask if mask != 0xFFFFFFFF else (r + sz) % size
-            parts.append(torch.stack([B, B[up]], dim=1).reshape(2 * size, 8))
-            at += 2 * size
-    return torch.cat(parts, dim=0).contiguous(), starts
-
-
 def corner_block_table(emb, offsets, levels):
-    """The 16-bit corner-block copy of a 2-channel grid table (csrc/grid_device.h, experiment build GFPP_LP_BLOCK_TABLE): row r of level l holds both
+    """The 16-bit corner-block copy of a 2-channel grid table (csrc/grid_device.h: level_block_issue / level_block_finish; gfpp_head_model.pos_grid_blk /
+    amb_grid_blk -- what the 16-bit head kernels read since round 4; layout pinned by tests/test_block_table_cpu.py): row r of level l holds both
     channels of the four corners (r, r + 1, r + sy, r + sy + 1) of the x-y cell that starts at r -- index arithmetic modulo the level size, the neighbours
     gfpp_grid_levels_fill's `sy` / `mask` give -- as 8 halves: c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1).
     emb [rows, 2] float tensor, offsets [L+1] ints (unpadded), levels: sequence of objects with sy / mask / size.  Returns [rows, 8] float16."""
@@ -433,26 +415,21 @@ class FramePipeline:
         return d
 
     def _grid_desc_block(self, enc):
-        """Experiment (GFPP_LP_BLOCK_TABLE=1 + a library built with -DGFPP_LP_BLOCK_TABLE=1): the grid as a 16-bit corner-block table, row_padded = 2."""
+        """The grid as a 16-bit corner-block table for the 16-bit head kernels (gfpp_head_model.*_grid_blk: f16, row_padded = 2), or an empty descriptor if a
+        level needs the hash / a true modulo (the kernels' generic lookup then reads the fp32 table)."""
         L = enc.num_levels
         off = np.ascontiguousarray(enc.offsets.cpu().numpy().astype(np.int32))
         lv = (GridLevel * L)()
         call("gfpp_grid_levels_fill", int(enc.input_dim), L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id),
              int(enc.align_corners), off.ctypes.data, 0, lv)
-        levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
         d = GridDesc()
-        mode = int(os.environ.get("GFPP_LP_BLOCK_TABLE", "1"))
-        if mode == 2:
-            table, starts = corner_block_table_xyz(enc.embeddings.detach(), off, lv)
-            for l in range(L):
-                lv[l].offset = starts[l]                    # in 16-byte units
-            levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
-        else:
-            table = corner_block_table(enc.embeddings.detach(), off, lv)
-        d.table = self._hold(table)
+        if any(int(lv[l].flags) & 1 for l in range(L)):                 # GFPP_LEVEL_SLOW
+            return d
+        levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
+        d.table = self._hold(corner_block_table(enc.embeddings.detach(), off, lv))
         self._keep.append(lv)
         d.levels_host = ctypes.addressof(lv)
-        d.row_padded = 1 + mode
+        d.row_padded = 2
         d.levels = self._hold(levels)
         d.dtype = 1                       # GFPP_F16
         d.D, d.L = enc.input_dim, L
@@ -477,6 +454,7 @@ class FramePipeline:
                 hm.occ_aabb[i] = v
         hm.pos_grid = self._grid_desc(m.position_embedder)
         hm.amb_grid = self._grid_desc(m.ambient_embedder)
+        hm.pos_grid_blk, hm.amb_grid_blk = GridDesc(), GridDesc()         # built with the first 16-bit precision (set_precision): the fp32 mode never reads them
         act = activation_pairs()
         enc32 = encoder_pairs(0, 32)
         A0, A1, A2 = (l.weight for l in m.ambient_net.net)
@@ -502,8 +480,6 @@ class FramePipeline:
         """'fp32' (exact-fp32 MFMA) | 'fp16' | 'bf16' (16-bit MFMA operands, fp32 accumulation; weights repacked on first use)."""
         if precision == "fp32":
             self.precision = "fp32"
-            if "plain_grids" in self._lp_images:            # (experiment GFPP_LP_BLOCK_TABLE: the fp32 kernels read the plain tables)
-                self.head.pos_grid, self.head.amb_grid = self._lp_images["plain_grids"]
             if self.torso is not None and self.fp32_torso == "mfma":
                 # the torso MLPs on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 = an fp32 fma chain): the same fragment image as the 16-bit modes, in fp32
                 if "torso_fp32" not in self._lp_images:
@@ -520,12 +496,10 @@ class FramePipeline:
             self._lp_images[precision] = (lp_weight_image(model, dt).to(self.device), lp_skinny_image(model, dt).to(self.device))
         self.head.lp_weights = self._lp_images[precision][0].data_ptr()
         self.head.lp_skinny = self._lp_images[precision][1].data_ptr()
-        if os.environ.get("GFPP_LP_BLOCK_TABLE", "0") in ("1", "2"):
-            # experiment: the 16-bit head kernels of a -DGFPP_LP_BLOCK_TABLE=1 library read corner-block tables (the fp32 kernels cannot: 16-bit modes only)
-            if "block_grids" not in self._lp_images:
-                self._lp_images["plain_grids"] = (GridDesc.from_buffer_copy(self.head.pos_grid), GridDesc.from_buffer_copy(self.head.amb_grid))
-                self._lp_images["block_grids"] = (self._grid_desc_block(model.position_embedder), self._grid_desc_block(model.ambient_embedder))
-            self.head.pos_grid, self.head.amb_grid = self._lp_images["block_grids"]
+        if "block_grids" not in self._lp_images:
+            # the 16-bit head kernels read the two tables as 16-bit corner-block copies (2 x the fp32 bytes: 14.5 MB per 3-D grid); the fp32 kernels keep pos_grid / amb_grid
+            self._lp_images["block_grids"] = (self._grid_desc_block(model.position_embedder), self._grid_desc_block(model.ambient_embedder))
+        self.head.pos_grid_blk, self.head.amb_grid_blk = self._lp_images["block_grids"]
         if self.torso is not None:
             key = "torso_" + precision
             if key not in self._lp_images:
@@ -696,6 +670,9 @@ class FramePipeline:
             ws.full_grid_trips = 0
             ws.snapshots = None
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane = 0, 0, None, 0
+            ws.clip_sub, ws.clip_advance, ws.n_frames = 0, 0, 0
+            t["timeouts"] = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: no kernel resets it (gfpp_frame_ws.timeouts)
+            ws.timeouts = t["timeouts"].data_ptr()
             ent = (ws, t)
             self._ws[(N, self.lane)] = ent
         if self.frames_in_flight <= 1:
@@ -979,16 +956,20 @@ class FramePipeline:
         return t.get("phase_cycles")
 
     def check_barriers(self):
-        """Raise if a device-wide barrier of a multi-trip launch (the trip-launch path of the 16-bit modes) timed out in any frame rendered since the
-        last check: the kernel then poisons counters[127] (negative) instead of hanging the GPU, later barriers of that launch fall through and the
-        frame may lack trips -- it must not be delivered.  One 4-byte read per workspace; synchronises."""
+        """Raise if a device-wide barrier of a multi-trip launch (the trip-launch path of the 16-bit modes) timed out in ANY frame rendered since the last
+        check: besides poisoning counters[127] (which the next frame's begin kernel zeroes again) the kernel adds one to the workspace's sticky word
+        (gfpp_frame_ws.timeouts), which nothing resets but this function -- so a frame in the middle of a clip that lacks trips is not delivered
+        silently.  One 4-byte read per workspace; synchronises."""
         bad = []
         for (n, lane), (ws, t) in self._ws.items():
-            if int(t["counters"][127].item()) < 0:
-                bad.append((n, lane))
+            count = int(t["timeouts"].item()) if "timeouts" in t else 0
+            if count > 0 or int(t["counters"][127].item()) < 0:
+                bad.append((n, lane, max(count, 1)))
+                t["timeouts"].zero_()
         if bad:
-            raise GfppError(f"a device-wide barrier of the multi-trip launch timed out (workspaces (rays, lane) = {bad}): the frames rendered there are "
-                            f"incomplete.  Other work held compute units for too long; render with lp_kernel='persist' (no barrier) or separate_trips >= max_steps")
+            raise GfppError(f"a device-wide barrier of the multi-trip launch timed out (workspaces (rays, lane, launches) = {bad}): frames rendered there "
+                            f"since the last check are incomplete.  Other work held compute units for too long; render with lp_kernel='persist' (no "
+                            f"barrier) or separate_trips >= max_steps")
 
     def budget(self, N):
         """The persistent 16-bit launch's own record of the last frame: histogram of the rays' end points [32], evaluated samples, workgroup rounds

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 5
+#define GFPP_ABI_VERSION 6
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -322,6 +322,16 @@ typedef struct gfpp_head_model {
      * -- and give a ray that misses them no sample; the sample times are the bits of the full march.  hi <= lo on an axis (e.g. all zero): unknown,
      * every ray is marched to `far`. */
     float occ_aabb[6];
+    /* (ABI 6) 16-bit CORNER-BLOCK copies of the two tables for the 16-bit kernels (gfpp_head_frame_persist_lp / _trips_lp / gfpp_head_eval_samples_lp), used when
+     * no level of either grid is GFPP_LEVEL_SLOW (hash-addressed or true modulo; such models are read through pos_grid / amb_grid by the generic lookup):
+     * dtype GFPP_F16, row_padded = 2, `levels` filled with row_pad = 0.  Row r of level l (16 bytes, 8 halves) holds both channels of the four corners
+     * (r, r + 1, r + sy, r + sy + 1) of the x-y cell that starts at r, indices modulo the level size:
+     *     c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1)
+     * so that a level costs one 16-byte gather per z plane (32 gathers from <= 25 cache lines per sample and 3-D grid instead of 64 from 64) and the
+     * interpolation is four packed dot products per plane (v_dot2_f32_f16: fp16 corner weights, fp32 accumulation).  The reference's autocast inference reads
+     * a half table too (grid.py:43-47).  The exact-fp32 kernels never read these. */
+    gfpp_grid_desc pos_grid_blk;
+    gfpp_grid_desc amb_grid_blk;
 } gfpp_head_model;
 
 /* per-frame device workspace (caller-allocated, reusable across frames) */
@@ -380,6 +390,21 @@ typedef struct gfpp_frame_ws {
     gfpp_clip_job *clip_job;  /* NULL, or (DEVICE pointer) the clip job this frame belongs to: gfpp_torso_frame_lp then also writes the frame as uint8
                                * into the job's output slot of lane `clip_lane` and advances that lane's cursor (= gfpp_clip_store_u8 fused) */
     uint32_t clip_lane;
+    /* (ABI 6) */
+    uint32_t clip_sub;        /* this frame is the clip_sub-th of its lane's frame GROUP: it takes job position cursor[clip_lane] + clip_sub */
+    uint32_t clip_advance;    /* what the storing launch adds to the lane's cursor when it is done: 0 = `lanes` (one frame per graph launch); a group of K
+                               * frames per launch sets 0xFFFFFFFF (no advance) on all but its last frame and K * lanes on the last */
+    uint32_t n_frames;        /* gfpp_head_frame_persist_lp only.  0 / 1: one frame.  K in 2..4: this workspace describes K frames of N rays each whose arrays
+                               * lie BEHIND EACH OTHER -- rays_o / rays_d [K N, 3], nears / fars [K N], ray_state [K N, 8], sample_t [K N, stride],
+                               * sample_cnt [K N], snapshots [K N, 7, 5], counters [K, 192], frame_consts [K, 256] -- and ONE launch renders all of them: a
+                               * workgroup pools the samples of its rays of all K frames, so the fixed costs of a launch (weight image into LDS, partly
+                               * filled sample blocks of every local round, the launch's tail) are paid once per K frames.  Per sample and per ray nothing
+                               * changes (same block evaluation, same compositing order): every frame is the bits of its own launch.  Each frame keeps its own
+                               * histogram / counters and is resolved on its own (gfpp_head_frame_resolve or the consumer's on-the-fly resolve, with the
+                               * frame's own gfpp_frame_ws).  Used by the clip renderer for small frames (256^2 rays: 0.117 ms per frame alone). */
+    int32_t *timeouts;        /* optional [1] i32 that NO kernel of this library resets: a device-wide barrier of the multi-trip launch
+                               * (gfpp_head_frame_trips_lp) that times out adds 1 -- unlike counters[127], which the next frame's begin kernel zeroes, so a
+                               * time-out in the middle of a clip stays visible until the caller has looked (FramePipeline.check_barriers) */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

@@ -1,5 +1,5 @@
-"""The 16-bit corner-block grid tables of the experiment build GFPP_LP_BLOCK_TABLE (csrc/grid_device.h: level_block_issue / level_block_finish,
-frame_pipeline.corner_block_table) against the oracle's grid encoder.  The lookup is restated in numpy with the kernel's index arithmetic -- one row per
+"""The 16-bit corner-block grid tables the 16-bit head kernels read (round 4; csrc/grid_device.h: level_block_issue / level_block_finish,
+gfpp_head_model.pos_grid_blk / amb_grid_blk, frame_pipeline.corner_block_table) against the oracle's grid encoder.  The lookup is restated in numpy with the kernel's index arithmetic -- one row per
 z plane, neighbours baked into the row -- so a wrong neighbour, stride, mask or row layout shows up here, without a GPU.  Tolerance: the table and the corner
 weights are rounded to fp16 (the reference's autocast path reads a half table as well, grid.py:43-47)."""
 import ctypes
@@ -23,9 +23,8 @@ def _levels(D, offsets, S, H, gridtype=1, align_corners=False):
     return lv
 
 
-def _block_lookup(u, table, lv, D, xyz_starts=None):
-    """level_block_issue + level_block_finish for all levels: u [B, D] in [0, 1] -> [L, B, 2].  xyz_starts: the level starts (16-byte units) of the x-y-z
-    block table (GFPP_LP_BLOCK_TABLE=2: 32-byte rows where the level keeps z, both planes of a cell in one row)."""
+def _block_lookup(u, table, lv, D):
+    """level_block_issue + level_block_finish for all levels: u [B, D] in [0, 1] -> [L, B, 2]."""
     B = u.shape[0]
     out = np.zeros((len(lv), B, 2), np.float64)
     tab = table.astype(np.float64)
@@ -37,12 +36,7 @@ def _block_lookup(u, table, lv, D, xyz_starts=None):
         if D == 3:
             row = row + base[:, 2] * int(d.sz)
         row &= int(d.mask)
-        if xyz_starts is not None:
-            sh = 1 if (D == 3 and int(d.sz) != 0) else 0
-            at = xyz_starts[l] + (row << sh)
-            rows = [at - int(d.offset)] if D == 2 else [at - int(d.offset), at + sh - int(d.offset)]      # (`tab[int(d.offset) + rz]` below)
-        else:
-            rows = [row] if D == 2 else [row, (row + int(d.sz)) & int(d.mask)]
+        rows = [row] if D == 2 else [row, (row + int(d.sz)) & int(d.mask)]
         wx = np.stack([1 - frac[:, 0], frac[:, 0]], 1).astype(f32)
         wy = [wx * (1 - frac[:, 1:2]), wx * frac[:, 1:2]]
         for z, rz in enumerate(rows):
@@ -74,12 +68,6 @@ def test_corner_block_lookup_matches_the_grid_encoder(D):
     # fp16 table values and fp16 corner weights: ~2^-11 relative per term of a sum of <= 8 terms of magnitude <= 1
     np.testing.assert_allclose(got, ref, rtol=0, atol=2.5e-3)
     assert np.sqrt(((got - ref) ** 2).mean()) < 2.5e-4
-    # x-y-z blocks: the same values from one row per level
-    table2, starts = fp.corner_block_table_xyz(torch.from_numpy(emb), offsets, lv)
-    n_z = sum(int(d.size) for d in lv if int(d.sz) != 0)
-    assert table2.shape == (int(offsets[-1]) + n_z, 8) and (D == 3) == (n_z > 0)
-    got2 = _block_lookup(u, table2.numpy(), lv, D, xyz_starts=starts)
-    np.testing.assert_array_equal(got2, got)
 
 
 def test_block_rows_hold_the_neighbours_of_the_plain_table():

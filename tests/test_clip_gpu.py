@@ -142,6 +142,28 @@ def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
         cr.render_to_host(clip)
     monkeypatch.delenv("GFPP_BARRIER_SPINS")
     cr.render_to_host(clip)                                       # the next frame resets the word (gfpp_head_frame_begin_premarch)
+    # a time-out in the MIDDLE of a clip (round-3 advisory): the frames after it zero counters[127] again, only the sticky word (gfpp_frame_ws.timeouts) still
+    # knows -- and the chunk must be refused BEFORE it reaches the sink.  Chunks of one frame; the sink of frame 0 arms the time-out for the frames issued
+    # next, the sink of frame 1 disarms it again
+    import os
+    long_clip = cr.prepare(_clip_batch(case["hp"], 8), dev)
+    seen = []
+
+    def sink(k, arr):
+        seen.append(k)
+        if k == 0:
+            os.environ["GFPP_BARRIER_SPINS"] = "1"
+        else:
+            os.environ.pop("GFPP_BARRIER_SPINS", None)
+    try:
+        with pytest.raises(GfppError, match="barrier"):
+            cr.render_to_host(long_clip, sink=sink, chunk=1)
+    finally:
+        os.environ.pop("GFPP_BARRIER_SPINS", None)
+    torch.cuda.synchronize()
+    assert seen and seen == list(range(len(seen))) and len(seen) < 8, seen      # delivery stopped at the damaged frame
+    cr.check()                                                    # the sticky word was cleared by the check that raised
+    np.testing.assert_array_equal(cr.render_to_host(long_clip)[:3], cr.render_to_host(clip))   # and the renderer is usable again
     pipe.lp_kernel, pipe.separate_trips = "persist", None
     cr2 = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], use_graph=True, render_kwargs=dict(case["hp"]),
                        lanes=2)

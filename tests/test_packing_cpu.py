@@ -113,7 +113,7 @@ def test_16bit_weight_image_reproduces_the_head_mlps():
 
 
 def _skinny_tile_row(i):
-    """skinny_tile_chunk (frame_head_lp.hip, experiment build GFPP_LP_SKINNY_MFMA): image row that lane row i of the gathered 32-row tile reads."""
+    """skinny_tile_chunk (frame_head_lp.hip, the skinny layers on the matrix pipe since round 4): image row that lane row i of the gathered 32-row tile reads."""
     i &= 15
     low = i & 3
     return 4 + min(low, 2) if i & 8 else low
