@@ -422,6 +422,7 @@ def main():
     out_u8 = torch.empty(K, HWO, HWO, 3, dtype=torch.uint8, device=dev)
     # multi-GPU: finished frames are all_gathered in chunks while the next chunk renders (RCCL runs on its own stream)
     chunk = max(1, min(K, args.gather_every)) if world > 1 else K
+    chunk = -(-chunk // cr.group_wanted) * cr.group_wanted          # whole frame groups per chunk (ClipRenderer.issue)
     bounds = [(c, min(c + chunk, K)) for c in range(0, K, chunk)]
     gathered = None
     if world > 1 and args.gather == "all":

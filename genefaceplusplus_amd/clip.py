@@ -37,6 +37,8 @@ class ClipJob(ctypes.Structure):
 
 _lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
+_lib.register("gfpp_clip_fetch_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
+_lib.register("gfpp_clip_store_u8_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                     ctypes.c_uint32])
 STRUCT_MIRRORS = {"clip_job": ClipJob}
@@ -50,7 +52,7 @@ class ClipRenderer:
     """
 
     def __init__(self, model, H, W, intrinsics, bg_img=None, T_thresh=1e-4, ring=4, use_graph=True, render_kwargs=None, lanes=None,
-                 calibrate_trips=True):
+                 calibrate_trips=True, group=None):
         """lanes: how many frames are in flight at once.  With 2, consecutive frames alternate between two streams (each with its own
         workspace and graph; weights and tables are shared), so one frame's prologue and epilogue (slab test + pre-march, conditioning nets, torso
         pass, uint8 store) overlap the tail of the other frame's head pass.  None = 2 for the 16-bit modes (the head pass is one launch that holds
@@ -59,7 +61,12 @@ class ClipRenderer:
         calibrate_trips (trip-launch paths only: fp32, lp_kernel='trips'): with several lanes every possible trip of the render loop is a launch of
         its own (gfpp_frame_ws.separate_trips); when a lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given
         a small grid, because a launch that finds nothing left still needs a whole CU per workgroup (results never depend on it, a later frame that
-        needs more trips is rendered by the small grid)."""
+        needs more trips is rendered by the small grid).
+        group: frames per graph launch (round 4).  K > 1: a lane takes K consecutive frames of the clip at a time and renders them with ONE persistent
+        head launch (RADNeRFTorso*.render_group, gfpp_frame_ws.n_frames) -- every frame the bits of its own launch, the fixed costs of a launch paid once
+        per K frames.  None: 4 for frames of up to 256^2 rays (the released checkpoint's geometry: a workgroup's share of ONE such frame is ~110
+        occupied rays, 27 sample blocks for 8 wavefronts), else 1; models / precisions without group support (head-only models, fp32, lp_kernel='trips')
+        and clips without precomputed conditioning render frame by frame whatever is asked."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
@@ -94,6 +101,10 @@ class ClipRenderer:
                        "u8": torch.empty(*self.out_hw, 3, dtype=torch.uint8, device=dev),
                        "stream": shared_stream(dev, "lane", _i) if self.lanes > 1 else None,
                        "graph": None, "key": None, "static_in": None} for _i in range(self.lanes)]
+        if group is None:
+            group = int(os.environ.get("GFPP_CLIP_GROUP", "0")) or (4 if H * W <= 256 * 256 else 1)
+        self.group_wanted = max(1, min(int(group), 4)) if fused else 1
+        self.group = 1                                       # what the captured graphs render with (decided with the first clip: _ensure_graphs)
         self.ring = max(2, int(ring), self.lanes)
         self._copy_stream = shared_stream(dev, "copy")
         # the job record (gfpp_clip_job) in device memory + a small ring of pinned staging copies (a staging slot is rewritten only after the
@@ -157,6 +168,33 @@ class ClipRenderer:
         call("gfpp_clip_store_u8", self._job_dev.data_ptr(), lane, rgb.data_ptr(), int(rgb.numel()), torch.cuda.current_stream().cuda_stream)
         return {}
 
+    def _frame_group(self, lane, rows):
+        """K frames on the current stream (rows: the views of the lane's K static input rows): per frame fetch + rays, then model.render_group -- ONE
+        persistent head launch for all K -- with each frame's uint8 store issued right behind its last kernel."""
+        L = self._lane[lane]
+        K = len(rows)
+        st = torch.cuda.current_stream().cuda_stream
+        model = getattr(self.model, "_orig_mod", self.model)
+        kw = dict(self.render_kwargs)
+        max_steps = int(kw.get("max_steps", 1024))
+        _g, _f, t = model.pipeline().group_workspace(self.rays_per_frame, K, max_steps)
+        fx, fy, cx, cy = self.intrinsics
+        for k, v in enumerate(rows):
+            call("gfpp_clip_fetch_at", self._job_dev.data_ptr(), lane, k, L["g_static_in"][k].data_ptr(), int(L["g_static_in"].shape[1]), st)
+            call("gfpp_get_rays", v["pose"].data_ptr(), fx, fy, cx, cy, self.H, self.W, t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(), st)
+
+        def store(k, res):
+            rgb = res["sr_rgb_map"].permute(0, 2, 3, 1) if self.with_sr else res["rgb_map"]
+            rgb = rgb.reshape(*self.out_hw, 3)
+            if not rgb.is_contiguous() or rgb.dtype != torch.float32:
+                rgb = rgb.float().contiguous()
+            advance = K * self.lanes if k == K - 1 else 0xFFFFFFFF
+            call("gfpp_clip_store_u8_at", self._job_dev.data_ptr(), lane, k, advance, rgb.data_ptr(), int(rgb.numel()), torch.cuda.current_stream().cuda_stream)
+        kw.pop("index", None)
+        kw.update(bg_color=self.bg_img, T_thresh=self.T_thresh)
+        model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store, **kw)
+        return {}
+
     # -- the job: which frames, where to ----------------------------------------------------------------------------------------------------------
     def _upload_job(self, job):
         slot = self._job_calls % len(self._job_stage)
@@ -172,8 +210,14 @@ class ClipRenderer:
     def _ensure_graphs(self, clip):
         """Capture the lanes' frame graphs (first use, or another clip layout / precision).  The warm-up runs and the capture execute the frame with
         an EMPTY job (n = 0: fetch and store do nothing, the static input keeps a copy of the clip's first row), so they cannot disturb a job."""
-        key = (clip["layout"], self.model.resolved_precision())
+        target = getattr(self.model, "_orig_mod", self.model)
+        group = self.group_wanted
+        if group > 1 and not (any(n == "cond_feat" for n, _ in clip["layout"]) and hasattr(target, "group_supported")
+                              and target.group_supported(self.rays_per_frame, group, int(self.render_kwargs.get("max_steps", 1024)))):
+            group = 1
+        key = (clip["layout"], self.model.resolved_precision(), group)
         todo = [k for k, L in enumerate(self._lane) if L["static_in"] is None or L["key"] != key or (self.use_graph and L["graph"] is None)]
+        self.group = group
         if not todo:
             return
         dry = ClipJob()
@@ -187,11 +231,18 @@ class ClipRenderer:
                 L["views"] = self._views(L["static_in"], clip["layout"])
                 L["key"] = key
                 L["graph"] = None
+                if group > 1:
+                    # K rows of driving signals per launch; a row's fields are views of it (the frames' folded constants: equally spaced, one per row)
+                    L["g_static_in"] = clip["packed"][:1].repeat(group, 1).contiguous()
+                    L["g_views"] = [self._views(L["g_static_in"][k], clip["layout"]) for k in range(group)]
                 if self.use_graph:
                     self._enter_lane(lane)
                     try:
-                        g = GraphedFrame(lambda **v: self._frame(lane, **v), L["views"], copy_inputs=False,
-                                         before_capture=(lambda: self._calibrate_trip_launches()) if self.calibrate else None)
+                        if group > 1:
+                            g = GraphedFrame(lambda **_v: self._frame_group(lane, L["g_views"]), {"rows": L["g_static_in"]}, copy_inputs=False)
+                        else:
+                            g = GraphedFrame(lambda **v: self._frame(lane, **v), L["views"], copy_inputs=False,
+                                             before_capture=(lambda: self._calibrate_trip_launches()) if self.calibrate else None)
                     finally:
                         self._leave_lane()
                     g.fn = None           # only needed for the capture; keeping it would tie the renderer into a reference cycle, and a cycle
@@ -222,8 +273,10 @@ class ClipRenderer:
         job.packed, job.order, job.out = clip["packed"].data_ptr(), order.data_ptr(), out.data_ptr()
         job.frame_bytes = self.out_hw[0] * self.out_hw[1] * 3
         job.row_floats, job.n, job.lanes, job.ring_frames = int(clip["packed"].shape[1]), len(idx), self.lanes, max(ring_frames, 1)
+        if job.frame_bytes != out[0].numel():
+            raise GfppError("ClipRenderer.start: a slot of `out` is not one frame")
         for l in range(8):
-            job.cursor[l] = l
+            job.cursor[l] = l * self.group                  # groups of `group` consecutive positions are dealt to the lanes round-robin
         self._upload_job(job)
         main = self._fork()
         self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip}       # (keeps the extended rows alive)
@@ -271,21 +324,26 @@ class ClipRenderer:
         return self.replay_mode == "c" and self.use_graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
 
     def issue(self, count=None):
-        """Issue the next `count` frames of the job (all that are left by default): frame k runs on lane k % lanes.  No host synchronisation."""
+        """Issue the next `count` frames of the job (all that are left by default): frame k runs on lane k % lanes -- with frame groups (self.group = K > 1)
+        the K frames [g K, g K + K) are one launch on lane g % lanes, `count` must be a multiple of K unless it finishes the job, and a last, partial group
+        renders its missing positions for nothing (they fetch and store nothing).  No host synchronisation."""
         J = self._job
         count = J["n"] - J["issued"] if count is None else min(int(count), J["n"] - J["issued"])
         if count <= 0:
             return 0
-        first = J["issued"] % self.lanes
+        K = self.group
+        if J["issued"] % K or (count % K and J["issued"] + count < J["n"]):
+            raise GfppError(f"ClipRenderer.issue: with frame groups of {K} frames a chunk must be a multiple of {K} frames (or finish the job)")
+        launches, first = -(-count // K), (J["issued"] // K) % self.lanes
         if self._replay_from_c():
             execs, streams = self._exec_arrays()
             if self.lanes == 1:
                 streams[0] = torch.cuda.current_stream().cuda_stream
-            call("gfpp_graph_replay", execs, streams, self.lanes, first, count, int(self.max_ahead))
+            call("gfpp_graph_replay", execs, streams, self.lanes, first, launches, int(self.max_ahead))
         else:
             inner, self.model.use_graph = self.model.use_graph, False
             try:
-                for k in range(count):
+                for k in range(launches):
                     lane = (first + k) % self.lanes
                     with self._on_lane(lane):
                         if self.use_graph:
@@ -293,7 +351,10 @@ class ClipRenderer:
                         else:
                             self._enter_lane(lane)
                             with torch.no_grad():
-                                self._frame(lane, **self._lane[lane]["views"])
+                                if K > 1:
+                                    self._frame_group(lane, self._lane[lane]["g_views"])
+                                else:
+                                    self._frame(lane, **self._lane[lane]["views"])
             finally:
                 self._leave_lane()
                 self.model.use_graph = inner
@@ -392,6 +453,7 @@ class ClipRenderer:
         if not idx:
             return collected
         M = max(1, int(chunk))
+        M = -(-M // self.group_wanted) * self.group_wanted          # whole frame groups per chunk (harmless when the clip falls back to single frames)
         if self._host_bufs is None or self._host_bufs["M"] != M:
             self._host_bufs = {"M": M, "ring": torch.empty(2 * M, *self.out_hw, 3, dtype=torch.uint8, device=self.device),
                                "host": [torch.empty(M, *self.out_hw, 3, dtype=torch.uint8).pin_memory() for _ in range(2)],

@@ -79,17 +79,19 @@ constexpr uint32_t kPTilesPerSub = 512u / kPTile;          // candidate tiles of
 constexpr uint32_t kPTilesPerStep = 2u * kPTilesPerSub;
 constexpr uint32_t kPRayBits = 22;        // alive entry: ray id | samples consumed << 22 | samples the ray owns << 27
 constexpr uint32_t kPRayMask = (1u << kPRayBits) - 1u;
+constexpr uint32_t kPMaxFrames = 4;       // frames one launch can render (gfpp_frame_ws.n_frames): rays are numbered frame * N + ray, (frames * N) <= 2^kPRayBits
 struct LpPoolP {
+    float bias_more[kPMaxFrames - 1][256];   // folded constants of the frames 1.. of a frame group: FIRST member, so that frame f's set is LpShared::bias + 256 f
     float px[kPoolSlots], py[kPoolSlots], pz[kPoolSlots], cb[kPoolSlots];   // sample position; after evaluation: sigma, r, g, b of the slot
     float t0[kPoolSlots];                                                    // t of the sample
-    uint32_t ray[kPoolSlots];        // ray id by local ray of the round (= index into the alive list)
-    uint32_t alive[kPoolSlots];      // the workgroup's alive list
+    uint32_t alive[kPoolSlots];      // the workgroup's alive list; entry i is also local ray i of the round (ray id = low kPRayBits bits)
     uint16_t order[kPoolSlots];      // compact index -> slot
     uint8_t cnt[kPoolSlots];         // samples the local ray takes in this round; kNoRay: no such ray
     uint32_t wave_valid[kLpWaves], wave_surv[kLpWaves];
     uint32_t tile_cnt[kPTilesPerStep];   // ingest: occupied rays | empty rays << 16 of each candidate tile
-    uint32_t hist[32];               // rays by the sample index their compositing ends at
-    __device__ __forceinline__ uint32_t ray_of(uint32_t local) const { return ray[local]; }
+    uint32_t hist[kPMaxFrames][32];  // per frame: rays by the sample index their compositing ends at
+    // (the list is compacted only after a round's evaluation and compositing: during both, entry `local` is the round's local ray `local`)
+    __device__ __forceinline__ uint32_t ray_of(uint32_t local) const { return alive[local] & kPRayMask; }
 };
 
 struct LpShared {
@@ -100,10 +102,12 @@ struct LpShared {
     union {
         LpWaveTile tile[kLpWaves]; //  27 648 B  one tile per wavefront (k_head_trip_lp, k_head_eval_lp)
         LpPool pool;               //  31 776 B  one pool per workgroup (k_head_trip_pool)
-        LpPoolP poolp;             //  32 448 B  pool + alive list of the persistent launch (k_head_frame_persist)
+        LpPoolP poolp;             //  31 808 B  pool + alive list (+ the further frames' constants) of the persistent launch (k_head_frame_persist)
     };
 };
 static_assert(sizeof(LpShared) <= 163840, "one workgroup per CU: everything must fit the 160 KiB LDS");
+static_assert(offsetof(LpShared, poolp) == offsetof(LpShared, bias) + 256 * sizeof(float) && offsetof(LpPoolP, bias_more) == 0,
+              "frame f's constants are addressed as bias + 256 f");
 
 struct LpGrid {
     const gfpp_grid_level *levels;   // [16] device memory, read with scalar loads
@@ -131,7 +135,9 @@ struct LpTripArgs {
     float T_thresh, density_scale;
     uint32_t N, trip, trip_end, max_steps;   // this launch runs the trips [trip, trip_end)
     // persistent launch (k_head_frame_persist)
-    int32_t *budget;                    // counters + 128: histogram [32], evaluated samples, rounds
+    uint32_t consts_stride;             // floats between the frames' folded constants (256 when they are a [n_frames, 256] array)
+    uint32_t n_frames, tiles_per_frame; // a frame group: n_frames (<= kPMaxFrames) frames of N rays behind each other in every per-ray array, ceil(N / kPTile) tiles each
+    int32_t *budget;                    // counters + 128 of the (first) frame: histogram [32], evaluated samples, rounds; frame f's: + f * kCounterWords
     float *snaps;                       // [N, 7, 5] ray state after max_steps .. max_steps + 6 composited samples
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
@@ -327,7 +333,9 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
 }
 
 // RADNeRF.forward for the 32 occupied samples [first, first+32) of a tile (one wavefront's LpWaveTile or a workgroup's pool).
-template <int AMB_D, typename H, bool SLOW, bool DBG = false, typename Tile>
+// MF (frame groups of the persistent launch): the block's samples may belong to different frames; each takes the folded constants of ITS frame -- the
+// biases enter as the accumulators' initial values, per column (= sample) of the block, so nothing else in the block depends on the frame.
+template <int AMB_D, typename H, bool SLOW, bool DBG = false, bool MF = false, typename Tile>
 __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpShared &sh, Tile &wt, uint32_t first, uint32_t n_valid,
                                                   uint32_t n_step, int lane_in) {
     typedef typename LpTraits<H>::vec vec;
@@ -341,7 +349,8 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
     // the descriptor tables are addressed through the laundered lane id too (hoisting 32 descriptors out of the tile loop would spill)
     const gfpp_grid_level *lv_pos = &sh.lv[0][0] + (lane & 0), *lv_amb = &sh.lv[1][0] + (lane & 0);
     const uint32_t ray = wt.ray_of(slot / n_step);
-    const float *bias = sh.bias;        // (one frame per launch: the frame's constants)
+    const float *bias = sh.bias;        // one frame per launch: the frame's constants; a frame group: the set of the sample's frame (rays are numbered frame * N + ray)
+    if constexpr (MF) bias += 256u * ((ray >= a.N ? 1u : 0u) + (ray >= 2u * a.N ? 1u : 0u) + (ray >= 3u * a.N ? 1u : 0u));
 
     vec bpos[2], bamb[2];
     float dir[3];
@@ -628,7 +637,12 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
 // What the schedule decides -- B and the n_alive sequence -- is reconstructed from the histogram of m (k_head_budget_resolve); rays that go past
 // max_steps samples leave a snapshot of their state after each of the samples max_steps .. max_steps + 6, and the resolve step picks the one at B.
 // Same evaluate_block_lp, same composite_sample, same order along a ray as k_head_trip_pool: results are bit-identical to the trip launches.
-template <int AMB_D, typename H, bool SLOW>
+// MF: a frame GROUP (gfpp_frame_ws.n_frames = 2..4 frames of N rays each, numbered frame * N + ray in every per-ray array).  The tiles of all frames go
+// through one permutation, so a workgroup owns rays of every frame and pools their samples in its rounds: what a launch costs whatever its size -- the
+// 124 KB weight image into LDS, a partly filled last block in each of the ~4 local rounds, ingest, the tail behind the busiest workgroup -- is paid once
+// per group.  At 256^2 rays a workgroup's share of ONE frame is ~110 occupied rays = 27 blocks for 8 wavefronts (0.117 ms per frame, 0.49 of the
+// yardstick); four frames give it the ~440 rays of a 512^2 frame.  Per frame: its own constants (LDS, by sample), histogram and counters.
+template <int AMB_D, typename H, bool SLOW, bool MF>
 __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_persist(LpTripArgs a) {
     __shared__ LpShared sh;
     LpPoolP &pool = sh.poolp;
@@ -641,7 +655,11 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     const uint32_t my_tiles = per_wg + (b < extra ? 1u : 0u), q0 = b * per_wg + (b < extra ? b : extra);
     if (my_tiles == 0u) return;                                   // tiny frames: fewer tiles than workgroups
     lp_fill_shared(sh, a, tid, lane);
-    if (tid < 32) pool.hist[tid] = 0u;
+    if constexpr (MF) {
+        for (uint32_t i = (uint32_t)tid; i < 256u * (a.n_frames - 1u); i += kLpThreads)
+            (&pool.bias_more[0][0])[i] = a.frame_consts[(size_t)((i >> 8) + 1u) * a.consts_stride + (i & 255u)];
+    }
+    if (tid < (int)(32u * kPMaxFrames)) (&pool.hist[0][0])[tid] = 0u;
     const uint32_t cap = a.max_steps + 7u;                        // a ray can never composite more samples than that (k_premarch stores no more)
     uint32_t j_next = 0, A = 0, evaluated = 0, round = 0;
     unsigned long long t_mark = __builtin_readcyclecounter(), cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
@@ -661,13 +679,18 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const uint32_t ts = (uint32_t)sub * kPTilesPerSub + (uint32_t)tid / kPTile, j = j_next + ts;
-                uint32_t ray = 0, c = 0;
+                uint32_t ray = 0, c = 0, frame = 0;
                 bool in_range = false;
                 if (j < my_tiles) {
-                    const uint32_t tile = ((q0 + j) * a.tile_mult) % a.n_tiles;
-                    ray = tile * kPTile + in_tile;
-                    if (ray < a.N) {
+                    uint32_t tile = ((q0 + j) * a.tile_mult) % a.n_tiles;
+                    if constexpr (MF) {
+                        frame = tile / a.tiles_per_frame;
+                        tile -= frame * a.tiles_per_frame;
+                    }
+                    const uint32_t in_frame = tile * kPTile + in_tile;
+                    if (in_frame < a.N) {
                         in_range = true;
+                        ray = frame * a.N + in_frame;
                         const uint32_t cc = a.sample_cnt[ray];
                         c = cc < cap ? cc : cap;
                     }
@@ -675,7 +698,8 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 occupied[sub] = c > 0u;
                 const unsigned long long bo = __ballot(occupied[sub]), be = __ballot(in_range && c == 0u);
                 const uint32_t so = (uint32_t)(bo >> seg) & ((1u << kPTile) - 1u), se = (uint32_t)(be >> seg) & ((1u << kPTile) - 1u);
-                if (in_tile == 0u) pool.tile_cnt[ts] = (uint32_t)__popc(so) | ((uint32_t)__popc(se) << 16);
+                // occupied rays | empty rays << 16 | frame << 24 (a tile never straddles two frames)
+                if (in_tile == 0u) pool.tile_cnt[ts] = (uint32_t)__popc(so) | ((uint32_t)__popc(se) << 16) | (frame << 24);
                 rank[sub] = (uint32_t)__popc(so & ((1u << in_tile) - 1u));
                 ent[sub] = ray | (c << 27);
             }
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 if (t == ts1) off1 = acc;
                 acc += n;
                 accepted = t + 1u;
-                if ((uint32_t)tid == t && (x >> 16)) atomicAdd(&pool.hist[0], x >> 16);   // rays without any occupied sample: m = 0
+                if ((uint32_t)tid == t && ((x >> 16) & 0xFFu)) atomicAdd(&pool.hist[x >> 24][0], (x >> 16) & 0xFFu);   // rays without any occupied sample: m = 0
             }
             if (ts0 < accepted && occupied[0]) pool.alive[A + off0 + rank[0]] = ent[0];
             if (ts1 < accepted && occupied[1]) pool.alive[A + off1 + rank[1]] = ent[1];
@@ -724,7 +748,6 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 const uint32_t ray = e & kPRayMask, used = (e >> kPRayBits) & 31u, c = e >> 27;
                 const uint32_t rem = c - used;                    // >= 1: a ray without samples left never stays on the list
                 cnt = rem < n_step ? rem : n_step;
-                pool.ray[idx] = ray;
                 const float *o = a.rays_o + 3ull * ray, *d = a.rays_d + 3ull * ray;
                 const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
                 const float *ts = a.sample_t + (size_t)ray * a.sample_stride + used;
@@ -776,7 +799,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         if (wave >= 4)
             for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
         for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
-            evaluate_block_lp<AMB_D, H, SLOW>(a, sh, pool, first, total, n_step, lane);
+            evaluate_block_lp<AMB_D, H, SLOW, false, MF>(a, sh, pool, first, total, n_step, lane);
         __syncthreads();
         lap(2);
 
@@ -811,7 +834,9 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 }
                 const uint32_t used2 = used + (stop ? s + 1u : cnt);
                 survives = !stop && used2 < c;
-                if (!survives) atomicAdd(&pool.hist[stop ? used + s : c], 1u);     // m = min(c, e) <= cap <= 31
+                uint32_t frame = 0;
+                if constexpr (MF) frame = (ray >= a.N ? 1u : 0u) + (ray >= 2u * a.N ? 1u : 0u) + (ray >= 3u * a.N ? 1u : 0u);
+                if (!survives) atomicAdd(&pool.hist[frame][stop ? used + s : c], 1u);     // m = min(c, e) <= cap <= 31
                 ray_state_store(a.state, ray, acc, __uint_as_float(used2));
                 a.state[(size_t)kRayRec * ray + 7] = __uint_as_float(used2);        // word 7 (zero since the frame began): samples composited, for k_head_budget_resolve
                 keep[sub] = (e & ~(31u << kPRayBits)) | (used2 << kPRayBits);
@@ -839,7 +864,10 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         __syncthreads();
         lap(3);
     }
-    if (tid < 32 && pool.hist[tid]) atomicAdd(&a.budget[tid], (int)pool.hist[tid]);
+    if (tid < (int)(32u * (MF ? a.n_frames : 1u))) {       // every frame's histogram into the frame's own counters
+        const uint32_t f = (uint32_t)tid >> 5, m = (uint32_t)tid & 31u;
+        if (pool.hist[f][m]) atomicAdd(&a.budget[f * (uint32_t)kCounterWords + m], (int)pool.hist[f][m]);
+    }
     if (tid == 0) {
         if (evaluated) atomicAdd(&a.budget[kBudgetSamples], (int)evaluated);
         atomicAdd(&a.budget[kBudgetRounds], (int)round);
@@ -1185,7 +1213,8 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
 
 template <int AMB_D, typename H, bool SLOW>
 static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
-    hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    if (a.n_frames > 1u) hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
 }
 
 // upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8" overrides, experiments).  The take is
@@ -1229,7 +1258,13 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
         set_error("gfpp_head_frame_persist_lp: the workspace needs ray_state, counters [192], frame_consts and snapshots [N, 7, 5]");
         return GFPP_EINVAL;
     }
-    if (max_steps > 24u || ws->N > (1u << kPRayBits)) { set_error("gfpp_head_frame_persist_lp: max_steps <= 24 and N <= 2^22 (use gfpp_head_frame_trips_lp beyond)"); return GFPP_EUNSUPPORTED; }
+    const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
+    if (frames > kPMaxFrames) { set_error("gfpp_head_frame_persist_lp: n_frames must be <= %u", kPMaxFrames); return GFPP_EUNSUPPORTED; }
+    if (max_steps > 24u || (unsigned long long)ws->N * frames > (1ull << kPRayBits)) {
+        set_error("gfpp_head_frame_persist_lp: max_steps <= 24 and n_frames * N <= 2^22 (use gfpp_head_frame_trips_lp beyond)");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (frames > 1u && ws->gcounters) { set_error("gfpp_head_frame_persist_lp: a frame group cannot be a ray tile of a frame shared between GPUs"); return GFPP_EUNSUPPORTED; }
     LpTripArgs a;
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
     { const int rc = lp_model_args("gfpp_head_frame_persist_lp", model, a); if (rc) return rc; }
@@ -1243,7 +1278,10 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
     a.N = ws->N; a.max_steps = max_steps; a.trip = 0; a.trip_end = 0;
     a.budget = ws->counters + kBudgetBase;
     a.snaps = ws->snapshots;
-    a.n_tiles = div_up(ws->N, kPTile);
+    a.n_frames = frames;
+    a.consts_stride = ws->frame_consts_stride ? ws->frame_consts_stride : 256u;
+    a.tiles_per_frame = div_up(ws->N, kPTile);
+    a.n_tiles = frames * a.tiles_per_frame;
     // q -> (q * mult) % n_tiles is a permutation of the tiles when gcd(mult, n_tiles) = 1: consecutive slots land ~1237 tiles apart, so that every
     // workgroup's share (slots b, b + G, ...) is spread over the whole image (equal work without any exchange between workgroups)
     a.tile_mult = 1u;
@@ -1262,7 +1300,9 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
              : (bf ? (slow ? launch_persist<2, __bf16, true> : launch_persist<2, __bf16, false>) : (slow ? launch_persist<2, _Float16, true> : launch_persist<2, _Float16, false>));
     launch(grid, (hipStream_t)stream, a);
     const int rc = check_launch("gfpp_head_frame_persist_lp");
-    if (rc || ws->gcounters || ws->defer_resolve) return rc;   // a ray tile of a shared frame: the caller sums the histograms of all tiles first; defer_resolve: the consumer kernel resolves
+    // a ray tile of a shared frame: the caller sums the histograms of all tiles first; defer_resolve: the consumer kernel resolves; a frame group: the
+    // caller resolves (or lets the consumer resolve) every frame with that frame's own workspace record
+    if (rc || ws->gcounters || ws->defer_resolve || frames > 1u) return rc;
     return gfpp_head_frame_resolve(ws, max_steps, stream);
 }
 

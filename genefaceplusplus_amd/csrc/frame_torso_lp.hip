@@ -48,7 +48,7 @@ struct TorsoLpArgs {
     uint8_t *mask_out;
     BudgetView bv;            // hist != null: the head pass was the persistent launch with the resolve deferred to this kernel
     gfpp_clip_job *job;       // != null: also store the frame as uint8 into the clip job's slot of lane `lane` and advance its cursor
-    uint32_t lane;
+    uint32_t lane, sub, advance;   // the frame takes job position cursor[lane] + sub; the launch moves the cursor by `advance` (0: the job's `lanes`; ~0: not at all)
 };
 
 template <typename H>
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         const int q0 = lane & ~3, ql = lane & 3;
         const uint32_t w0 = (uint32_t)__shfl((int)packed, q0), w1 = (uint32_t)__shfl((int)packed, q0 + 1);
         const uint32_t w2 = (uint32_t)__shfl((int)packed, q0 + 2), w3 = (uint32_t)__shfl((int)packed, q0 + 3);
-        const uint32_t pos = a.job->cursor[a.lane];
+        const uint32_t pos = a.job->cursor[a.lane] + a.sub;
         if (in_frame && pos < a.job->n) {
             uint8_t *frame = a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes;
             const uint32_t nq = n & ~3u;
@@ -344,11 +344,11 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     if (a.job) {
         // the lane's cursor moves on when every workgroup has read it: the last one to get here advances it (as k_clip_store_u8 does)
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && a.advance != 0xFFFFFFFFu) {
             const uint32_t pos = a.job->cursor[a.lane];
             if (atomicAdd(&a.job->ticket[a.lane], 1u) == gridDim.x - 1u) {
                 a.job->ticket[a.lane] = 0u;
-                a.job->cursor[a.lane] = pos + a.job->lanes;
+                a.job->cursor[a.lane] = pos + (a.advance ? a.advance : a.job->lanes);
             }
         }
     }
@@ -397,7 +397,7 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
         if (!ws->snapshots || !ws->counters || ws->resolve_max_steps == 0 || ws->resolve_max_steps > 24u) { set_error("gfpp_torso_frame_lp: defer_resolve needs snapshots, counters and resolve_max_steps"); return GFPP_EINVAL; }
         a.bv = BudgetView{ws->gcounters ? ws->gcounters : ws->counters + 128, ws->snapshots, ws->gcounters ? ws->N_global : ws->N, ws->resolve_max_steps};
     }
-    a.job = ws->clip_job; a.lane = ws->clip_lane;
+    a.job = ws->clip_job; a.lane = ws->clip_lane; a.sub = ws->clip_sub; a.advance = ws->clip_advance;
     if (a.job && a.lane >= 8) { set_error("gfpp_torso_frame_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
     const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);

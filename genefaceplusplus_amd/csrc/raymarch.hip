@@ -162,20 +162,23 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_u8(const float *__restrict__ 
     } while (0)
 
 // ---- clip job: a frame's graph fetches its inputs and stores its output by a device-side cursor ---------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_clip_fetch(const gfpp_clip_job *__restrict__ job, uint32_t lane, float *__restrict__ static_in, uint32_t row_floats) {
-    const uint32_t pos = job->cursor[lane];
+__global__ __launch_bounds__(kBlock) void k_clip_fetch(const gfpp_clip_job *__restrict__ job, uint32_t lane, uint32_t sub, float *__restrict__ static_in,
+                                                       uint32_t row_floats) {
+    const uint32_t pos = job->cursor[lane] + sub;
     if (pos >= job->n) return;
     const float *row = job->packed + (size_t)job->order[pos] * job->row_floats;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < row_floats; i += gridDim.x * kBlock) static_in[i] = row[i];
 }
 
-__global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restrict__ job, uint32_t lane, const float *__restrict__ rgb, size_t n) {
+__global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restrict__ job, uint32_t lane, uint32_t sub, uint32_t advance,
+                                                          const float *__restrict__ rgb, size_t n) {
     // a grid-stride loop over a FEW workgroups: the launch ends with one ticket per workgroup on the same word, and 768 of those (one float4 per thread)
     // took longer than the 3.9 MB they guard (9.8 us per launch in the trace)
-    const uint32_t pos = job->cursor[lane];
+    const uint32_t pos = job->cursor[lane] + sub;
     if (pos < job->n) {
         uint8_t *out = job->out + (size_t)(pos % job->ring_frames) * job->frame_bytes;
-        const size_t quads = n / 4;
+        // whole float4 / uchar4 quads where the slot is 4-byte aligned (every even frame size); a scalar tail / fallback otherwise (frames of odd H x W)
+        const size_t quads = (job->frame_bytes & 3ull) == 0ull ? n / 4 : 0;
         for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += (size_t)gridDim.x * kBlock) {
             const float4 v = *reinterpret_cast<const float4 *>(rgb + 4 * q);
             uchar4 o;
@@ -183,12 +186,14 @@ __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restr
             o.z = (uint8_t)clampf(v.z * 255.0f, 0.0f, 255.0f); o.w = (uint8_t)clampf(v.w * 255.0f, 0.0f, 255.0f);
             *reinterpret_cast<uchar4 *>(out + 4 * q) = o;
         }
+        for (size_t k = 4 * quads + (size_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (size_t)gridDim.x * kBlock)
+            out[k] = (uint8_t)clampf(rgb[k] * 255.0f, 0.0f, 255.0f);
     }
-    // the cursor moves on when every workgroup of the launch has read it: the last one to get here advances it
+    // the cursor moves on when every workgroup of the launch has read it: the last one to get here advances it (a frame group: only its last frame's store)
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&job->ticket[lane], 1u) == gridDim.x - 1u) {
+    if (advance != 0xFFFFFFFFu && threadIdx.x == 0 && atomicAdd(&job->ticket[lane], 1u) == gridDim.x - 1u) {
         job->ticket[lane] = 0u;
-        job->cursor[lane] = pos + job->lanes;
+        job->cursor[lane] = job->cursor[lane] + (advance ? advance : job->lanes);
     }
 }
 
@@ -196,19 +201,27 @@ __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restr
 
 using namespace gfpp;
 
-GFPP_API int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {
+GFPP_API int gfpp_clip_fetch_at(const gfpp_clip_job *job, uint32_t lane, uint32_t sub, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {
     GFPP_REQUIRE_EARLY(job && static_in && lane < 8 && row_floats > 0, "gfpp_clip_fetch");
-    hipLaunchKernelGGL(k_clip_fetch, dim3((row_floats + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, job, lane, static_in, row_floats);
+    hipLaunchKernelGGL(k_clip_fetch, dim3((row_floats + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, job, lane, sub, static_in, row_floats);
     return check_launch("gfpp_clip_fetch");
 }
 
-GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {
-    GFPP_REQUIRE_EARLY(job && rgb && lane < 8 && n_values > 0 && ((uintptr_t)rgb & 15u) == 0 && (n_values & 3u) == 0, "gfpp_clip_store_u8");
+GFPP_API int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {
+    return gfpp_clip_fetch_at(job, lane, 0u, static_in, row_floats, stream);
+}
+
+GFPP_API int gfpp_clip_store_u8_at(gfpp_clip_job *job, uint32_t lane, uint32_t sub, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {
+    GFPP_REQUIRE_EARLY(job && rgb && lane < 8 && n_values > 0 && ((uintptr_t)rgb & 15u) == 0, "gfpp_clip_store_u8");
     const uint64_t threads = (n_values + 3) / 4;
     uint64_t blocks = (threads + kBlock - 1) / kBlock;
     if (blocks > 128) blocks = 128;
-    hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)blocks), dim3(kBlock), 0, (hipStream_t)stream, job, lane, rgb, (size_t)n_values);
+    hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)blocks), dim3(kBlock), 0, (hipStream_t)stream, job, lane, sub, advance, rgb, (size_t)n_values);
     return check_launch("gfpp_clip_store_u8");
+}
+
+GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {
+    return gfpp_clip_store_u8_at(job, lane, 0u, 0u, rgb, n_values, stream);
 }
 
 GFPP_API int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_t lanes, uint32_t first_lane, uint32_t count, uint32_t max_ahead) {

@@ -45,7 +45,7 @@ class FrameWs(ctypes.Structure):
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
                 ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32),
-                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("timeouts", c_p)]
+                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("frame_consts_stride", c_u32), ("timeouts", c_p)]
 
 
 class CondModel(ctypes.Structure):
@@ -670,7 +670,7 @@ class FramePipeline:
             ws.full_grid_trips = 0
             ws.snapshots = None
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane = 0, 0, None, 0
-            ws.clip_sub, ws.clip_advance, ws.n_frames = 0, 0, 0
+            ws.clip_sub, ws.clip_advance, ws.n_frames, ws.frame_consts_stride = 0, 0, 0, 0
             t["timeouts"] = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: no kernel resets it (gfpp_frame_ws.timeouts)
             ws.timeouts = t["timeouts"].data_ptr()
             ent = (ws, t)
@@ -932,6 +932,93 @@ class FramePipeline:
              out["torso_mask"].data_ptr(), torch.cuda.current_stream().cuda_stream)
         return out
 
+    # -- frame groups: K consecutive frames of a clip through ONE persistent head launch (gfpp_frame_ws.n_frames) ------------------------------------
+    GROUP_MAX = 4           # kPMaxFrames of csrc/frame_head_lp.hip
+
+    def group_supported(self, N, K, max_steps):
+        """Frame groups run on the persistent 16-bit launch with the MFMA torso kernel (what a clip renders with unless told otherwise)."""
+        return (self.precision != "fp32" and self.lp_kernel == "persist" and self.torso is not None and 2 <= int(K) <= self.GROUP_MAX and int(max_steps) <= 24
+                and int(K) * int(N) <= (1 << 22) and bool(self.torso.lp_weights))
+
+    def group_workspace(self, N, K, max_steps):
+        """The workspaces of K frames of N rays BEHIND EACH OTHER in every per-ray array (what gfpp_head_frame_persist_lp needs to render them with one
+        launch) -> (group record, [the K frames' own records], tensors).  `tensors['rays_o' / 'rays_d']` [K, N, 3] are where the caller puts the rays."""
+        key = ("group", int(N), int(K), self.lane)
+        ent = self._ws.get(key)
+        stride = (int(max_steps) + 7 + 7) // 8 * 8
+        if ent is not None and ent[2]["sample_t"].shape[1] >= stride:
+            return ent
+        dev = self.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        t = {"nears": f(K * N), "fars": f(K * N), "ray_state": f(K * N, 8), "counters": torch.zeros(K, 192, dtype=torch.int32, device=dev),
+             "sample_t": f(K * N, stride), "sample_cnt": torch.empty(K * N, dtype=torch.int32, device=dev), "snapshots": f(K * N, 7, 5),
+             "rays_o": f(K, N, 3), "rays_d": f(K, N, 3), "timeouts": torch.zeros(1, dtype=torch.int32, device=dev)}
+
+        def record(k, n_frames):
+            ws = FrameWs()
+            ws.N = N
+            ws.nears, ws.fars = t["nears"][k * N:].data_ptr(), t["fars"][k * N:].data_ptr()
+            ws.ray_state, ws.counters = t["ray_state"][k * N:].data_ptr(), t["counters"][k:].data_ptr()
+            ws.sample_t, ws.sample_cnt, ws.sample_stride = t["sample_t"][k * N:].data_ptr(), t["sample_cnt"][k * N:].data_ptr(), stride
+            ws.snapshots = t["snapshots"][k * N:].data_ptr()
+            ws.alive[0], ws.alive[1] = None, None
+            ws.frame_consts, ws.phase_cycles, ws.gcounters = None, None, None
+            ws.separate_trips = ws.N_global = ws.trip_first = ws.trip_count = ws.full_grid_trips = 0
+            ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = 0, 0, None, 0, 0, 0
+            ws.n_frames, ws.frame_consts_stride, ws.timeouts = n_frames, 0, t["timeouts"].data_ptr()
+            return ws
+        ent = (record(0, K), [record(k, 0) for k in range(K)], t)
+        self._ws[key] = ent
+        return ent
+
+    def render_group_head_torso(self, consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head_for_torso,
+                                after_frame=None):
+        """K frames (K = len(consts)) whose rays the caller has put into group_workspace()['rays_o' / 'rays_d']: per frame slab test + pre-march, then ONE
+        persistent head launch over the rays of all K frames, then per frame resolve + torso pass (+ `after_frame(k, out)`: the SR stage, the uint8 store).
+        consts[k]: the frame's 256 folded constants (FoldedConsts of equally spaced views, e.g. of the clip's rows); torso_inputs[k]: lm68 [136] or poses [6].
+        Every frame is the bits of its own render_head_torso.  Returns the K result dicts."""
+        K = len(consts)
+        N = int(bg_coords.reshape(-1, 2).shape[0])
+        if not self.group_supported(N, K, max_steps):
+            raise GfppError("render_group_head_torso: needs a 16-bit precision, lp_kernel='persist', a torso model, 2 <= K <= 4, max_steps <= 24")
+        gws, frames, t = self.group_workspace(N, K, max_steps)
+        st = torch.cuda.current_stream().cuda_stream
+        dev = self.device
+        c = [x.consts if isinstance(x, FoldedConsts) else x for x in consts]
+        for x in c:
+            if x.numel() != 256 or x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
+                raise GfppError("render_group_head_torso: every frame needs 256 contiguous float32 folded constants on the GPU")
+        step = (c[1].data_ptr() - c[0].data_ptr()) // 4
+        if step < 256 or any(c[k].data_ptr() - c[0].data_ptr() != 4 * step * k for k in range(K)):
+            raise GfppError("render_group_head_torso: the frames' constants must be equally spaced views (frame_consts_stride)")
+        for k in range(K):
+            call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
+                 float(dt_gamma), int(max_steps), st)
+        gws.frame_consts, gws.frame_consts_stride = c[0].data_ptr(), step
+        call("gfpp_head_frame_persist_lp", ctypes.byref(self.head), ctypes.byref(gws), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps),
+             float(T_thresh), st)
+        bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
+        code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
+        bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        outs = []
+        for k in range(K):
+            ws = frames[k]
+            call("gfpp_head_frame_resolve", ctypes.byref(ws), int(max_steps), st)
+            cond_in = self._dev_f32(torso_inputs[k].reshape(-1), "lm68 / poses")
+            if cond_in.numel() != (136 if self.torso.variant == 1 else 6):
+                raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")
+            out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
+                   "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
+            call("gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws), bg_coords.data_ptr(), cond_in.data_ptr(),
+                 code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
+                 out["depth"].data_ptr(), out["torso_alpha"].data_ptr(), out["torso_bg"].data_ptr(), out["deform_dense"].data_ptr(),
+                 out["torso_mask"].data_ptr(), st)
+            if after_frame is not None:
+                after_frame(k, out)
+            outs.append(out)
+        return outs
+
     def graphed(self, key, fn, inputs):
         """Run `fn(**inputs)` through a per-`key` captured graph (captured on first use, re-captured if shapes change)."""
         key = (key, self.precision)
@@ -961,7 +1048,10 @@ class FramePipeline:
         (gfpp_frame_ws.timeouts), which nothing resets but this function -- so a frame in the middle of a clip that lacks trips is not delivered
         silently.  One 4-byte read per workspace; synchronises."""
         bad = []
-        for (n, lane), (ws, t) in self._ws.items():
+        for key, ent in self._ws.items():
+            if key[0] == "group":                  # frame groups run on the persistent launch only: no barrier
+                continue
+            (n, lane), t = key, ent[1]
             count = int(t["timeouts"].item()) if "timeouts" in t else 0
             if count > 0 or int(t["counters"][127].item()) < 0:
                 bad.append((n, lane, max(count, 1)))

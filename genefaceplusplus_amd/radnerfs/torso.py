@@ -201,6 +201,50 @@ class _TorsoBase(RADNeRF):
         return out
 
 
+    # -- K consecutive frames of a clip through one persistent head launch (clip.ClipRenderer, frame groups) ---------------------------------------
+    def group_supported(self, N, K, max_steps, perturb=False):
+        return (self.executor == "fused" and not self.training and self._fused_ok(perturb, max_steps) and self.pipeline().group_supported(N, K, max_steps))
+
+    def render_group(self, consts, bg_coords, poses, lm68s, index=0, dt_gamma=0, bg_color=None, max_steps=1024, T_thresh=1e-4, upscale_torso=False,
+                     sr_noise_mode="random", after_frame=None, **kwargs):
+        """render() for K = len(consts) frames whose RAYS the caller has put into pipeline().group_workspace(N, K, max_steps)[2]['rays_o' / 'rays_d'] and
+        whose conditioning is given as folded constants (consts[k]: 256 values, RADNeRF.frame_consts_rows) -- the frame loop of
+        inference/genefacepp_infer.py:460-469 taken K frames at a time.  Every frame is the bits of its own render() call (per sample and per ray nothing
+        changes; the super-resolution noise of 'random' mode is drawn per launch either way).  poses [K, 1, 6] / lm68s [K, 136]: per frame.
+        after_frame(k, result dict of frame k): issued right behind the frame's last kernel (the clip renderer's uint8 store).  Returns the K result dicts
+        with render()'s keys."""
+        K = len(consts)
+        N = int(bg_coords.reshape(-1, 2).shape[0])
+        if not self.group_supported(N, K, max_steps):
+            raise GfppError("render_group: not available for this model / precision / executor (see FramePipeline.group_supported)")
+        ind_code, torso_code = self._individual_code(index), self._torso_code(index)
+        use_head = True if self.landmark_conditioned else (kwargs.get("use_head_for_torso") if self.hparams["torso_head_aware"] else False)
+        if use_head is None:
+            use_head = random.random() < 0.5               # one coin per frame group (render(): one per frame; only torso_head_aware non-SR models draw it)
+        sr = getattr(self, "sr_net", None)
+        side = sr.input_resolution if sr is not None else None
+        results = [None] * K
+
+        def finish(k, out):
+            if sr is not None:
+                rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
+                res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2),
+                       "depth_map": out["depth"].view(1, N), "rgb_map": rgb}
+                if sr.ready:
+                    res["sr_rgb_map"] = sr(rgb, noise_mode=sr_noise_mode, clamp01=True)
+                    if upscale_torso:
+                        res["sr_torso_rgb_map"] = sr(res["torso_rgb_map"], noise_mode=sr_noise_mode, clamp01=True)
+            else:
+                res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"], "depth_map": out["depth"].view(1, N), "rgb_map": out["image"].view(1, N, 3)}
+            results[k] = res
+            if after_frame is not None:
+                after_frame(k, res)
+        torso_inputs = lm68s if self.landmark_conditioned else poses
+        self.pipeline().render_group_head_torso(consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head,
+                                                after_frame=finish)
+        return results
+
+
 class RADNeRFTorso(_TorsoBase):
     _render_passes_eye = False        # radnerf_torso.py:106 calls cal_cond_feat(cond) without eye_area_percent
 

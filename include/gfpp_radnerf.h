@@ -169,9 +169,17 @@ typedef struct gfpp_clip_job {
 int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
 
 /* the conversion of gfpp_rgb_to_u8 (inference/genefacepp_infer.py:468) written to the job's output slot of this lane's frame; the launch's last
- * workgroup then advances cursor[lane] by `lanes`.  rgb [n_values] f32 16-byte aligned; n_values must equal the job's frame_bytes.
+ * workgroup then advances cursor[lane] by `lanes`.  rgb [n_values] f32 16-byte aligned; n_values must equal the job's frame_bytes (any size: slots that
+ * are not 4-byte aligned are written byte by byte).
  * (gfpp_torso_frame_lp does the same itself when ws->clip_job is set: no separate launch on the frame's critical path.) */
 int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
+
+/* (ABI 6) The same two for a frame GROUP -- K consecutive positions of a lane rendered by one graph launch (the caller's loop of
+ * inference/genefacepp_infer.py:460-469 taken K frames at a time): frame `sub` of the group takes position cursor[lane] + sub; the store adds `advance` to the
+ * lane's cursor when it is done (0: the job's `lanes`; 0xFFFFFFFF: nothing -- every frame of a group but the last, which passes K * lanes).  Groups are dealt
+ * to the lanes round-robin: the host starts cursor[l] at l * K.  Frame sizes need not be multiples of four bytes. */
+int gfpp_clip_fetch_at(const gfpp_clip_job *job, uint32_t lane, uint32_t sub, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
+int gfpp_clip_store_u8_at(gfpp_clip_job *job, uint32_t lane, uint32_t sub, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
 
 /* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
  * (first_lane + k) % lanes on that lane's stream.  execs: [lanes] hipGraphExec_t, streams: [lanes] hipStream_t (host arrays).
@@ -396,12 +404,14 @@ typedef struct gfpp_frame_ws {
                                * frames per launch sets 0xFFFFFFFF (no advance) on all but its last frame and K * lanes on the last */
     uint32_t n_frames;        /* gfpp_head_frame_persist_lp only.  0 / 1: one frame.  K in 2..4: this workspace describes K frames of N rays each whose arrays
                                * lie BEHIND EACH OTHER -- rays_o / rays_d [K N, 3], nears / fars [K N], ray_state [K N, 8], sample_t [K N, stride],
-                               * sample_cnt [K N], snapshots [K N, 7, 5], counters [K, 192], frame_consts [K, 256] -- and ONE launch renders all of them: a
+                               * sample_cnt [K N], snapshots [K N, 7, 5], counters [K, 192], frame_consts [K, frame_consts_stride] -- and ONE launch renders all of them: a
                                * workgroup pools the samples of its rays of all K frames, so the fixed costs of a launch (weight image into LDS, partly
                                * filled sample blocks of every local round, the launch's tail) are paid once per K frames.  Per sample and per ray nothing
                                * changes (same block evaluation, same compositing order): every frame is the bits of its own launch.  Each frame keeps its own
                                * histogram / counters and is resolved on its own (gfpp_head_frame_resolve or the consumer's on-the-fly resolve, with the
                                * frame's own gfpp_frame_ws).  Used by the clip renderer for small frames (256^2 rays: 0.117 ms per frame alone). */
+    uint32_t frame_consts_stride; /* frame groups: floats between the folded constants of consecutive frames (0 = 256: a [K, 256] array) -- the clip renderer's
+                                   * constants sit inside the frames' rows of driving signals */
     int32_t *timeouts;        /* optional [1] i32 that NO kernel of this library resets: a device-wide barrier of the multi-trip launch
                                * (gfpp_head_frame_trips_lp) that times out adds 1 -- unlike counters[127], which the next frame's begin kernel zeroes, so a
                                * time-out in the middle of a clip stays visible until the caller has looked (FramePipeline.check_barriers) */
