@@ -39,7 +39,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 161536          # head MLPs after folding the per-frame-constant input columns
 FLOP_PER_SAMPLE_LP = 128768       # 16-bit kernel: additionally sigma_net.2 (geo rows) x color_net.0 merged into one 128x128 layer
-GATHER_BYTES_PER_SAMPLE = 2060    # fused pipeline: 12 B position + 2 encodes x 16 levels x 8 corners x 8 B
+GATHER_BYTES_PER_SAMPLE = 2060    # fused pipeline: 12 B position + 2 encodes x 16 levels x 8 corners x 8 B: the yardstick's unit in every round
+GATHER_BYTES_PER_SAMPLE_BLOCK = 1036   # what the 16-bit kernels request since round 4: 12 B + 2 encodes x 32 gathers x 16 B (16-bit corner-block tables; SURVEY 8d with s_tab = 2)
 PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense f16 / bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 GRID_BYTES_PER_POINT = 1164       # 3-D, 16 levels x 8 corners x 8 B + 12 B in + 128 B out
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
@@ -546,56 +547,98 @@ def main():
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
 
     # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
-    def head_roofline(model, hp, x, N, variant):
-        """HIP events around the head-pass launches of 5 frames issued back to back on the launch stream (production prologue before them)."""
+    def head_roofline(model, hp, x, N, variant, frames_per_launch=1, ms_per_frame_period=None, pmc_tag=None):
+        """HIP events around the head-pass launches of 5 frames (frame groups: 5 launches of `frames_per_launch` frames each) issued back to back on the
+        launch stream, production prologue before them.  ms_per_frame_period: the clip loop's measured frame period (several frames in flight), for
+        `effective_frac_per_frame_period`; pmc_tag: name of this workload's committed counter pass (profiles/<round>_pmc_<tag>.json) for the ratios."""
         pipe = model.pipeline()
         with torch.no_grad():
             cond_feat = model.cal_cond_feat(x["cond"]) if variant != "may_torso_sr" else model.cal_cond_feat(x["cond"], eye_area_percent=x["eye"])
         reps = 5
         import ctypes
         from genefaceplusplus_amd._lib import call
-        ro, rd = x["rays_o"].view(-1, 3), x["rays_d"].view(-1, 3)
-        ws, tbuf = pipe.workspace(N)
+        ro, rd = x["rays_o"].view(-1, 3).contiguous(), x["rays_d"].view(-1, 3).contiguous()
+        max_steps = int(hp["max_steps"])
         st = torch.cuda.current_stream().cuda_stream
         ind = model.individual_embeddings[0].detach().float().contiguous()
         cf = cond_feat.detach().float().contiguous()
         persist = args.precision != "fp32" and pipe.lp_kernel == "persist"
+        G = int(frames_per_launch) if (persist and frames_per_launch > 1 and pipe.group_supported(N, frames_per_launch, max_steps)) else 1
         trips_fn = "gfpp_head_frame_trips" if args.precision == "fp32" else ("gfpp_head_frame_persist_lp" if persist else "gfpp_head_frame_trips_lp")
-        if persist and "snapshots" not in tbuf:
-            tbuf["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=dev)
-            ws.snapshots = tbuf["snapshots"].data_ptr()
+        if G > 1:
+            gws, fws, gt = pipe.group_workspace(N, G, max_steps)
+            for k in range(G):
+                gt["rays_o"][k].copy_(ro)
+                gt["rays_d"][k].copy_(rd)
+            consts = pipe.fold_rows(cf.reshape(1, -1).repeat(G, 1).contiguous(), ind)           # [G, 256]: the production fold, once per clip job
+            gws.frame_consts, gws.frame_consts_stride = consts.data_ptr(), 256
+        else:
+            ws, tbuf = pipe.workspace(N)
+            if ws.sample_stride < max_steps + 7:                      # (a clip that rendered through frame groups never used this workspace)
+                stride = (max_steps + 7 + 7) // 8 * 8
+                tbuf["sample_t"] = torch.empty(N, stride, dtype=torch.float32, device=dev)
+                tbuf["sample_cnt"] = torch.empty(N, dtype=torch.int32, device=dev)
+                ws.sample_t, ws.sample_cnt, ws.sample_stride = tbuf["sample_t"].data_ptr(), tbuf["sample_cnt"].data_ptr(), stride
+            ws.frame_consts = tbuf["frame_consts"].data_ptr()
+            if persist and "snapshots" not in tbuf:
+                tbuf["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=dev)
+            if persist:
+                ws.snapshots = tbuf["snapshots"].data_ptr()
+            ws.defer_resolve = 0
 
-        def one_frame(ev=None):
-            # the production prologue (slab test + state reset + pre-march in one launch, then the bias fold), then the launches the roofline is about
-            call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]),
-                 int(hp["max_steps"]), st)
+        def one_launch(ev=None):
+            # the production prologue (slab test + state reset + pre-march in one launch per frame, then the bias fold), then the launch(es) the roofline is about
+            if G > 1:
+                for k in range(G):
+                    call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(fws[k]), gt["rays_o"][k].data_ptr(), gt["rays_d"][k].data_ptr(),
+                         float(hp["dt_gamma"]), max_steps, st)
+                if ev is not None:
+                    ev[0].record()
+                call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(gws), gt["rays_o"].data_ptr(), gt["rays_d"].data_ptr(), float(hp["dt_gamma"]), max_steps, 0.01, st)
+                if ev is not None:
+                    ev[1].record()
+                return
+            call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), max_steps, st)
             call("gfpp_head_frame_fold", ctypes.byref(pipe.head), ctypes.byref(ws), cf.data_ptr(), ind.data_ptr(), st)
             if ev is not None:
                 ev[0].record()
-            call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), int(hp["max_steps"]), 0.01, st)
+            call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), max_steps, 0.01, st)
             if ev is not None:
                 ev[1].record()
 
-        # the frames are issued back to back (no host synchronisation in between, two untimed ones first): an idle gap lets the GPU clock down
+        # the launches are issued back to back (no host synchronisation in between, two untimed ones first): an idle gap lets the GPU clock down
         # and the next launches would be timed at the low clock
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        one_frame()
-        one_frame()
+        one_launch()
+        one_launch()
         for ev in events:
-            one_frame(ev)
+            one_launch(ev)
         torch.cuda.synchronize()
         t_march = sum(a0.elapsed_time(a1) for a0, a1 in events) * 1e-3
-        alive, smp = pipe.trip_counters(N)                       # the same frame every time: counters of the last one
-        samples = reps * int(smp.sum())
-        launches = reps * (1 if persist else int((smp > 0).sum()))
-        common = {"samples_per_frame": samples // reps, ("launches_per_frame" if persist else "nonempty_trips_per_frame"): launches // reps,
-                  "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4), "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4),
-                  "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
-        if persist:
-            b = pipe.budget(N)
-            common["workgroup_rounds"] = {"max": b["rounds_max"], "mean": round(b["rounds_sum"] / max(pipe.cu_count, 1), 2)}
-            common["workgroup_balance"] = {"samples_busiest": b["samples_max_wg"], "samples_mean": round(b["samples"] / max(pipe.cu_count, 1), 1)}
-            common["workgroup_kcycles"] = b["kcycles"]        # thread 0's shader clock by phase, summed over the workgroups (units of 1024 cycles)
+        if G > 1:
+            c = gt["counters"].cpu().numpy()
+            per_launch = int(c[0, 168])                              # the launch's evaluated samples (all its frames; kept in the first frame's counters)
+            samples = reps * per_launch
+            launches = reps
+            common = {"frames_per_launch": G, "samples_per_launch": per_launch, "samples_per_frame": per_launch // G, "launches_per_frame": round(1.0 / G, 4),
+                      "avg_launch_ms": round(1e3 * t_march / reps, 4), "ms_per_frame_all_trips": round(1e3 * t_march / (reps * G), 4), "traffic": None,
+                      "workgroup_rounds": {"max": int(c[0, 170]), "mean": round(int(c[0, 169]) / max(pipe.cu_count, 1), 2)},
+                      "workgroup_balance": {"samples_busiest": int(c[0, 171]), "samples_mean": round(per_launch / max(pipe.cu_count, 1), 1)},
+                      "workgroup_kcycles": {"fetch": int(c[0, 172]), "compact": int(c[0, 173]), "evaluate": int(c[0, 174]), "composite": int(c[0, 175]), "longest_wg": int(c[0, 176])}}
+            frames_timed = reps * G
+        else:
+            alive, smp = pipe.trip_counters(N)                       # the same frame every time: counters of the last one
+            samples = reps * int(smp.sum())
+            launches = reps * (1 if persist else int((smp > 0).sum()))
+            common = {"samples_per_frame": samples // reps, ("launches_per_frame" if persist else "nonempty_trips_per_frame"): launches // reps,
+                      "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4), "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4),
+                      "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
+            if persist:
+                b = pipe.budget(N)
+                common["workgroup_rounds"] = {"max": b["rounds_max"], "mean": round(b["rounds_sum"] / max(pipe.cu_count, 1), 2)}
+                common["workgroup_balance"] = {"samples_busiest": b["samples_max_wg"], "samples_mean": round(b["samples"] / max(pipe.cu_count, 1), 1)}
+                common["workgroup_kcycles"] = b["kcycles"]        # thread 0's shader clock by phase, summed over the workgroups (units of 1024 cycles)
+            frames_timed = reps
         if args.precision == "fp32":
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
             kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
@@ -603,29 +646,61 @@ def main():
             return {"kernel": kname, "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
-        else:
-            # the 16-bit kernel is bound by the hash-grid gathers (L2 / texture path), not by the matrix pipe: quote the gather stream against the
-            # HBM peak (the north star's yardstick for the hash-grid stage) and the MFMA fraction beside it
-            gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
-            tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
-            kname = "k_head_frame_persist" if persist else "k_head_trip_pool"
-            what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
-                    else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
-            return {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
-                                  "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (algorithmic gather bytes vs the 8 TB/s HBM peak), not what "
-                                                "limits the kernel: the tables are L2 / Infinity-Cache resident (fabric traffic 0.17x the algorithmic bytes, `traffic`), "
-                                                "the counters show an issue / latency bound (VALU : MFMA = 15 : 1, ~half the wave-cycles waiting), see `limiter`",
-                                  "limiter": "instruction issue + LDS-fed MFMA + gather latency (no single saturated unit)",
-                                  "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                                  "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
-                                  "l2": {"achieved": round(gbps, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L2_GBPS, 4),
-                                         "what": "the same algorithmic gather stream against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves it"},
-                                  "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP}, **common}
+        # the 16-bit kernel is bound by instruction issue / gather latency, not by a memory level: quote the ALGORITHMIC gather stream of SURVEY 8d (fp32
+        # tables: 2 060 B per sample -- the unit every round's fraction is in) against the HBM peak (the north star's yardstick for the hash-grid stage),
+        # and beside it the bytes the kernel really asks for since round 4 (16-bit corner-block tables: 12 B + 2 grids x 32 gathers x 16 B)
+        gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
+        gbps_blk = samples * GATHER_BYTES_PER_SAMPLE_BLOCK / t_march / 1e9
+        tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
+        kname = "k_head_frame_persist" if persist else "k_head_trip_pool"
+        what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
+                else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
+        if G > 1:
+            what = f"the whole march / evaluate / composite loop of {G} consecutive frames as ONE launch (frame group), workgroup-local trips over the pooled samples"
+        roof = {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
+                "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (SURVEY 8d's algorithmic gather bytes, fp32 tables, vs the 8 TB/s HBM peak), not "
+                              "what limits the kernel: the tables are L2 / Infinity-Cache resident and the counters show an issue / latency bound (`limiter`, `pmc`)",
+                "limiter": "instruction issue + LDS-fed MFMA + gather latency (no single saturated unit)",
+                "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
+                "as_read": {"bytes_per_sample": GATHER_BYTES_PER_SAMPLE_BLOCK, "achieved": round(gbps_blk, 1), "unit": "GB/s", "frac": round(gbps_blk / PEAK_HBM_GBPS, 4),
+                            "what": "the same launches counted with the bytes the kernel requests since round 4: 16-bit corner-block tables, 32 gathers of 16 B per grid "
+                                    "and sample (SURVEY 8d's formula with s_tab = 2 B gives the same 1 036 B)"},
+                "l2": {"achieved": round(gbps_blk, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps_blk / PEAK_L2_GBPS, 4),
+                       "what": "the requested gather bytes against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves them"},
+                "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP,
+                         "flop_per_sample_note": "128 768 algorithmic (folded, merged) -- the fraction's unit; the launch issues 148 MFMAs per 32-sample block = 151 552 FLOP per "
+                                                 "sample since the skinny rows run as MFMA chains on a gathered tile"}, **common}
+        if ms_per_frame_period:
+            # production overlaps several frames (clip lanes): what the frame PERIOD delivers of the yardstick, next to the one-launch-at-a-time figure above
+            eff = (samples / frames_timed) * GATHER_BYTES_PER_SAMPLE / (ms_per_frame_period * 1e-3) / 1e9
+            roof["effective_frac_per_frame_period"] = round(eff / PEAK_HBM_GBPS, 4)
+            roof["effective_note"] = (f"algorithmic bytes of one frame / the clip loop's frame period ({ms_per_frame_period:.4f} ms, several frames in flight: the period also "
+                                      f"holds the frame's other kernels)")
+        pmc = load_pmc(pmc_tag)
+        if pmc:
+            roof["pmc"] = pmc
+        return roof
 
+    def load_pmc(tag):
+        """The committed counter pass of THIS workload and precision (profiles/<round>_pmc_<tag>.json, written by tools/pmc_summary.py from separate
+        rocprofv3 --pmc runs), or None: ratios are quoted from measurements of the same workload or not at all."""
+        if not tag:
+            return None
+        path = os.path.join(ROOT, "profiles", f"r04_pmc_{tag}.json")
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                d["source"] = os.path.relpath(path, ROOT) + " (committed counter pass of this workload; not measured in this run)"
+                return d
+            except Exception:
+                return None
+        return None
 
     if rank == 0 and args.executor == "fused":
-        result["roofline"] = head_roofline(model, hp, inputs[W], N, args.variant)
+        result["roofline"] = head_roofline(model, hp, inputs[W], N, args.variant, frames_per_launch=cr.group, ms_per_frame_period=1e3 * elapsed / K if world == 1 else None,
+                                           pmc_tag=f"{args.variant}_{HW}_{args.precision}")
 
     # ---- the other precision modes, briefly (same model, same inputs; graphs are kept per precision) -------------------------------
     if rank == 0 and world == 1 and not args.no_modes:
@@ -719,7 +794,9 @@ def main():
                            "eye": torch.from_numpy(fi_s[0]["eye_area_percent"]).to(dev)}
                     sr_cfg = {"baseline_config": "the released May checkpoint's class (RADNeRFTorsowithSR): 256x256 rays, landmark-conditioned head-aware torso, "
                                                  "StyleGAN2 super-resolution to 512x512", "value": modes["may_torso_sr"]["value"], "unit": "frames/s",
-                              "frames_in_flight": cr_sr.lanes, "roofline": head_roofline(m_sr, hp_sr, x_s, 256 * 256, "may_torso_sr")}
+                              "frames_in_flight": cr_sr.lanes, "frames_per_graph_launch": cr_sr.group,
+                              "roofline": head_roofline(m_sr, hp_sr, x_s, 256 * 256, "may_torso_sr", frames_per_launch=cr_sr.group, ms_per_frame_period=1e3 * dt / n_s,
+                                                        pmc_tag=f"may_torso_sr_256_{args.precision}")}
                     result.setdefault("configs", {})["may_torso_sr_256"] = sr_cfg
                 except Exception as exc:
                     result.setdefault("configs", {})["may_torso_sr_256"] = {"error": str(exc)}
@@ -788,35 +865,21 @@ def main():
             cfgs["crop64_cpu_oracle"] = {"error": str(exc)}
         result["configs"] = cfgs
 
-    # ---- HBM-side traffic of the trip launches: from the committed rocprofv3 --pmc pass of this same workload ---------------------------
-    if rank == 0 and "roofline" in result:
-        tfile, tnote = None, ""
-        # the committed counter passes are of the headline workload (may_torso, 512 x 512); any other workload has none and says so.  The two 16-bit
-        # modes run the same kernel template over the same tables, so the newest pass of either stands for both (labelled)
-        same_traffic = {"bf16": ("bf16", "fp16"), "fp16": ("fp16", "bf16")}.get(args.precision, (args.precision,))
-        if args.variant == "may_torso" and HW == 512:
-            for rnd in ("r03", "r02", "r01"):
-                for prec in same_traffic:
-                    cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{prec}.json")
-                    if tfile is None and os.path.exists(cand):
-                        tfile = cand
-                        tnote = "" if prec == args.precision else f"; measured in {prec} -- the same kernel template and tables as {args.precision}"
+    # ---- HBM-side traffic of the dominant launch: from the committed rocprofv3 --pmc pass of this same workload and precision, or null --------
+    def attach_traffic(roof):
+        pmc = roof.get("pmc")
+        if pmc and pmc.get("fabric_bytes_per_launch"):
+            roof["traffic"] = int(pmc["fabric_bytes_per_launch"])
+            roof["traffic_source"] = pmc.get("source")
+            per_launch = roof.get("samples_per_launch") or roof.get("samples_per_frame", 0)
+            roof["algorithmic_bytes_per_launch"] = int(per_launch * GATHER_BYTES_PER_SAMPLE)
         else:
-            result["roofline"]["traffic_source"] = "no counter pass committed for this workload (profiles/*_pmc_traffic_* are of may_torso at 512 x 512)"
-        if tfile is not None:
-            try:
-                detail = json.load(open(tfile))
-                # per launch, like `achieved`: fabric-side bytes (FETCH_SIZE x 2 as the guide prescribes for 16-B-per-lane reads, + WRITE_SIZE)
-                nl = result["roofline"].get("launches_per_frame") or result["roofline"].get("nonempty_trips_per_frame") or 1
-                # the committed pass counted per FRAME where available (the launch structure changed in round 3: one launch per frame)
-                per_frame = detail.get("bytes_per_frame") or (detail.get("bytes_per_launch") or 0) * (detail.get("launches_per_frame") or detail.get("nonempty_launches_per_frame") or 1)
-                result["roofline"]["traffic"] = int(per_frame / nl) if per_frame else detail.get("bytes_per_launch")
-                result["roofline"]["traffic_source"] = "committed rocprofv3 --pmc pass of this workload: " + os.path.relpath(tfile, ROOT) + " (not measured in this run" + tnote + ")"
-                result["roofline"]["algorithmic_bytes_per_launch"] = int(result["roofline"]["samples_per_frame"] * GATHER_BYTES_PER_SAMPLE
-                                                                         / max(nl, 1))
-                result["roofline"]["traffic_detail"] = detail
-            except Exception:
-                pass
+            roof["traffic_source"] = "no counter pass committed for this workload and precision (profiles/r04_pmc_<variant>_<hw>_<precision>.json)"
+    if rank == 0 and "roofline" in result:
+        attach_traffic(result["roofline"])
+        sr = result.get("configs", {}).get("may_torso_sr_256", {}).get("roofline")
+        if sr:
+            attach_traffic(sr)
 
     if rank == 0 and not args.no_grid_stage:
         from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw

@@ -1052,9 +1052,9 @@ class FramePipeline:
             if key[0] == "group":                  # frame groups run on the persistent launch only: no barrier
                 continue
             (n, lane), t = key, ent[1]
-            count = int(t["timeouts"].item()) if "timeouts" in t else 0
-            if count > 0 or int(t["counters"][127].item()) < 0:
-                bad.append((n, lane, max(count, 1)))
+            count = int(t["timeouts"].item())
+            if count > 0:
+                bad.append((n, lane, count))
                 t["timeouts"].zero_()
         if bad:
             raise GfppError(f"a device-wide barrier of the multi-trip launch timed out (workspaces (rays, lane, launches) = {bad}): frames rendered there "

@@ -134,7 +134,7 @@ def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
     pipe.lp_kernel, pipe.separate_trips = "trips", 1              # trips 1.. in ONE launch
     batch = _clip_batch(case["hp"], 3)
     cr = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], use_graph=False, render_kwargs=dict(case["hp"]),
-                      lanes=1)
+                      lanes=1, group=1)
     clip = cr.prepare(batch, dev)
     cr.render_to_host(clip)                                       # healthy: no error
     monkeypatch.setenv("GFPP_BARRIER_SPINS", "1")
