@@ -81,6 +81,11 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[0] / configs[1] entries")
     ap.add_argument("--long-run-frames", type=int, default=2000, help="frames of modes.long_run (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (control-flow checks of the N>1 path on one GPU)")
+    ap.add_argument("--ckpt-dir", default=None, help="a checkpoint directory in the reference's layout (model_ckpt_steps_*.ckpt + config.yaml, utils/commons/ckpt_utils.py:29-76, "
+                                                     "e.g. checkpoints/motion2video_nerf/may_torso): bench THESE weights instead of the synthetic ones (SURVEY 8d, last bullet)")
+    ap.add_argument("--data-dir", default=None, help="with --ckpt-dir: the directory holding trainval_dataset.npy (data/binary/videos/May, tasks/radnerfs/dataset_utils.py:160-296): "
+                                                     "poses, landmarks, background and intrinsics of the clip come from it; without it the synthetic driving signals are used")
+    ap.add_argument("--ckpt-parity", type=int, default=2, help="with --ckpt-dir: this many frames are also rendered by the CPU oracle from the same weights and compared (0 = skip)")
     return ap.parse_args()
 
 
@@ -389,15 +394,28 @@ def main():
         return run_ray_tiles(args, rank, world, dev, dinfo)
 
     HW, K, W = args.hw, args.steps, args.warmup
+    real = None              # --ckpt-dir: {"ckpt": path, "dataset": RADNeRFDataset | None}
+    if args.ckpt_dir:
+        # a real checkpoint in the reference's layout (last bullet): the loader's own steps -- flat config.yaml (utils/commons/hparams.py:167-170),
+        # newest model_ckpt_steps_*.ckpt, state_dict['model'], strict load (utils/commons/ckpt_utils.py:29-76, genefacepp_infer.py:163-191)
+        import yaml
+        with open(os.path.join(args.ckpt_dir, "config.yaml")) as f:
+            hp = yaml.safe_load(f)
+        sd_t, ckpt_path = syn.read_checkpoint(args.ckpt_dir, model_name="model")
+        args.variant = "may_torso_sr" if hp.get("with_sr") else "may_torso"
+        HW = args.hw = 256 if hp.get("with_sr") else 512
+        sd = {k: v.numpy() for k, v in sd_t.items()}
+        real = {"ckpt": ckpt_path, "dataset": None}
+    else:
+        hp = may_hparams(args.variant)
+        sd = syn.synthetic_state_dict(hp, args.variant)
+        if args.variant == "may_torso_sr":
+            sd = dict(sd)
+            sd.update(syn.synthetic_sr_state())
     N = HW * HW
-    hp = may_hparams(args.variant)
     if args.variant == "may_torso_sr":
         assert HW == 256, "the *_sr models render 256x256 rays"
-    sd = syn.synthetic_state_dict(hp, args.variant)
     model = getattr(radnerfs, CLASSES[args.variant])(hp)
-    if args.variant == "may_torso_sr":
-        sd = dict(sd)
-        sd.update(syn.synthetic_sr_state())
     model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     model.executor = args.executor
@@ -414,6 +432,22 @@ def main():
     batch = {"ngp_poses": np.stack([syn.synthetic_pose(fidx) for fidx in my_frames]).astype(np.float32),
              "cond_wins": np.stack([f["cond"] for f in fi_all]), "lm68": np.stack([f["lm68"] for f in fi_all]),
              "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_all])}
+    if real is not None and args.data_dir:
+        # the clip's own poses / landmarks / eye values / background / intrinsics (tasks/radnerfs/dataset_utils.py:160-296), frames cycled to the bench length
+        from genefaceplusplus_amd.dataset import RADNeRFDataset
+        ds = RADNeRFDataset("trainval", dict(hp, binary_data_dir=os.path.dirname(os.path.abspath(args.data_dir))), data_dir=args.data_dir, training=False, device=dev,
+                            allow_bfm68_fallback=True)
+        real["dataset"] = ds
+        assert (ds.H, ds.W) == (HW, HW), f"the dataset's frames are {ds.H}x{ds.W}, the model renders {HW}x{HW} rays"
+        full = ds.clip_batch()
+        take = [f % full["ngp_poses"].shape[0] for f in my_frames]
+        batch = {k: np.asarray(v.cpu() if torch.is_tensor(v) else v)[take] for k, v in full.items()}
+        intr = tuple(float(v) for v in ds.intrinsics)
+        bg_color = ds.bg_img.reshape(1, -1, 3).to(dev).float()
+        batch.setdefault("lm68", np.zeros((len(take), 136), np.float32))
+        batch.setdefault("eye_area_percent", np.zeros((len(take), 1, 1), np.float32))
+        fi_all = [{"cond": batch["cond_wins"][j], "lm68": batch["lm68"][j].reshape(-1), "eye_area_percent": np.asarray(batch["eye_area_percent"][j]).reshape(1, 1)}
+                  for j in range(len(take))]
     # the clip renderer = the caller's frame loop (genefacepp_infer.py:246-269, 460-469): pose -> rays on the device -> model.render() -> uint8 HWC
     # on the device, one hipGraph per frame.  The driving signals of all frames are resident in HBM before the timed region starts.
     from genefaceplusplus_amd.clip import ClipRenderer
@@ -545,6 +579,35 @@ def main():
                              **({"dist": dinfo} if dinfo else {}),
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
+
+    if rank == 0 and real is not None:
+        result["data"] = "real checkpoint" + (" + real driving signals" if real["dataset"] is not None else " + synthetic driving signals")
+        result["config"]["workload"] = (f"{args.variant} from {real['ckpt']} ({HW}x{HW} rays" + (" + super-resolution to 512x512" if args.variant == "may_torso_sr" else "")
+                                        + f", max_steps {hp.get('max_steps')}, T_thresh 0.01)" + (f", driving signals of {args.data_dir}" if real["dataset"] is not None else ""))
+        if args.ckpt_parity > 0:
+            # the same weights through the CPU oracle (test infrastructure, used here as the checker only): SURVEY 8c's tolerance per frame
+            try:
+                from oracle import oracle as orc
+                orc.build()
+                checks = []
+                for j in range(min(args.ckpt_parity, len(inputs))):
+                    x = inputs[j]
+                    pose_np = batch["ngp_poses"][j:j + 1]
+                    rays = orc.get_rays(pose_np, np.asarray(intr, np.float32), HW, HW)
+                    kwo = dict(bg_color=bg_color.cpu().numpy(), dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=0.01,
+                               eye_area_percent=np.asarray(fi_all[j]["eye_area_percent"], np.float32))
+                    ref = orc.render_torso(rays["rays_o"], rays["rays_d"], np.asarray(fi_all[j]["cond"], np.float32), orc.get_bg_coords(HW, HW), orc.convert_poses(pose_np), sd, hp,
+                                           lm68=np.asarray(fi_all[j]["lm68"], np.float32), sr_variant=(args.variant == "may_torso_sr"), **kwo)
+                    model.precision = "fp32"
+                    got = render(j)["rgb_map"].float().cpu().numpy()
+                    model.precision = args.precision
+                    if args.variant == "may_torso_sr":
+                        got = np.transpose(got, (0, 2, 3, 1))
+                    err = np.abs(got.reshape(-1, 3) - ref["rgb_map"].reshape(-1, 3)).max(axis=1)
+                    checks.append({"frame": j, "rgb_max_abs": float(err.max()), "frac_over_2e-4": float((err > 2e-4).mean())})
+                result["config"]["ckpt_parity_fp32_vs_oracle"] = checks
+            except Exception as exc:
+                result["config"]["ckpt_parity_fp32_vs_oracle"] = {"error": str(exc)}
 
     # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
     def head_roofline(model, hp, x, N, variant, frames_per_launch=1, ms_per_frame_period=None, pmc_tag=None):
@@ -859,6 +922,55 @@ def main():
             del m_h
         except Exception as exc:
             cfgs["may_head_fp32_latency"] = {"error": str(exc)}
+        try:
+            # "with sigma ~ 1 (alpha 0.03 per step) no ray ever terminates: worst case, report it separately as no-termination" -- 7 trips
+            # (n_step 1,2,2,2,2,3,4), ~1.5 M evaluated slots, rays composite past max_steps: the snapshot path of the persistent launch
+            hp_n = may_hparams("may_torso")
+            m_n = getattr(radnerfs, CLASSES["may_torso"])(hp_n)
+            m_n.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synthetic_state_dict(hp_n, "may_torso", sigma_gain=0.05).items()}, strict=True)
+            m_n = m_n.to(dev).eval()
+            m_n.precision, m_n.use_graph, m_n.executor = args.precision, model.use_graph, args.executor
+            cr_n = ClipRenderer(m_n, HW, HW, intr, bg_img=bg_color, T_thresh=0.01, use_graph=model.use_graph, lanes=args.lanes)
+            n_n = 120
+            stack = out_u8 if K >= n_n else torch.empty(n_n, HWO, HWO, 3, dtype=torch.uint8, device=dev)
+            idx_n = [W + (i % max(len(my_frames) - W, 1)) for i in range(n_n)]
+            cr_n.render_to_device(clip, idx_n[:4], out=stack[:4])
+            torch.cuda.synchronize()
+            dt_n = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                cr_n.render_to_device(clip, idx_n, out=stack[:n_n])
+                torch.cuda.synchronize()
+                dt_n = time.perf_counter() - t1
+            x_n = inputs[W]
+            roof_n = head_roofline(m_n, hp_n, x_n, N, "may_torso", frames_per_launch=cr_n.group, ms_per_frame_period=1e3 * dt_n / n_n, pmc_tag=None)
+            cfgs["may_torso_no_termination"] = {"workload": "the headline model with sigma_net's density row scaled to sigma ~ 1 (alpha ~ 0.03 per step: no ray terminates by "
+                                                            "transmittance; SURVEY 8d 'report separately as no-termination'), 512x512 head+torso, same frame loop",
+                                                "value": round(n_n / dt_n, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_n / n_n, 4), "steps": n_n, "precision": args.precision,
+                                                "frames_in_flight": cr_n.lanes, "roofline": roof_n}
+            del cr_n, m_n
+        except Exception as exc:
+            cfgs["may_torso_no_termination"] = {"error": str(exc)}
+        try:
+            # a second baseline next to cpu_baseline, on the SAME MI355X: the reference-shaped loop (executor 'staged': one C-ABI launch per reference extension
+            # call, torch layers on rocBLAS between them, a device->host synchronisation per loop trip -- renderer.py:354-384 as written), same model and inputs
+            model.executor = "staged"
+            for i in range(2):
+                render(i, slot=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(8):
+                render(W + k, slot=0)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t1
+            cfgs["reference_shaped_loop_same_gpu"] = {"value": round(8 / dt_s, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_s / 8, 3), "steps": 8,
+                                                      "what": "executor='staged': the reference's own loop structure (one launch per extension call, nn.Linear GEMMs in between, a "
+                                                              "host sync per trip) on this MI355X with this package's kernels -- a baseline for what the fused path removes, "
+                                                              "not the reference's CUDA build", "precision": "fp32 torch layers" if args.precision == "fp32" else "torch autocast-free fp32 layers"}
+        except Exception as exc:
+            cfgs["reference_shaped_loop_same_gpu"] = {"error": str(exc)}
+        finally:
+            model.executor = args.executor
         try:
             cfgs["crop64_cpu_oracle"] = cpu_crop_config()
         except Exception as exc:

@@ -1,4 +1,6 @@
 """RADNeRFDataset.__getitem__ on the device, and a clip rendered straight from the dataset's driving signals."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -96,3 +98,33 @@ def test_sample_key_set_matches_the_reference(tmp_path):
                 assert bool((s["bg_coords"][0, :, None, :] == full[0, None, :, :]).all(-1).any(-1).all())
             else:
                 assert torch.equal(s["bg_coords"].cpu(), ds.bg_coords.cpu())
+
+
+@pytest.mark.parametrize("variant", ["may_torso", "may_torso_sr"])
+def test_bench_takes_a_checkpoint_directory_and_a_dataset_in_the_reference_layout(tmp_path, variant):
+    """SURVEY 8d, last bullet: files dropped at checkpoints/motion2video_nerf/<name> + data/binary/videos/<id>/trainval_dataset.npy are benched by the same harness.
+    Here: a synthetic checkpoint written the way the reference's trainer leaves it (synthetic.write_checkpoint) and a synthetic dataset file in the binarizer's
+    schema; `bench.py --ckpt-dir --data-dir` must load both through the reference layout, say so in the line, and agree with the CPU oracle on the same weights."""
+    import json
+    import subprocess
+    import sys
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.configs import may_hparams
+    side = 256 if variant.endswith("_sr") else 512
+    hp = may_hparams(variant)
+    data_dir = tmp_path / "binary" / hp["video_id"]
+    data_dir.mkdir(parents=True)
+    write_synthetic_dataset(str(data_dir / "trainval_dataset.npy"), T=11, H=side, W=side)
+    ckpt_dir = str(tmp_path / "ckpt")
+    syn.write_checkpoint(ckpt_dir, variant, extra_hparams={"binary_data_dir": str(tmp_path / "binary"), "infer_bg_img_fname": "", "infer_smooth_camera_path": False,
+                                                           "polygon_face_mask": False, "n_rays": 65536, "load_imgs_to_memory": False})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ckpt-dir", ckpt_dir, "--data-dir", str(data_dir / "trainval_dataset.npy"), "--steps", "12", "--warmup", "4",
+                        "--precision", "fp16", "--no-modes", "--no-configs", "--no-grid-stage", "--no-cpu-baseline", "--ckpt-parity", "1"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["data"] == "real checkpoint + real driving signals" and "model_ckpt_steps_250000.ckpt" in d["config"]["workload"] and d["value"] > 0
+    chk = d["config"]["ckpt_parity_fp32_vs_oracle"]
+    assert isinstance(chk, list) and len(chk) == 1, chk
+    assert chk[0]["frac_over_2e-4"] <= 5e-4, chk                                    # SURVEY 8c's tolerance, on the checkpoint's own weights and the dataset's own pose

@@ -138,3 +138,29 @@ def test_bench_identities_two_ranks_gloo():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["identities"] == 2 and d["config"]["dist"]["ranks_seen"] == 2 and d["value"] > 0
+
+
+def test_bench_eight_ranks_on_one_gpu_gloo():
+    """The driver's 8-GPU command shape on the 1-GPU box: `python bench.py --gpus 8 --dist-backend gloo --steps 20` -- eight ranks share the one GPU, so
+    this checks control flow only: every rank seen, each rendering its own block of 20 frames, the timed window bracketed by barriers, the finished frames
+    gathered to the writer in chunks with the exposed gather time reported (what a scaling efficiency computed from a 20-step run rests on)."""
+    r = _bench(["--gpus", "8", "--steps", "20", "--warmup", "2", "--hw", "96", "--dist-backend", "gloo", "--no-modes", "--no-cpu-baseline", "--no-grid-stage",
+                "--no-configs"], timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    ev = d["config"]["dist"]
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
+    assert ev["ranks_seen"] == 8 and ev["world_size"] == 8 and len(ev["per_rank_fps"]) == 8 and all(v > 0 for v in ev["per_rank_fps"])
+    assert ev["gather"] == "writer" and ev["gather_ms_exposed"] >= 0 and ev["gathered_MB"] == round(8 * 20 * 96 * 96 * 3 / 1e6, 2)
+    assert ev["writer_holds_own_frames"] and all(ev["writer_frames_nonzero_per_rank"]) and len(ev["writer_frames_nonzero_per_rank"]) == 8
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]            # whole-job frames / the slowest rank's time
+
+
+def test_bench_four_identities_on_eight_ranks_gloo():
+    """BASELINE configs[4] literally: 4 person-specific models on 8 ranks (2 each), shared driving signals broadcast once (gloo, one GPU: control flow)."""
+    r = _bench(["--gpus", "8", "--identities", "4", "--steps", "4", "--warmup", "2", "--hw", "64", "--dist-backend", "gloo"], timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["config"]["identities"] == 4 and d["config"]["dist"]["ranks_seen"] == 8 and d["config"]["frames_total"] == 32 and d["value"] > 0
