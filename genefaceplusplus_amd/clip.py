@@ -292,6 +292,15 @@ class ClipRenderer:
         fn = getattr(self.model, "frame_consts_rows", None)
         if not self.precompute_cond or fn is None or clip["frames"] == 0:
             return clip
+        # a caller that starts one job per chunk of the same clip (render_to_host in a loop, bench's chunked gather) gets the extended rows from a one-entry
+        # cache: the constants depend on the clip's rows and on the weights (parameter versions), nothing else -- recomputing them per start() is O(F) work
+        # and a full copy of the rows per chunk, O(F^2 / chunk) per clip
+        target = getattr(self.model, "_orig_mod", self.model)
+        stamp = (clip["packed"].data_ptr(), clip["packed"]._version, tuple(clip["packed"].shape), self.model.resolved_precision(),
+                 tuple((p.data_ptr(), p._version) for p in target.parameters()))
+        hit = getattr(self, "_cond_cache", None)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
         at, cols = 0, {}
         for (name, _shape), width in zip(clip["layout"], clip["strides"]):
             cols[name] = at
@@ -304,8 +313,10 @@ class ClipRenderer:
         pad = (-width) % 4
         if pad:
             feats = torch.nn.functional.pad(feats, (0, pad))
-        return {"packed": torch.cat([clip["packed"], feats], dim=1).contiguous(), "layout": clip["layout"] + (("cond_feat", (width,)),),
-                "strides": clip["strides"] + (width + pad,), "frames": clip["frames"]}
+        ext = {"packed": torch.cat([clip["packed"], feats], dim=1).contiguous(), "layout": clip["layout"] + (("cond_feat", (width,)),),
+               "strides": clip["strides"] + (width + pad,), "frames": clip["frames"], "_source": clip["packed"]}      # (_source keeps the keyed tensor's address alive)
+        self._cond_cache = (stamp, ext)
+        return ext
 
     def _exec_arrays(self):
         if getattr(self, "_execs", None) is None:
@@ -423,10 +434,15 @@ class ClipRenderer:
         return {"packed": packed, "layout": tuple((n, s) for n, s, _ in layout), "strides": tuple(w for _, _, w in layout), "frames": F}
 
     # -- public API -----------------------------------------------------------------------------------------------------------
-    def render_to_device(self, clip, frame_indices=None, out=None, after_caller_stream=True):
+    def render_to_device(self, clip, frame_indices=None, out=None, after_caller_stream=None):
         """Render frames (all, or the given indices) into a uint8 stack [F,h,w,3] that stays on the GPU (the multi-GPU path
         gathers these with frames.gather_clip).  No host synchronisation; the stack is complete in the caller's stream order.
-        (= start + issue + join; callers that exchange finished chunks while later frames render use those three directly.)"""
+        (= start + issue + join; callers that exchange finished chunks while later frames render use those three directly.)
+        `after_caller_stream` (rounds 1-2) is gone: the lanes always start behind everything queued on the caller's stream."""
+        if after_caller_stream is not None:
+            import warnings
+            warnings.warn("ClipRenderer.render_to_device: after_caller_stream is ignored since round 3 (the lanes always wait for the caller's stream)",
+                          DeprecationWarning, stacklevel=2)
         idx = list(range(clip["frames"])) if frame_indices is None else list(frame_indices)
         if out is None:
             out = torch.empty(len(idx), *self.out_hw, 3, dtype=torch.uint8, device=self.device)

@@ -37,7 +37,7 @@ struct WgArgs {
 // A chunk = the rows [m0, m0 + R) of a row-major [M, C] matrix = ONE contiguous byte range, whatever C is (3, 129, 148 ... columns): it is copied as
 // 16-byte vectors from the aligned address below its start -- first into registers (issued before the previous chunk is computed, so the loads fly
 // under its MFMAs), then into LDS with the same flat layout (pitch = C, element (r, c) at shift + r C + c).  Vectors that start beyond the chunk's
-// last valid row are zero; the one that straddles the end of the matrix may read up to 15 bytes past it (see the header).
+// last valid row are zero; the one that straddles the end of the matrix is assembled element by element (no read past the matrix).
 template <typename G, int MAXV>
 struct WgChunk {
     uint4 v[MAXV];
@@ -49,7 +49,16 @@ struct WgChunk {
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
             const size_t at = ga + ((size_t)q * kWgThreads + (size_t)tid) * 16u;
-            v[q] = at < g1 ? *reinterpret_cast<const uint4 *>(p + at) : make_uint4(0, 0, 0, 0);
+            if (at + 16u <= g1) {
+                v[q] = *reinterpret_cast<const uint4 *>(p + at);
+            } else {
+                // the vector that straddles the end of the matrix (at most one per chunk load): element by element, nothing is read past the last row --
+                // the buffer may sit at the very end of an allocation
+                G tmp[16 / sizeof(G)];
+#pragma unroll
+                for (uint32_t e = 0; e < 16u / sizeof(G); ++e) tmp[e] = at + (e + 1u) * sizeof(G) <= g1 ? *reinterpret_cast<const G *>(p + at + e * sizeof(G)) : (G)0.0f;
+                v[q] = *reinterpret_cast<const uint4 *>(tmp);
+            }
         }
     }
     __device__ __forceinline__ void store(G *lds, int tid) const {

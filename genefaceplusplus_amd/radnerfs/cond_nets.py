@@ -76,6 +76,7 @@ class _LinearNoBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         if torch.is_autocast_enabled():
+            # (the caller -- MLP.forward -- only comes here under fp16 autocast or none: bf16 autocast takes the plain nn.Linear path)
             x, w = x.to(torch.float16), weight.to(torch.float16)
         else:
             x, w = x.float(), weight.float()
@@ -117,6 +118,10 @@ class MLP(nn.Module):
         # training batches (a step's samples x features): the layers' weight gradients through the split-M kernel
         own = (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and max(l.out_features for l in self.net) <= 256
                and max(l.in_features for l in self.net) <= 160 and x.dtype in (torch.float32, torch.float16))
+        if own and torch.is_autocast_enabled():
+            # the split-M kernel has f16 and f32 operand forms: under bf16 autocast the layers run as nn.Linear does (F.linear casts to the autocast dtype)
+            dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+            own = dt == torch.float16
         for i, layer in enumerate(self.net):
             x = _LinearNoBias.apply(x, layer.weight) if own and layer.weight.requires_grad else layer(x)
             if i != last:

@@ -23,6 +23,12 @@ c_p = ctypes.c_void_p
 c_f = ctypes.c_float
 
 
+def _as_i64(u):
+    """An unsigned 64-bit value as the int64 torch stores."""
+    u &= 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
 class SrModel(ctypes.Structure):
     _fields_ = [("w_first", c_p), ("w_b0c1", c_p), ("w_up", c_p), ("w_b1c1", c_p), ("bias", c_p * 4), ("noise_strength", c_f * 4),
                 ("rgb0_w", c_p), ("rgb0_b", c_p), ("rgb1_w", c_p), ("rgb1_b", c_p), ("fir", c_f * 4), ("conv_clamp", c_f)]
@@ -244,17 +250,28 @@ class Superresolution(nn.Module):
             for k, v in bufs.items():
                 setattr(ws, k, v.data_ptr())
             # noise_mode 'random' is drawn inside the kernels: frame counter + ticket word of this lane, key = torch's seed mixed with the lane
-            bufs["rng_state"] = torch.zeros(2, dtype=torch.int64, device=dev)
-            bufs["rng_seed"] = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(self.lane) + 1)) & 0xFFFFFFFFFFFFFFFF
+            # [frame counter, ticket, seed word]: the key is rng_seed (a launch argument, frozen in captured graphs) XOR the seed word (device memory)
+            bufs["rng_state"] = torch.zeros(3, dtype=torch.int64, device=dev)
+            bufs["rng_seed"] = self._lane_seed(torch.initial_seed(), self.lane)
+            if getattr(self, "_reseed", None) is not None:
+                bufs["rng_state"][2] = _as_i64(bufs["rng_seed"] ^ self._lane_seed(self._reseed, self.lane))
             ent = P["ws"][self.lane] = (ws, bufs)
         return ent
 
+    @staticmethod
+    def _lane_seed(seed, lane):
+        return (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(lane) + 1)) & 0xFFFFFFFFFFFFFFFF
+
     def reseed(self, seed):
-        """Restart the in-kernel noise of every lane from `seed` (frame counter 0): the same seed gives the same frames."""
+        """Restart the in-kernel noise of every lane from `seed` (frame counter 0): the same seed gives the same frames -- also for launches that are
+        frozen in a captured graph (the seed WORD lives in device memory; the `rng_seed` launch argument a graph bakes in stays what it was, the key is
+        their XOR).  NB: the 'random' noise of the HIP path is NOT governed by torch.manual_seed (torch's generator is never touched: nothing for a graph
+        replay to re-seed); it starts from torch.initial_seed() at the time a lane's workspace is created, and from `seed` after reseed(seed).
+        Call it outside a graph capture (it writes device memory)."""
         if self._packed is not None:
             for lane, (ws, bufs) in self._packed["ws"].items():
-                bufs["rng_state"].zero_()
-                bufs["rng_seed"] = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(lane) + 1)) & 0xFFFFFFFFFFFFFFFF
+                state = torch.tensor([0, 0, _as_i64(bufs["rng_seed"] ^ self._lane_seed(seed, lane))], dtype=torch.int64)
+                bufs["rng_state"].copy_(state.to(bufs["rng_state"].device))
         self._reseed = int(seed)
 
     # -- training: the same network in autograd-visible torch ops (the convolutions go to MIOpen) ----------------------------------------
@@ -313,10 +330,6 @@ class Superresolution(nn.Module):
             noises = None
         arr = (c_p * 4)(*[n.data_ptr() for n in noises]) if noises is not None else None
         ws, bufs = self._workspace(P)
-        if getattr(self, "_reseed", None) is not None and bufs.get("seeded") != self._reseed:
-            bufs["rng_state"].zero_()
-            bufs["rng_seed"] = (self._reseed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (int(self.lane) + 1)) & 0xFFFFFFFFFFFFFFFF
-            bufs["seeded"] = self._reseed
         ws.rng_state = bufs["rng_state"].data_ptr() if noise_mode == "random" else None
         ws.rng_seed = bufs["rng_seed"]
         ws.clamp01 = 1 if clamp01 else 0

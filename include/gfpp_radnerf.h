@@ -623,8 +623,8 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
  * radnerf.py:60-100) computes with a BLAS call per layer.  M = the samples of the step: the output is small and the reduction very long, so the M
  * rows are cut into <= 512 slices, one workgroup each with the whole O x I output in MFMA accumulators (fp32 accumulation; dtype GFPP_F16: half
  * operands as under `amp: true`, GFPP_F32: exact-fp32 MFMA), and the slices are summed.  partial: scratch [512, O, I] fp32.  O <= 256, I <= 160
- * (GFPP_EUNSUPPORTED beyond: the caller keeps its BLAS call).  grad_weight is overwritten.  grad_out and input: 16-byte aligned, read as 16-byte vectors
- * up to the vector that holds their last element (i.e. at most 15 bytes past the end: inside any allocator's granule). */
+ * (GFPP_EUNSUPPORTED beyond: the caller keeps its BLAS call).  grad_weight is overwritten.  grad_out and input: 16-byte aligned, read as 16-byte vectors;
+ * nothing is read past their last element (the vector that straddles the end is assembled element by element). */
 int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
                             gfpp_stream_t stream);
 
@@ -688,10 +688,11 @@ typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
     void *x2;      /* [512][512][64]  f16 */
     float *img256; /* [256][256][3]   f32 */
     /* noise_mode 'random' generated inside the kernels (networks_stylegan2.py:329-331 draws a fresh unit-normal field per layer and frame with
-     * torch.randn): rng_state != NULL and noise == NULL -> every output pixel of every layer gets normal(Philox4x32-10(key = rng_seed,
+     * torch.randn): rng_state != NULL and noise == NULL -> every output pixel of every layer gets normal(Philox4x32-10(key = rng_seed ^ rng_state[2],
      * counter = (pixel, layer, frame))), Box-Muller; frame = rng_state[0], which the last launch of the call increments (rng_state[1] is its ticket
-     * word; both zero-initialised by the caller, one pair per stream that runs this workspace). */
-    uint64_t *rng_state; /* [2] u64, or NULL */
+     * word; both zero-initialised by the caller, one triple per stream that runs this workspace).  rng_state[2] (ABI 6) lives in DEVICE memory so that a
+     * caller can re-seed a workspace whose launches are frozen in a captured graph (the `rng_seed` argument is baked into the graph's kernel arguments). */
+    uint64_t *rng_state; /* [3] u64, or NULL */
     uint64_t rng_seed;
     uint32_t clamp01;    /* 1: rgb_out = clamp(result, 0, 1) (the caller's `.clamp(0, 1)` of radnerf_torso_sr.py:221,231 folded in) */
 } gfpp_sr_ws;

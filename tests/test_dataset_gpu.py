@@ -110,7 +110,7 @@ def test_bench_takes_a_checkpoint_directory_and_a_dataset_in_the_reference_layou
     import sys
     from genefaceplusplus_amd import synthetic as syn
     from genefaceplusplus_amd.configs import may_hparams
-    side = 256 if variant.endswith("_sr") else 512
+    side = 512                  # the file holds the 512 x 512 video frames; the *_sr models' reader halves the ray grid (dataset_utils.py:216-230)
     hp = may_hparams(variant)
     data_dir = tmp_path / "binary" / hp["video_id"]
     data_dir.mkdir(parents=True)

@@ -357,6 +357,26 @@ def test_superresolution_random_noise_is_drawn_in_the_kernels(dev):
     np.testing.assert_array_equal(a0, b0)
     np.testing.assert_array_equal(a1, b1)
     assert not np.array_equal(a0, a1) and not np.array_equal(a0, c0)
+    # launches frozen in a captured graph take a new seed too (round-3 advisory): the seed WORD lives in device memory, the launch argument the graph
+    # baked in is XOR-ed with it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        net(x, noise_mode="random")
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        out = net(x, noise_mode="random")
+    net.reseed(1234)
+    graph.replay()
+    g0 = out.cpu().numpy().copy()
+    graph.replay()
+    g1 = out.cpu().numpy().copy()
+    net.reseed(99)
+    graph.replay()
+    np.testing.assert_array_equal(out.cpu().numpy(), c0)
+    np.testing.assert_array_equal(g0, a0)
+    np.testing.assert_array_equal(g1, a1)
     np.testing.assert_array_equal(clamped, np.clip(none, 0.0, 1.0))
     # moments of the perturbation against the oracle run with numpy normals of the same law (4 independent fields)
     ref_none = sr_oracle.superresolution(x.cpu().numpy(), sd, prefix="", noise_mode="none")
