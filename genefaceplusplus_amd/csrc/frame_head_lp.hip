@@ -177,14 +177,20 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
     const bool smooth = g.interp == 1, ac = g.align_corners != 0;
     float f[16];
     if constexpr (SLOW) {
+        // (interpolation type as a compile-time constant of two copies of the loop: with the run-time select the smoothstep constants are kept in registers
+        // across the whole block loop and the kernel spills)
+        auto levels = [&](auto smooth_tag) {
+            constexpr uint32_t INTERP = decltype(smooth_tag)::value ? 1u : 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float o[2];
-            const gfpp_grid_level lv = g.levels[2 * i + hi];
-            grid_level_lookup<D, 2, float>(uc, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, g.interp, o);
-            f[2 * i] = ok ? o[0] : 0.0f;
-            f[2 * i + 1] = ok ? o[1] : 0.0f;
-        }
+            for (int i = 0; i < 8; ++i) {
+                float o[2];
+                const gfpp_grid_level lv = lvl[2 * i + hi];      // (the LDS copy, like the fast path: a 32-bit address per lane instead of a 64-bit global one per level)
+                grid_level_lookup<D, 2, float, true>(uc, reinterpret_cast<const float *>(g.table), lv.offset, lv.size, lv.scale, lv.resolution, g.gridtype, ac, INTERP, o);
+                f[2 * i] = ok ? o[0] : 0.0f;
+                f[2 * i + 1] = ok ? o[1] : 0.0f;
+            }
+        };
+        if (smooth) levels(std::true_type{}); else levels(std::false_type{});
     } else {
         // all eight descriptors of this half-wave first (LDS, two distinct addresses per wavefront), then the straight-line lookups: left to the
         // compiler the descriptor of level i is read right before its use, one exposed LDS round trip per level in front of the gathers

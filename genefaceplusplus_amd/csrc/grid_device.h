@@ -111,7 +111,9 @@ __device__ __forceinline__ void load_row_pair(const T *__restrict__ p, float (&l
 // (gridencoder.cu:70-75), so unless the level is hashed or the row wraps at the end of the level they are adjacent
 // table rows -- one 16-byte gather instead of two 8-byte ones, which halves the number of cache lines the texture
 // path has to look up (the bound of this kernel is tag-lookup rate, not bytes).
-template <int D, int C, typename T>
+// OFF32: rows are addressed by 32-bit byte offsets against the (wave-uniform) table pointer -- for callers whose tables are known to be below 4 GiB (the fused
+// head kernels: 16 levels x 2 channels); a 64-bit per-lane address per level cost them spilled registers.
+template <int D, int C, typename T, bool OFF32 = false>
 __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *__restrict__ table, uint32_t level_offset,
                                                   uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
                                                   bool align_corners, uint32_t interp, float (&out)[C]) {
@@ -128,7 +130,10 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = 0.0f;
-    const T *level_table = table + (size_t)level_offset * C;
+    auto row_ptr = [&](uint32_t row) -> const T * {
+        if constexpr (OFF32) return reinterpret_cast<const T *>(reinterpret_cast<const char *>(table) + (level_offset + row) * (uint32_t)(C * sizeof(T)));
+        else return table + ((size_t)level_offset + row) * C;
+    };
 
     // is the level addressed by the hash?  (stride after all D dimensions > level size, hash grid type)
     // does the tiled index drop the last dimension?  (stride already > level size before dimension D-1 is reached:
@@ -165,12 +170,12 @@ __device__ __forceinline__ void grid_level_lookup(const float (&u)[D], const T *
         } else {
             const uint32_t row0 = grid_row<D>(pg, gridtype, align_corners, hashmap_size, resolution);
             if (!hashed && row0 + 1u < hashmap_size) {
-                load_row_pair<C, T>(level_table + (size_t)row0 * C, v0, v1);
+                load_row_pair<C, T>(row_ptr(row0), v0, v1);
             } else {
                 pg[0] = base[0] + 1u;
                 const uint32_t row1 = grid_row<D>(pg, gridtype, align_corners, hashmap_size, resolution);
-                TableIO<T>::template load<C>(level_table + (size_t)row0 * C, v0);
-                TableIO<T>::template load<C>(level_table + (size_t)row1 * C, v1);
+                TableIO<T>::template load<C>(row_ptr(row0), v0);
+                TableIO<T>::template load<C>(row_ptr(row1), v1);
             }
             if (D == 3 && !upper) {
 #pragma unroll
