@@ -183,7 +183,13 @@ class ClipRenderer:
             call("gfpp_clip_fetch_at", self._job_dev.data_ptr(), lane, k, L["g_static_in"][k].data_ptr(), int(L["g_static_in"].shape[1]), st)
             call("gfpp_get_rays", v["pose"].data_ptr(), fx, fy, cx, cy, self.H, self.W, t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(), st)
 
+        pipe = model.pipeline()
+        if not self.with_sr:
+            pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane, self.lanes), False      # (GFPP_FUSE_TAIL: the torso kernel may store the uint8 frames itself)
+
         def store(k, res):
+            if pipe.clip_job_consumed:
+                return
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1) if self.with_sr else res["rgb_map"]
             rgb = rgb.reshape(*self.out_hw, 3)
             if not rgb.is_contiguous() or rgb.dtype != torch.float32:
@@ -192,7 +198,10 @@ class ClipRenderer:
             call("gfpp_clip_store_u8_at", self._job_dev.data_ptr(), lane, k, advance, rgb.data_ptr(), int(rgb.numel()), torch.cuda.current_stream().cuda_stream)
         kw.pop("index", None)
         kw.update(bg_color=self.bg_img, T_thresh=self.T_thresh)
-        model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store, **kw)
+        try:
+            model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store, **kw)
+        finally:
+            pipe.clip_job, pipe.clip_job_consumed = None, False
         return {}
 
     # -- the job: which frames, where to ----------------------------------------------------------------------------------------------------------

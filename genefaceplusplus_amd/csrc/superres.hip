@@ -47,16 +47,14 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 struct SrRng {
-    const unsigned long long *state;   // [0] = frame counter, [1] = ticket, [2] = seed word XOR-ed into the key (null: no in-kernel noise)
+    const unsigned long long *state;   // [0] = frame counter (null: no in-kernel noise)
     unsigned long long seed;
     uint32_t layer;
 };
 
 // one unit normal per (pixel, layer, frame): Box-Muller on two of the four Philox words
 __device__ __forceinline__ float sr_randn(const SrRng &g, unsigned long long frame, uint32_t pixel) {
-    // key = the launch's seed argument XOR the workspace's own seed word (state[2], device memory): a captured graph bakes the argument, the word stays settable
-    const unsigned long long seed = g.seed ^ g.state[2];
-    const uint4 r = philox4x32_10(make_uint4(pixel, g.layer, (uint32_t)frame, (uint32_t)(frame >> 32)), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const uint4 r = philox4x32_10(make_uint4(pixel, g.layer, (uint32_t)frame, (uint32_t)(frame >> 32)), make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
     const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
     const float u2 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
@@ -137,13 +135,9 @@ __device__ __forceinline__ void sr_lds_wait(f16x8 (&a)[NA], f16x8 (&b)[NB2]) {
 // FIRST: the layer's input is not read from memory but computed in place -- block 0's first convolution (3 -> 128, K = 27; k_sr_first) evaluated
 // for the 18 x 18 halo pixels of the patch, straight into the LDS patch: one launch, a 16.8 MB activation write and its 1.27x re-read less per frame.
 // Same fragments, same MFMA order, same epilogue as k_sr_first: the values in the patch are the bits k_sr_first would have stored.
-// PH = rows of the output patch (16, or 8: half the pixels, half the wavefronts per workgroup).  A layer of 256 patches of 16 x 16 puts ONE workgroup on
-// every CU, and nothing runs under its halo load, its 18 chunk barriers and its epilogue; 512 patches of 8 x 16 put two there, each the other's cover
-// (the halo grows from 1.27 x to 1.41 x the patch).
-template <int CIN, int NT, int EPI, int NU, int KS, bool FIRST = false, int PH = 16>
-__global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) void k_sr_conv3(SrConvArgs a) {   // NU = 2, KS = 2: two 4-wavefront workgroups per CU   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
-    constexpr int kSrThreads = 32 * PH / NU;       // (shadows the namespace constant: this kernel's workgroup size) 2 NU rows of 16 pixels per wavefront
-    constexpr int kHaloRows = PH + 2;
+template <int CIN, int NT, int EPI, int NU, int KS, bool FIRST = false>
+__global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) void k_sr_conv3(SrConvArgs a) {   // NU = 2, KS = 2: two 4-wavefront workgroups per CU   // (HIP: second argument = wavefronts per SIMD the register budget must allow)
+    constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
     constexpr int CINH = CIN / KS;               // channels of one K slice
     constexpr int PS = CINH + 8;                 // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
@@ -154,9 +148,9 @@ __global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FI
     static_assert(CHUNKFRAGS % kSrThreads == 0, "chunk weights must split evenly over the workgroup");
     // halo patch | two weight-chunk buffers; after the last chunk the same memory stages the f16 output of the workgroup (a row of 128 halves + 16 B
     // of padding per input-grid pixel), so that it leaves as whole 256-byte rows instead of 8-byte pieces
-    constexpr int PATCH_BYTES = kHaloRows * kSrHalo * PS * 2, WBUF_BYTES = 2 * CHUNKFRAGS * 16;
+    constexpr int PATCH_BYTES = kSrHalo * kSrHalo * PS * 2, WBUF_BYTES = 2 * CHUNKFRAGS * 16;
     constexpr int SROW = NT * 32 + 8;            // staging row in halves
-    constexpr int STAGE_BYTES = (EPI != kSrFinal) ? PH * kSrPatch * SROW * 2 : 0;
+    constexpr int STAGE_BYTES = (EPI != kSrFinal) ? kSrPatch * kSrPatch * SROW * 2 : 0;
     constexpr int LDS_BYTES = PATCH_BYTES + WBUF_BYTES > STAGE_BYTES ? PATCH_BYTES + WBUF_BYTES : STAGE_BYTES;
     static_assert(PATCH_BYTES % 16 == 0, "weight buffers must stay 16-byte aligned");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -165,14 +159,14 @@ __global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FI
     _Float16 *stage = reinterpret_cast<_Float16 *>(lds_raw);
     __shared__ float s_rgb[(EPI == kSrRgbAdd || EPI == kSrFinal) ? NT * 32 * 3 + 4 : 1];
     __shared__ __attribute__((aligned(16))) float s_bias[NT * 32];   // this pass's output-channel biases (UpPhases: the 64 channels, twice)
-    constexpr int kInSide = kSrHalo + 2, kInRows = kHaloRows + 2;    // FIRST: the image patch under the halo's own 3 x 3 taps
-    __shared__ float s_in[FIRST ? kInRows * kInSide * 3 : 1];
+    constexpr int kInSide = kSrHalo + 2;                             // FIRST: the image patch under the halo's own 3 x 3 taps
+    __shared__ float s_in[FIRST ? kInSide * kInSide * 3 : 1];
     __shared__ uint4 s_wf[FIRST ? 2 * 4 * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_fb[FIRST ? 128 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
-    const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * PH;
+    const int x0 = blockIdx.x * kSrPatch, y0 = blockIdx.y * kSrPatch;
     const uint32_t pass = blockIdx.z;
     const uint4 *wg = a.w + (size_t)pass * 9 * TAPFRAGS;
     auto chunk_src = [&](int it) { return wg + (size_t)((it % 9) * STEPS + (it / 9) * STEPS_H) * NT * 64; };   // iteration it = slice * 9 + tap
@@ -182,7 +176,7 @@ __global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FI
     // value, so there is no branch around a load (a conditional load makes the compiler wait vmcnt(0) per element: 20 serial memory round
     // trips per thread, ~20 us of the 44 us this kernel took in round 1).
     auto load_patch = [&](int kh) {
-        constexpr int HALO_CHUNKS = kHaloRows * kSrHalo * (CINH / 8);
+        constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CINH / 8);
         constexpr int HALO_ITERS = (HALO_CHUNKS + kSrThreads - 1) / kSrThreads;
         uint4 hv[HALO_ITERS];
 #pragma unroll
@@ -209,7 +203,7 @@ __global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FI
     };
     // FIRST: channels [kh CINH, (kh + 1) CINH) of the first convolution at the 324 halo pixels, 32 pixels per MFMA tile, tiles dealt out to the wavefronts
     [[maybe_unused]] auto first_patch = [&](int kh) {
-        constexpr int HP = kHaloRows * kSrHalo, TILES = (HP + 31) / 32, TL = CINH / 32;
+        constexpr int HP = kSrHalo * kSrHalo, TILES = (HP + 31) / 32, TL = CINH / 32;
         const unsigned long long fctr = a.first_rng.state ? a.first_rng.state[0] : 0ull;
         for (int tile = wave; tile < TILES; tile += kSrThreads / 64) {
             const int pp = tile * 32 + j, ppc = pp < HP ? pp : HP - 1;
@@ -260,7 +254,7 @@ __global__ __launch_bounds__(32 * PH / NU, PH == 8 ? 2 : (NU == 1 ? 2 : 1) * (FI
     if constexpr (FIRST) {
         for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) s_wf[i] = a.first_w[i];
         if (tid < 128) s_fb[tid] = a.first_bias[tid];
-        constexpr int N = kInRows * kInSide * 3, IT = (N + kSrThreads - 1) / kSrThreads;
+        constexpr int N = kInSide * kInSide * 3, IT = (N + kSrThreads - 1) / kSrThreads;
         float hv[IT];
 #pragma unroll
         for (int q = 0; q < IT; ++q) {
@@ -626,9 +620,6 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     if (const char *e = getenv("GFPP_SR_TILES_UP")) nu_up = atoi(e) == 2 ? 2 : 1;
     int nu_fin = nu;
     if (const char *e = getenv("GFPP_SR_TILES_FINAL")) nu_fin = atoi(e) == 2 ? 2 : 1;
-    // patch rows per layer (16 or 8; A/B: GFPP_SR_PH_B0 / _UP / _FIN)
-    auto patch_rows = [](const char *name, int dflt) { const char *e = getenv(name); return e ? (atoi(e) == 8 ? 8 : 16) : dflt; };
-    const int ph_b0 = patch_rows("GFPP_SR_PH_B0", 16), ph_up = patch_rows("GFPP_SR_PH_UP", 16), ph_fin = patch_rows("GFPP_SR_PH_FIN", 16);
     bool fuse_first = nu == 1 && ks == 2;                           // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, A/B runs)
     if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = fuse_first && atoi(e) != 0;
     if (!fuse_first) {
@@ -646,8 +637,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         if (fuse_first) {
             a.first_rgb = rgb_in; a.first_w = (const uint4 *)m->w_first; a.first_bias = m->bias[0];
             a.first_noise = noise ? noise[0] : nullptr; a.first_noise_strength = m->noise_strength[0]; a.first_rng = rng_of(0);
-            if (ph_b0 == 8) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2, true, 8>), dim3(R / kSrPatch, R / 8, 1), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2, true>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2, true>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         } else if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
@@ -659,8 +649,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
-        if (nu_up == 1 && ks == 2 && ph_up == 8) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2, false, 8>), dim3(R / kSrPatch, R / 8, 2), dim3(256), 0, st, a);
-        else if (nu_up == 2 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
+        if (nu_up == 2 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
         else if (nu_up == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         else if (nu_up == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
@@ -676,8 +665,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        if (nu_fin == 1 && ph_fin == 8) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1, false, 8>), dim3(2 * R / kSrPatch, 2 * R / 8, 1), dim3(256), 0, st, a);
-        else if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
+        if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;

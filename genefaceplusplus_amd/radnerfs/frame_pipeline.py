@@ -1002,9 +1002,18 @@ class FramePipeline:
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         outs = []
+        defer = self.fuse_tail in ("1", "resolve")          # the torso kernel picks budget and snapshot per ray itself (one launch less per frame)
+        store = self.clip_job is not None and self.fuse_tail in ("1", "store")      # ... and writes the uint8 frame into the clip job's slot
         for k in range(K):
             ws = frames[k]
-            call("gfpp_head_frame_resolve", ctypes.byref(ws), int(max_steps), st)
+            ws.defer_resolve, ws.resolve_max_steps = (1, int(max_steps)) if defer else (0, 0)
+            ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = None, 0, 0, 0
+            if store:
+                ws.clip_job, ws.clip_lane, ws.clip_sub = int(self.clip_job[0]), int(self.clip_job[1]), k
+                ws.clip_advance = K * int(self.clip_job[2]) if k == K - 1 else 0xFFFFFFFF
+                self.clip_job_consumed = True
+            if not defer:
+                call("gfpp_head_frame_resolve", ctypes.byref(ws), int(max_steps), st)
             cond_in = self._dev_f32(torso_inputs[k].reshape(-1), "lm68 / poses")
             if cond_in.numel() != (136 if self.torso.variant == 1 else 6):
                 raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")
