@@ -64,9 +64,10 @@ class ClipRenderer:
         needs more trips is rendered by the small grid).
         group: frames per graph launch (round 4).  K > 1: a lane takes K consecutive frames of the clip at a time and renders them with ONE persistent
         head launch (RADNeRFTorso*.render_group, gfpp_frame_ws.n_frames) -- every frame the bits of its own launch, the fixed costs of a launch paid once
-        per K frames.  None: 4 for frames of up to 256^2 rays (the released checkpoint's geometry: a workgroup's share of ONE such frame is ~110
-        occupied rays, 27 sample blocks for 8 wavefronts), else 1; models / precisions without group support (head-only models, fp32, lp_kernel='trips')
-        and clips without precomputed conditioning render frame by frame whatever is asked."""
+        per K frames.  None: 4 (measured, frames/s with K = 1 / 2 / 3 / 4: 256^2 rays + SR 4 806 / 5 107 / 5 205 / 5 286 -- a workgroup's share of ONE
+        such frame is ~110 occupied rays, 27 sample blocks for 8 wavefronts --; 512^2 3 684 / 3 778 / 3 861 / 3 846; a 20-frame job 3 090 / - / 2 920 / 3 140);
+        models / precisions without group support (head-only models, fp32, lp_kernel='trips', more than 2^22 rays per group) and clips without precomputed
+        conditioning render frame by frame whatever is asked."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":
             raise GfppError("ClipRenderer: the model must live on the GPU (there is no CPU path)")
@@ -102,7 +103,7 @@ class ClipRenderer:
                        "stream": shared_stream(dev, "lane", _i) if self.lanes > 1 else None,
                        "graph": None, "key": None, "static_in": None} for _i in range(self.lanes)]
         if group is None:
-            group = int(os.environ.get("GFPP_CLIP_GROUP", "0")) or (4 if H * W <= 256 * 256 else 1)
+            group = int(os.environ.get("GFPP_CLIP_GROUP", "0")) or 4
         self.group_wanted = max(1, min(int(group), 4)) if fused else 1
         self.group = 1                                       # what the captured graphs render with (decided with the first clip: _ensure_graphs)
         self.ring = max(2, int(ring), self.lanes)

@@ -15,6 +15,9 @@
 // that the 16 pixels of a row hit distinct banks); each wavefront owns 4 rows = 64 pixels = two 32-column MFMA tiles x NT row tiles
 // of output channels.  The weights of one tap (CIN/16 steps x NT fragments, pre-packed in fragment order) are double-buffered
 // through LDS: the next tap's fragments are in flight (global -> registers) while the current tap's MFMAs run.
+// (Round 4, measured and dropped: 8 x 16 patches -- twice the workgroups, two co-resident per CU for block 0's 256-patch layer, each the other's cover for halo
+// load, chunk barriers and epilogue: 128.9 us per forward against 128.2 for that layer, +5 us for the up-sampling layer, +10 us for the last one.  Co-residency
+// is NOT what the stage lacks.)
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -47,14 +50,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 struct SrRng {
-    const unsigned long long *state;   // [0] = frame counter (null: no in-kernel noise)
+    const unsigned long long *state;   // [0] = frame counter, [1] = ticket, [2] = seed word XOR-ed into the key (null: no in-kernel noise)
     unsigned long long seed;
     uint32_t layer;
 };
 
 // one unit normal per (pixel, layer, frame): Box-Muller on two of the four Philox words
 __device__ __forceinline__ float sr_randn(const SrRng &g, unsigned long long frame, uint32_t pixel) {
-    const uint4 r = philox4x32_10(make_uint4(pixel, g.layer, (uint32_t)frame, (uint32_t)(frame >> 32)), make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+    // key = the launch's seed argument XOR the workspace's own seed word (state[2], device memory): a captured graph bakes the argument, the word stays settable
+    const unsigned long long seed = g.seed ^ g.state[2];
+    const uint4 r = philox4x32_10(make_uint4(pixel, g.layer, (uint32_t)frame, (uint32_t)(frame >> 32)), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
     const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
     const float u2 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
