@@ -38,6 +38,7 @@ class ClipJob(ctypes.Structure):
 _lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_clip_fetch_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
+_lib.register("gfpp_clip_fetch_group", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                     ctypes.c_uint32])
@@ -180,9 +181,8 @@ class ClipRenderer:
         max_steps = int(kw.get("max_steps", 1024))
         _g, _f, t = model.pipeline().group_workspace(self.rays_per_frame, K, max_steps)
         fx, fy, cx, cy = self.intrinsics
-        for k, v in enumerate(rows):
-            call("gfpp_clip_fetch_at", self._job_dev.data_ptr(), lane, k, L["g_static_in"][k].data_ptr(), int(L["g_static_in"].shape[1]), st)
-            call("gfpp_get_rays", v["pose"].data_ptr(), fx, fy, cx, cy, self.H, self.W, t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(), st)
+        # the K rows of driving signals in one launch; the rays are generated inside the group's prologue launch (gfpp_head_group_begin)
+        call("gfpp_clip_fetch_group", self._job_dev.data_ptr(), lane, K, L["g_static_in"].data_ptr(), int(L["g_static_in"].shape[1]), st)
 
         pipe = model.pipeline()
         if not self.with_sr:
@@ -200,7 +200,8 @@ class ClipRenderer:
         kw.pop("index", None)
         kw.update(bg_color=self.bg_img, T_thresh=self.T_thresh)
         try:
-            model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store, **kw)
+            model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store,
+                               ngp_poses=[v["pose"] for v in rows], camera=(fx, fy, cx, cy, self.H, self.W), **kw)
         finally:
             pipe.clip_job, pipe.clip_job_consumed = None, False
         return {}

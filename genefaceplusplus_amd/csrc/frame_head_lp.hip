@@ -921,6 +921,13 @@ struct PremarchArgs {
     // conservative bounds of the occupied cells (gfpp_head_model.occ_aabb; occ_valid = 0: unknown)
     float occ[6];
     uint32_t occ_valid;
+    // a frame GROUP (k_group_begin): `frames` frames of N rays behind each other in every array, counters [frames, kCounterWords]; the rays are generated here
+    // from each frame's pose (the arithmetic of k_get_rays, raymarch.hip) and stored for the head launch
+    uint32_t frames;
+    const float *poses;            // frame f's cam2world [4,4] (ngp convention) at poses + f * pose_stride
+    uint32_t pose_stride, W;
+    float fx, fy, cx, cy;
+    float *rays_o_out, *rays_d_out;
 };
 
 // Where the marcher may stop: beyond the point where the ray leaves the bounds of the occupied cells no cell is occupied, so the loop of
@@ -974,6 +981,61 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     float *out = p.sample_t + (size_t)n * p.stride;
     p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
                                     [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+}
+
+// The prologue of a frame group as ONE launch: ray generation (k_get_rays' expressions: utils.py:352-363) + slab test + state / counter reset + pre-march
+// for the K frames' rays.  In the clip loop's kernel trace the four frames' `k_get_rays` + `k_begin_premarch` of a group (8 launches, ~140 us end to end)
+// were the one piece of a lane's prologue that nothing overlapped when both lanes' head launches had just ended.  Same expressions, same bits as the
+// separate kernels.
+__global__ __launch_bounds__(256) void k_group_begin(PremarchArgs p) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x < p.frames && threadIdx.x < kCounterWords) p.counters[blockIdx.x * kCounterWords + threadIdx.x] = threadIdx.x == 0 ? (int32_t)p.N : 0;
+    if (n >= p.frames * p.N) return;
+    const uint32_t f = n / p.N, pix = n - f * p.N;
+    const float *pose = p.poses + (size_t)f * p.pose_stride;
+    const uint32_t h = pix / p.W, w = pix - h * p.W;
+    const float xs = ((float)w + 0.5f - p.cx) / p.fx;
+    const float ys = ((float)h + 0.5f - p.cy) / p.fy;
+    const float norm = sqrtf(fmaf(xs, xs, fmaf(ys, ys, 1.0f)));
+    const float ux = xs / norm, uy = ys / norm, uz = 1.0f / norm;
+    float o3[3], d3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d3[r] = fmaf(pose[4 * r + 2], uz, fmaf(pose[4 * r + 1], uy, pose[4 * r] * ux));      // rays_d = R @ dir
+        o3[r] = pose[4 * r + 3];
+        p.rays_d_out[3ull * n + r] = d3[r];
+        p.rays_o_out[3ull * n + r] = o3[r];
+    }
+    const float ox = o3[0], oy = o3[1], oz = o3[2], dx = d3[0], dy = d3[1], dz = d3[2];
+    const RayBox rb = ray_box(ox, oy, oz, dx, dy, dz, p.aabb, p.min_near);
+    p.nears_out[n] = rb.near;
+    p.fars_out[n] = rb.far;
+    *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
+    float t = rb.near;
+    float *out = p.sample_t + (size_t)n * p.stride;
+    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
+                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+}
+
+// k_head_budget_resolve for the K frames of a group in one launch (each frame against its own histogram / counters)
+__global__ __launch_bounds__(256) void k_group_budget_resolve(float *__restrict__ state, const float *__restrict__ snaps, int32_t *__restrict__ counters, uint32_t N,
+                                                              uint32_t frames, uint32_t max_steps) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n < frames) {
+        int32_t *c = counters + (size_t)n * kCounterWords;
+        (void)budget_from_hist(c + kBudgetBase, N, max_steps, c);
+        if (n == 0) c[64] = c[kBudgetBase + kBudgetSamples];            // the launch's evaluated samples, where trip 0's count used to be (kept in the first frame's counters)
+    }
+    if (n >= frames * N) return;
+    const uint32_t done = __float_as_uint(state[(size_t)kRayRec * n + 7]);
+    if (done <= max_steps || done > max_steps + 7u) return;
+    const uint32_t f = n / N;
+    const uint32_t B = budget_from_hist(counters + (size_t)f * kCounterWords + kBudgetBase, N, max_steps, nullptr);
+    if (done <= B || B < max_steps) return;
+    const float *sp = snaps + ((size_t)n * 7u + (B - max_steps)) * 5u;
+    *reinterpret_cast<float4 *>(state + (size_t)kRayRec * n) = float4{sp[0], sp[1], sp[2], sp[3]};
+    *reinterpret_cast<float2 *>(state + (size_t)kRayRec * n + 4) = float2{sp[4], __uint_as_float(B)};
 }
 
 // ---- per-sample evaluation (RADNeRF.forward, radnerf.py:108-141) with the 16-bit trip kernel's own arithmetic -----------------------------
@@ -1145,6 +1207,7 @@ GFPP_API int gfpp_head_frame_premarch(const gfpp_head_model *model, const gfpp_f
     p.min_near = 0.0f; p.nears_out = nullptr; p.fars_out = nullptr; p.state = nullptr; p.counters = nullptr;
     for (int i = 0; i < 6; ++i) p.aabb[i] = 0.0f;
     premarch_occupancy(p, model);
+    p.frames = 1; p.poses = nullptr; p.pose_stride = 0; p.W = 0; p.fx = p.fy = p.cx = p.cy = 0.0f; p.rays_o_out = nullptr; p.rays_d_out = nullptr;
     hipLaunchKernelGGL(k_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gfpp_head_frame_premarch");
 }
@@ -1164,8 +1227,44 @@ GFPP_API int gfpp_head_frame_begin_premarch(const gfpp_head_model *model, const 
     for (int i = 0; i < 6; ++i) p.aabb[i] = model->aabb[i];
     p.nears_out = ws->nears; p.fars_out = ws->fars; p.state = ws->ray_state; p.counters = ws->counters;
     premarch_occupancy(p, model);
+    p.frames = 1; p.poses = nullptr; p.pose_stride = 0; p.W = 0; p.fx = p.fy = p.cx = p.cy = 0.0f; p.rays_o_out = nullptr; p.rays_d_out = nullptr;
     hipLaunchKernelGGL(k_begin_premarch, dim3(div_up(ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gfpp_head_frame_begin_premarch");
+}
+
+GFPP_API int gfpp_head_group_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *poses, uint32_t pose_stride, float fx, float fy, float cx,
+                                   float cy, uint32_t H, uint32_t W, float *rays_o, float *rays_d, float dt_gamma, uint32_t max_steps, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_group_begin", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
+    if (!poses || !ws->ray_state || !ws->counters || ws->N == 0 || H * W != ws->N || frames > kPMaxFrames || pose_stride < 16u) {
+        set_error("gfpp_head_group_begin: needs poses (stride >= 16 floats), ray_state, counters [n_frames, 192], H * W == N, n_frames <= %u", kPMaxFrames);
+        return GFPP_EINVAL;
+    }
+    PremarchArgs p;
+    p.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
+    p.bitfield = model->density_bitfield;
+    p.rays_o = nullptr; p.rays_d = nullptr; p.nears = nullptr; p.fars = nullptr;
+    p.sample_t = ws->sample_t; p.sample_cnt = ws->sample_cnt;
+    p.N = ws->N; p.stride = ws->sample_stride; p.max_samples = max_steps + 7u;
+    p.min_near = model->min_near;
+    for (int i = 0; i < 6; ++i) p.aabb[i] = model->aabb[i];
+    p.nears_out = ws->nears; p.fars_out = ws->fars; p.state = ws->ray_state; p.counters = ws->counters;
+    premarch_occupancy(p, model);
+    p.frames = frames; p.poses = poses; p.pose_stride = pose_stride; p.W = W;
+    p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
+    p.rays_o_out = rays_o; p.rays_d_out = rays_d;
+    hipLaunchKernelGGL(k_group_begin, dim3(div_up(frames * ws->N, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("gfpp_head_group_begin");
+}
+
+GFPP_API int gfpp_head_group_resolve(const gfpp_frame_ws *ws, uint32_t max_steps, gfpp_stream_t stream) {
+    if (!ws || !ws->ray_state || !ws->counters || !ws->snapshots || ws->N == 0 || ws->gcounters) { set_error("gfpp_head_group_resolve: incomplete workspace"); return GFPP_EINVAL; }
+    if (max_steps == 0 || max_steps > 24u) { set_error("gfpp_head_group_resolve: max_steps must be in 1..24"); return GFPP_EUNSUPPORTED; }
+    const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
+    hipLaunchKernelGGL(k_group_budget_resolve, dim3(div_up(frames * ws->N, 256)), dim3(256), 0, (hipStream_t)stream, ws->ray_state, ws->snapshots, ws->counters, ws->N, frames,
+                       max_steps);
+    return check_launch("gfpp_head_group_resolve");
 }
 
 GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,

@@ -164,10 +164,12 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_u8(const float *__restrict__ 
 // ---- clip job: a frame's graph fetches its inputs and stores its output by a device-side cursor ---------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_clip_fetch(const gfpp_clip_job *__restrict__ job, uint32_t lane, uint32_t sub, float *__restrict__ static_in,
                                                        uint32_t row_floats) {
-    const uint32_t pos = job->cursor[lane] + sub;
+    // (blockIdx.y: the frames of a group, one row of static_in each)
+    const uint32_t pos = job->cursor[lane] + sub + blockIdx.y;
     if (pos >= job->n) return;
     const float *row = job->packed + (size_t)job->order[pos] * job->row_floats;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < row_floats; i += gridDim.x * kBlock) static_in[i] = row[i];
+    float *dst = static_in + (size_t)blockIdx.y * row_floats;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < row_floats; i += gridDim.x * kBlock) dst[i] = row[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restrict__ job, uint32_t lane, uint32_t sub, uint32_t advance,
@@ -205,6 +207,12 @@ GFPP_API int gfpp_clip_fetch_at(const gfpp_clip_job *job, uint32_t lane, uint32_
     GFPP_REQUIRE_EARLY(job && static_in && lane < 8 && row_floats > 0, "gfpp_clip_fetch");
     hipLaunchKernelGGL(k_clip_fetch, dim3((row_floats + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, job, lane, sub, static_in, row_floats);
     return check_launch("gfpp_clip_fetch");
+}
+
+GFPP_API int gfpp_clip_fetch_group(const gfpp_clip_job *job, uint32_t lane, uint32_t count, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {
+    GFPP_REQUIRE_EARLY(job && static_in && lane < 8 && row_floats > 0 && count >= 1 && count <= 16, "gfpp_clip_fetch_group");
+    hipLaunchKernelGGL(k_clip_fetch, dim3((row_floats + kBlock - 1) / kBlock, count), dim3(kBlock), 0, (hipStream_t)stream, job, lane, 0u, static_in, row_floats);
+    return check_launch("gfpp_clip_fetch_group");
 }
 
 GFPP_API int gfpp_clip_fetch(const gfpp_clip_job *job, uint32_t lane, float *static_in, uint32_t row_floats, gfpp_stream_t stream) {

@@ -85,6 +85,8 @@ _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POI
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_persist_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_resolve", [ctypes.POINTER(FrameWs), c_u32, c_p])
+_lib.register("gfpp_head_group_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_u32, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_f, c_u32, c_p])
+_lib.register("gfpp_head_group_resolve", [ctypes.POINTER(FrameWs), c_u32, c_p])
 _lib.register("gfpp_head_eval_samples", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_eval_samples_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_u32, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_head_frame_finish", [ctypes.POINTER(FrameWs), c_p, c_f, c_p, c_p, c_p])
@@ -972,10 +974,12 @@ class FramePipeline:
         return ent
 
     def render_group_head_torso(self, consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head_for_torso,
-                                after_frame=None):
+                                after_frame=None, poses=None, camera=None):
         """K frames (K = len(consts)) whose rays the caller has put into group_workspace()['rays_o' / 'rays_d']: per frame slab test + pre-march, then ONE
         persistent head launch over the rays of all K frames, then per frame resolve + torso pass (+ `after_frame(k, out)`: the SR stage, the uint8 store).
         consts[k]: the frame's 256 folded constants (FoldedConsts of equally spaced views, e.g. of the clip's rows); torso_inputs[k]: lm68 [136] or poses [6].
+        poses + camera = (fx, fy, cx, cy, H, W): the rays are GENERATED here from the frames' cam2world matrices (equally spaced [4, 4] views) in the same launch
+        as the slab test and the pre-march (gfpp_head_group_begin) instead of being read from the workspace.
         Every frame is the bits of its own render_head_torso.  Returns the K result dicts."""
         K = len(consts)
         N = int(bg_coords.reshape(-1, 2).shape[0])
@@ -991,9 +995,17 @@ class FramePipeline:
         step = (c[1].data_ptr() - c[0].data_ptr()) // 4
         if step < 256 or any(c[k].data_ptr() - c[0].data_ptr() != 4 * step * k for k in range(K)):
             raise GfppError("render_group_head_torso: the frames' constants must be equally spaced views (frame_consts_stride)")
-        for k in range(K):
-            call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
-                 float(dt_gamma), int(max_steps), st)
+        if poses is not None:
+            pstep = (poses[1].data_ptr() - poses[0].data_ptr()) // 4
+            if pstep < 16 or any(poses[k].data_ptr() - poses[0].data_ptr() != 4 * pstep * k or poses[k].numel() != 16 for k in range(K)):
+                raise GfppError("render_group_head_torso: the frames' poses must be equally spaced [4, 4] views")
+            fx, fy, cx, cy, H, W = camera
+            call("gfpp_head_group_begin", ctypes.byref(self.head), ctypes.byref(gws), poses[0].data_ptr(), int(pstep), float(fx), float(fy), float(cx), float(cy), int(H),
+                 int(W), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps), st)
+        else:
+            for k in range(K):
+                call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
+                     float(dt_gamma), int(max_steps), st)
         gws.frame_consts, gws.frame_consts_stride = c[0].data_ptr(), step
         call("gfpp_head_frame_persist_lp", ctypes.byref(self.head), ctypes.byref(gws), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps),
              float(T_thresh), st)
@@ -1003,6 +1015,8 @@ class FramePipeline:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         outs = []
         defer = self.fuse_tail in ("1", "resolve")          # the torso kernel picks budget and snapshot per ray itself (one launch less per frame)
+        if not defer:
+            call("gfpp_head_group_resolve", ctypes.byref(gws), int(max_steps), st)       # every frame against its own histogram, one launch
         store = self.clip_job is not None and self.fuse_tail in ("1", "store")      # ... and writes the uint8 frame into the clip job's slot
         for k in range(K):
             ws = frames[k]
@@ -1012,8 +1026,6 @@ class FramePipeline:
                 ws.clip_job, ws.clip_lane, ws.clip_sub = int(self.clip_job[0]), int(self.clip_job[1]), k
                 ws.clip_advance = K * int(self.clip_job[2]) if k == K - 1 else 0xFFFFFFFF
                 self.clip_job_consumed = True
-            if not defer:
-                call("gfpp_head_frame_resolve", ctypes.byref(ws), int(max_steps), st)
             cond_in = self._dev_f32(torso_inputs[k].reshape(-1), "lm68 / poses")
             if cond_in.numel() != (136 if self.torso.variant == 1 else 6):
                 raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")

@@ -179,6 +179,9 @@ int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint
  * lane's cursor when it is done (0: the job's `lanes`; 0xFFFFFFFF: nothing -- every frame of a group but the last, which passes K * lanes).  Groups are dealt
  * to the lanes round-robin: the host starts cursor[l] at l * K.  Frame sizes need not be multiples of four bytes. */
 int gfpp_clip_fetch_at(const gfpp_clip_job *job, uint32_t lane, uint32_t sub, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
+/* ... and the rows of all `count` frames of the lane's next group in one launch: row k -> static_in + k * row_floats (the indexing
+ * `cond_inp[i], poses[i], lm68s[i]` of inference/genefacepp_infer.py:461-463 for `count` consecutive i) */
+int gfpp_clip_fetch_group(const gfpp_clip_job *job, uint32_t lane, uint32_t count, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
 int gfpp_clip_store_u8_at(gfpp_clip_job *job, uint32_t lane, uint32_t sub, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
 
 /* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
@@ -498,6 +501,15 @@ int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws
  * (the frame-wide sums, with ws->N_global rays), else ws->counters[128..191] -- which yields the budget B and counters[k]; then the snapshot
  * selection for rays that composited more than B samples (raymarching.cu:978-1022 stops them at the end of the last trip's window). */
 int gfpp_head_frame_resolve(const gfpp_frame_ws *ws, uint32_t max_steps, gfpp_stream_t stream);
+
+/* (ABI 6) The prologue and the resolve step of a frame GROUP (ws->n_frames = K frames of N = H * W rays behind each other in every array, see gfpp_frame_ws.n_frames),
+ * each as ONE launch.  gfpp_head_group_begin = for every frame f: the rays of get_rays (modules/radnerfs/utils.py:283-364, the expressions of gfpp_get_rays) from the
+ * frame's cam2world matrix at poses + f * pose_stride (floats; e.g. a field of the frame's row of driving signals), stored to rays_o / rays_d [K N, 3] for the head
+ * launch, + what gfpp_head_frame_begin_premarch does (slab test = raymarching.cu:91-145, state / counter reset, pre-march = raymarching.cu:827-929 once per ray).
+ * gfpp_head_group_resolve = gfpp_head_frame_resolve for every frame against its own histogram (counters [K, 192]).  Same bits as the per-frame entries. */
+int gfpp_head_group_begin(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *poses, uint32_t pose_stride, float fx, float fy, float cx, float cy,
+                          uint32_t H, uint32_t W, float *rays_o, float *rays_d, float dt_gamma, uint32_t max_steps, gfpp_stream_t stream);
+int gfpp_head_group_resolve(const gfpp_frame_ws *ws, uint32_t max_steps, gfpp_stream_t stream);
 
 /* Head-only epilogue (renderer.py:385-397): image = clamp(image + (1 - weights_sum) * bg, 0, 1),
  * depth = clamp(depth - near, 0) / (far - near).  bg_color [N,3] or NULL (then bg_scalar is used; reference default 1). */
