@@ -38,7 +38,6 @@ class ClipJob(ctypes.Structure):
 _lib.register("gfpp_clip_fetch", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_clip_fetch_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
-_lib.register("gfpp_clip_store_u8_group", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_clip_fetch_group", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p])
 _lib.register("gfpp_clip_store_u8_at", [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p])
 _lib.register("gfpp_graph_replay", [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
@@ -97,8 +96,7 @@ class ClipRenderer:
             # that holds every CU for ~0.29 ms) 2 535 / 2 956 / 2 769 / 2 693 with 1 / 2 / 3 / 4, and 2 980 / 2 995 with 2 / 3 once the conditioning left the
             # frames: a third frame's launches only queue behind the head pass.  The super-resolution models (256^2 rays: a 0.12 ms head pass + four SR
             # launches) do gain from a third frame: 3 860 -> 4 050 frames/s
-            # (round 4, frame groups of 4: 512^2 3 836 / 3 839 / 3 852 frames/s with 2 / 3 / 4 lanes -- still nothing to gain; SR models 4 822 / 5 153 / 5 375)
-            lanes = 4 if self.with_sr else (3 if getattr(model, "precision", "auto") == "fp32" else 2)
+            lanes = 3 if (getattr(model, "precision", "auto") == "fp32" or self.with_sr) else 2
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
@@ -186,21 +184,26 @@ class ClipRenderer:
         # the K rows of driving signals in one launch; the rays are generated inside the group's prologue launch (gfpp_head_group_begin)
         call("gfpp_clip_fetch_group", self._job_dev.data_ptr(), lane, K, L["g_static_in"].data_ptr(), int(L["g_static_in"].shape[1]), st)
 
-        def store(k, res):                  # super-resolution models: each frame's 512^2 image as it leaves its SR stage
-            rgb = res["sr_rgb_map"].permute(0, 2, 3, 1).reshape(*self.out_hw, 3)
+        pipe = model.pipeline()
+        if not self.with_sr:
+            pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane, self.lanes), False      # (GFPP_FUSE_TAIL: the torso kernel may store the uint8 frames itself)
+
+        def store(k, res):
+            if pipe.clip_job_consumed:
+                return
+            rgb = res["sr_rgb_map"].permute(0, 2, 3, 1) if self.with_sr else res["rgb_map"]
+            rgb = rgb.reshape(*self.out_hw, 3)
             if not rgb.is_contiguous() or rgb.dtype != torch.float32:
                 rgb = rgb.float().contiguous()
             advance = K * self.lanes if k == K - 1 else 0xFFFFFFFF
             call("gfpp_clip_store_u8_at", self._job_dev.data_ptr(), lane, k, advance, rgb.data_ptr(), int(rgb.numel()), torch.cuda.current_stream().cuda_stream)
-
-        def store_all(big):                 # the K frames of the group in one launch (their images lie behind each other)
-            img = big["image"]
-            call("gfpp_clip_store_u8_group", self._job_dev.data_ptr(), lane, K, K * self.lanes, img.data_ptr(), int(img[0].numel()), torch.cuda.current_stream().cuda_stream)
         kw.pop("index", None)
         kw.update(bg_color=self.bg_img, T_thresh=self.T_thresh)
-        model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0,
-                           after_frame=store if self.with_sr else None, after_group=None if self.with_sr else store_all,
-                           ngp_poses=[v["pose"] for v in rows], camera=(fx, fy, cx, cy, self.H, self.W), **kw)
+        try:
+            model.render_group([v["cond_feat"] for v in rows], self.bg_coords, [v["pose6"] for v in rows], [v["lm68"] for v in rows], index=0, after_frame=store,
+                               ngp_poses=[v["pose"] for v in rows], camera=(fx, fy, cx, cy, self.H, self.W), **kw)
+        finally:
+            pipe.clip_job, pipe.clip_job_consumed = None, False
         return {}
 
     # -- the job: which frames, where to ----------------------------------------------------------------------------------------------------------

@@ -49,9 +49,6 @@ struct TorsoLpArgs {
     BudgetView bv;            // hist != null: the head pass was the persistent launch with the resolve deferred to this kernel
     gfpp_clip_job *job;       // != null: also store the frame as uint8 into the clip job's slot of lane `lane` and advance its cursor
     uint32_t lane, sub, advance;   // the frame takes job position cursor[lane] + sub; the launch moves the cursor by `advance` (0: the job's `lanes`; ~0: not at all)
-    // a frame GROUP in one launch: `frames` frames of N pixels behind each other in state / nears / fars and in every output; frame f's conditioning vector
-    // at cond_in + f * cond_stride, its job position cursor + sub + f
-    uint32_t frames, cond_stride, blocks_per_frame;
 };
 
 template <typename H>
@@ -127,18 +124,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     const int j = lane & 31, hi = lane >> 5;
 
     // ---- this thread's pixel: occupancy test first (most workgroups of a frame have no torso pixel and skip the weights) ----------
-    uint32_t block = blockIdx.x;
-    if (a.frames > 1u) {
-        // a workgroup belongs to ONE frame of the group: everything per frame is shifted to that frame here, the rest of the kernel is the one-frame kernel
-        const uint32_t f = block / a.blocks_per_frame;
-        block -= f * a.blocks_per_frame;
-        const size_t at = (size_t)f * a.N;
-        a.state += (size_t)kRayRec * at; a.nears += at; a.fars += at;
-        a.out_image += 3 * at; a.out_depth += at; a.torso_alpha += at; a.torso_bg += 3 * at; a.deform += 2 * at; a.mask_out += at;
-        a.cond_in += (size_t)f * a.cond_stride;
-        a.sub += f;
-    }
-    const uint32_t n = block * kTlThreads + tid;
+    const uint32_t n = blockIdx.x * kTlThreads + tid;
     const bool in_frame = n < a.N;
     float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f, hdepth = 0.0f;
     bool masked = false;
@@ -413,14 +399,7 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     }
     a.job = ws->clip_job; a.lane = ws->clip_lane; a.sub = ws->clip_sub; a.advance = ws->clip_advance;
     if (a.job && a.lane >= 8) { set_error("gfpp_torso_frame_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
-    a.frames = ws->n_frames > 1u ? ws->n_frames : 1u;
-    a.cond_stride = ws->torso_cond_stride;
-    a.blocks_per_frame = div_up(ws->N, kTlThreads);
-    if (a.frames > 1u && (ws->defer_resolve || a.cond_stride == 0u)) {
-        set_error("gfpp_torso_frame_lp: a frame group needs torso_cond_stride and resolved ray records (gfpp_head_group_resolve; defer_resolve is per frame)");
-        return GFPP_EINVAL;
-    }
-    const dim3 grid(a.frames * a.blocks_per_frame), block(kTlThreads);
+    const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
     else if (m->lp_dtype == GFPP_F32) hipLaunchKernelGGL(k_torso_lp<float>, grid, block, 0, (hipStream_t)stream, a);   // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
     else hipLaunchKernelGGL(k_torso_lp<_Float16>, grid, block, 0, (hipStream_t)stream, a);

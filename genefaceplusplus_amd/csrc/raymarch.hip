@@ -176,9 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restr
                                                           const float *__restrict__ rgb, size_t n) {
     // a grid-stride loop over a FEW workgroups: the launch ends with one ticket per workgroup on the same word, and 768 of those (one float4 per thread)
     // took longer than the 3.9 MB they guard (9.8 us per launch in the trace)
-    // (blockIdx.y: the frames of a group, n values each, behind each other in rgb)
-    const uint32_t pos = job->cursor[lane] + sub + blockIdx.y;
-    rgb += (size_t)blockIdx.y * n;
+    const uint32_t pos = job->cursor[lane] + sub;
     if (pos < job->n) {
         uint8_t *out = job->out + (size_t)(pos % job->ring_frames) * job->frame_bytes;
         // whole float4 / uchar4 quads where the slot is 4-byte aligned (every even frame size); a scalar tail / fallback otherwise (frames of odd H x W)
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_clip_store_u8(gfpp_clip_job *__restr
     }
     // the cursor moves on when every workgroup of the launch has read it: the last one to get here advances it (a frame group: only its last frame's store)
     __syncthreads();
-    if (advance != 0xFFFFFFFFu && threadIdx.x == 0 && atomicAdd(&job->ticket[lane], 1u) == gridDim.x * gridDim.y - 1u) {
+    if (advance != 0xFFFFFFFFu && threadIdx.x == 0 && atomicAdd(&job->ticket[lane], 1u) == gridDim.x - 1u) {
         job->ticket[lane] = 0u;
         job->cursor[lane] = job->cursor[lane] + (advance ? advance : job->lanes);
     }
@@ -228,16 +226,6 @@ GFPP_API int gfpp_clip_store_u8_at(gfpp_clip_job *job, uint32_t lane, uint32_t s
     if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)blocks), dim3(kBlock), 0, (hipStream_t)stream, job, lane, sub, advance, rgb, (size_t)n_values);
     return check_launch("gfpp_clip_store_u8");
-}
-
-GFPP_API int gfpp_clip_store_u8_group(gfpp_clip_job *job, uint32_t lane, uint32_t count, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {
-    GFPP_REQUIRE_EARLY(job && rgb && lane < 8 && n_values > 0 && count >= 1 && count <= 16 && ((uintptr_t)rgb & 15u) == 0 && (count == 1 || (n_values & 3u) == 0),
-                       "gfpp_clip_store_u8_group");
-    const uint64_t threads = (n_values + 3) / 4;
-    uint64_t blocks = (threads + kBlock - 1) / kBlock;
-    if (blocks > 128) blocks = 128;
-    hipLaunchKernelGGL(k_clip_store_u8, dim3((uint32_t)blocks, count), dim3(kBlock), 0, (hipStream_t)stream, job, lane, 0u, advance, rgb, (size_t)n_values);
-    return check_launch("gfpp_clip_store_u8_group");
 }
 
 GFPP_API int gfpp_clip_store_u8(gfpp_clip_job *job, uint32_t lane, const float *rgb, uint64_t n_values, gfpp_stream_t stream) {

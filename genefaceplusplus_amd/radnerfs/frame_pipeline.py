@@ -45,7 +45,7 @@ class FrameWs(ctypes.Structure):
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
                 ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32),
-                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("torso_cond_stride", c_u32), ("frame_consts_stride", c_u32), ("timeouts", c_p)]
+                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("frame_consts_stride", c_u32), ("timeouts", c_p)]
 
 
 class CondModel(ctypes.Structure):
@@ -672,7 +672,7 @@ class FramePipeline:
             ws.full_grid_trips = 0
             ws.snapshots = None
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane = 0, 0, None, 0
-            ws.clip_sub, ws.clip_advance, ws.n_frames, ws.frame_consts_stride, ws.torso_cond_stride = 0, 0, 0, 0, 0
+            ws.clip_sub, ws.clip_advance, ws.n_frames, ws.frame_consts_stride = 0, 0, 0, 0
             t["timeouts"] = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: no kernel resets it (gfpp_frame_ws.timeouts)
             ws.timeouts = t["timeouts"].data_ptr()
             ent = (ws, t)
@@ -967,17 +967,16 @@ class FramePipeline:
             ws.frame_consts, ws.phase_cycles, ws.gcounters = None, None, None
             ws.separate_trips = ws.N_global = ws.trip_first = ws.trip_count = ws.full_grid_trips = 0
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = 0, 0, None, 0, 0, 0
-            ws.n_frames, ws.frame_consts_stride, ws.torso_cond_stride, ws.timeouts = n_frames, 0, 0, t["timeouts"].data_ptr()
+            ws.n_frames, ws.frame_consts_stride, ws.timeouts = n_frames, 0, t["timeouts"].data_ptr()
             return ws
         ent = (record(0, K), [record(k, 0) for k in range(K)], t)
         self._ws[key] = ent
         return ent
 
     def render_group_head_torso(self, consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head_for_torso,
-                                after_frame=None, poses=None, camera=None, after_group=None):
+                                after_frame=None, poses=None, camera=None):
         """K frames (K = len(consts)) whose rays the caller has put into group_workspace()['rays_o' / 'rays_d']: per frame slab test + pre-march, then ONE
-        persistent head launch over the rays of all K frames, then resolve and torso pass of all K frames as one launch each (+ `after_group(outputs [K, N, ..])`
-        and `after_frame(k, out)`: the SR stage, the uint8 store).
+        persistent head launch over the rays of all K frames, then per frame resolve + torso pass (+ `after_frame(k, out)`: the SR stage, the uint8 store).
         consts[k]: the frame's 256 folded constants (FoldedConsts of equally spaced views, e.g. of the clip's rows); torso_inputs[k]: lm68 [136] or poses [6].
         poses + camera = (fx, fy, cx, cy, H, W): the rays are GENERATED here from the frames' cam2world matrices (equally spaced [4, 4] views) in the same launch
         as the slab test and the pre-march (gfpp_head_group_begin) instead of being read from the workspace.
@@ -1014,30 +1013,31 @@ class FramePipeline:
         code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        # every frame against its own histogram (one launch), then the torso pass of all K frames as ONE launch (a workgroup belongs to one frame)
-        call("gfpp_head_group_resolve", ctypes.byref(gws), int(max_steps), st)
-        width = 136 if self.torso.variant == 1 else 6
-        ci = [self._dev_f32(x.reshape(-1), "lm68 / poses") for x in torso_inputs]
-        if any(x.numel() != width for x in ci):
-            raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")
-        cstep = (ci[1].data_ptr() - ci[0].data_ptr()) // 4
-        if cstep < width or any(ci[k].data_ptr() - ci[0].data_ptr() != 4 * cstep * k for k in range(K)):
-            ci = list(torch.stack(ci).contiguous())               # (not views of one matrix: a copy that is)
-            cstep = width
-        big = {"image": f(K, N, 3), "depth": f(K, N), "torso_alpha": f(K, N, 1), "torso_bg": f(K, N, 3), "deform_dense": f(K, N, 2),
-               "torso_mask": torch.empty(K, N, dtype=torch.uint8, device=dev)}
-        gws.torso_cond_stride = int(cstep)
-        gws.defer_resolve, gws.resolve_max_steps, gws.clip_job, gws.clip_lane, gws.clip_sub, gws.clip_advance = 0, 0, None, 0, 0, 0
-        call("gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(gws), bg_coords.data_ptr(), ci[0].data_ptr(),
-             code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), big["image"].data_ptr(),
-             big["depth"].data_ptr(), big["torso_alpha"].data_ptr(), big["torso_bg"].data_ptr(), big["deform_dense"].data_ptr(),
-             big["torso_mask"].data_ptr(), st)
-        outs = [dict({name: v[k] for name, v in big.items()}, deform=None) for k in range(K)]
-        if after_group is not None:
-            after_group(big)
-        if after_frame is not None:
-            for k in range(K):
-                after_frame(k, outs[k])
+        outs = []
+        defer = self.fuse_tail in ("1", "resolve")          # the torso kernel picks budget and snapshot per ray itself (one launch less per frame)
+        if not defer:
+            call("gfpp_head_group_resolve", ctypes.byref(gws), int(max_steps), st)       # every frame against its own histogram, one launch
+        store = self.clip_job is not None and self.fuse_tail in ("1", "store")      # ... and writes the uint8 frame into the clip job's slot
+        for k in range(K):
+            ws = frames[k]
+            ws.defer_resolve, ws.resolve_max_steps = (1, int(max_steps)) if defer else (0, 0)
+            ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = None, 0, 0, 0
+            if store:
+                ws.clip_job, ws.clip_lane, ws.clip_sub = int(self.clip_job[0]), int(self.clip_job[1]), k
+                ws.clip_advance = K * int(self.clip_job[2]) if k == K - 1 else 0xFFFFFFFF
+                self.clip_job_consumed = True
+            cond_in = self._dev_f32(torso_inputs[k].reshape(-1), "lm68 / poses")
+            if cond_in.numel() != (136 if self.torso.variant == 1 else 6):
+                raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")
+            out = {"image": f(N, 3), "depth": f(N), "torso_alpha": f(N, 1), "torso_bg": f(N, 3), "deform_dense": f(N, 2),
+                   "torso_mask": torch.empty(N, dtype=torch.uint8, device=dev), "deform": None}
+            call("gfpp_torso_frame_lp", ctypes.byref(self.torso), ctypes.byref(ws), bg_coords.data_ptr(), cond_in.data_ptr(),
+                 code.data_ptr() if code is not None else None, bg_ptr, bg_scalar, int(bool(use_head_for_torso)), out["image"].data_ptr(),
+                 out["depth"].data_ptr(), out["torso_alpha"].data_ptr(), out["torso_bg"].data_ptr(), out["deform_dense"].data_ptr(),
+                 out["torso_mask"].data_ptr(), st)
+            if after_frame is not None:
+                after_frame(k, out)
+            outs.append(out)
         return outs
 
     def graphed(self, key, fn, inputs):

@@ -206,13 +206,12 @@ class _TorsoBase(RADNeRF):
         return (self.executor == "fused" and not self.training and self._fused_ok(perturb, max_steps) and self.pipeline().group_supported(N, K, max_steps))
 
     def render_group(self, consts, bg_coords, poses, lm68s, index=0, dt_gamma=0, bg_color=None, max_steps=1024, T_thresh=1e-4, upscale_torso=False,
-                     sr_noise_mode="random", after_frame=None, ngp_poses=None, camera=None, after_group=None, **kwargs):
+                     sr_noise_mode="random", after_frame=None, ngp_poses=None, camera=None, **kwargs):
         """render() for K = len(consts) frames whose RAYS the caller has put into pipeline().group_workspace(N, K, max_steps)[2]['rays_o' / 'rays_d'] and
         whose conditioning is given as folded constants (consts[k]: 256 values, RADNeRF.frame_consts_rows) -- the frame loop of
         inference/genefacepp_infer.py:460-469 taken K frames at a time.  Every frame is the bits of its own render() call (per sample and per ray nothing
         changes; the super-resolution noise of 'random' mode is drawn per launch either way).  poses [K, 1, 6] / lm68s [K, 136]: per frame.
-        after_frame(k, result dict of frame k): issued right behind the frame's last kernel (the clip renderer's uint8 store); after_group(dict of the K frames'
-        stacked pipeline outputs, 'image' [K, N, 3] ...): right behind the group's torso launch (the clip renderer's uint8 store of all K frames at once).
+        after_frame(k, result dict of frame k): issued right behind the frame's last kernel (the clip renderer's uint8 store).
         ngp_poses (K equally spaced [4, 4] cam2world views) + camera (fx, fy, cx, cy, H, W): generate the rays on the device inside the group's prologue launch
         instead of reading them from the workspace.  Returns the K result dicts with render()'s keys."""
         K = len(consts)
@@ -243,7 +242,7 @@ class _TorsoBase(RADNeRF):
                 after_frame(k, res)
         torso_inputs = lm68s if self.landmark_conditioned else poses
         self.pipeline().render_group_head_torso(consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head,
-                                                after_frame=finish, poses=ngp_poses, camera=camera, after_group=after_group)
+                                                after_frame=finish, poses=ngp_poses, camera=camera)
         return results
 
 

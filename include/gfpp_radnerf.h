@@ -183,9 +183,6 @@ int gfpp_clip_fetch_at(const gfpp_clip_job *job, uint32_t lane, uint32_t sub, fl
  * `cond_inp[i], poses[i], lm68s[i]` of inference/genefacepp_infer.py:461-463 for `count` consecutive i) */
 int gfpp_clip_fetch_group(const gfpp_clip_job *job, uint32_t lane, uint32_t count, float *static_in, uint32_t row_floats, gfpp_stream_t stream);
 int gfpp_clip_store_u8_at(gfpp_clip_job *job, uint32_t lane, uint32_t sub, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
-/* ... and all `count` frames of a group in one launch (the `.cpu()` + uint8 conversion of inference/genefacepp_infer.py:465-469 for `count` consecutive frames):
- * rgb [count, n_values] f32, frame k -> position cursor[lane] + k; `advance` as above */
-int gfpp_clip_store_u8_group(gfpp_clip_job *job, uint32_t lane, uint32_t count, uint32_t advance, const float *rgb, uint64_t n_values, gfpp_stream_t stream);
 
 /* The frame loop of inference/genefacepp_infer.py:460-469 for `count` frames: frame k is one launch of the captured graph of lane
  * (first_lane + k) % lanes on that lane's stream.  execs: [lanes] hipGraphExec_t, streams: [lanes] hipStream_t (host arrays).
@@ -416,9 +413,6 @@ typedef struct gfpp_frame_ws {
                                * changes (same block evaluation, same compositing order): every frame is the bits of its own launch.  Each frame keeps its own
                                * histogram / counters and is resolved on its own (gfpp_head_frame_resolve or the consumer's on-the-fly resolve, with the
                                * frame's own gfpp_frame_ws).  Used by the clip renderer for small frames (256^2 rays: 0.117 ms per frame alone). */
-    uint32_t torso_cond_stride;   /* frame groups, gfpp_torso_frame_lp: floats between the frames' conditioning vectors (lm68 / poses: fields of the frames' rows of
-                                   * driving signals).  With n_frames = K the torso launch covers the K frames in ONE launch: ray records, nears / fars and every
-                                   * output [K N, ...] behind each other, frame f's job position = cursor + clip_sub + f, the launch's last workgroup advances the cursor */
     uint32_t frame_consts_stride; /* frame groups: floats between the folded constants of consecutive frames (0 = 256: a [K, 256] array) -- the clip renderer's
                                    * constants sit inside the frames' rows of driving signals */
     int32_t *timeouts;        /* optional [1] i32 that NO kernel of this library resets: a device-wide barrier of the multi-trip launch
