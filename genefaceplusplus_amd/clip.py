@@ -96,7 +96,8 @@ class ClipRenderer:
             # that holds every CU for ~0.29 ms) 2 535 / 2 956 / 2 769 / 2 693 with 1 / 2 / 3 / 4, and 2 980 / 2 995 with 2 / 3 once the conditioning left the
             # frames: a third frame's launches only queue behind the head pass.  The super-resolution models (256^2 rays: a 0.12 ms head pass + four SR
             # launches) do gain from a third frame: 3 860 -> 4 050 frames/s
-            lanes = 3 if (getattr(model, "precision", "auto") == "fp32" or self.with_sr) else 2
+            # (round 4, frame groups of 4: 512^2 3 836 / 3 839 / 3 852 frames/s with 2 / 3 / 4 lanes -- still nothing to gain; SR models 4 822 / 5 153 / 5 375)
+            lanes = 4 if self.with_sr else (3 if getattr(model, "precision", "auto") == "fp32" else 2)
         self.lanes = max(1, int(lanes)) if fused else 1        # the staged executor synchronises with the host every trip: nothing to overlap
         self._lane = [{"rays_o": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
                        "rays_d": torch.empty(1, H * W, 3, dtype=torch.float32, device=dev),
