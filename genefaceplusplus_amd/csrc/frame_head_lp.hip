@@ -152,6 +152,17 @@ __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int s
     mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);
 }
 
+// Transcendentals of the 16-bit kernels on the hardware's exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm's range-reduced forms and IEEE
+// divisions: ~100 of a block's ~1 380 vector instructions.  Their inputs carry 8-11 significant bits (16-bit MFMA operands): the forms differ from libm's by a few
+// ulp of fp32, four orders of magnitude below that.  (The exact-fp32 kernels keep expf / tanhf.)
+__device__ __forceinline__ float lp_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float lp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + lp_exp(-x)); }
+__device__ __forceinline__ float lp_tanh(float x) {
+    // 1 - 2 / (e^{2x} + 1); |x| clamped where the result is +-1 to the last bit, so that e^{2x} never overflows
+    const float xc = fminf(fmaxf(x, -10.0f), 10.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(lp_exp(2.0f * xc) + 1.0f);
+}
+
 template <typename H>
 __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTraits<H>::vec (&b)[8]) {
     act_pack<H, 4, 1>(acc, b);
@@ -311,7 +322,7 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
         skinny_mfma<H>(sh.skinny, bh, lane, sk);
         logit = sk[3];
     }
-    const float sigma = a.density_scale * expf(logit);
+    const float sigma = a.density_scale * lp_exp(logit);
     {
         vec bcol[9];
         float shv[16];
@@ -332,9 +343,9 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     }
     if (valid && hi == 0) {
         wt.px[slot] = sigma;
-        wt.py[slot] = 1.0f / (1.0f + expf(-rgb[0]));
-        wt.pz[slot] = 1.0f / (1.0f + expf(-rgb[1]));
-        wt.cb[slot] = 1.0f / (1.0f + expf(-rgb[2]));
+        wt.py[slot] = lp_sigmoid(rgb[0]);
+        wt.pz[slot] = lp_sigmoid(rgb[1]);
+        wt.cb[slot] = lp_sigmoid(rgb[2]);
     }
 }
 
@@ -377,7 +388,7 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) {
-            const float th = tanhf(amb[d]);
+            const float th = lp_tanh(amb[d]);
             if constexpr (DBG) { if (a.dbg_ambient && valid && hi == 0) a.dbg_ambient[(size_t)c * AMB_D + d] = th; }
             ua[d] = (th + 1.0f) / 2.0f;
         }

@@ -29,6 +29,20 @@
 #ifndef GFPP_SR_ABLATE
 #define GFPP_SR_ABLATE 0
 #endif
+// experiment builds only (tools/sr_phase.py): every workgroup's first lane stamps the 100 MHz wall clock at its phase boundaries into the buffer whose address
+// the environment variable GFPP_SR_PROF_PTR carries ([layer][workgroup][8] uint64)
+#ifndef GFPP_SR_PROF
+#define GFPP_SR_PROF 0
+#endif
+#if GFPP_SR_PROF
+#define GFPP_SR_MARK(k)                                                                                                                   \
+    do {                                                                                                                                  \
+        if (a.prof && threadIdx.x == 0)                                                                                                   \
+            a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GFPP_SR_MARK(k) do { } while (0)
+#endif
 
 namespace gfpp {
 
@@ -92,6 +106,9 @@ struct SrConvArgs {
     const float *first_noise; // [H][W] or null
     float first_noise_strength;
     SrRng first_rng;
+#if GFPP_SR_PROF
+    unsigned long long *prof;
+#endif
 };
 
 __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
         }
     };
+    GFPP_SR_MARK(0);
     sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(0), wbuf[0], tid, lane);
     if constexpr (FIRST) {
         for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) s_wf[i] = a.first_w[i];
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    GFPP_SR_MARK(1);
 
     v16f acc[NU][NT];
 #pragma unroll
@@ -313,8 +332,10 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
         if (KS > 1 && it > 0 && tap == 0) {
             // next K slice: every wavefront is done with the old half patch (barrier at the end of the last iteration); its first weight chunk is
             // already in wbuf[cur]
+            GFPP_SR_MARK(5);
             if constexpr (FIRST) first_patch(it / 9); else load_patch(it / 9);
             __syncthreads();
+            GFPP_SR_MARK(6);
         }
         // the next chunk's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
         // cost half of the tap loop), into the buffer the previous chunk's MFMAs released at the last barrier; they land while this one computes
@@ -354,6 +375,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     // The noise value depends on the output pixel only (for the up-sampling layer: on the pixel and the phase = pair of row tiles), the bias on
     // the channel: both are fetched BEFORE the 2 x NT x 4 store loop (noise: at most 4 loads per lane; bias: LDS).  Inside the loop a
     // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
+    GFPP_SR_MARK(2);
     constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
     const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
     float nzv[NU][NPH];
@@ -456,6 +478,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
         }
     }
+    GFPP_SR_MARK(3);
     if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
         // the wavefront's 32 NU pixels leave as rows: 16 lanes x 16 B = the 256 contiguous bytes of one input-grid pixel (plain layers: its 128 channels;
         // up-sampling layer: the two output pixels (2Y + pass, 2X) and (2Y + pass, 2X + 1) x 64 channels, adjacent in memory), four pixels per store
@@ -473,6 +496,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             *reinterpret_cast<uint4 *>(a.y + base + chunk * 8) = row;
         }
     }
+    GFPP_SR_MARK(4);
     if constexpr (EPI == kSrFinal) {
         // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
         if (a.rng_tick) {
@@ -620,6 +644,13 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     if (const char *e = getenv("GFPP_SR_TILES")) nu = atoi(e) == 2 ? 2 : 1;
     int ks = 2;                                                     // K slices of the 128-channel layers (GFPP_SR_KSLICES=1: whole halo patch in LDS, one workgroup per CU)
     if (const char *e = getenv("GFPP_SR_KSLICES")) ks = atoi(e) == 1 ? 1 : 2;
+#if GFPP_SR_PROF
+    unsigned long long *prof_base = nullptr;
+    if (const char *e = getenv("GFPP_SR_PROF_PTR")) prof_base = (unsigned long long *)strtoull(e, nullptr, 0);
+#define GFPP_SR_PROF_SET(a, layer) (a).prof = prof_base ? prof_base + (size_t)(layer) * 2048 * 8 : nullptr
+#else
+#define GFPP_SR_PROF_SET(a, layer) do { } while (0)
+#endif
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
     int nu_up = nu;                                                 // the up-sampling layer alone (GFPP_SR_TILES_UP)
     if (const char *e = getenv("GFPP_SR_TILES_UP")) nu_up = atoi(e) == 2 ? 2 : 1;
@@ -639,6 +670,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
         a.rng = rng_of(1);
+        GFPP_SR_PROF_SET(a, 0);
         if (fuse_first) {
             a.first_rgb = rgb_in; a.first_w = (const uint4 *)m->w_first; a.first_bias = m->bias[0];
             a.first_noise = noise ? noise[0] : nullptr; a.first_noise_strength = m->noise_strength[0]; a.first_rng = rng_of(0);
@@ -654,6 +686,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
+        GFPP_SR_PROF_SET(a, 1);
         if (nu_up == 2 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
         else if (nu_up == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         else if (nu_up == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
@@ -670,6 +703,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
+        GFPP_SR_PROF_SET(a, 2);
         if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
