@@ -38,10 +38,24 @@
 #define GFPP_SR_MARK(k)                                                                                                                   \
     do {                                                                                                                                  \
         if (a.prof && threadIdx.x == 0)                                                                                                   \
-            a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+            a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// accumulated shader-clock cycles of the sections of the tap loop (wavefront 0; summed in registers, stored once: slots 8.. of the workgroup's row)
+#define GFPP_SR_CYC(var) const unsigned long long var = __builtin_readcyclecounter()
+#define GFPP_SR_SUMS unsigned long long sr_sum[4] = {0ull, 0ull, 0ull, 0ull}
+#define GFPP_SR_ACC(k, t0, t1) sr_sum[k] += (t1) - (t0)
+#define GFPP_SR_SUMS_OUT                                                                                                                  \
+    do {                                                                                                                                  \
+        if (a.prof && threadIdx.x == 0)                                                                                                   \
+            for (int k_ = 0; k_ < 4; ++k_)                                                                                                \
+                a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8 + k_] = sr_sum[k_];              \
     } while (0)
 #else
 #define GFPP_SR_MARK(k) do { } while (0)
+#define GFPP_SR_CYC(var) do { } while (0)
+#define GFPP_SR_SUMS do { } while (0)
+#define GFPP_SR_ACC(k, t0, t1) do { } while (0)
+#define GFPP_SR_SUMS_OUT do { } while (0)
 #endif
 
 namespace gfpp {
@@ -115,6 +129,23 @@ __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
     v = (v >= 0.0f ? v : 0.2f * v) * gain;
     return fminf(fmaxf(v, -clamp), clamp);
 }
+// The same function on two values in packed fp32 instructions, bit for bit: v g for v >= 0 and (0.2 v) g for v < 0 are both computed (the same roundings as the
+// select) and the larger one IS the selected one (v >= 0: v g >= 0.2 v g; v < 0: the other way round); the clamp is one median-of-three.  4.5 vector
+// instructions per value instead of 8.4 -- the epilogues of these kernels are vector-ALU bound (tools/sr_phase.py), not matrix bound.
+typedef float sr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sr_f32x2 sr_act2(sr_f32x2 v, float gain, float clamp) {
+    const sr_f32x2 pos = v * gain, neg = (v * 0.2f) * gain;
+    sr_f32x2 o;
+    o[0] = __builtin_amdgcn_fmed3f(fmaxf(pos[0], neg[0]), -clamp, clamp);
+    o[1] = __builtin_amdgcn_fmed3f(fmaxf(pos[1], neg[1]), -clamp, clamp);
+    return o;
+}
+// four accumulators + the pixel's noise + four channel biases -> activation ((acc + noise) + bias, as everywhere)
+__device__ __forceinline__ void sr_act4(const float (&acc)[4], float nz, const float4 &b, float gain, float clamp, float (&out)[4]) {
+    const sr_f32x2 lo = sr_act2((sr_f32x2{acc[0], acc[1]} + nz) + sr_f32x2{b.x, b.y}, gain, clamp);
+    const sr_f32x2 hi = sr_act2((sr_f32x2{acc[2], acc[3]} + nz) + sr_f32x2{b.z, b.w}, gain, clamp);
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = hi[0]; out[3] = hi[1];
+}
 
 // One tap's weight fragments (PER_THREAD x 256 x 16 B, already in [step][tile][lane] order) from global memory straight into LDS: the LDS address
 // of a direct load is wave-uniform base + lane x 16, which is exactly the fragment layout.
@@ -147,6 +178,54 @@ __device__ __forceinline__ void sr_lds_wait(f16x8 (&a)[NA], f16x8 (&b)[NB2]) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
 }
 
+// ---- the image side of a ToRGB epilogue: skip image (block 0: the NeRF image; block 1: upsample2d(img256)) + clamp(torgb + bias) -> image ----------------------
+template <int EPI, typename Args>
+__device__ __forceinline__ void sr_image_out(const Args &a, const float (&rgb)[3], const float *b_rgb, int Y, int X) {
+    float base[3];
+    if constexpr (EPI == kSrRgbAdd) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) base[k] = a.img_in[((size_t)Y * a.W + X) * 3 + k];
+    } else {
+        // upsample2d(img256) at (Y, X): zero insertion, [1,3,3,1] FIR, gain 4 (upfirdn2d.py:330-355) = two taps per axis.  The four source
+        // pixels are loaded unconditionally from clamped coordinates and zeroed by a select (no branch around a load, see the halo)
+        const int h2 = (int)a.H / 2, w2 = (int)a.W / 2;
+        const int ya = (Y & 1) ? (Y - 1) / 2 : Y / 2 - 1, xa = (X & 1) ? (X - 1) / 2 : X / 2 - 1;
+        const float wy[2] = {(Y & 1) ? a.fir[1] : a.fir[0], (Y & 1) ? a.fir[3] : a.fir[2]};
+        const float wx[2] = {(X & 1) ? a.fir[1] : a.fir[0], (X & 1) ? a.fir[3] : a.fir[2]};
+        float src[2][2][3];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int yy = ya + iy, xx = xa + ix;
+                const int yc = yy < 0 ? 0 : (yy >= h2 ? h2 - 1 : yy), xc = xx < 0 ? 0 : (xx >= w2 ? w2 - 1 : xx);
+                const bool in = yy >= 0 && yy < h2 && xx >= 0 && xx < w2;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float v = a.img_in[((size_t)yc * w2 + xc) * 3 + k];
+                    src[iy][ix][k] = in ? v : 0.0f;
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            base[k] = wy[0] * (wx[0] * src[0][0][k] + wx[1] * src[0][1][k]) + wy[1] * (wx[0] * src[1][0][k] + wx[1] * src[1][1][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t = fminf(fmaxf(rgb[k] + b_rgb[k], -a.clamp), a.clamp);
+        float o = base[k] + t;
+        if (EPI == kSrFinal && a.clamp01) o = fminf(fmaxf(o, 0.0f), 1.0f);
+        a.img_out[((size_t)Y * a.W + X) * 3 + k] = o;
+    }
+}
+
+// the same with `ahead` younger LDS reads allowed to stay in flight (LDS reads return in order; `ahead` must fold to a constant: the callers' loops are unrolled)
+template <int NA, int NB2>
+__device__ __forceinline__ void sr_lds_wait_n(f16x8 (&a)[NA], f16x8 (&b)[NB2], const int ahead) {
+    static_assert(NB2 == 1 && NA == 2, "the operand set of the walk that uses it");
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]) : "n"(ahead) : "memory");
+}
+
 // NU = 32-column MFMA tiles per wavefront: 2 (round 1-2) = 4 wavefronts of 64 pixels, one per SIMD; 1 = 8 wavefronts of 32 pixels, two per SIMD --
 // a weight fragment then feeds one MFMA instead of two (1.25 KB of LDS operands per MFMA instead of 0.75: still below the LDS's 128 B/clk), but the
 // second wavefront of a SIMD runs under the first one's LDS latency, tap barriers and epilogue stores.
@@ -162,7 +241,10 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     constexpr int kSrThreads = 512 / NU;           // (shadows the namespace constant: this kernel's workgroup size)
     typedef LpTraits<_Float16>::vec vec;
     constexpr int CINH = CIN / KS;               // channels of one K slice
-    constexpr int PS = CINH + 8;                 // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
+    // FIRST computes its input itself, once, for all channels: the whole patch stays in LDS (the launch has one workgroup per CU anyway); the weight chunks
+    // and the accumulation order stay those of the K-sliced walk
+    constexpr int PCH = FIRST ? CIN : CINH;      // channels of the LDS patch
+    constexpr int PS = PCH + 8;                  // pixel stride in halves (16 B of padding: conflict-free ds_read_b128 across a row)
     constexpr int STEPS = CIN / 16, STEPS_H = CINH / 16;
     constexpr int TAPFRAGS = STEPS * NT * 64;    // 16-byte fragments of one tap (all channels)
     constexpr int CHUNKFRAGS = STEPS_H * NT * 64;   // ... of one (tap, K slice) chunk: what is staged through LDS at a time
@@ -170,6 +252,9 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     static_assert(CHUNKFRAGS % kSrThreads == 0, "chunk weights must split evenly over the workgroup");
     // halo patch | two weight-chunk buffers; after the last chunk the same memory stages the f16 output of the workgroup (a row of 128 halves + 16 B
     // of padding per input-grid pixel), so that it leaves as whole 256-byte rows instead of 8-byte pieces
+    // (Measured and dropped for the FIRST instantiation, which has registers and LDS to spare: a ring of three weight chunks with the operand reads three steps
+    // ahead of the MFMAs across the chunk barrier -- wavefront 0's walk 11.2 -> 9.4 k-cycles, the launch unchanged: the tap loops run at 85-90 % MFMA-pipe
+    // occupancy IN CYCLES already, at the ~1.4 GHz the chip sustains under dense MFMA on every CU (tools/sr_phase.py, tools/clock_probe_sr.py).)
     constexpr int PATCH_BYTES = kSrHalo * kSrHalo * PS * 2, WBUF_BYTES = 2 * CHUNKFRAGS * 16;
     constexpr int SROW = NT * 32 + 8;            // staging row in halves
     constexpr int STAGE_BYTES = (EPI != kSrFinal) ? kSrPatch * kSrPatch * SROW * 2 : 0;
@@ -185,6 +270,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     __shared__ float s_in[FIRST ? kInSide * kInSide * 3 : 1];
     __shared__ uint4 s_wf[FIRST ? 2 * 4 * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_fb[FIRST ? 128 : 1];
+    __shared__ float s_nz[FIRST ? kSrHalo * kSrHalo : 1];           // FIRST: the first layer's noise term per halo pixel (drawn once, not once per tile and slice)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
@@ -223,11 +309,11 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
         }
     };
-    // FIRST: channels [kh CINH, (kh + 1) CINH) of the first convolution at the 324 halo pixels, 32 pixels per MFMA tile, tiles dealt out to the wavefronts
-    [[maybe_unused]] auto first_patch = [&](int kh) {
+    // FIRST: the first convolution at the 324 halo pixels, 32 pixels x 64 channels per unit (11 pixel tiles x 2 channel halves), units dealt out to the wavefronts
+    [[maybe_unused]] auto first_patch = [&]() {
         constexpr int HP = kSrHalo * kSrHalo, TILES = (HP + 31) / 32, TL = CINH / 32;
-        const unsigned long long fctr = a.first_rng.state ? a.first_rng.state[0] : 0ull;
-        for (int tile = wave; tile < TILES; tile += kSrThreads / 64) {
+        for (int unit = wave; unit < TILES * KS; unit += kSrThreads / 64) {
+            const int tile = unit % TILES, kh = unit / TILES;
             const int pp = tile * 32 + j, ppc = pp < HP ? pp : HP - 1;
             const int hy = ppc / kSrHalo, hx = ppc % kSrHalo;
             v16f facc[TL];
@@ -254,9 +340,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
             const int Y = y0 - 1 + hy, X = x0 - 1 + hx;
             const bool in = Y >= 0 && Y < (int)a.H && X >= 0 && X < (int)a.W;
-            const size_t at = in ? (size_t)Y * a.W + X : 0;
-            const float nz = a.first_noise ? a.first_noise[at] * a.first_noise_strength
-                                           : (a.first_rng.state ? sr_randn(a.first_rng, fctr, (uint32_t)at) * a.first_noise_strength : 0.0f);
+            const float nz = s_nz[ppc];
             if (pp < HP) {
 #pragma unroll
                 for (int t = 0; t < TL; ++t)
@@ -264,10 +348,13 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
                     for (int q = 0; q < 4; ++q) {
                         const int nl = 32 * t + 8 * q + 4 * hi, ng = kh * CINH + nl;
                         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        const float av[4] = {facc[t][4 * q], facc[t][4 * q + 1], facc[t][4 * q + 2], facc[t][4 * q + 3]};
+                        float v[4];
+                        sr_act4(av, nz, *reinterpret_cast<const float4 *>(&s_fb[ng]), a.act_gain, a.clamp, v);
                         h4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = in ? (_Float16)sr_act(facc[t][4 * q + e] + nz + s_fb[ng + e], a.act_gain, a.clamp) : (_Float16)0.0f;   // zero padding of THIS layer's input
-                        *reinterpret_cast<h4 *>(&patch[pp * PS + nl]) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = in ? (_Float16)v[e] : (_Float16)0.0f;   // zero padding of THIS layer's input
+                        *reinterpret_cast<h4 *>(&patch[pp * PS + ng]) = o;
                     }
             }
         }
@@ -288,6 +375,15 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
             hv[q] = a.first_rgb[((size_t)py * a.W + px) * 3 + c];
         }
+        // (the noise of the halo pixels is drawn while the image loads are in flight)
+        if (tid < kSrHalo * kSrHalo) {
+            const int Y = y0 - 1 + tid / kSrHalo, X = x0 - 1 + tid % kSrHalo;
+            const bool in = Y >= 0 && Y < (int)a.H && X >= 0 && X < (int)a.W;
+            const size_t at = in ? (size_t)Y * a.W + X : 0;
+            const unsigned long long fctr = a.first_rng.state ? a.first_rng.state[0] : 0ull;
+            s_nz[tid] = a.first_noise ? a.first_noise[at] * a.first_noise_strength
+                                      : (a.first_rng.state ? sr_randn(a.first_rng, fctr, (uint32_t)at) * a.first_noise_strength : 0.0f);
+        }
 #pragma unroll
         for (int q = 0; q < IT; ++q) {
             const int i = q * kSrThreads + tid;
@@ -299,7 +395,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
         }
         __syncthreads();
-        first_patch(0);
+        first_patch();
     } else {
         load_patch(0);
     }
@@ -327,38 +423,41 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     const int prow = 2 * NU * wave + (j >> 4), pcol = j & 15;
     int cur = 0;
     constexpr int ITERS = 9 * KS;
+    auto b_base = [&](int it2) {
+        const int tap = it2 % 9;
+        return sr_lds_addr(&patch[((prow + tap / 3) * kSrHalo + pcol + tap % 3) * PS + (FIRST ? (it2 / 9) * CINH : 0) + 8 * hi]);
+    };
+    vec Bq[2][NU], Aq[2][NT];
+    GFPP_SR_SUMS;
+    auto read_ops = [&](uint32_t b0, uint32_t wl, int s2, vec (&B)[NU], vec (&A)[NT]) {   // (sr_lds_read128: see above)
+        sr_lds_read128(B[0], b0 + 32u * (uint32_t)s2);
+        if constexpr (NU == 2) sr_lds_read128(B[1], b0 + 2u * kSrHalo * PS * 2u + 32u * (uint32_t)s2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sr_lds_read128(A[t], wl + (uint32_t)(s2 * NT + t) * 1024u);
+    };
     for (int it = 0; it < ((GFPP_SR_ABLATE & 1) ? 0 : ITERS); ++it) {
+        GFPP_SR_CYC(c_top);
         const int tap = it % 9;
-        if (KS > 1 && it > 0 && tap == 0) {
+        if (KS > 1 && !FIRST && it > 0 && tap == 0) {
             // next K slice: every wavefront is done with the old half patch (barrier at the end of the last iteration); its first weight chunk is
             // already in wbuf[cur]
             GFPP_SR_MARK(5);
-            if constexpr (FIRST) first_patch(it / 9); else load_patch(it / 9);
+            load_patch(it / 9);
             __syncthreads();
             GFPP_SR_MARK(6);
         }
         // the next chunk's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
         // cost half of the tap loop), into the buffer the previous chunk's MFMAs released at the last barrier; they land while this one computes
-        if (it + 1 < ITERS && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[cur ^ 1], tid, lane);
-        const int dy = tap / 3, dx = tap % 3;
-        const uint32_t b0 = sr_lds_addr(&patch[((prow + dy) * kSrHalo + pcol + dx) * PS + 8 * hi]);
-        const uint32_t b1 = b0 + 2u * kSrHalo * PS * 2u;
-        const uint32_t wl = sr_lds_addr(wbuf[cur]) + (uint32_t)lane * 16u;
-        // operands of step s + 1 are read while the NU x NT MFMAs of step s run (sr_lds_read128: see above)
-        vec Bq[2][NU], Aq[2][NT];
-        sr_lds_read128(Bq[0][0], b0);
-        if constexpr (NU == 2) sr_lds_read128(Bq[0][1], b1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) sr_lds_read128(Aq[0][t], wl + (uint32_t)t * 1024u);
+        const int nxt = cur ^ 1;
+        if (it + 1 < ITERS && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[nxt], tid, lane);
+        GFPP_SR_CYC(c_begin);
+        const uint32_t b0 = b_base(it), wl = sr_lds_addr(wbuf[cur]) + (uint32_t)lane * 16u;
+        // operands of step s + 1 are read while the NU x NT MFMAs of step s run
+        read_ops(b0, wl, 0, Bq[0], Aq[0]);
         sr_lds_wait<NT, NU>(Aq[0], Bq[0]);
 #pragma unroll
         for (int s = 0; s < STEPS_H; ++s) {
-            if (s + 1 < STEPS_H) {
-                sr_lds_read128(Bq[(s + 1) & 1][0], b0 + 32u * (uint32_t)(s + 1));
-                if constexpr (NU == 2) sr_lds_read128(Bq[(s + 1) & 1][1], b1 + 32u * (uint32_t)(s + 1));
-#pragma unroll
-                for (int t = 0; t < NT; ++t) sr_lds_read128(Aq[(s + 1) & 1][t], wl + (uint32_t)((s + 1) * NT + t) * 1024u);
-            }
+            if (s + 1 < STEPS_H) read_ops(b0, wl, s + 1, Bq[(s + 1) & 1], Aq[(s + 1) & 1]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[0][t] = LpTraits<_Float16>::mfma(Aq[s & 1][t], Bq[s & 1][0], acc[0][t]);
@@ -366,9 +465,16 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
             if (s + 1 < STEPS_H) sr_lds_wait<NT, NU>(Aq[(s + 1) & 1], Bq[(s + 1) & 1]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the next chunk has landed in LDS
+        GFPP_SR_CYC(c_walked);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the chunk being staged has landed in LDS
+        GFPP_SR_CYC(c_landed);
         __syncthreads();
-        cur ^= 1;
+        GFPP_SR_CYC(c_met);
+        GFPP_SR_ACC(0, c_begin, c_walked);
+        GFPP_SR_ACC(1, c_walked, c_landed);
+        GFPP_SR_ACC(2, c_landed, c_met);
+        GFPP_SR_ACC(3, c_top, c_begin);
+        cur = nxt;
     }
 
     // ---- epilogue: noise + bias, leaky relu * gain, clamp; store / ToRGB ----------------------------------------------------------
@@ -376,6 +482,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     // the channel: both are fetched BEFORE the 2 x NT x 4 store loop (noise: at most 4 loads per lane; bias: LDS).  Inside the loop a
     // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
     GFPP_SR_MARK(2);
+    GFPP_SR_SUMS_OUT;
     constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
     const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
     float nzv[NU][NPH];
@@ -410,10 +517,8 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
                     OW = 2 * a.W; OC = 64;
                 }
                 const float nz = nzv[u][EPI == kSrUpPhases ? t / 2 : 0];
-                const float4 bq = *reinterpret_cast<const float4 *>(&s_bias[n0]);
-                const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = sr_act(acc[u][t][4 * q + e] + nz + bv[e], a.act_gain, a.clamp);
+                const float av[4] = {acc[u][t][4 * q], acc[u][t][4 * q + 1], acc[u][t][4 * q + 2], acc[u][t][4 * q + 3]};
+                sr_act4(av, nz, *reinterpret_cast<const float4 *>(&s_bias[n0]), a.act_gain, a.clamp, v);
 
                 if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
                     // into the wavefront's own rows of the staging area (every wavefront is past the last chunk's barrier: patch and weight buffers are free)
@@ -438,44 +543,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
         if constexpr (EPI == kSrRgbAdd || EPI == kSrFinal) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
-            if (hi == 0) {
-                float base[3];
-                if constexpr (EPI == kSrRgbAdd) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) base[k] = a.img_in[((size_t)Y * a.W + X) * 3 + k];
-                } else {
-                    // upsample2d(img256) at (Y, X): zero insertion, [1,3,3,1] FIR, gain 4 (upfirdn2d.py:330-355) = two taps per axis.  The four source
-                    // pixels are loaded unconditionally from clamped coordinates and zeroed by a select (no branch around a load, see the halo)
-                    const int h2 = (int)a.H / 2, w2 = (int)a.W / 2;
-                    const int ya = (Y & 1) ? (Y - 1) / 2 : Y / 2 - 1, xa = (X & 1) ? (X - 1) / 2 : X / 2 - 1;
-                    const float wy[2] = {(Y & 1) ? a.fir[1] : a.fir[0], (Y & 1) ? a.fir[3] : a.fir[2]};
-                    const float wx[2] = {(X & 1) ? a.fir[1] : a.fir[0], (X & 1) ? a.fir[3] : a.fir[2]};
-                    float src[2][2][3];
-#pragma unroll
-                    for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                        for (int ix = 0; ix < 2; ++ix) {
-                            const int yy = ya + iy, xx = xa + ix;
-                            const int yc = yy < 0 ? 0 : (yy >= h2 ? h2 - 1 : yy), xc = xx < 0 ? 0 : (xx >= w2 ? w2 - 1 : xx);
-                            const bool in = yy >= 0 && yy < h2 && xx >= 0 && xx < w2;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const float v = a.img_in[((size_t)yc * w2 + xc) * 3 + k];
-                                src[iy][ix][k] = in ? v : 0.0f;
-                            }
-                        }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        base[k] = wy[0] * (wx[0] * src[0][0][k] + wx[1] * src[0][1][k]) + wy[1] * (wx[0] * src[1][0][k] + wx[1] * src[1][1][k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float t = fminf(fmaxf(rgb[k] + s_rgb[NT * 32 * 3 + k], -a.clamp), a.clamp);
-                    float o = base[k] + t;
-                    if (EPI == kSrFinal && a.clamp01) o = fminf(fmaxf(o, 0.0f), 1.0f);
-                    a.img_out[((size_t)Y * a.W + X) * 3 + k] = o;
-                }
-            }
+            if (hi == 0) sr_image_out<EPI>(a, rgb, &s_rgb[NT * 32 * 3], Y, X);
         }
     }
     GFPP_SR_MARK(3);
@@ -509,6 +577,144 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
                     atomicAdd(&a.rng_tick[0], 1ull);
                 }
             }
+        }
+    }
+}
+
+// ---- block 1's last layer (64 -> 64 @ 512^2 + ToRGB + image up-sampling) with its weights RESIDENT -------------------------------------------------------------
+// The layer's folded weights are 72 KB: they fit in LDS next to one 46 KB halo patch.  One workgroup per CU loads them once and walks over its share of the
+// 1 024 patches: no weight chunk and no barrier inside a patch's 72 MFMAs per wavefront (the per-patch launch had nine barrier-separated 8 KB chunks: 5.6 us of
+// tap loop for 1.9 us of matrix work, tools/sr_phase.py), the index arithmetic of the halo load done once, and the NEXT patch's halo in flight (registers) under
+// the current patch's taps and epilogue.  The 36-step walk keeps its operands DEPTH steps ahead of the MFMAs: a step is only two MFMAs (64 cycles) and an LDS
+// read under eight wavefronts' traffic takes longer than that.
+// (Measured and dropped: the eight wavefronts as two groups of four on 16 x 8 half patches in opposite phases -- one multiplies while the other runs its epilogue
+// -- 34.5 us per launch against 31.5: a wavefront's walk and its epilogue are latency chains, not throughput, and halving the wavefronts per phase halves what
+// hides them.)
+// Same fragments, same tap / step order, same epilogue arithmetic per pixel as k_sr_conv3<64, 2, kSrFinal>: the same bits (that launch stays as the A/B partner,
+// GFPP_SR_FINAL_RESIDENT=0; tests/test_kernels_gpu.py compares the two).
+__global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
+    typedef LpTraits<_Float16>::vec vec;
+    constexpr int CIN = 64, NT = 2, STEPS = CIN / 16, PS = CIN + 8, TAPFRAGS = STEPS * NT * 64, THREADS = 512;
+    constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CIN / 8), HALO_ITERS = (HALO_CHUNKS + THREADS - 1) / THREADS;
+    __shared__ __attribute__((aligned(16))) uint4 wall[9 * TAPFRAGS];
+    __shared__ __attribute__((aligned(16))) _Float16 patch[kSrHalo * kSrHalo * PS];
+    __shared__ float s_rgb[NT * 32 * 3 + 4];
+    __shared__ __attribute__((aligned(16))) float s_bias[NT * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int n_px = (int)a.W / kSrPatch, n_patches = n_px * ((int)a.H / kSrPatch);
+    GFPP_SR_MARK(0);
+
+    sr_stage_tap<9 * TAPFRAGS / THREADS, THREADS>(a.w, wall, tid, lane);
+    for (int i = tid; i < NT * 32; i += THREADS) s_bias[i] = a.bias[i];
+    for (int i = tid; i < NT * 32 * 3; i += THREADS) s_rgb[i] = a.w_rgb[i];
+    if (tid < 3) s_rgb[NT * 32 * 3 + tid] = a.b_rgb[tid];
+
+    // this thread's chunks of a halo: (row, column) in the 18 x 18 patch and the 8-channel group, the same for every patch
+    // (one packed word per chunk: halo pixel | 8-channel group << 9 | row << 12 | column << 17 -- four separate arrays cost the walk its registers)
+    int hpk[HALO_ITERS];
+#pragma unroll
+    for (int q = 0; q < HALO_ITERS; ++q) {
+        const int i = q * THREADS + tid, ic = i < HALO_CHUNKS ? i : HALO_CHUNKS - 1;
+        const int pp = ic / (CIN / 8), c8 = ic % (CIN / 8);
+        hpk[q] = pp | (c8 << 9) | ((pp / kSrHalo) << 12) | ((pp % kSrHalo) << 17);
+    }
+    uint4 hv[HALO_ITERS];
+    auto issue = [&](int p) {        // unconditional loads from clamped coordinates (no branch around a load, see k_sr_conv3)
+        const int y0 = (p / n_px) * kSrPatch - 1, x0 = (p % n_px) * kSrPatch - 1;
+#pragma unroll
+        for (int q = 0; q < HALO_ITERS; ++q) {
+            int py = y0 + ((hpk[q] >> 12) & 31), px = x0 + ((hpk[q] >> 17) & 31);
+            py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
+            px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
+            hv[q] = *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + ((hpk[q] >> 9) & 7) * 8);
+        }
+    };
+    auto commit = [&](int p) {       // zero padding outside the image by select
+        const int y0 = (p / n_px) * kSrPatch - 1, x0 = (p % n_px) * kSrPatch - 1;
+#pragma unroll
+        for (int q = 0; q < HALO_ITERS; ++q) {
+            if (q * THREADS + tid < HALO_CHUNKS) {
+                const int py = y0 + ((hpk[q] >> 12) & 31), px = x0 + ((hpk[q] >> 17) & 31);
+                const bool in = py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W;
+                *reinterpret_cast<uint4 *>(&patch[(hpk[q] & 511) * PS + ((hpk[q] >> 9) & 7) * 8]) = in ? hv[q] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
+    const int prow = 2 * wave + (j >> 4), pcol = j & 15;
+    const uint32_t wl = sr_lds_addr(wall) + (uint32_t)lane * 16u;
+    int p = (int)blockIdx.x;
+    if (p < n_patches) issue(p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the weights have landed (and the first halo)
+    for (; p < n_patches; p += (int)gridDim.x) {
+        commit(p);
+        if (p + (int)gridDim.x < n_patches) issue(p + (int)gridDim.x);
+        __syncthreads();
+        GFPP_SR_MARK(1);
+        const int y0 = (p / n_px) * kSrPatch, x0 = (p % n_px) * kSrPatch;
+
+        v16f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        constexpr int DEPTH = 3, RING = DEPTH + 1, TOTAL = 9 * STEPS;
+        vec Bq[RING][1], Aq[RING][NT];
+        auto read_step = [&](int gs, vec (&B)[1], vec (&A)[NT]) {       // gs = tap * STEPS + s
+            const int tap = gs / STEPS, s2 = gs % STEPS;
+            const uint32_t b0 = sr_lds_addr(&patch[((prow + tap / 3) * kSrHalo + pcol + tap % 3) * PS + 8 * hi]) + 32u * (uint32_t)s2;
+            sr_lds_read128(B[0], b0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sr_lds_read128(A[t], wl + (uint32_t)(gs * NT + t) * 1024u);
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) read_step(d, Bq[d], Aq[d]);
+#pragma unroll
+        for (int gs = 0; gs < TOTAL; ++gs) {
+            if (gs + DEPTH < TOTAL) read_step(gs + DEPTH, Bq[(gs + DEPTH) % RING], Aq[(gs + DEPTH) % RING]);
+            // the reads of the steps after this one may stay in flight: (NT + 1) each
+            const int ahead = (TOTAL - 1 - gs < DEPTH ? TOTAL - 1 - gs : DEPTH) * (NT + 1);
+            sr_lds_wait_n<NT, 1>(Aq[gs % RING], Bq[gs % RING], ahead);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = LpTraits<_Float16>::mfma(Aq[gs % RING][t], Bq[gs % RING][0], acc[t]);
+        }
+        GFPP_SR_MARK(2);
+
+        // epilogue of k_sr_conv3<64, 2, kSrFinal>: noise + bias, leaky relu * gain, clamp; ToRGB on the f16-rounded activation; image
+        const int Y = y0 + prow, X = x0 + pcol;
+        const size_t at = (size_t)Y * a.W + X;
+        const float nz = a.noise ? a.noise[at] * a.noise_strength : (a.rng.state ? sr_randn(a.rng, frame_ctr, (uint32_t)at) * a.noise_strength : 0.0f);
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = 32 * t + 8 * q + 4 * hi;
+                const float av[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                float v[4];
+                sr_act4(av, nz, *reinterpret_cast<const float4 *>(&s_bias[n0]), a.act_gain, a.clamp, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xv = (float)(_Float16)v[e];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rgb[k] = fmaf(xv, s_rgb[(n0 + e) * 3 + k], rgb[k]);
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
+        if (hi == 0) sr_image_out<kSrFinal>(a, rgb, &s_rgb[NT * 32 * 3], Y, X);
+        GFPP_SR_MARK(3);
+        __syncthreads();                 // every wavefront is done with the patch
+    }
+    GFPP_SR_MARK(4);
+    // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
+    if (a.rng_tick && tid == 0) {
+        if (atomicAdd(&a.rng_tick[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            a.rng_tick[1] = 0ull;
+            __threadfence();
+            atomicAdd(&a.rng_tick[0], 1ull);
         }
     }
 }
@@ -647,7 +853,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
 #if GFPP_SR_PROF
     unsigned long long *prof_base = nullptr;
     if (const char *e = getenv("GFPP_SR_PROF_PTR")) prof_base = (unsigned long long *)strtoull(e, nullptr, 0);
-#define GFPP_SR_PROF_SET(a, layer) (a).prof = prof_base ? prof_base + (size_t)(layer) * 2048 * 8 : nullptr
+#define GFPP_SR_PROF_SET(a, layer) (a).prof = prof_base ? prof_base + (size_t)(layer) * 2048 * 16 : nullptr
 #else
 #define GFPP_SR_PROF_SET(a, layer) do { } while (0)
 #endif
@@ -704,7 +910,18 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
         GFPP_SR_PROF_SET(a, 2);
-        if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
+        bool resident = true;                                       // GFPP_SR_FINAL_RESIDENT=0: one workgroup per patch, weights streamed (A/B runs, parity partner)
+        if (const char *e = getenv("GFPP_SR_FINAL_RESIDENT")) resident = atoi(e) != 0;
+        if (resident && nu_fin == 1) {
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                cus = n;
+            }
+            const int patches = (int)(2 * R / kSrPatch) * (int)(2 * R / kSrPatch);
+            hipLaunchKernelGGL(k_sr_final_resident, dim3(cus < patches ? cus : patches), dim3(512), 0, st, a);
+        } else if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;

@@ -421,6 +421,30 @@ def test_superresolution_first_layer_inside_the_second_equals_its_own_launch(dev
     assert (noise_mode == "random") == (not np.array_equal(outs[0][0], outs[0][1]))
 
 
+@pytest.mark.parametrize("noise_mode", ["const", "random", "none"])
+def test_superresolution_last_layer_with_resident_weights_equals_the_per_patch_launch(dev, monkeypatch, noise_mode):
+    """Block 1's last convolution as one workgroup per CU walking over its patches with the layer's 72 KB of weights resident in LDS (k_sr_final_resident)
+    against one workgroup per patch with streamed weight chunks (k_sr_conv3<64, 2, final>, GFPP_SR_FINAL_RESIDENT=0): same fragments, same tap and step order,
+    same epilogue -- the 512^2 image bit for bit over two frames (the frame counter advances the same way), image borders included."""
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.radnerfs.superres import Superresolution
+    sd = syn.synthetic_sr_state(prefix="")
+    rng = np.random.default_rng(13)
+    x = torch.from_numpy(rng.random((1, 3, 256, 256)).astype(np.float32)).to(dev)
+    outs = []
+    for resident in ("0", "1"):
+        monkeypatch.setenv("GFPP_SR_FINAL_RESIDENT", resident)
+        net = Superresolution(channels=3)
+        net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+        net = net.to(dev).eval()
+        with torch.no_grad():
+            net.reseed(78)
+            outs.append([net(x, noise_mode=noise_mode).cpu().numpy() for _ in range(3)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert (noise_mode == "random") == (not np.array_equal(outs[0][0], outs[0][1]))
+
+
 def test_occupancy_bounds_enclose_exactly_the_set_cells(dev):
     """gfpp_occupancy_bounds against a numpy walk over the set bits (Morton order, raymarching.cu:56-88; two cascades), plus the empty bitfield."""
     import ctypes
