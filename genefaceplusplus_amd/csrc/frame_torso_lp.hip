@@ -202,7 +202,8 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
                 for (int e = 0; e < 8; ++e) {
                     const int k = 16 * s + 8 * hi + e;
                     const float xk = (k & 1) ? x1 : x0;
-                    const float v = k < 2 ? xk : (k < 42 ? freq_feature(xk, (uint32_t)(k / 2 - 1)) : 0.0f);
+                    float v = k < 2 ? xk : (k < 42 ? freq_feature(xk, (uint32_t)(k / 2 - 1)) : 0.0f);
+                    if constexpr (sizeof(H) == 2) v = k < 2 ? xk : (k < 42 ? freq_feature_fast(xk, (uint32_t)(k / 2 - 1)) : 0.0f);   // (the exact-fp32 instantiation keeps sinf)
                     bex[s][e] = (H)v;
                 }
 

@@ -3,8 +3,8 @@
 //                 reference's kernel_sh (modules/radnerfs/encoders/shencoder/src/shencoder.cu:44-68).
 //   freq_feature: one sin/cos feature of the frequency encoding (encoders/freqencoder/src/freqencoder.cu:46-56):
 //                 column `col` = 2*octave + is_cos, value sin(x * 2^octave + is_cos * pi/2).
-//                 The reference uses the __sinf fast intrinsic; we use the correctly-rounded-ish ocml sinf
-//                 (documented tolerance against either).
+//                 The reference uses the __sinf fast intrinsic; the fp32 paths use the correctly-rounded-ish ocml sinf
+//                 (documented tolerance against either), the 16-bit torso kernel the hardware sine (freq_feature_fast).
 #pragma once
 
 #include "gfpp_common.h"
@@ -60,6 +60,15 @@ __device__ __forceinline__ float freq_feature(float x, uint32_t col) {
     const uint32_t octave = col >> 1;
     const float phase = (float)(col & 1u) * (3.141592653589793f / 2);
     return sinf(scalbnf(x, (int)octave) + phase);
+}
+
+// The same feature on the hardware sine (v_sin_f32 on the argument in revolutions -- what the reference's __sinf compiles to on its GPU, freqencoder.cu:56), for
+// features that become 16-bit MFMA operands: |argument| <= 2^9 here, absolute error ~1e-5, two orders of magnitude below the operand rounding.  ocml's sinf
+// carries a Payne-Hanek reduction for large arguments that the compiler inlines at every call: ~140 vector instructions per feature against 4.
+__device__ __forceinline__ float freq_feature_fast(float x, uint32_t col) {
+    const uint32_t octave = col >> 1;
+    const float phase = (float)(col & 1u) * (3.141592653589793f / 2);
+    return __sinf(scalbnf(x, (int)octave) + phase);
 }
 
 }  // namespace gfpp

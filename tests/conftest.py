@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun); everything else runs on CPU")
 
 
+def pytest_report_header(config):
+    # an experiment build selected with GFPP_LIB_PATH (tools/build_variant.sh) must never pass for the shipped library unnoticed
+    lib = os.environ.get("GFPP_LIB_PATH")
+    return f"WARNING: GFPP_LIB_PATH={lib}: these tests run on an experiment build, not on genefaceplusplus_amd/libgfpp_radnerf.so" if lib else None
+
+
+def pytest_sessionstart(session):
+    lib = os.environ.get("GFPP_LIB_PATH")
+    if lib and os.environ.get("GFPP_ALLOW_LIB_OVERRIDE") != "1" and not os.path.basename(lib).startswith("lib_"):
+        raise pytest.UsageError(f"GFPP_LIB_PATH={lib} is neither the shipped library nor a tools/build_variant.sh build (lib_<name>.so); "
+                                "set GFPP_ALLOW_LIB_OVERRIDE=1 to run the suite on it anyway")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
