@@ -861,6 +861,30 @@ def main():
                               "frames_in_flight": cr_sr.lanes, "frames_per_graph_launch": cr_sr.group,
                               "roofline": head_roofline(m_sr, hp_sr, x_s, 256 * 256, "may_torso_sr", frames_per_launch=cr_sr.group, ms_per_frame_period=1e3 * dt / n_s,
                                                         pmc_tag=f"may_torso_sr_256_{args.precision}")}
+                    # the super-resolution stage alone (4 launches, 77.3 GFLOP of f16 MFMA work per forward), HIP events on torch's current stream (the one
+                    # Superresolution.forward launches on), noise drawn in the kernels as the frame loop does
+                    try:
+                        x_img = torch.rand(1, 3, 256, 256, device=dev)
+                        for _ in range(5):
+                            m_sr.sr_net(x_img, noise_mode="random", clamp01=True)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        reps = 100
+                        e0.record()
+                        for _ in range(reps):
+                            m_sr.sr_net(x_img, noise_mode="random", clamp01=True)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us = e0.elapsed_time(e1) / reps * 1e3
+                        gflop = 19.327 + 38.655 + 19.327
+                        sr_cfg["sr_stage"] = {"kernels": "k_sr_conv3<128,first fused> + k_sr_conv3<128,up> + k_sr_final_resident (3 launches; genefaceplusplus_amd/csrc/superres.hip)",
+                                              "us_per_forward": round(us, 2), "gflop_per_forward": round(gflop, 2), "bound": "mfma",
+                                              "achieved": round(gflop / us * 1e-3, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gflop / us * 1e-3 / 2500.0, 4),
+                                              "sustained_clock_note": "the tap loops of these kernels run at 85-91 % MFMA-pipe occupancy in cycles, at the ~1.4 GHz the part sustains "
+                                                                      "under dense f16 MFMA on all 256 CUs (tools/sr_phase.py, tools/clock_probe_sr.py; docs/LAB_NOTEBOOK.md): "
+                                                                      "the data-sheet peak assumes 2.4 GHz",
+                                              "frac_of_sustained_clock_peak": round(gflop / us * 1e-3 / (2500.0 * 1.4 / 2.4), 4)}
+                    except Exception as exc:
+                        sr_cfg["sr_stage"] = {"error": str(exc)}
                     result.setdefault("configs", {})["may_torso_sr_256"] = sr_cfg
                 except Exception as exc:
                     result.setdefault("configs", {})["may_torso_sr_256"] = {"error": str(exc)}
