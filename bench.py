@@ -878,11 +878,11 @@ def main():
                         gflop = 19.327 + 38.655 + 19.327
                         sr_cfg["sr_stage"] = {"kernels": "k_sr_conv3<128,first fused> + k_sr_conv3<128,up> + k_sr_final_resident (3 launches; genefaceplusplus_amd/csrc/superres.hip)",
                                               "us_per_forward": round(us, 2), "gflop_per_forward": round(gflop, 2), "bound": "mfma",
-                                              "achieved": round(gflop / us * 1e-3, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gflop / us * 1e-3 / 2500.0, 4),
+                                              "achieved": round(gflop / us * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gflop / us * 1e3 / 2500.0, 4),
                                               "sustained_clock_note": "the tap loops of these kernels run at 85-91 % MFMA-pipe occupancy in cycles, at the ~1.4 GHz the part sustains "
                                                                       "under dense f16 MFMA on all 256 CUs (tools/sr_phase.py, tools/clock_probe_sr.py; docs/LAB_NOTEBOOK.md): "
                                                                       "the data-sheet peak assumes 2.4 GHz",
-                                              "frac_of_sustained_clock_peak": round(gflop / us * 1e-3 / (2500.0 * 1.4 / 2.4), 4)}
+                                              "frac_of_sustained_clock_peak": round(gflop / us * 1e3 / (2500.0 * 1.4 / 2.4), 4)}
                     except Exception as exc:
                         sr_cfg["sr_stage"] = {"error": str(exc)}
                     result.setdefault("configs", {})["may_torso_sr_256"] = sr_cfg

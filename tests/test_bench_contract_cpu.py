@@ -6,28 +6,45 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(HERE, "..", "profiles", "r03_bench_final.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+    d = json.load(open(os.path.join(HERE, "..", "profiles", "r04_bench_final.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["dtype"] in ("f16", "bf16", "f32") and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]          # whole-job throughput == frames / time
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["steps"] == 20 and d["warmup"] == 5                     # the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 2e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches_per_frame"] == 1 and "limiter" in r and r["l2"]["peak"] > r["peak"]      # one persistent launch; the level that serves the stream is labelled
-    assert d["config"]["host_issue_ms_per_frame"] <= 0.05                          # the frame loop is issued from C
-    assert "roofline" in d["configs"]["may_torso_sr_256"]                          # the released checkpoint's own configuration carries its own roofline
-    assert d["dtype"] == "bf16" and "bf16" not in d["modes"]                       # BASELINE configs[2] literally is the headline
-    assert d["modes"]["long_run"]["frames"] >= 2000 and d["modes"]["long_run"]["block_std"] >= 0
-    assert d["configs"]["may_head_fp32_latency"]["frames"] >= 200 and d["configs"]["may_head_fp32_latency"]["latency_ms_p99"] >= d["configs"]["may_head_fp32_latency"]["latency_ms_p50"]
-    assert d["configs"]["crop64_cpu_oracle"]["rays_per_step"] == 1024
-    assert d["grid_stage_ray_stream"]["frac"] is None                              # a cache-served stream carries no HBM fraction
+    # round 4: a head launch renders a group of consecutive frames; the line says so and prices the launch on all its samples
+    assert r["frames_per_launch"] == 4 and r["launches_per_frame"] == 0.25
+    assert r["samples_per_launch"] == r["frames_per_launch"] * r["samples_per_frame"]
+    assert abs(r["achieved"] - r["samples_per_launch"] * r["bytes_per_sample"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 2e-3
+    assert 0.0 < r["effective_frac_per_frame_period"] <= r["frac"]
+    assert r["as_read"]["bytes_per_sample"] == 1036 and r["mfma"]["frac"] > 0.15
+    # the counter pass attached to the line is the one of THIS workload (variant, frame side, precision, frames per launch)
+    assert r["pmc"]["workload"].startswith("may_torso 512x512 bf16, 4 frame(s) per head launch")
+    assert abs(r["traffic"] - r["pmc"]["fabric_bytes_per_launch"]) <= 1
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    cfg = d["configs"]
+    assert {"may_torso_sr_256", "may_torso_no_termination"} <= set(cfg)
+    sr = cfg["may_torso_sr_256"]
+    assert sr["roofline"]["frames_per_launch"] == 4 and sr["roofline"]["frac"] >= 0.60
+    st = sr["sr_stage"]
+    assert abs(st["achieved"] - st["gflop_per_forward"] / st["us_per_forward"] * 1e3) / st["achieved"] < 2e-3 and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-3
+    assert d["modes"]["may_torso_sr"]["value"] >= 4000.0
+    assert d["unit"] == "frames/s" and d["data"] == "synthetic" and d["dtype"] == "bf16" and "bf16" not in d["modes"]   # BASELINE configs[2] literally is the headline
+    assert "limiter" in r and r["l2"]["peak"] > r["peak"]                          # the level that serves the stream is labelled
+    assert d["config"]["host_issue_ms_per_frame"] <= 0.05                          # the frame loop is issued from C
+    assert d["modes"]["long_run"]["frames"] >= 2000 and d["modes"]["long_run"]["block_std"] >= 0
+    lat = cfg["may_head_fp32_latency"]
+    assert lat["frames"] >= 200 and lat["latency_ms_p99"] >= lat["latency_ms_p50"]
+    assert cfg["crop64_cpu_oracle"]["rays_per_step"] == 1024
+    assert "roofline" in cfg["may_torso_no_termination"] and cfg["reference_shaped_loop_same_gpu"]["value"] > 0
+    assert d["grid_stage_ray_stream"]["frac"] is None                              # a cache-served stream carries no HBM fraction
 
 
 def test_bench_starts_its_own_ranks_and_reports_their_failure():

@@ -65,8 +65,10 @@ def main(tag, precision, bench_args=None):
             last = tr[-5 * per_frame:]
             dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
             busy = [d for d in dur if d > 15.0]
-            out += ["", f"last {len(last)} trip dispatches of the trace (= the roofline section's 5 frames): {len(busy)} non-empty launches, average {sum(busy) / max(len(busy), 1):.2f} us "
-                        f"({sum(dur) / 5:.1f} us of trip launches per frame); bench.py's HIP-event measurement of the same launches: {rf.get('avg_launch_ms')} ms per non-empty launch, "
+            fpl = int(rf.get("frames_per_launch") or 1)                    # round 4: a head launch renders a group of consecutive frames
+            what = f"5 launches of {fpl} frames each" if fpl > 1 else "5 frames"
+            out += ["", f"last {len(last)} head dispatches of the trace (= the roofline section's {what}): {len(busy)} non-empty launches, average {sum(busy) / max(len(busy), 1):.2f} us "
+                        f"({sum(dur) / 5 / fpl:.1f} us of head launches per frame); bench.py's HIP-event measurement of the same launches: {rf.get('avg_launch_ms')} ms per non-empty launch, "
                         f"{rf.get('ms_per_frame_all_trips')} ms per frame."]
             rest = tr[:-5 * per_frame]
             rdur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rest]
