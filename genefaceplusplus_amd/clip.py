@@ -308,8 +308,10 @@ class ClipRenderer:
         # cache: the constants depend on the clip's rows and on the weights (parameter versions), nothing else -- recomputing them per start() is O(F) work
         # and a full copy of the rows per chunk, O(F^2 / chunk) per clip
         target = getattr(self.model, "_orig_mod", self.model)
-        stamp = (clip["packed"].data_ptr(), clip["packed"]._version, tuple(clip["packed"].shape), self.model.resolved_precision(),
-                 tuple((p.data_ptr(), p._version) for p in target.parameters()))
+        precision = getattr(self.model, "resolved_precision", None)
+        params = target.parameters() if hasattr(target, "parameters") else ()
+        stamp = (clip["packed"].data_ptr(), clip["packed"]._version, tuple(clip["packed"].shape), precision() if callable(precision) else None,
+                 tuple((p.data_ptr(), p._version) for p in params))
         hit = getattr(self, "_cond_cache", None)
         if hit is not None and hit[0] == stamp:
             return hit[1]

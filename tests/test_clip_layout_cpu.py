@@ -65,7 +65,11 @@ def test_rows_grow_by_the_per_frame_constants_of_a_job():
         np.testing.assert_array_equal(v["cond"].numpy(), batch["cond_wins"][i])
         np.testing.assert_array_equal(v["cond_feat"].numpy(), np.arange(i * 258, (i + 1) * 258, dtype=np.float32))
         assert (v["cond_feat"].data_ptr() - ext["packed"][i].data_ptr()) % 16 == 0
+    # the same clip under the same weights again (a caller that starts one job per chunk): the extended rows come from the one-entry cache
+    asked.clear()
+    assert cr._with_cond_features(clip) is ext and not asked
     # no constants from the model, or the switch off: the clip itself
+    cr._cond_cache = None
     Model.frame_consts_rows = lambda self, rows, cond_at, eye_at, count: None
     assert cr._with_cond_features(clip) is clip
     cr.precompute_cond = False
