@@ -626,9 +626,10 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         ind = model.individual_embeddings[0].detach().float().contiguous()
         cf = cond_feat.detach().float().contiguous()
-        persist = args.precision != "fp32" and pipe.lp_kernel == "persist"
-        G = int(frames_per_launch) if (persist and frames_per_launch > 1 and pipe.group_supported(N, frames_per_launch, max_steps)) else 1
-        trips_fn = "gfpp_head_frame_trips" if args.precision == "fp32" else ("gfpp_head_frame_persist_lp" if persist else "gfpp_head_frame_trips_lp")
+        fp32 = args.precision == "fp32"
+        persist = pipe.lp_kernel == "persist" and (not fp32 or pipe.fp32_kernel == "wave")
+        G = int(frames_per_launch) if (persist and not fp32 and frames_per_launch > 1 and pipe.group_supported(N, frames_per_launch, max_steps)) else 1
+        trips_fn = ("gfpp_head_frame_persist" if persist else "gfpp_head_frame_trips") if fp32 else ("gfpp_head_frame_persist_lp" if persist else "gfpp_head_frame_trips_lp")
         if G > 1:
             gws, fws, gt = pipe.group_workspace(N, G, max_steps)
             for k in range(G):
@@ -707,6 +708,8 @@ def main():
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
             kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
                 else "k_head_trip_wp<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, workgroup sample pool)"
+            if persist:
+                kname = "k_head_frame_persist<3,float> (the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips; exact-fp32 MFMA MLP)"
             return {"kernel": kname, "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}

@@ -59,7 +59,7 @@ class ClipRenderer:
         pass, uint8 store) overlap the tail of the other frame's head pass.  None = 2 for the 16-bit modes (the head pass is one launch that holds
         every CU: a third frame only queues behind it), 3 for the exact-fp32 mode (one launch per trip) and for the super-resolution models (numbers
         at the assignment below).
-        calibrate_trips (trip-launch paths only: fp32, lp_kernel='trips'): with several lanes every possible trip of the render loop is a launch of
+        calibrate_trips (trip-launch paths only: lp_kernel='trips', fp32_kernel='tile'): with several lanes every possible trip of the render loop is a launch of
         its own (gfpp_frame_ws.separate_trips); when a lane's graph is captured, the trips beyond the ones its warm-up frame needed (+ 1) are given
         a small grid, because a launch that finds nothing left still needs a whole CU per workgroup (results never depend on it, a later frame that
         needs more trips is rendered by the small grid).

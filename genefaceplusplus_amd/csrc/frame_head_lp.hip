@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "head_eval_device.h"
+#include "head_eval_f32_device.h"
 #include "lp_mfma_device.h"
 
 // Round 4 (measured on the GPU, then adopted; the A/B numbers are in docs/LAB_NOTEBOOK.md): the two hash grids are read as 16-bit CORNER-BLOCK tables
@@ -659,8 +660,37 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_trip_pool
 // 124 KB weight image into LDS, a partly filled last block in each of the ~4 local rounds, ingest, the tail behind the busiest workgroup -- is paid once
 // per group.  At 256^2 rays a workgroup's share of ONE frame is ~110 occupied rays = 27 blocks for 8 wavefronts (0.117 ms per frame, 0.49 of the
 // yardstick); four frames give it the ~440 rays of a 512^2 frame.  Per frame: its own constants (LDS, by sample), histogram and counters.
+// H = float (round 4): the exact-fp32 parity mode on the same structure.  Nothing of the launch's control flow depends on the operand type: the fp32 instantiation
+// runs the trip kernels' own evaluate_block (head_eval_f32_device.h: v_mfma_f32_32x32x2_f32, weights streamed from L2) on the workgroup pool through a view that gives
+// the pool's arrays the names that function uses, keeps no weight image in LDS, and takes the fp32 kernels' argument record next to this launch's.  Bit-identical
+// to gfpp_head_frame_trips (k_head_trip_wp) for the same reasons the 16-bit instantiations are to k_head_trip_pool.
+template <typename H>
+struct PersistArgs {
+    LpTripArgs a;
+};
+template <>
+struct PersistArgs<float> {
+    LpTripArgs a;
+    TripArgs t;
+};
+struct PoolViewF32 {
+    struct Dir {
+        const LpPoolP *pool;
+        const float *rays_d;
+        __device__ __forceinline__ float operator[](uint32_t ray_local) const { return rays_d[3ull * pool->ray_of(ray_local)]; }
+    };
+    float *px, *py, *pz;              // sample positions by slot ...
+    float *sigma, *cr, *cg, *cb;      // ... and, after the evaluation, density and colour in the same words (as evaluate_block_lp leaves them)
+    const uint16_t *order;
+    uint32_t n_valid;
+    Dir dx, dy, dz;
+};
+
 template <int AMB_D, typename H, bool SLOW, bool MF>
-__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_persist(LpTripArgs a) {
+__global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_persist(PersistArgs<H> pa) {
+    constexpr bool F32 = std::is_same<H, float>::value;
+    static_assert(!F32 || (!SLOW && !MF), "the fp32 instantiation: generic lookups are its only ones, one frame per launch");
+    const LpTripArgs &a = pa.a;
     __shared__ LpShared sh;
     LpPoolP &pool = sh.poolp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -671,7 +701,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     const uint32_t per_wg = a.n_tiles / G, extra = a.n_tiles % G;
     const uint32_t my_tiles = per_wg + (b < extra ? 1u : 0u), q0 = b * per_wg + (b < extra ? b : extra);
     if (my_tiles == 0u) return;                                   // tiny frames: fewer tiles than workgroups
-    lp_fill_shared(sh, a, tid, lane);
+    if constexpr (!F32) lp_fill_shared(sh, a, tid, lane);
     if constexpr (MF) {
         for (uint32_t i = (uint32_t)tid; i < 256u * (a.n_frames - 1u); i += kLpThreads)
             (&pool.bias_more[0][0])[i] = a.frame_consts[(size_t)((i >> 8) + 1u) * a.consts_stride + (i & 255u)];
@@ -815,8 +845,14 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         // one's gathers run under the other's MFMA layers (it never has more blocks than the first, so the round does not get longer)
         if (wave >= 4)
             for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-        for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
-            evaluate_block_lp<AMB_D, H, SLOW, false, MF>(a, sh, pool, first, total, n_step, lane);
+        if constexpr (F32) {
+            PoolViewF32 view{pool.px, pool.py, pool.pz, pool.px, pool.py, pool.pz, pool.cb, pool.order, total,
+                             {&pool, a.rays_d}, {&pool, a.rays_d + 1}, {&pool, a.rays_d + 2}};
+            for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves) evaluate_block<AMB_D>(pa.t, view, first, n_step, lane);
+        } else {
+            for (uint32_t first = 32u * (uint32_t)wave; first < total; first += 32u * kLpWaves)
+                evaluate_block_lp<AMB_D, H, SLOW, false, MF>(a, sh, pool, first, total, n_step, lane);
+        }
         __syncthreads();
         lap(2);
 
@@ -1329,8 +1365,9 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
 
 template <int AMB_D, typename H, bool SLOW>
 static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
-    if (a.n_frames > 1u) hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, a);
-    else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, a);
+    const PersistArgs<H> pa{a};
+    if (a.n_frames > 1u) hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, pa);
+    else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, pa);
 }
 
 // upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8" overrides, experiments).  The take is
@@ -1366,24 +1403,10 @@ GFPP_API int gfpp_head_frame_resolve(const gfpp_frame_ws *ws, uint32_t max_steps
     return check_launch("gfpp_head_frame_resolve");
 }
 
-GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
-                                        float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
-    const int bad = lp_check_common("gfpp_head_frame_persist_lp", model, ws, rays_o, rays_d, max_steps);
-    if (bad) return bad;
-    if (!ws->ray_state || !ws->counters || !ws->frame_consts || !ws->snapshots) {
-        set_error("gfpp_head_frame_persist_lp: the workspace needs ray_state, counters [192], frame_consts and snapshots [N, 7, 5]");
-        return GFPP_EINVAL;
-    }
-    const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
-    if (frames > kPMaxFrames) { set_error("gfpp_head_frame_persist_lp: n_frames must be <= %u", kPMaxFrames); return GFPP_EUNSUPPORTED; }
-    if (max_steps > 24u || (unsigned long long)ws->N * frames > (1ull << kPRayBits)) {
-        set_error("gfpp_head_frame_persist_lp: max_steps <= 24 and n_frames * N <= 2^22 (use gfpp_head_frame_trips_lp beyond)");
-        return GFPP_EUNSUPPORTED;
-    }
-    if (frames > 1u && ws->gcounters) { set_error("gfpp_head_frame_persist_lp: a frame group cannot be a ray tile of a frame shared between GPUs"); return GFPP_EUNSUPPORTED; }
-    LpTripArgs a;
+// The launch-control part of the argument record: what the persistent kernel needs whatever the operand type (shared by the 16-bit and the fp32 entry).
+static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d, float dt_gamma,
+                                     uint32_t max_steps, float T_thresh, uint32_t frames) {
     a.mp = make_march_params(model->bound, dt_gamma, max_steps, model->cascade, model->grid_size);
-    { const int rc = lp_model_args("gfpp_head_frame_persist_lp", model, a); if (rc) return rc; }
     a.rays_o = rays_o; a.rays_d = rays_d;
     a.sample_t = ws->sample_t; a.sample_cnt = ws->sample_cnt; a.sample_stride = ws->sample_stride;
     a.state = ws->ray_state;
@@ -1410,6 +1433,66 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
     uint32_t grid = (uint32_t)lp_cu_count();
     if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
     if (grid > a.n_tiles) grid = a.n_tiles;
+    return grid;
+}
+
+GFPP_API int gfpp_head_frame_persist(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                     float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_frame_persist", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    if (!ws->ray_state || !ws->counters || !ws->frame_consts || !ws->snapshots) {
+        set_error("gfpp_head_frame_persist: the workspace needs ray_state, counters [192], frame_consts and snapshots [N, 7, 5]");
+        return GFPP_EINVAL;
+    }
+    if (ws->n_frames > 1u) { set_error("gfpp_head_frame_persist: frame groups are rendered by the 16-bit entry (gfpp_head_frame_persist_lp)"); return GFPP_EUNSUPPORTED; }
+    if (max_steps > 24u || (unsigned long long)ws->N > (1ull << kPRayBits)) {
+        set_error("gfpp_head_frame_persist: max_steps <= 24 and N <= 2^22 (use gfpp_head_frame_trips beyond)");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (!lp_grid_ok(model->pos_grid, 3) || !(lp_grid_ok(model->amb_grid, 2) || lp_grid_ok(model->amb_grid, 3))) {
+        set_error("gfpp_head_frame_persist: grids must be 16-level fp32, position D=3, ambient D in {2,3}");
+        return GFPP_EUNSUPPORTED;
+    }
+    PersistArgs<float> pa{};
+    LpTripArgs &a = pa.a;
+    const uint32_t grid = persist_control_args(a, model, ws, rays_o, rays_d, dt_gamma, max_steps, T_thresh, 1u);
+    a.dbg_ambient = nullptr;
+    a.phase_cycles = nullptr;
+    TripArgs &t = pa.t;
+    t.mp = a.mp;
+    t.pos = make_grid_dev(model->pos_grid);
+    t.amb = make_grid_dev(model->amb_grid);
+    t.w = HeadWeights{(const float4 *)model->amb_w0, (const float4 *)model->amb_w1, (const float4 *)model->sig_w0, (const float4 *)model->sig_w1,
+                      (const float4 *)model->sig_w2_geo, (const float4 *)model->col_w0, model->amb_w2, model->sig_w2_sig, model->col_w1};
+    t.frame_consts = ws->frame_consts;
+    t.density_scale = model->density_scale;
+    t.T_thresh = T_thresh;
+    t.dbg_ambient = nullptr;
+    if (model->amb_grid.D == 3) hipLaunchKernelGGL((k_head_frame_persist<3, float, false, false>), dim3(grid), dim3(kLpThreads), 0, (hipStream_t)stream, pa);
+    else hipLaunchKernelGGL((k_head_frame_persist<2, float, false, false>), dim3(grid), dim3(kLpThreads), 0, (hipStream_t)stream, pa);
+    const int rc = check_launch("gfpp_head_frame_persist");
+    if (rc || ws->gcounters || ws->defer_resolve) return rc;      // (a ray tile of a shared frame: the caller sums the tiles' histograms first)
+    return gfpp_head_frame_resolve(ws, max_steps, stream);
+}
+
+GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                                        float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream) {
+    const int bad = lp_check_common("gfpp_head_frame_persist_lp", model, ws, rays_o, rays_d, max_steps);
+    if (bad) return bad;
+    if (!ws->ray_state || !ws->counters || !ws->frame_consts || !ws->snapshots) {
+        set_error("gfpp_head_frame_persist_lp: the workspace needs ray_state, counters [192], frame_consts and snapshots [N, 7, 5]");
+        return GFPP_EINVAL;
+    }
+    const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
+    if (frames > kPMaxFrames) { set_error("gfpp_head_frame_persist_lp: n_frames must be <= %u", kPMaxFrames); return GFPP_EUNSUPPORTED; }
+    if (max_steps > 24u || (unsigned long long)ws->N * frames > (1ull << kPRayBits)) {
+        set_error("gfpp_head_frame_persist_lp: max_steps <= 24 and n_frames * N <= 2^22 (use gfpp_head_frame_trips_lp beyond)");
+        return GFPP_EUNSUPPORTED;
+    }
+    if (frames > 1u && ws->gcounters) { set_error("gfpp_head_frame_persist_lp: a frame group cannot be a ray tile of a frame shared between GPUs"); return GFPP_EUNSUPPORTED; }
+    LpTripArgs a;
+    const uint32_t grid = persist_control_args(a, model, ws, rays_o, rays_d, dt_gamma, max_steps, T_thresh, frames);
+    { const int rc = lp_model_args("gfpp_head_frame_persist_lp", model, a); if (rc) return rc; }
     const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
     void (*launch)(uint32_t, hipStream_t, const LpTripArgs &) =
         amb3 ? (bf ? (slow ? launch_persist<3, __bf16, true> : launch_persist<3, __bf16, false>) : (slow ? launch_persist<3, _Float16, true> : launch_persist<3, _Float16, false>))

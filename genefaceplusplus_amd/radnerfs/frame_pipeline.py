@@ -84,6 +84,7 @@ _lib.register("gfpp_head_frame_trips", [ctypes.POINTER(HeadModel), ctypes.POINTE
 _lib.register("gfpp_head_frame_trips_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_march_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_persist_lp", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
+_lib.register("gfpp_head_frame_persist", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_p, c_f, c_u32, c_f, c_p])
 _lib.register("gfpp_head_frame_resolve", [ctypes.POINTER(FrameWs), c_u32, c_p])
 _lib.register("gfpp_head_group_begin", [ctypes.POINTER(HeadModel), ctypes.POINTER(FrameWs), c_p, c_u32, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_f, c_u32, c_p])
 _lib.register("gfpp_head_group_resolve", [ctypes.POINTER(FrameWs), c_u32, c_p])
@@ -702,7 +703,7 @@ class FramePipeline:
         grid (gfpp_frame_ws.full_grid_trips / separate_trips).  Results never depend on it: a later frame that needs more trips is rendered by the
         small grid.  Returns the number of full-grid trips."""
         ws, t = self.workspace(N)
-        if self.precision != "fp32" and self.lp_kernel == "persist":
+        if self.lp_kernel == "persist" and (self.precision != "fp32" or self.fp32_kernel == "wave"):
             ws.full_grid_trips = 0                       # one launch per frame: nothing to calibrate
             return 0
         torch.cuda.synchronize(self.device)
@@ -724,8 +725,9 @@ class FramePipeline:
     #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
     separate_trips = None
 
-    #: 16-bit modes: 'persist' = the whole loop as ONE launch with workgroup-local trips (gfpp_head_frame_persist_lp, the production path since
-    #: round 3), 'trips' = one launch per trip (gfpp_head_frame_trips_lp, the A/B partner; also taken for max_steps > 24 or more than 2^22 rays)
+    #: 'persist' = the whole loop as ONE launch with workgroup-local trips (gfpp_head_frame_persist_lp, the production path of the 16-bit modes since
+    #: round 3; gfpp_head_frame_persist for the exact-fp32 mode since round 4), 'trips' = one launch per trip (gfpp_head_frame_trips_lp / _trips, the A/B
+    #: partners; also taken for max_steps > 24 or more than 2^22 rays)
     lp_kernel = os.environ.get("GFPP_LP_KERNEL", "persist")
 
     #: set > 1 by a caller that keeps frames of several lanes in flight at once (ClipRenderer)
@@ -811,11 +813,11 @@ class FramePipeline:
         if side is not None:
             main.wait_stream(side)                      # join
         trips = "gfpp_head_frame_trips_lp" if lp else ("gfpp_head_frame_trips" if premarched else "gfpp_head_frame_march")
-        persist = lp and self.lp_kernel == "persist" and int(max_steps) <= 24 and N <= (1 << 22)
+        persist = premarched and self.lp_kernel == "persist" and int(max_steps) <= 24 and N <= (1 << 22)
         ws.defer_resolve, ws.resolve_max_steps = 0, 0
         t["deferred"] = 0
         if persist:
-            trips = "gfpp_head_frame_persist_lp"
+            trips = "gfpp_head_frame_persist_lp" if lp else "gfpp_head_frame_persist"
             if "snapshots" not in t:
                 t["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=self.device)
             ws.snapshots = t["snapshots"].data_ptr()

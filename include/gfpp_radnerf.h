@@ -496,6 +496,13 @@ int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_frame_ws *
 int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
                                float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
 
+/* The same one-launch loop in the exact-fp32 parity mode (round 4): the fp32 trip kernels' own block evaluation (v_mfma_f32_32x32x2_f32 on the fp32 tables and the
+ * fragment-ordered fp32 weights of gfpp_head_model) inside the persistent structure -- results bit-identical to gfpp_head_frame_trips, counters[k] as the trip
+ * launches leave them (renderer.py:354-384; RADNeRF.forward radnerf.py:108-141).  One frame per launch (ws->n_frames <= 1); same preconditions, same resolve
+ * step and the same ws->gcounters convention as gfpp_head_frame_persist_lp. */
+int gfpp_head_frame_persist(const gfpp_head_model *model, const gfpp_frame_ws *ws, const float *rays_o, const float *rays_d,
+                            float dt_gamma, uint32_t max_steps, float T_thresh, gfpp_stream_t stream);
+
 /* Second step of gfpp_head_frame_persist_lp (issued by it unless ws->gcounters is set): replays the loop control of renderer.py:359-364,384
  * (n_step = clamp(N // n_alive, 1, 8), step += n_step, exit at max_steps or when nobody is alive) on the histogram -- ws->gcounters[0..63] if set
  * (the frame-wide sums, with ws->N_global rays), else ws->counters[128..191] -- which yields the budget B and counters[k]; then the snapshot

@@ -66,7 +66,7 @@ def main():
         # the frame-wide alive counts the tiles agreed on == the single-GPU loop's
         lo, hi = frames.ray_tile(HW * HW, rank, world)
         pipe = model.pipeline()
-        if precision != "fp32" and pipe.lp_kernel == "persist":
+        if pipe.lp_kernel == "persist" and (precision != "fp32" or pipe.fp32_kernel == "wave"):
             # one launch per tile + ONE all_reduce of the end-point histogram: the resolve step leaves the frame-wide alive counts in the tile's counters
             g = pipe.workspace(hi - lo)[1]["counters"].cpu().numpy()
             hist = pipe.workspace(hi - lo)[1]["gcounters"].cpu().numpy()

@@ -148,11 +148,14 @@ def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, va
                                                         # the released checkpoint's geometry (256^2 rays, smo 3, blink, head-aware torso)
                                                         ("may_torso_sr", 256, "fp16", None),
                                                         # more rays than the workgroups' lists hold at once (2.5 x 1024 per workgroup): tiles are taken in as rays end
-                                                        ("may_head", 800, "bf16", None)])
+                                                        ("may_head", 800, "bf16", None),
+                                                        # the exact-fp32 parity mode on the same structure (gfpp_head_frame_persist vs gfpp_head_frame_trips, round 4)
+                                                        ("may_torso", 256, "fp32", None), ("may_head", 37, "fp32", None), ("may_torso", 96, "fp32", {"sigma_gain": 0.05}),
+                                                        ("may_torso_sr", 256, "fp32", None), ("may_torso", 2, "fp32", None)])
 def test_persistent_launch_equals_trip_launches(dev, oracle_mod, variant, HW, precision, over):
-    """gfpp_head_frame_persist_lp (ONE launch, workgroup-local trips, budget resolved from the histogram of the rays' end points) against
-    gfpp_head_frame_trips_lp (one launch per trip, the reference's global schedule): every output bit for bit, and the alive counts that the resolve
-    step reconstructs equal the ones the trip launches counted."""
+    """gfpp_head_frame_persist_lp / gfpp_head_frame_persist (ONE launch, workgroup-local trips, budget resolved from the histogram of the rays' end points)
+    against gfpp_head_frame_trips_lp / gfpp_head_frame_trips (one launch per trip, the reference's global schedule): every output bit for bit, and the alive
+    counts that the resolve step reconstructs equal the ones the trip launches counted."""
     outs = {}
     for kernel in ("persist", "trips"):
         case = frame_case(variant, HW, **(over or {}))

@@ -59,7 +59,7 @@ def _outputs(res):
 
 
 def check_all_modes(dev, orc, case, tag, frac16=None, psnr16=None, alive16_rel=2e-3, precisions=("fp16", "bf16")):
-    """fp32 vs oracle (+ identical trip schedule); 16-bit modes vs oracle inside their bars; persist == trips bit for bit (+ alive counts)."""
+    """fp32 vs oracle (+ identical trip schedule); 16-bit modes vs oracle inside their bars; persist == trips bit for bit (+ alive counts) in every precision."""
     variant, HW = case["variant"], case["HW"]
     N = HW * HW
     trace = []
@@ -81,6 +81,13 @@ def check_all_modes(dev, orc, case, tag, frac16=None, psnr16=None, alive16_rel=2
     worst = max(abs(a - b) for a, b in zip(got_alive, n_alive_ref))
     print(tag, "fp32 n_alive: largest difference to the reference's loop", worst, "rays")
     assert worst <= max(2, int(2e-5 * N)), (got_alive, n_alive_ref)
+    # the fp32 frame above came from ONE launch (gfpp_head_frame_persist, round 4): the trip launches give the same bits and the same counts
+    assert model.pipeline().lp_kernel == "persist" and int(model.pipeline().budget(N)["hist"].sum()) == N
+    trips_model = _model(case, dev, "fp32", "trips")
+    res_trips = _outputs(product_render(trips_model, case, dev, "oracle", orc))
+    for k, v in _outputs(res).items():
+        np.testing.assert_array_equal(v, res_trips[k], err_msg=f"{tag} fp32 {k}")
+    np.testing.assert_array_equal(alive[:26], trips_model.pipeline().trip_counters(N)[0][:26])
 
     for precision in precisions:
         outs = {}
