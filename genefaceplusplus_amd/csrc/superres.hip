@@ -846,10 +846,9 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     const uint32_t R = 256;
     const float gain = 1.4142135623730951f, clamp = m->conv_clamp;
     const bool draw = !noise && ws->rng_state;                      // noise_mode 'random' inside the kernels
-    int nu = 1;                                                     // column tiles per wavefront of the 3x3 convolutions (GFPP_SR_TILES=2: the round-2 shape, A/B runs)
-    if (const char *e = getenv("GFPP_SR_TILES")) nu = atoi(e) == 2 ? 2 : 1;
-    int ks = 2;                                                     // K slices of the 128-channel layers (GFPP_SR_KSLICES=1: whole halo patch in LDS, one workgroup per CU)
-    if (const char *e = getenv("GFPP_SR_KSLICES")) ks = atoi(e) == 1 ? 1 : 2;
+    // Shapes: 8 wavefronts of 32 pixels (NU = 1), the 128-channel layers in two K slices (KS = 2).  The other shapes the kernel template describes -- 4 wavefronts
+    // of 64 pixels, the whole 128-channel patch in LDS -- were the round-2 / round-3 A/B partners (GFPP_SR_TILES, GFPP_SR_KSLICES: measured, docs/LAB_NOTEBOOK.md)
+    // and are no longer instantiated.
 #if GFPP_SR_PROF
     unsigned long long *prof_base = nullptr;
     if (const char *e = getenv("GFPP_SR_PROF_PTR")) prof_base = (unsigned long long *)strtoull(e, nullptr, 0);
@@ -858,12 +857,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
 #define GFPP_SR_PROF_SET(a, layer) do { } while (0)
 #endif
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
-    int nu_up = nu;                                                 // the up-sampling layer alone (GFPP_SR_TILES_UP)
-    if (const char *e = getenv("GFPP_SR_TILES_UP")) nu_up = atoi(e) == 2 ? 2 : 1;
-    int nu_fin = nu;
-    if (const char *e = getenv("GFPP_SR_TILES_FINAL")) nu_fin = atoi(e) == 2 ? 2 : 1;
-    bool fuse_first = nu == 1 && ks == 2;                           // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, A/B runs)
-    if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = fuse_first && atoi(e) != 0;
+    bool fuse_first = true;                                         // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, the parity partner)
+    if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = atoi(e) != 0;
     if (!fuse_first) {
         SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
         hipLaunchKernelGGL(k_sr_first, dim3(R / kSrPatch, R / kSrPatch), dim3(kSrThreads), 0, st, a);
@@ -881,9 +876,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
             a.first_rgb = rgb_in; a.first_w = (const uint4 *)m->w_first; a.first_bias = m->bias[0];
             a.first_noise = noise ? noise[0] : nullptr; a.first_noise_strength = m->noise_strength[0]; a.first_rng = rng_of(0);
             hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2, true>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
-        } else if (nu == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
-        else if (nu == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(256), 0, st, a);
+        } else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrRgbAdd, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 1), dim3(512), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
         if (rc) return rc;
     }
@@ -893,10 +886,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
         GFPP_SR_PROF_SET(a, 1);
-        if (nu_up == 2 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
-        else if (nu_up == 1 && ks == 2) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
-        else if (nu_up == 1) hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 2, 1>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
     }
@@ -912,7 +902,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         GFPP_SR_PROF_SET(a, 2);
         bool resident = true;                                       // GFPP_SR_FINAL_RESIDENT=0: one workgroup per patch, weights streamed (A/B runs, parity partner)
         if (const char *e = getenv("GFPP_SR_FINAL_RESIDENT")) resident = atoi(e) != 0;
-        if (resident && nu_fin == 1) {
+        if (resident) {
             static int cus = 0;
             if (cus == 0) {
                 int dev = 0, n = 0;
@@ -921,8 +911,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
             }
             const int patches = (int)(2 * R / kSrPatch) * (int)(2 * R / kSrPatch);
             hipLaunchKernelGGL(k_sr_final_resident, dim3(cus < patches ? cus : patches), dim3(512), 0, st, a);
-        } else if (nu_fin == 1) hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 2, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(256), 0, st, a);
+        } else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv1 + torgb)");
         if (rc) return rc;
     }
