@@ -1,23 +1,25 @@
 // superres.hip -- the StyleGAN2 super-resolution stage of the *_sr models (radnerf_sr.py:14-43: SynthesisBlockNoUp 3 -> 128 @ 256^2,
-// SynthesisBlock 128 -> 64 @ 512^2, networks_stylegan2.py:286-478) as four launches of implicit-GEMM convolutions on 16-bit MFMA.
+// SynthesisBlock 128 -> 64 @ 512^2, networks_stylegan2.py:286-478) as three launches of implicit-GEMM convolutions on 16-bit MFMA.
 //
 // Superresolution feeds ws = ones (radnerf_sr.py:32-33), so every style vector is a constant of the checkpoint: modulation and
 // demodulation (networks_stylegan2.py:37-94) are folded into the convolution weights ONCE on the host, in fp64.  What remains per frame:
-//   k_sr_first   conv 3x3,   3 -> 128 @ 256^2 (+ noise + bias, lrelu * sqrt 2, clamp)                      K = 27 (padded to 32)
-//   k_sr_conv3   conv 3x3, 128 -> 128 @ 256^2  + ToRGB 128 -> 3 fused: img256 = rgb_in + clamp(torgb)       K = 1152
-//   k_sr_conv3   up-conv 128 -> 64, 256^2 -> 512^2: the transposed stride-2 convolution AND the [1,3,3,1] FIR of conv2d_resample.py:
-//                117-133 composed on the host into one 3x3 convolution with 4 x 64 output channels (one set per output phase),
-//                written depth-to-space                                                                    K = 1152, N = 256
-//   k_sr_conv3   conv 3x3,  64 -> 64 @ 512^2  + ToRGB 64 -> 3 + upsample2d(img256) fused -> rgb 512^2       K = 576
+//   k_sr_conv3<128, FIRST>   block 0: conv 3x3 3 -> 128 (+ noise + bias, lrelu * sqrt 2, clamp; K = 27 padded to 32) computed for the 18 x 18 halo of the patch,
+//                            straight into LDS, then conv 3x3 128 -> 128 @ 256^2 + ToRGB 128 -> 3 fused: img256 = rgb_in + clamp(torgb)      K = 1152
+//                            (k_sr_first + k_sr_conv3<128> as two launches: the parity partner, GFPP_SR_FUSE_FIRST=0)
+//   k_sr_conv3<128, up>      up-conv 128 -> 64, 256^2 -> 512^2: the transposed stride-2 convolution AND the [1,3,3,1] FIR of conv2d_resample.py:
+//                            117-133 composed on the host into one 3x3 convolution with 4 x 64 output channels (one set per output phase),
+//                            written depth-to-space                                                                              K = 1152, N = 256
+//   k_sr_final_resident      conv 3x3 64 -> 64 @ 512^2 + ToRGB 64 -> 3 + upsample2d(img256) fused -> rgb 512^2, one workgroup per CU with the layer's
+//                            72 KB of weights resident in LDS (k_sr_conv3<64, final> per patch: the parity partner, GFPP_SR_FINAL_RESIDENT=0)  K = 576
 // Activations travel as f16 NHWC (the reference runs both blocks in fp16 on the GPU, use_fp16=True), images as fp32; accumulation fp32.
 //
-// Kernel shape: a 256-thread workgroup owns a 16x16 output patch; its 18x18 input halo sits in LDS (pixel stride padded by 16 B so
-// that the 16 pixels of a row hit distinct banks); each wavefront owns 4 rows = 64 pixels = two 32-column MFMA tiles x NT row tiles
-// of output channels.  The weights of one tap (CIN/16 steps x NT fragments, pre-packed in fragment order) are double-buffered
-// through LDS: the next tap's fragments are in flight (global -> registers) while the current tap's MFMAs run.
-// (Round 4, measured and dropped: 8 x 16 patches -- twice the workgroups, two co-resident per CU for block 0's 256-patch layer, each the other's cover for halo
-// load, chunk barriers and epilogue: 128.9 us per forward against 128.2 for that layer, +5 us for the up-sampling layer, +10 us for the last one.  Co-residency
-// is NOT what the stage lacks.)
+// Kernel shape (k_sr_conv3): a 512-thread workgroup owns a 16x16 output patch; its 18x18 input halo sits in LDS (pixel stride padded by 16 B so
+// that the 16 pixels of a row hit distinct banks); each of the 8 wavefronts owns 2 rows = 32 pixels = one 32-column MFMA tile x NT row tiles
+// of output channels.  The weights of one (tap, K slice) chunk (pre-packed in fragment order) are double-buffered through LDS by direct
+// global -> LDS loads: the next chunk lands while the current one's MFMAs run.
+// Where a forward's ~115 us go (tools/sr_phase.py) and why the tap loops stop where they are -- 85-91 % MFMA-pipe occupancy in cycles at the ~1.4 GHz the part
+// sustains under dense MFMA (tools/clock_probe_sr.py) -- : DESIGN.md 2.2, docs/LAB_NOTEBOOK.md.  Measured and dropped: 8 x 16 patches for co-residency, the
+// 4 x 2 register tile, a three-chunk weight ring with deeper operand prefetch, the last layer's wavefronts in two opposite-phase groups.
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
