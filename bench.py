@@ -707,7 +707,8 @@ def main():
                       "avg_launch_ms": round(1e3 * t_march / reps, 4), "ms_per_frame_all_trips": round(1e3 * t_march / (reps * G), 4), "traffic": None,
                       "workgroup_rounds": {"max": int(c[0, 170]), "mean": round(int(c[0, 169]) / max(pipe.cu_count, 1), 2)},
                       "workgroup_balance": {"samples_busiest": int(c[0, 171]), "samples_mean": round(per_launch / max(pipe.cu_count, 1), 1)},
-                      "workgroup_kcycles": {"fetch": int(c[0, 172]), "compact": int(c[0, 173]), "evaluate": int(c[0, 174]), "composite": int(c[0, 175]), "longest_wg": int(c[0, 176])}}
+                      "workgroup_kcycles": {"fetch": int(c[0, 172]), "compact": int(c[0, 173]), "evaluate": int(c[0, 174]), "composite": int(c[0, 175]), "longest_wg": int(c[0, 176]),
+                                            "ingest_of_fetch": int(c[0, 177])}}
             frames_timed = reps * G
         else:
             alive, smp = pipe.trip_counters(N)                       # the same frame every time: counters of the last one

@@ -710,6 +710,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     const uint32_t cap = a.max_steps + 7u;                        // a ray can never composite more samples than that (k_premarch stores no more)
     uint32_t j_next = 0, A = 0, evaluated = 0, round = 0;
     unsigned long long t_mark = __builtin_readcyclecounter(), cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
+    unsigned long long cyc_ingest = 0ull;                          // the ingest steps alone (part of cyc[0])
     auto lap = [&](int k) {
         const unsigned long long now = __builtin_readcyclecounter();
         cyc[k] += now - t_mark;
@@ -776,6 +777,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
             A += acc;
             j_next += accepted;
             __syncthreads();
+            cyc_ingest += __builtin_readcyclecounter() - t_mark;
         }
         if (A == 0u) {
             if (j_next >= my_tiles) break;
@@ -938,6 +940,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         // where this workgroup's time went (thread 0's clock, units of 1024 shader cycles; sums over the workgroups + the longest workgroup)
         for (int k = 0; k < 4; ++k) atomicAdd(&a.budget[kBudgetCycles + k], (int)(cyc[k] >> 10));
         atomicMax(&a.budget[kBudgetCycles + 4], (int)((cyc[0] + cyc[1] + cyc[2] + cyc[3]) >> 10));
+        atomicAdd(&a.budget[kBudgetCycles + 5], (int)(cyc_ingest >> 10));
     }
 }
 

@@ -18,7 +18,7 @@ constexpr int kTile = 128;     // sample slots per workgroup tile (4 wavefronts 
 constexpr int kThreads = 256;
 constexpr int kMaxTrips = 63;      // counters[0..63] alive counts, counters[64..127] evaluated samples
 constexpr int kCounterWords = 192; // gfpp_frame_ws.counters: + [128..191] the budget array of the persistent 16-bit launch (histogram, sample / round counts)
-constexpr int kBudgetBase = 128, kBudgetSamples = 40, kBudgetRounds = 41, kBudgetRoundsMax = 42, kBudgetSamplesMax = 43, kBudgetCycles = 44;   // [44..47] phase cycles / 1024 (sums), [48] longest workgroup
+constexpr int kBudgetBase = 128, kBudgetSamples = 40, kBudgetRounds = 41, kBudgetRoundsMax = 42, kBudgetSamplesMax = 43, kBudgetCycles = 44;   // [44..47] phase cycles / 1024 (sums), [48] longest workgroup, [49] the ingest steps' share of [44]
 
 struct GridDev {
     const void *table;

@@ -1091,7 +1091,8 @@ class FramePipeline:
         return {"hist": c[128:160].copy(), "samples": int(c[168]), "rounds_sum": int(c[169]), "rounds_max": int(c[170]), "samples_max_wg": int(c[171]),
                 # thread 0's shader clock per workgroup, summed over the workgroups, in units of 1024 cycles: fetch (+ ingest) | compaction | evaluate |
                 # composite + list upkeep; and the longest workgroup
-                "kcycles": {"fetch": int(c[172]), "compact": int(c[173]), "evaluate": int(c[174]), "composite": int(c[175]), "longest_wg": int(c[176])}}
+                "kcycles": {"fetch": int(c[172]), "compact": int(c[173]), "evaluate": int(c[174]), "composite": int(c[175]), "longest_wg": int(c[176]),
+                            "ingest_of_fetch": int(c[177])}}
 
     def trip_counters(self, N):
         """(alive rays at the start of each trip, samples evaluated by each trip) of the last frame; synchronises.  After the persistent 16-bit
