@@ -175,3 +175,47 @@ def test_round_geometry_never_overflows_the_pool():
             n_step = max(1, min(128 // rw, cap, 8))
             assert 8 * rw * n_step <= 1024 and rw <= 128
             assert (8 * rw - 1) * n_step + n_step - 1 < 1024                               # the last slot index
+
+
+def _ingest_loop(counts, exists, room):
+    """The ingest step as the kernel ran it until round 4: candidate tiles in order, the first that does not exist or does not fit ends the step."""
+    acc, accepted, offsets = 0, 0, []
+    for t, n in enumerate(counts):
+        if not exists[t] or acc + n > room:
+            break
+        offsets.append(acc)
+        acc += n
+        accepted = t + 1
+    return accepted, acc, offsets
+
+
+def _ingest_scan(counts, exists, room):
+    """The same decision as the kernel takes it now (k_head_frame_persist, frame_head_lp.hip): inclusive prefix sums of the 128 candidates' occupied-ray counts
+    (two wavefront scans), population count of "exists and fits", offsets = exclusive prefix sums."""
+    inc = np.cumsum(counts)
+    fits = exists & (inc <= room)
+    accepted = int(fits.sum())
+    acc = int(inc[accepted - 1]) if accepted else 0
+    return accepted, acc, [int(v) for v in (inc - counts)[:accepted]]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ingest_step_accepts_the_same_tiles_by_scan_as_by_loop(seed):
+    """Tiles are accepted in order and a tile that does not fit ends the step, so the accepted tiles are a prefix of the candidates -- which is what lets the
+    kernel replace its 128-iteration loop by prefix sums and a population count.  Random occupancies (0..8 occupied rays per 8-ray tile: image borders, holes),
+    rooms from 256 (the smallest at which a step runs) to the whole pool, and workgroups whose tile share ends inside the step."""
+    rng = np.random.default_rng(seed)
+    for _ in range(400):
+        kind = rng.integers(0, 4)
+        counts = rng.integers(0, 9, 128) if kind else np.full(128, 8)
+        if kind == 2:
+            counts[rng.random(128) < 0.6] = 0                                   # mostly empty tiles (image border)
+        left = int(rng.integers(1, 200))                                        # tiles this workgroup still owns
+        exists = np.arange(128) < left
+        room = int(rng.integers(256, 1025))
+        a = _ingest_loop(counts, exists, room)
+        b = _ingest_scan(counts, exists, room)
+        assert a == b, (counts.tolist(), left, room, a, b)
+        # monotone: nothing after the first rejected tile could have been taken
+        assert b[0] == 128 or not exists[b[0]] or np.cumsum(counts)[b[0]] > room
+        assert b[1] <= room
