@@ -309,9 +309,9 @@ class ClipRenderer:
         # and a full copy of the rows per chunk, O(F^2 / chunk) per clip
         target = getattr(self.model, "_orig_mod", self.model)
         precision = getattr(self.model, "resolved_precision", None)
-        params = target.parameters() if hasattr(target, "parameters") else ()
-        stamp = (clip["packed"].data_ptr(), clip["packed"]._version, tuple(clip["packed"].shape), precision() if callable(precision) else None,
-                 tuple((p.data_ptr(), p._version) for p in params))
+        from .radnerfs.frame_pipeline import FramePipeline
+        weights = FramePipeline._fingerprint(target) if hasattr(target, "modules") else ()
+        stamp = (clip["packed"].data_ptr(), clip["packed"]._version, tuple(clip["packed"].shape), precision() if callable(precision) else None, weights)
         hit = getattr(self, "_cond_cache", None)
         if hit is not None and hit[0] == stamp:
             return hit[1]

@@ -381,7 +381,24 @@ class FramePipeline:
     # -- change detection ----------------------------------------------------------------------------------------
     @staticmethod
     def _fingerprint(model):
-        return tuple((p.data_ptr(), p._version) for p in list(model.parameters()) + list(model.buffers()))
+        """(address, version) of every parameter and buffer.  Called on every model.pipeline() -- several times per rendered frame -- so the module tree is
+        not walked through nn.Module.parameters() / buffers() (recursive generators with a de-duplication set: ~0.25 ms for this model, a fifth of a frame at
+        the per-frame API's rate, and most of ClipRenderer.start()'s host time): the list of sub-modules is cached on the model and validated by identity of
+        every module's children (a replaced or added sub-module rebuilds it); parameters and buffers are read from the modules' own dictionaries, so a replaced
+        Parameter object, a moved tensor (.to()) and an in-place update (optimizer step, load_state_dict) all change the fingerprint as before."""
+        cache = model.__dict__.get("_gfpp_module_list")
+        if cache is None or any(tuple(m._modules.values()) != kids for m, kids in cache):
+            cache = [(m, tuple(m._modules.values())) for m in model.modules()]
+            model.__dict__["_gfpp_module_list"] = cache
+        out = []
+        for m, _ in cache:
+            for t in m._parameters.values():
+                if t is not None:
+                    out.append((t.data_ptr(), t._version))
+            for t in m._buffers.values():
+                if t is not None:
+                    out.append((t.data_ptr(), t._version))
+        return tuple(out)
 
     def matches(self, model):
         return model.density_bitfield.device == self.device and self._fingerprint(model) == self._versions

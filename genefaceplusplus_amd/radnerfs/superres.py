@@ -201,7 +201,8 @@ class Superresolution(nn.Module):
 
     # -- packing (once per parameter version) -------------------------------------------------------------------------------------
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        from .frame_pipeline import FramePipeline
+        return FramePipeline._fingerprint(self)         # (address, version) of every parameter and buffer without walking the module tree through generators
 
     def _pack(self):
         fp = self._fingerprint()
