@@ -10,12 +10,25 @@
 // with the 28 KB weight image resident in LDS.  Columns that are constant over the frame (pose / landmark encoding, individual code)
 // are folded into fp32 bias vectors in the block prologue, exactly as in the fp32 kernel.  Everything outside the MLPs (occupancy
 // test, frequency features, grid interpolation, sigmoid, compositing, depth) is fp32 and shared with frame_torso.hip's semantics.
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "grid_device.h"
 #include "lp_mfma_device.h"
 #include "march_device.h"
 #include "sh_device.h"
+
+// experiment builds only (tools/torso_phase.py): every workgroup's first lane stamps the 100 MHz wall clock at its phase boundaries into the buffer whose address the
+// environment variable GFPP_TORSO_PROF_PTR carries ([workgroup][8] uint64)
+#ifndef GFPP_TORSO_PROF
+#define GFPP_TORSO_PROF 0
+#endif
+#if GFPP_TORSO_PROF
+#define GFPP_TORSO_MARK(k) do { if (a.prof && threadIdx.x == 0) a.prof[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GFPP_TORSO_MARK(k) do { } while (0)
+#endif
 
 namespace gfpp {
 
@@ -49,6 +62,9 @@ struct TorsoLpArgs {
     BudgetView bv;            // hist != null: the head pass was the persistent launch with the resolve deferred to this kernel
     gfpp_clip_job *job;       // != null: also store the frame as uint8 into the clip job's slot of lane `lane` and advance its cursor
     uint32_t lane, sub, advance;   // the frame takes job position cursor[lane] + sub; the launch moves the cursor by `advance` (0: the job's `lanes`; ~0: not at all)
+#if GFPP_TORSO_PROF
+    unsigned long long *prof;
+#endif
 };
 
 template <typename H>
@@ -86,33 +102,40 @@ __device__ __forceinline__ void tl_load_bias(v16f (&acc)[T], const float *__rest
         for (int r = 0; r < 16; ++r) acc[t][r] = b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi];
 }
 
-// one level of the 2-D tiled grid, index arithmetic resolved on the host, padded table (see frame_head_lp.hip)
-__device__ __forceinline__ void tl_level2(const float (&u)[2], const float *__restrict__ table, const gfpp_grid_level &lv, float (&out)[2]) {
+// One level of the 2-D tiled grid, index arithmetic resolved on the host, padded table (see frame_head_lp.hip) -- in two halves, so that the caller can request
+// the rows of ALL its levels before it interpolates the first: as one function per level the compiler waited for a level's two rows before it computed the next
+// level's addresses -- eight memory round trips in a row per 32-pixel pass (tools/torso_phase.py: 5 us per pass).  Same arithmetic, same order.
+struct TlRows {
     float frac[2];
+    f32x4_a8 v0, v1;
+};
+__device__ __forceinline__ void tl_level2_issue(const float (&u)[2], const float *__restrict__ table, const gfpp_grid_level &lv, TlRows &g) {
     uint32_t base[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         const float pos = fmaf(u[d], lv.scale, 0.5f);
         const float fl = floorf(pos);
         base[d] = (uint32_t)fl;
-        frac[d] = pos - fl;
+        g.frac[d] = pos - fl;
     }
     const float *lt = table + 2ull * lv.offset;
     const uint32_t y0 = __umul24(base[1], lv.sy), y1 = y0 + lv.sy;
     const uint32_t r0 = (base[0] + y0) & lv.mask, r1 = (base[0] + y1) & lv.mask;
-    const f32x4_a8 v0 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r0);
-    const f32x4_a8 v1 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r1);
+    g.v0 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r0);
+    g.v1 = *reinterpret_cast<const f32x4_a8 *>(lt + 2ull * r1);
+}
+__device__ __forceinline__ void tl_level2_finish(const TlRows &g, float (&out)[2]) {
     out[0] = 0.0f;
     out[1] = 0.0f;
     {
-        const float w0 = (1.0f - frac[0]) * (1.0f - frac[1]), w1 = frac[0] * (1.0f - frac[1]);
-        out[0] = fmaf(w1, v0[2], fmaf(w0, v0[0], out[0]));
-        out[1] = fmaf(w1, v0[3], fmaf(w0, v0[1], out[1]));
+        const float w0 = (1.0f - g.frac[0]) * (1.0f - g.frac[1]), w1 = g.frac[0] * (1.0f - g.frac[1]);
+        out[0] = fmaf(w1, g.v0[2], fmaf(w0, g.v0[0], out[0]));
+        out[1] = fmaf(w1, g.v0[3], fmaf(w0, g.v0[1], out[1]));
     }
     {
-        const float w0 = (1.0f - frac[0]) * frac[1], w1 = frac[0] * frac[1];
-        out[0] = fmaf(w1, v1[2], fmaf(w0, v1[0], out[0]));
-        out[1] = fmaf(w1, v1[3], fmaf(w0, v1[1], out[1]));
+        const float w0 = (1.0f - g.frac[0]) * g.frac[1], w1 = g.frac[0] * g.frac[1];
+        out[0] = fmaf(w1, g.v1[2], fmaf(w0, g.v1[0], out[0]));
+        out[1] = fmaf(w1, g.v1[3], fmaf(w0, g.v1[1], out[1]));
     }
 }
 
@@ -124,6 +147,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     const int j = lane & 31, hi = lane >> 5;
 
     // ---- this thread's pixel: occupancy test first (most workgroups of a frame have no torso pixel and skip the weights) ----------
+    GFPP_TORSO_MARK(0);
     const uint32_t n = blockIdx.x * kTlThreads + tid;
     const bool in_frame = n < a.N;
     float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f, hdepth = 0.0f;
@@ -136,12 +160,14 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
     }
     const bool block_has_work = __syncthreads_or(masked ? 1 : 0) != 0;
+    GFPP_TORSO_MARK(1);
     if (in_frame) {
         const RayAccum head = ray_state_final(a.state, a.bv, s_budget, n);
         hr = head.r; hg = head.g; hb = head.b; wsum = head.wsum; hdepth = head.depth;
     }
 
     float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
+    GFPP_TORSO_MARK(2);
     if (block_has_work) {
         // ---- prologue: weights -> LDS, per-frame constant columns folded into biases (same arithmetic as frame_torso.hip) ----------
         for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = reinterpret_cast<const vec *>(a.w16)[i];
@@ -175,7 +201,10 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
             for (uint32_t k = 0; k < a.const_dim; ++k) s = fmaf(a.can_w0_c[(size_t)q * a.const_dim + k], sh.consts[k], s);
             sh.bcan[q] = s;
         }
+        // (measured, dropped: the row's weights 32 at a time before the fma chain -- the landmark variant's 134 columns 8.5 -> 7.0 us of prologue, the pose
+        // variant's 62 columns 5.0 -> 6.2; tools/torso_phase.py)
         __syncthreads();
+        GFPP_TORSO_MARK(3);
 
         // ---- compaction of the wavefront's masked pixels -------------------------------------------------------------------------
         const unsigned long long ballot = __ballot(masked);
@@ -258,10 +287,14 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
                 u[0] = (clampf(x0 + dxy[0], -1.0f, 1.0f) + 1.0f) / 2.0f;
                 u[1] = (clampf(x1 + dxy[1], -1.0f, 1.0f) + 1.0f) / 2.0f;
                 float f[16];
+                TlRows rows[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tl_level2_issue(u, a.table, sh.lv[2 * i + hi], rows[i]);
+                __builtin_amdgcn_sched_barrier(0);             // all sixteen rows are requested before the first is used
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float o[2];
-                    tl_level2(u, a.table, sh.lv[2 * i + hi], o);
+                    tl_level2_finish(rows[i], o);
                     f[2 * i] = o[0];
                     f[2 * i + 1] = o[1];
                 }
@@ -299,6 +332,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GFPP_TORSO_MARK(4);
         if (masked) {
             const float *r = &sh.res[wave][0][0];
             alpha = r[lane]; tr = r[64 + lane]; tg = r[128 + lane]; tb = r[192 + lane]; ddx = r[256 + lane]; ddy = r[320 + lane];
@@ -324,6 +358,7 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         a.mask_out[n] = masked ? 1 : 0;
         a.out_depth[n] = fmaxf(hdepth - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
     }
+    GFPP_TORSO_MARK(5);
     if (a.job) {
         // the uint8 frame, fused: four consecutive pixels hold 12 bytes = three dwords, assembled inside the lane quad and written as dwords (a wavefront
         // writes 192 contiguous bytes with ONE store instruction; per-pixel byte stores took 45 us per 512^2 frame, the whole torso pass takes 30)
@@ -400,6 +435,10 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     }
     a.job = ws->clip_job; a.lane = ws->clip_lane; a.sub = ws->clip_sub; a.advance = ws->clip_advance;
     if (a.job && a.lane >= 8) { set_error("gfpp_torso_frame_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
+#if GFPP_TORSO_PROF
+    a.prof = nullptr;
+    if (const char *e = getenv("GFPP_TORSO_PROF_PTR")) a.prof = (unsigned long long *)strtoull(e, nullptr, 0);
+#endif
     const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
     else if (m->lp_dtype == GFPP_F32) hipLaunchKernelGGL(k_torso_lp<float>, grid, block, 0, (hipStream_t)stream, a);   // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
