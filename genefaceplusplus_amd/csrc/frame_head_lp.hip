@@ -164,6 +164,21 @@ __device__ __forceinline__ float lp_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(lp_exp(2.0f * xc) + 1.0f);
 }
 
+// The operand type of ambient_net inside a precision mode (round 5).  ambient_net's output is not a colour or a density but a COORDINATE of the second hash grid:
+// 8-bit significands (bf16) displace it by up to 5e-3 of the unit cube -- five cells of the finest level, whose features then belong to other cells -- and that, not
+// the radiance layers, is what held bf16 frames at 43-47 dB on the non-convex scenes (tools/lp_emulate.py renders them on the CPU with the rounding points moved
+// layer group by layer group: everything bf16 46-47 dB, ambient_net alone on 11-bit operands 57-59 dB, only the OTHER layers on 11 bits 47 dB).  So the bf16 mode
+// multiplies ambient_net's two wide layers and three rows as f16 (same MFMA rate; its inputs are the grid features, read from f16 tables in every 16-bit mode,
+// and a tanh follows) and everything behind the ambient grid as bf16.  The weight image carries the steps 0..9 and the skinny rows 0..2 in this type.
+template <typename H>
+struct LpAmbient {
+    typedef H type;
+};
+template <>
+struct LpAmbient<__bf16> {
+    typedef _Float16 type;
+};
+
 template <typename H>
 __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTraits<H>::vec (&b)[8]) {
     act_pack<H, 4, 1>(acc, b);
@@ -176,9 +191,10 @@ __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTrait
 //     lane are issued before the first is interpolated -- two memory round trips per block and grid.  Measured at 512^2 bf16 (head pass, same box): fp32
 //     tables with two levels in flight 0.290 ms, block tables 0.263, with eight levels in flight 0.249 (with fp32 tables eight levels spill 7 registers).
 //   SLOW = true (hash-addressed or true-modulo levels present): the generic lookup on the fp32 table, level by level.
-template <int D, typename H, bool SLOW>
+// H2: the features a second time as operands of another type (the position features feed ambient_net -- LpAmbient<H> -- and sigma_net); H2 = H: `b2` is not written.
+template <int D, typename H, bool SLOW, typename H2 = H>
 __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, const gfpp_grid_level *lvl, int hi, bool valid,
-                                               typename LpTraits<H>::vec (&b)[2]) {
+                                               typename LpTraits<H>::vec (&b)[2], typename LpTraits<H2>::vec (*b2)[2] = nullptr) {
     bool ok = valid;
     float uc[D];
 #pragma unroll
@@ -240,6 +256,14 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
         if constexpr (!SLOW) {
             const u32x4 w = __builtin_bit_cast(u32x4, b[s]);
             b[s] = __builtin_bit_cast(typename LpTraits<H>::vec, ok ? w : u32x4{0u, 0u, 0u, 0u});
+        }
+        if constexpr (!std::is_same<H2, H>::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) (*b2)[s][e] = (H2)f[8 * s + e];
+            if constexpr (!SLOW) {
+                const u32x4 w = __builtin_bit_cast(u32x4, (*b2)[s]);
+                (*b2)[s] = __builtin_bit_cast(typename LpTraits<H2>::vec, ok ? w : u32x4{0u, 0u, 0u, 0u});
+            }
         }
     }
 }
@@ -370,7 +394,9 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
     const float *bias = sh.bias;        // one frame per launch: the frame's constants; a frame group: the set of the sample's frame (rays are numbered frame * N + ray)
     if constexpr (MF) bias += 256u * ((ray >= a.N ? 1u : 0u) + (ray >= 2u * a.N ? 1u : 0u) + (ray >= 3u * a.N ? 1u : 0u));
 
+    typedef typename LpAmbient<H>::type HA;        // ambient_net's operand type (f16 in the bf16 mode, see LpAmbient)
     vec bpos[2], bamb[2];
+    typename LpTraits<HA>::vec bpos_a[2];
     float dir[3];
     {
         const float *dp = a.rays_d + 3ull * ray;
@@ -382,11 +408,12 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
         u3[0] = (wt.px[slot] + a.mp.bound) / b2;
         u3[1] = (wt.py[slot] + a.mp.bound) / b2;
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
-        encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
+        encode_half_lp<3, H, SLOW, HA>(u3, a.pos, lv_pos, hi, valid, bpos, &bpos_a);
     }
     {
         float amb[AMB_D], ua[AMB_D];
-        ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
+        if constexpr (std::is_same<HA, H>::value) ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
+        else ambient_block<AMB_D, HA>(sh, bias, bpos_a, lane, hi, amb);
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) {
             const float th = lp_tanh(amb[d]);

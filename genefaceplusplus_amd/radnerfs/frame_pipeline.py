@@ -163,8 +163,21 @@ def pack_lp(weight, cols):
     return P.reshape(S, 4, 64, 8).contiguous()
 
 
+def lp_ambient_dtype(dtype):
+    """Operand type of ambient_net inside a 16-bit mode (csrc/frame_head_lp.hip::LpAmbient): its output is a coordinate of the second hash grid, which 8-bit
+    significands displace by several cells of the finest level -- the bf16 mode multiplies ambient_net as f16 (steps 0..9 of the weight image, skinny rows 0..2)."""
+    return torch.float16 if dtype == torch.bfloat16 else dtype
+
+
+def _as_bits(t, dtype):
+    """round to `dtype`; 16-bit types are returned as their bit patterns (an image may mix f16 and bf16 parts), wider ones (layout tests) as they are."""
+    t = t.to(dtype).contiguous()
+    return t.view(torch.int16) if t.element_size() == 2 else t
+
+
 def lp_weight_image(model, dtype):
-    """The five wide layers of the head as one [31, 4, 64, 8] tensor of `dtype` (steps: amb0 2 | amb1 8 | sig0 4 | sig1 8 | colour 9)."""
+    """The five wide layers of the head as one [31, 4, 64, 8] tensor of 16-bit patterns (steps: amb0 2 | amb1 8 | sig0 4 | sig1 8 | colour 9): `dtype`, except
+    ambient_net's ten steps, which are lp_ambient_dtype(dtype)."""
     A0, A1, _ = (l.weight.detach().double() for l in model.ambient_net.net)
     S0, S1, S2 = (l.weight.detach().double() for l in model.sigma_net.net)
     C0 = model.color_net.net[0].weight.detach().double()
@@ -172,9 +185,10 @@ def lp_weight_image(model, dtype):
     parts = [pack_lp(A0[:, :32], lp_cols_encoder(0)), pack_lp(A1, lp_cols_act()),
              pack_lp(S0, lp_cols_encoder(0) + lp_cols_encoder(32)), pack_lp(S1, lp_cols_act()),
              pack_lp(merged, lp_cols_sh() + lp_cols_act(16))]
-    img = torch.cat(parts, dim=0)
+    adt = lp_ambient_dtype(dtype)
+    img = torch.cat([_as_bits(p, adt if k < 2 else dtype) for k, p in enumerate(parts)], dim=0)
     assert img.shape == (31, 4, 64, 8)
-    return img.to(dtype).contiguous()
+    return img.contiguous()
 
 
 def pack_frag(weight, cols, tiles):
@@ -230,7 +244,8 @@ def torso_lp_images(m, dtype):
 
 
 def lp_skinny_image(model, dtype):
-    """[2, 7, 64] of `dtype`: the skinny output rows in the operand order of the preceding layer's activations."""
+    """[2, 7, 64] 16-bit patterns: the skinny output rows in the operand order of the preceding layer's activations; rows 0-2 (ambient_net.2) in
+    lp_ambient_dtype(dtype), rows 3-6 in `dtype`."""
     A2 = model.ambient_net.net[2].weight.detach().double()
     S2 = model.sigma_net.net[2].weight.detach().double()
     C1 = model.color_net.net[1].weight.detach().double()
@@ -239,8 +254,8 @@ def lp_skinny_image(model, dtype):
     rows[3] = S2[0]
     rows[4:7] = C1
     cols = torch.tensor(lp_cols_act(), dtype=torch.long, device=A2.device)      # [8 steps, 2 halves, 8]
-    img = rows[:, cols]                                                          # [7, 8, 2, 8]
-    return img.permute(2, 0, 1, 3).reshape(2, 7, 64).to(dtype).contiguous()
+    img = rows[:, cols].permute(2, 0, 1, 3).reshape(2, 7, 64)                    # [7, 8, 2, 8] -> [half, row, 64]
+    return torch.cat([_as_bits(img[:, :3], lp_ambient_dtype(dtype)), _as_bits(img[:, 3:], dtype)], dim=1).contiguous()
 
 
 def corner_block_table(emb, offsets, levels):

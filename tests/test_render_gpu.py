@@ -35,8 +35,9 @@ def _psnr(a, b):
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, precision):
     """16-bit MFMA operands / fp32 accumulation (gfpp_head_frame_march_lp) vs the fp32 oracle.  Stated tolerance:
-    PSNR >= 45 dB and max-abs <= 2e-2 (fp16, 11-bit significand) / 5e-2 (bf16, 8-bit) on rgb, except rays whose transmittance
-    crosses T_thresh within the rounding (<= 0.05 % of pixels).  Random-init weights are a harsher case than a trained field:
+    PSNR >= 45 dB and max-abs <= 2e-2 on rgb in BOTH 16-bit modes (round 5: the bf16 mode multiplies ambient_net -- whose output is a hash-grid coordinate --
+    as f16, csrc/frame_head_lp.hip::LpAmbient; before that its bar was 5e-2), except rays whose transmittance crosses T_thresh within the rounding
+    (<= 0.05 % of pixels).  Random-init weights are a harsher case than a trained field:
     the synthetic sigma spans e^-3..e^3 within one voxel."""
     case = frame_case(variant, HW)
     ref = oracle_render(oracle_mod, case)
@@ -50,7 +51,7 @@ def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, 
     rgb = rgb.reshape(-1, 3)
     rref = ref["rgb_map"].reshape(-1, 3)
     err = np.abs(rgb - rref).max(axis=1)
-    tol = {"fp16": 2e-2, "bf16": 5e-2}[precision]
+    tol = 2e-2
     if variant != "may_head":
         # the torso field (16-bit MFMA too): alpha of every pixel, and the mask must be identical (it is computed in fp32)
         ta = res["torso_alpha_map"].float().cpu().numpy().reshape(-1)
@@ -375,7 +376,7 @@ def test_full_size_frame_matches_oracle(dev, oracle_mod):
     ref = oracle_render(oracle_mod, case)
     rref = ref["rgb_map"].reshape(-1, 3)
     model = build_model(case, dev, "fused")
-    for precision, tol in (("fp32", 2e-4), ("fp16", 2e-2), ("bf16", 5e-2)):
+    for precision, tol in (("fp32", 2e-4), ("fp16", 2e-2), ("bf16", 2e-2)):
         model.precision = precision
         res = product_render(model, case, dev, "oracle", oracle_mod)
         err = np.abs(_rgb(res) - rref).max(axis=1)
@@ -415,7 +416,7 @@ def test_frame_instantiations_match_oracle(dev, oracle_mod, tag, variant, HW, ov
         rgb = res["rgb_map"].float().cpu().numpy().reshape(-1, 3)
         rref = ref["rgb_map"].reshape(-1, 3)
         err = np.abs(rgb - rref).max(axis=1)
-        tol = {"fp16": 2e-2, "bf16": 5e-2}[precision]
+        tol = 2e-2
         stats = {"psnr": _psnr(rgb, rref), "rgb_max": float(err.max()), "frac_over_tol": float((err > tol).mean())}
         assert stats["psnr"] >= 45.0 and stats["frac_over_tol"] <= 1e-3, stats
     print(tag, precision, stats)

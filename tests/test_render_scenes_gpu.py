@@ -17,12 +17,13 @@ from helpers import frame_case, oracle_render, build_model, product_render, comp
 
 pytestmark = pytest.mark.gpu
 
-BARS = {"fp16": 2e-2, "bf16": 5e-2}
-# Frame bars per 16-bit precision: (PSNR vs the fp32 oracle, share of pixels beyond BARS).  fp16 -- the reference's own inference precision (autocast) -- keeps
-# SURVEY 8c's 45 dB / 0.05 % on every scene here (measured 56-67 dB).  bf16 (BASELINE configs[2]'s arithmetic: 8 significant bits) measures 50 dB on the convex
-# bench scene but 43.1-47.3 dB on these non-convex ones, whose rays composite 15-23 samples through random-init weights with gains of 3-6 per layer: its bar
-# here is 42 dB / 0.1 %, stated, not the reference's precision -- `auto` follows the caller's autocast (fp16) and is the serving default.
-FRAME_BARS = {"fp16": (45.0, 5e-4), "bf16": (42.0, 1e-3)}
+BARS = {"fp16": 2e-2, "bf16": 2e-2}
+# Frame bars per 16-bit precision: (PSNR vs the fp32 oracle, share of pixels beyond BARS) = SURVEY 8c's 45 dB / 2e-2 / 0.05 % for BOTH modes.  fp16 -- the
+# reference's own inference precision (autocast) -- measures 56-67 dB on these scenes.  bf16 (BASELINE configs[2]'s arithmetic) measured 43.1-47.3 dB here in
+# round 4 and ran under a lowered bar (42 dB / 5e-2 / 0.1 %); tools/lp_emulate.py located the loss in ONE layer group -- ambient_net, whose output is a coordinate
+# of the second hash grid -- and since round 5 the bf16 mode multiplies that group as f16 (csrc/frame_head_lp.hip::LpAmbient; CPU emulation of the same scenes:
+# 57-59 dB), so the lowered bar is gone.
+FRAME_BARS = {"fp16": (45.0, 5e-4), "bf16": (45.0, 5e-4)}
 
 
 @pytest.fixture(scope="module")

@@ -19,10 +19,14 @@ from helpers import frame_case, build_model
 # Bars per precision over ALL samples: (max relative error of sigma = max abs error of the density logit, max abs error of colour, of the
 # ambient coordinate), and the same three as MEANS -- a permuted weight row or a mis-folded bias moves most samples by O(0.1..1), far above
 # the mean bars, while the max bars bound the worst rounding case.  Measured on the MI355X (random-init weights with gains of 3..6 per layer,
-# harsher than a trained field): fp32 1.3e-5..3.5e-5 / 1.2e-5 / 5e-7; fp16 1.5e-2..4.1e-2 / 1.4e-2 / 6e-4; bf16 0.10..0.41 / 0.10 / 5e-3.
+# harsher than a trained field): fp32 1.3e-5..3.5e-5 / 1.2e-5 / 5e-7; fp16 1.5e-2..4.1e-2 / 1.4e-2 / 6e-4; bf16 with ambient_net on bf16 operands (round 4)
+# 0.10..0.41 / 0.10 / 5e-3.
 BARS = {"fp32": ((1e-4, 5e-5, 2e-6), (1e-5, 2e-6, 2e-7)),
         "fp16": ((1e-1, 4e-2, 2e-3), (1e-2, 3e-3, 3e-4)),
-        "bf16": ((8e-1, 2e-1, 1.5e-2), (8e-2, 2.5e-2, 2.5e-3))}
+        # round 5: ambient_net runs on f16 operands inside the bf16 mode (LpAmbient): the ambient coordinate is the fp16 mode's, and sigma / colour lose the
+        # part of their error that came from the features of displaced ambient cells -- the fp16 bars hold (round 4's bf16 bars: 8e-1 / 2e-1 / 1.5e-2 max,
+        # 8e-2 / 2.5e-2 / 2.5e-3 mean; CPU emulation of the new mode, tools/lp_emulate.py's rounding points: 2.8e-2 / 1.3e-2 / 5.6e-4 max)
+        "bf16": ((1e-1, 4e-2, 2e-3), (1e-2, 3e-3, 3e-4))}
 
 
 @pytest.fixture(scope="module")
