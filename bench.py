@@ -18,10 +18,11 @@ single-frame latency p50 / p99) and configs[0] (64x64 crop, 1 024 rays per step,
 
 Extra objects in the JSON line:
   roofline      dominant kernel = the fused head trip kernel (sample fetch + 2 grid encodes + MLPs + composite).
-                16-bit modes: bound "hbm" -- the kernel is bound by the hash-grid gathers; achieved = evaluated samples x 2 060 B
-                (12 B position + 2 encodes x 16 levels x 8 corners x 8 B) / time of the trip launches (HIP events on the
-                launch stream) vs the 8 TB/s HBM peak (the tables are L2 / Infinity-Cache resident, so the fraction can exceed what
-                DRAM could deliver; `traffic` = fabric bytes per frame from the FETCH_SIZE PMC pass committed under profiles/);
+                16-bit modes: bound "hbm" -- the north star's yardstick for the hash-grid stage; achieved = evaluated samples x the gather
+                bytes the mode REQUESTS (SURVEY 8d's formula at the precision of the tables read: 1 036 B with the 16-bit corner-block
+                tables, 2 060 B for hash-addressed models on fp32 tables) / time of the head launches (HIP events on the launch stream)
+                vs the 8 TB/s HBM peak; `frac_fp32_equiv` = the same launches at 2 060 B (the unit of rounds 1-3, continuity only);
+                `traffic` = fabric bytes per launch from the FETCH_SIZE PMC pass committed under profiles/;
                 the MFMA fraction (128 768 FLOP/sample vs 2.5 PFLOP/s) is reported beside it.
                 fp32 mode: bound "mfma", 161 536 FLOP/sample vs 157.3 TFLOP/s (fp32-input MFMA, exact fp32)
   modes         frames/s of the other precision modes (short runs of the same pipeline)
@@ -578,7 +579,9 @@ def main():
                   "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
                   "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision],
                   "dtype_note": "MLP layers on MFMA: f32 = exact-fp32 MFMA; f16 / bf16 = 16-bit operands with fp32 accumulation; marcher, grid interpolation, "
-                                "activations' transcendental parts and compositing are fp32 in every mode",
+                                "activations' transcendental parts and compositing are fp32 in every mode.  bf16 mode: ambient_net (two wide layers + three rows, 48 of a "
+                                "block's 148 MFMAs) multiplies f16 operands -- its output is a coordinate of the second hash grid, which 8-bit significands displace by up to "
+                                "five cells of the finest level (tools/lp_emulate.py); sigma_net, the merged geo / colour layer, colour rows and the torso MLPs are bf16",
                   "data": "synthetic",
                   "config": {"workload": f"{args.variant}: May-shaped head+torso NeRF, {HW}x{HW} = {N} rays/frame"
                                          + (" + StyleGAN2 super-resolution to 512x512 (random noise inputs, like the reference)" if args.variant == "may_torso_sr" else "")
@@ -598,6 +601,56 @@ def main():
                              **({"dist": dinfo} if dinfo else {}),
                              "executor": args.executor,
                              "launch": "hipGraph replay per frame" if model.use_graph else "eager"}}
+
+    # ---- the timed frames themselves: rendered, and rendered RIGHT (round-4 review: the line must not be able to report black frames) -------------------------
+    # >= 2 of the K timed frames (first, middle, last: different frame groups / lanes) are re-rendered through the per-frame API -- model.render() on
+    # pre-materialised rays, the reference's own call (genefacepp_infer.py:460-469) -- and compared BYTE FOR BYTE with what the timed job left in its output
+    # stack; the same frames in the exact-fp32 mode give the PSNR of the timed bytes.  A failed check sets `value` to null.  (The *_sr models draw fresh
+    # super-resolution noise per launch like the reference: no byte comparison there, PSNR only against the head+torso input of the SR stage is not defined.)
+    if rank == 0:
+        check = {"frames_checked": [], "bytes_equal_per_frame_api": None, "psnr_vs_fp32_mode_db": [], "ok": False}
+        try:
+            def frame_input(j):
+                pose = torch.from_numpy(batch["ngp_poses"][j]).to(dev)[None]
+                rays = camera.get_rays(pose, intr, HW, HW)
+                return {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose), "cond": torch.from_numpy(fi_all[j]["cond"]).to(dev),
+                        "lm68": torch.from_numpy(fi_all[j]["lm68"]).to(dev), "eye": torch.from_numpy(fi_all[j]["eye_area_percent"]).to(dev)}
+
+            def api_frame(x):
+                with torch.no_grad():
+                    res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=0, staged=False, bg_color=bg_color, lm68=x["lm68"], perturb=False,
+                                       force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
+                return res["rgb_map"].reshape(HW, HW, 3).float().contiguous()
+            picks = sorted({0, K // 2, K - 1})
+            equal, psnrs, spread = [], [], []
+            sr_variant = args.variant == "may_torso_sr"
+            for k in picks:
+                timed = out_u8[k]
+                spread.append(float(timed.float().std().item()))
+                if sr_variant:
+                    continue
+                x = frame_input(W + k)
+                model.precision = args.precision
+                u8 = torch.empty(HW, HW, 3, dtype=torch.uint8, device=dev)
+                frames.to_uint8_hwc(api_frame(x), u8)
+                equal.append(bool(torch.equal(u8, timed)))
+                model.precision = "fp32"
+                ref32 = api_frame(x)
+                mse = float(((timed.float() / 255.0 - ref32) ** 2).mean().item())
+                psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
+            model.precision = args.precision
+            bar = 45.0 if args.precision != "fp32" else 55.0         # SURVEY 8c's 16-bit bar; fp32 frames differ from themselves by the uint8 step only (58.9 dB)
+            check.update({"frames_checked": [W + k for k in picks], "bytes_equal_per_frame_api": (all(equal) if equal else None), "psnr_vs_fp32_mode_db": psnrs,
+                          "uint8_std_per_frame": [round(v, 2) for v in spread], "psnr_bar_db": bar,
+                          "what": "timed frames (output stack of the timed job) vs model.render() on the same inputs: bytes; vs the exact-fp32 mode: PSNR"
+                                  + (" -- *_sr model: fresh SR noise per launch, only the frames' spread is checked" if sr_variant else "")})
+            check["ok"] = bool(all(v > 5.0 for v in spread) and (sr_variant or (all(equal) and all(p >= bar for p in psnrs))))
+        except Exception as exc:
+            check["error"] = f"{type(exc).__name__}: {exc}"
+        result["config"]["timed_frames_check"] = check
+        if not check["ok"]:
+            result["value_unchecked"] = result["value"]
+            result["value"] = None
 
     if rank == 0 and real is not None:
         result["data"] = "real checkpoint" + (" + real driving signals" if real["dataset"] is not None else " + synthetic driving signals")
@@ -732,11 +785,14 @@ def main():
             return {"kernel": kname, "bound": "mfma",
                                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
-        # the 16-bit kernel is bound by instruction issue / gather latency, not by a memory level: quote the ALGORITHMIC gather stream of SURVEY 8d (fp32
-        # tables: 2 060 B per sample -- the unit every round's fraction is in) against the HBM peak (the north star's yardstick for the hash-grid stage),
-        # and beside it the bytes the kernel really asks for since round 4 (16-bit corner-block tables: 12 B + 2 grids x 32 gathers x 16 B)
-        gbps = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
-        gbps_blk = samples * GATHER_BYTES_PER_SAMPLE_BLOCK / t_march / 1e9
+        # the 16-bit kernel is bound by instruction issue / gather latency, not by a memory level.  `achieved` / `frac` = the gather bytes THIS MODE REQUESTS (SURVEY 8d's
+        # formula with the s_tab of the tables the kernel reads: 16-bit corner-block tables since round 4 -> 12 B + 2 grids x 32 gathers x 16 B = 1 036 B per sample;
+        # hash-addressed models keep the fp32 tables -> 2 060 B) against the HBM peak (the north star's yardstick for the hash-grid stage); `frac_fp32_equiv` keeps the
+        # rounds 1-3 unit (2 060 B whatever is read) for continuity and is NOT a hardware quantity
+        blk_tables = bool(pipe.head.pos_grid_blk.table) and bool(pipe.head.amb_grid_blk.table)
+        bytes_read = GATHER_BYTES_PER_SAMPLE_BLOCK if blk_tables else GATHER_BYTES_PER_SAMPLE
+        gbps = samples * bytes_read / t_march / 1e9
+        gbps_eq = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
         tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
         kname = "k_head_frame_persist" if persist else "k_head_trip_pool"
         what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
@@ -744,15 +800,18 @@ def main():
         if G > 1:
             what = f"the whole march / evaluate / composite loop of {G} consecutive frames as ONE launch (frame group), workgroup-local trips over the pooled samples"
         roof = {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
-                "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (SURVEY 8d's algorithmic gather bytes, fp32 tables, vs the 8 TB/s HBM peak), not "
-                              "what limits the kernel: the tables are L2 / Infinity-Cache resident and the counters show an issue / latency bound (`limiter`, `pmc`)",
+                "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (SURVEY 8d's algorithmic gather bytes at the table precision the kernel reads, vs the "
+                              "8 TB/s HBM peak), not what limits the kernel: the tables are L2 / Infinity-Cache resident and the counters show an issue / latency bound "
+                              "(`limiter`, `pmc`)",
                 "limiter": "instruction issue + LDS-fed MFMA + gather latency (no single saturated unit)",
                 "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                "bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
-                "as_read": {"bytes_per_sample": GATHER_BYTES_PER_SAMPLE_BLOCK, "achieved": round(gbps_blk, 1), "unit": "GB/s", "frac": round(gbps_blk / PEAK_HBM_GBPS, 4),
-                            "what": "the same launches counted with the bytes the kernel requests since round 4: 16-bit corner-block tables, 32 gathers of 16 B per grid "
-                                    "and sample (SURVEY 8d's formula with s_tab = 2 B gives the same 1 036 B)"},
-                "l2": {"achieved": round(gbps_blk, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps_blk / PEAK_L2_GBPS, 4),
+                "bytes_per_sample": bytes_read,
+                "bytes_note": ("16-bit corner-block tables: 12 B position + 2 grids x 32 gathers x 16 B (SURVEY 8d's formula with s_tab = 2 B)" if blk_tables
+                               else "fp32 tables through the generic lookup (hash-addressed levels): 12 B + 2 grids x 16 levels x 8 corners x 8 B"),
+                "frac_fp32_equiv": round(gbps_eq / PEAK_HBM_GBPS, 4),
+                "fp32_equiv_note": "the same launches priced at 2 060 B per sample (fp32 tables), the unit of rounds 1-3's fractions -- for continuity only, the kernel does "
+                                   "not move these bytes",
+                "l2": {"achieved": round(gbps, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L2_GBPS, 4),
                        "what": "the requested gather bytes against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves them"},
                 "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP,
@@ -760,10 +819,10 @@ def main():
                                                  "sample since the skinny rows run as MFMA chains on a gathered tile"}, **common}
         if ms_per_frame_period:
             # production overlaps several frames (clip lanes): what the frame PERIOD delivers of the yardstick, next to the one-launch-at-a-time figure above
-            eff = (samples / frames_timed) * GATHER_BYTES_PER_SAMPLE / (ms_per_frame_period * 1e-3) / 1e9
+            eff = (samples / frames_timed) * bytes_read / (ms_per_frame_period * 1e-3) / 1e9
             roof["effective_frac_per_frame_period"] = round(eff / PEAK_HBM_GBPS, 4)
-            roof["effective_note"] = (f"algorithmic bytes of one frame / the clip loop's frame period ({ms_per_frame_period:.4f} ms, several frames in flight: the period also "
-                                      f"holds the frame's other kernels)")
+            roof["effective_note"] = (f"requested gather bytes of one frame / the clip loop's frame period ({ms_per_frame_period:.4f} ms, several frames in flight: the period "
+                                      f"also holds the frame's other kernels)")
         pmc = load_pmc(pmc_tag)
         if pmc:
             roof["pmc"] = pmc
@@ -774,14 +833,15 @@ def main():
         rocprofv3 --pmc runs), or None: ratios are quoted from measurements of the same workload or not at all."""
         if not tag:
             return None
-        path = os.path.join(ROOT, "profiles", f"r04_pmc_{tag}.json")
-        if os.path.exists(path):
-            try:
-                d = json.load(open(path))
-                d["source"] = os.path.relpath(path, ROOT) + " (committed counter pass of this workload; not measured in this run)"
-                return d
-            except Exception:
-                return None
+        for rnd in ("r05", "r04"):                # the newest committed pass of this workload (the r04 passes belong to round 4's kernels and say so in `source`)
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.json")
+            if os.path.exists(path):
+                try:
+                    d = json.load(open(path))
+                    d["source"] = os.path.relpath(path, ROOT) + " (committed counter pass of this workload; not measured in this run)"
+                    return d
+                except Exception:
+                    return None
         return None
 
     if rank == 0 and args.executor == "fused":
@@ -1031,9 +1091,9 @@ def main():
             roof["traffic"] = int(pmc["fabric_bytes_per_launch"])
             roof["traffic_source"] = pmc.get("source")
             per_launch = roof.get("samples_per_launch") or roof.get("samples_per_frame", 0)
-            roof["algorithmic_bytes_per_launch"] = int(per_launch * GATHER_BYTES_PER_SAMPLE)
+            roof["requested_bytes_per_launch"] = int(per_launch * roof.get("bytes_per_sample", GATHER_BYTES_PER_SAMPLE))
         else:
-            roof["traffic_source"] = "no counter pass committed for this workload and precision (profiles/r04_pmc_<variant>_<hw>_<precision>.json)"
+            roof["traffic_source"] = "no counter pass committed for this workload and precision (profiles/r0N_pmc_<variant>_<hw>_<precision>.json)"
     if rank == 0 and "roofline" in result:
         attach_traffic(result["roofline"])
         sr = result.get("configs", {}).get("may_torso_sr_256", {}).get("roofline")

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GFPP_LIB_PATH") or os.path.join(_HERE, "libgfpp_radnerf.so")   # (GFPP_LIB_PATH: experiment builds of tools/*, e.g. -DGFPP_SR_ABLATE)
-ABI_VERSION = 6          # include/gfpp_radnerf.h GFPP_ABI_VERSION (6: corner-block grid copies, frame groups, sticky barrier word; 5: gfpp_head_model.occ_aabb; 4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
+ABI_VERSION = 7          # include/gfpp_radnerf.h GFPP_ABI_VERSION (7: gfpp_torso_fold_batch / gfpp_torso_group_lp, f16 ambient_net steps inside the bf16 image; 6: corner-block grid copies, frame groups, sticky barrier word; 5: gfpp_head_model.occ_aabb; 4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
 _lib = None
 
 c_u32 = ctypes.c_uint32

@@ -1075,7 +1075,9 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
 // separate kernels.
 __global__ __launch_bounds__(256) void k_group_begin(PremarchArgs p) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x < p.frames && threadIdx.x < kCounterWords) p.counters[blockIdx.x * kCounterWords + threadIdx.x] = threadIdx.x == 0 ? (int32_t)p.N : 0;
+    // every frame's counters from block 0 (a launch of tiny frames has fewer blocks than frames: one block per frame left the later frames' histograms stale)
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < p.frames * (uint32_t)kCounterWords; i += 256u) p.counters[i] = i % (uint32_t)kCounterWords == 0u ? (int32_t)p.N : 0;
     if (n >= p.frames * p.N) return;
     const uint32_t f = n / p.N, pix = n - f * p.N;
     const float *pose = p.poses + (size_t)f * p.pose_stride;

@@ -71,6 +71,8 @@ _lib.register("gfpp_cond_feat", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p])
 _lib.register("gfpp_cond_feat_batch", [ctypes.POINTER(CondModel), c_p, c_u32, c_p, c_u32, c_p, c_u32, c_u32, c_p])
 _lib.register("gfpp_torso_frame_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_p])
+_lib.register("gfpp_torso_fold_batch", [ctypes.POINTER(TorsoModel), c_p, c_u32, c_p, c_u32, c_p, c_p])
+_lib.register("gfpp_torso_group_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_occupancy_bounds", [c_p, c_u32, c_u32, c_f, c_p, c_p])
 _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
 _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
@@ -970,6 +972,9 @@ class FramePipeline:
 
     # -- frame groups: K consecutive frames of a clip through ONE persistent head launch (gfpp_frame_ws.n_frames) ------------------------------------
     GROUP_MAX = 4           # kPMaxFrames of csrc/frame_head_lp.hip
+    #: the K torso passes of a group (+ resolve + the clip job's uint8 stores) as ONE launch of persistent workgroups (gfpp_torso_group_lp, round 5);
+    #: GFPP_GROUP_TORSO=0: one gfpp_torso_frame_lp (+ store) per frame behind a resolve launch, the A/B partner (same bits)
+    group_torso = os.environ.get("GFPP_GROUP_TORSO", "1") != "0"
 
     def group_supported(self, N, K, max_steps):
         """Frame groups run on the persistent 16-bit launch with the MFMA torso kernel (what a clip renders with unless told otherwise)."""
@@ -1040,13 +1045,49 @@ class FramePipeline:
             for k in range(K):
                 call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
                      float(dt_gamma), int(max_steps), st)
+        code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
+        folded = None
+        if self.group_torso and self.torso.lp_dtype in (GFPP_F16, GFPP_BF16):
+            # the torso MLPs' per-frame constant columns folded into biases for all K frames, AHEAD of the head launch (they do not depend on it)
+            want = 136 if self.torso.variant == 1 else 6
+            ins = [self._dev_f32(x.reshape(-1), "lm68 / poses") for x in torso_inputs]
+            if any(x.numel() != want for x in ins):
+                raise GfppError("render_group_head_torso: torso_inputs must hold lm68 [136] (landmark-conditioned torso) or poses [6]")
+            tstep = (ins[1].data_ptr() - ins[0].data_ptr()) // 4
+            if tstep < want or any(ins[k].data_ptr() - ins[0].data_ptr() != 4 * tstep * k for k in range(K)):
+                ins = [torch.stack(ins)]                  # not equally spaced views (a caller outside the clip renderer): one small copy
+                tstep = want
+            folded = torch.empty(K, 96, dtype=torch.float32, device=dev)
+            call("gfpp_torso_fold_batch", ctypes.byref(self.torso), ins[0].data_ptr(), int(tstep), code.data_ptr() if code is not None else None, K, folded.data_ptr(), st)
         gws.frame_consts, gws.frame_consts_stride = c[0].data_ptr(), step
         call("gfpp_head_frame_persist_lp", ctypes.byref(self.head), ctypes.byref(gws), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps),
              float(T_thresh), st)
         bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
-        code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        if folded is not None:
+            # ONE launch for the K torso passes: resolve (budget + snapshot per ray), torso field, compositing and -- inside a clip job -- the uint8 stores and the
+            # cursor's advance (gfpp_torso_group_lp; every value the bits of the per-frame kernel)
+            gws.clip_job, gws.clip_lane, gws.clip_sub, gws.clip_advance = None, 0, 0, 0
+            if self.clip_job is not None:
+                gws.clip_job, gws.clip_lane, gws.clip_advance = int(self.clip_job[0]), int(self.clip_job[1]), K * int(self.clip_job[2])
+                self.clip_job_consumed = True
+            stack = {"image": f(K * N, 3), "depth": f(K * N), "torso_alpha": f(K * N, 1), "torso_bg": f(K * N, 3), "deform_dense": f(K * N, 2),
+                     "torso_mask": torch.empty(K * N, dtype=torch.uint8, device=dev)}
+            try:
+                call("gfpp_torso_group_lp", ctypes.byref(self.torso), ctypes.byref(gws), bg_coords.data_ptr(), folded.data_ptr(), code.data_ptr() if code is not None else None,
+                     bg_ptr, bg_scalar, int(bool(use_head_for_torso)), int(max_steps), stack["image"].data_ptr(), stack["depth"].data_ptr(), stack["torso_alpha"].data_ptr(),
+                     stack["torso_bg"].data_ptr(), stack["deform_dense"].data_ptr(), stack["torso_mask"].data_ptr(), st)
+            finally:
+                gws.clip_job, gws.clip_lane, gws.clip_advance = None, 0, 0
+            outs = []
+            for k in range(K):
+                out = {name: v[k * N:(k + 1) * N] for name, v in stack.items()}
+                out["deform"] = None
+                if after_frame is not None:
+                    after_frame(k, out)
+                outs.append(out)
+            return outs
         outs = []
         defer = self.fuse_tail in ("1", "resolve")          # the torso kernel picks budget and snapshot per ray itself (one launch less per frame)
         if not defer:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 6
+#define GFPP_ABI_VERSION 7
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -321,7 +321,10 @@ typedef struct gfpp_head_model {
      *   steps 22-30  MERGED colour layer  [ C0[:, :16] | C0[:, 16:144] @ S2[1:129, :] ]  (color_net.0 x sigma_net.2 geo rows,
      *                no activation lies between them, radnerf.py:126-137): step 22 SH col = 8*h + e, steps 23-30 16 + act(s-23)
      * with h = lane >> 5, rr(r) = (r&3) + 8*(r>>2).  lp_dtype = GFPP_F16 (what the reference's autocast inference uses) or
-     * GFPP_BF16.  The folded biases and all accumulation stay fp32. */
+     * GFPP_BF16.  The folded biases and all accumulation stay fp32.
+     * (ABI 7) With lp_dtype = GFPP_BF16 the steps 0-9 (ambient_net.0 / .1) and the rows 0-2 of lp_skinny (ambient_net.2) are F16 bit patterns: ambient_net's
+     * output is a COORDINATE of the second hash grid, and 8-bit significands displace it by up to five cells of the finest level (the one layer group whose
+     * rounding kept bf16 frames below SURVEY 8c's 45 dB; csrc/frame_head_lp.hip::LpAmbient, tools/lp_emulate.py).  Everything behind the ambient grid is bf16. */
     const void *lp_weights;
     /* the three skinny output layers for the same kernel, 16-bit, [2 half-waves][7 rows][64]: rows 0-2 ambient_net.2 (zero rows beyond
      * ambient_coord_dim), row 3 sigma_net.2 row 0 (density logit), rows 4-6 color_net.1; entry k = 8*s + e of half h = W[row][act(s)] as above,
@@ -594,6 +597,22 @@ int gfpp_torso_frame(const gfpp_torso_model *model, const gfpp_frame_ws *ws, con
 int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *cond_in,
                         const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
                         float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
+
+/* (ABI 7) The torso passes of a frame GROUP as one launch (radnerf_torso.py:156-197 / radnerf_torso_sr.py:186-231 for K consecutive frames of the caller's loop,
+ * genefacepp_infer.py:460-469).  gfpp_torso_fold_batch: the per-frame constant columns of torso_deform_net.0 / torso_canonicial_net.0 (frequency-encoded pose or
+ * chin landmarks + individual code) folded into bias vectors, one workgroup per frame -- the arithmetic of gfpp_torso_frame_lp's prologue: frame f reads
+ * cond_in + f * cond_stride (poses [6] or lm68 [136]) and writes folded[f] = bdef [64] | bcan [32].  It does not depend on the head pass: issue it ahead of it.
+ * gfpp_torso_group_lp: `ws` is a frame-group record (gfpp_frame_ws.n_frames = K, every per-ray array the stack of the K frames) whose head pass was
+ * gfpp_head_frame_persist_lp WITHOUT a resolve step; persistent workgroups walk over 64-pixel spans of all K frames: step budget from each frame's histogram and
+ * snapshot selection per ray (= gfpp_head_group_resolve; workgroup 0 also writes counters[f][k], the alive counts of the reference's loop), torso field, compositing,
+ * depth, and -- when ws->clip_job is set -- the uint8 store of frame f into job position cursor[clip_lane] + f and the cursor's advance by ws->clip_advance
+ * (= gfpp_clip_store_u8_at).  Outputs are stacks over the frames: out_image / torso_bg [K N, 3], out_depth / torso_alpha [K N], deform [K N, 2], mask [K N].
+ * Every value is the bits of the per-frame entry (same per-pixel code, torso_pass).  16-bit weight images only (model->lp_dtype GFPP_F16 / GFPP_BF16). */
+int gfpp_torso_fold_batch(const gfpp_torso_model *model, const float *cond_in, uint32_t cond_stride, const float *code, uint32_t frames, float *folded,
+                          gfpp_stream_t stream);
+int gfpp_torso_group_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *folded, const float *code,
+                        const float *bg_color, float bg_scalar, uint32_t use_head, uint32_t max_steps, float *out_image, float *out_depth,
+                        float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section A.3 -- training-side entry points of _raymarching_face and _gridencoder.  Same conventions as Section A:

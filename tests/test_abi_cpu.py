@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     # and the ctypes table binds exactly the declared set
     assert set(built_lib.declared_symbols()) <= set(names)
     lib = built_lib.lib()
-    assert lib.gfpp_abi_version() == 6
+    assert lib.gfpp_abi_version() == 7
 
 
 def test_ctypes_mirrors_have_the_librarys_struct_sizes(built_lib):

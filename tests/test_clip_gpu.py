@@ -176,7 +176,8 @@ def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
 
 
 # ---- frame groups: K consecutive frames through ONE persistent head launch (round 4) ---------------------------------------------------------
-@pytest.mark.parametrize("variant,HW,precision,F", [("may_torso_sr", 256, "fp16", 10), ("may_torso", 96, "bf16", 9), ("may_torso", 37, "fp16", 5)])
+@pytest.mark.parametrize("variant,HW,precision,F", [("may_torso_sr", 256, "fp16", 10), ("may_torso", 96, "bf16", 9), ("may_torso", 37, "fp16", 5),
+                                                    ("may_torso", 8, "fp16", 9)])      # 8 x 8: a group's prologue launch has fewer blocks than frames (counter reset, round-4 advisory)
 @pytest.mark.parametrize("K", [2, 3, 4])
 def test_frame_groups_deliver_the_bytes_of_single_frames(dev, variant, HW, precision, F, K):
     """ClipRenderer(group=K): a lane takes K consecutive frames at a time and renders them with one persistent head launch (gfpp_frame_ws.n_frames: the rays of
@@ -227,3 +228,90 @@ def test_frame_groups_fall_back_where_they_are_not_supported(dev):
         got = a.render_to_device(clip).cpu().numpy()
         assert a.group == 1, (variant, precision, kernel)
         np.testing.assert_array_equal(got, b.render_to_device(clip).cpu().numpy())
+
+
+def _group_inputs(cr, clip, K, first=0):
+    """What ClipRenderer._frame_group hands to model.render_group for the clip rows [first, first + K): views of the rows (equally spaced)."""
+    ext = cr._with_cond_features(clip)
+    views = [cr._views(ext["packed"][first + k], ext["layout"]) for k in range(K)]
+    fx, fy, cx, cy = cr.intrinsics
+    return dict(consts=[v["cond_feat"] for v in views], bg_coords=cr.bg_coords, poses=[v["pose6"] for v in views], lm68s=[v["lm68"] for v in views], index=0,
+                ngp_poses=[v["pose"] for v in views], camera=(fx, fy, cx, cy, cr.H, cr.W), bg_color=cr.bg_img, T_thresh=cr.T_thresh)
+
+
+@pytest.mark.parametrize("variant,HW,precision,over", [("may_torso", 128, "bf16", None), ("may_torso_sr", 256, "fp16", None), ("may_torso", 37, "fp16", None),
+                                                       ("may_torso", 96, "fp16", {"sigma_gain": 0.05})],
+                         ids=["torso128_bf16", "torso_sr256_fp16", "ragged37_fp16", "thin_scene_snapshots"])
+def test_group_torso_launch_equals_per_frame_torso_launches(dev, variant, HW, precision, over):
+    """gfpp_torso_group_lp (round 5: the K torso passes + resolve of a frame group as ONE launch of persistent workgroups) against its A/B partner, one
+    gfpp_torso_frame_lp per frame behind gfpp_head_group_resolve: every output map of every frame bit for bit (same per-pixel code, torso_pass), and the alive
+    counts the resolve reconstructs.  The thin scene's rays run past max_steps: the snapshot selection inside the torso kernel."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    K, F = 4, 6
+    case = frame_case(variant, HW, **(over or {}))
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    if hasattr(model, "sr_net"):
+        model.sr_net.ready = False
+    kw = dict(case["hp"], use_head_for_torso=True)
+    cr = ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, group=K, lanes=1)
+    clip = cr.prepare(_clip_batch(case["hp"], F), dev)
+    pipe = model.pipeline()
+    got = {}
+    for on in (True, False):
+        pipe.group_torso = on
+        with torch.no_grad():
+            args = dict(kw)
+            args.update(_group_inputs(cr, clip, K, first=1))
+            res = model.render_group(**args)
+        torch.cuda.synchronize()
+        t = pipe.group_workspace(HW * HW, K, int(case["hp"]["max_steps"]))[2]
+        got[on] = ([{k: v.detach().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)} for r in res], t["counters"][:, :27].cpu().numpy().copy())
+    pipe.group_torso = True
+    assert len(got[True][0]) == K
+    for k in range(K):
+        assert set(got[True][0][k]) == set(got[False][0][k])
+        for name, v in got[True][0][k].items():
+            np.testing.assert_array_equal(v, got[False][0][k][name], err_msg=f"frame {k} {name}")
+        assert got[True][0][k]["torso_alpha_map"].max() > 0.05 and got[True][0][k]["rgb_map"].std() > 0.01
+    np.testing.assert_array_equal(got[True][1], got[False][1])                 # counters[f][trip]: the reference loop's alive counts
+    assert (got[True][1][:, 0] == HW * HW).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_headline_shape_frame_groups_bytes_and_oracle(dev, oracle_mod, precision):
+    """The bench headline's own code path (round-4 review, Missing 1): may_torso, 512 x 512, K = 4 frames per persistent launch, two lanes, graph replay from C.
+    (a) the bytes of the frame-by-frame renderer (group = 1) and of the per-frame torso launches (GFPP_GROUP_TORSO = 0's path); (b) a frame rendered INSIDE a
+    group against the CPU oracle directly, SURVEY 8c's 16-bit bar (PSNR >= 45 dB, <= 0.05 % of the pixels beyond 2e-2 -- plus half a uint8 step)."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    from helpers import oracle_render
+    HW, F, K = 512, 9, 4
+    case = frame_case("may_torso", HW)
+    model = build_model(case, dev, "fused")
+    model.precision = precision
+    kw = dict(case["hp"], use_head_for_torso=True)
+    batch = _clip_batch(case["hp"], F)
+    mk = lambda **o: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, **o)
+    single = mk(group=1, lanes=2)
+    clip = single.prepare(batch, dev)
+    want = single.render_to_device(clip).cpu().numpy()
+    grouped = mk(group=K, lanes=2, use_graph=True)
+    got = grouped.render_to_device(clip).cpu().numpy()
+    assert grouped.group == K and single.group == 1
+    np.testing.assert_array_equal(got, want)
+    pipe = model.pipeline()
+    pipe.group_torso = False
+    try:
+        np.testing.assert_array_equal(mk(group=K, lanes=2, use_graph=True).render_to_device(clip).cpu().numpy(), want)
+    finally:
+        pipe.group_torso = True
+    # frame 5 = the second frame of the second group
+    i = 5
+    fcase = frame_case("may_torso", HW, frame_idx=i)
+    ref = oracle_render(oracle_mod, fcase)["rgb_map"].reshape(-1, 3)
+    rgb = got[i].reshape(-1, 3).astype(np.float32) / 255.0
+    err = np.abs(rgb - ref).max(axis=1)
+    mse = float(np.mean((rgb.astype(np.float64) - ref.astype(np.float64)) ** 2))
+    stats = {"psnr": 10.0 * np.log10(1.0 / mse), "max": float(err.max()), "frac_over": float((err > 2e-2 + 1.0 / 255.0).mean())}
+    print("headline group frame vs oracle", precision, stats)
+    assert stats["psnr"] >= 45.0 and stats["frac_over"] <= 5e-4, stats
