@@ -141,6 +141,7 @@ struct LpTripArgs {
     int32_t *budget;                    // counters + 128 of the (first) frame: histogram [32], evaluated samples, rounds; frame f's: + f * kCounterWords
     float *snaps;                       // [N, 7, 5] ray state after max_steps .. max_steps + 6 composited samples
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
+    uint32_t xcd_cols8;                 // != 0: XCD-local ownership (gfpp_frame_ws.row_rays): tile columns per image row / 8; tile_mult then permutes the n_tiles / 8 tiles of ONE XCD
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
     uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 8 128 cycles late
     uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
@@ -725,8 +726,16 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     // this workgroup owns the tile slots [q0, q0 + my_tiles): equal counts of CONSECUTIVE slots, whose tiles the multiplicative permutation spreads
     // over the rows and columns of the image (slots strided by G would all land in one column block: (G * mult) % n_tiles has a large common
     // factor with n_tiles)
-    const uint32_t per_wg = a.n_tiles / G, extra = a.n_tiles % G;
-    const uint32_t my_tiles = per_wg + (b < extra ? 1u : 0u), q0 = b * per_wg + (b < extra ? b : extra);
+    // XCD-local ownership (a.xcd_cols8 != 0; round 5): the dispatcher places workgroup b on XCD b % 8 (observed, not promised: a wrong guess costs speed, never
+    // bits), and the 8-ray tile column c of the image belongs to XCD c % 8 -- every XCD renders a comb of 8-pixel columns, the same share of every part of the
+    // image (balance as before) but 1/8 of the x range: at the levels of the position grid whose tiled index drops z (res >= 256: half of them) and wherever a
+    // cell is narrower than the comb's period, the x-y rows it gathers are 1/8 of the level's, which an XCD's 4 MiB L2 holds (all workgroups spread over the whole
+    // image: every XCD's L2 saw every row -- L2 hit rate 80 %, 510 MB of fabric traffic per frame in round 4's counters).  The G / 8 workgroups of an XCD share
+    // its n_tiles / 8 tiles exactly as all G shared all tiles before: consecutive slots, spread by the multiplicative permutation.
+    const bool xcd = a.xcd_cols8 != 0u;
+    const uint32_t nt = xcd ? a.n_tiles >> 3 : a.n_tiles, Gs = xcd ? G >> 3 : G, bs = xcd ? b >> 3 : b;
+    const uint32_t per_wg = nt / Gs, extra = nt % Gs;
+    const uint32_t my_tiles = per_wg + (bs < extra ? 1u : 0u), q0 = bs * per_wg + (bs < extra ? bs : extra);
     if (my_tiles == 0u) return;                                   // tiny frames: fewer tiles than workgroups
     if constexpr (!F32) lp_fill_shared(sh, a, tid, lane);
     if constexpr (MF) {
@@ -757,7 +766,9 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
                 uint32_t ray = 0, c = 0, frame = 0;
                 bool in_range = false;
                 if (j < my_tiles) {
-                    uint32_t tile = ((q0 + j) * a.tile_mult) % a.n_tiles;
+                    uint32_t tile = ((q0 + j) * a.tile_mult) % nt;
+                    // the XCD's tile number (row of the frame group, column / 8) -> tile: column = 8 (column / 8) + XCD, and a row holds 8 xcd_cols8 tiles
+                    if (xcd) tile = tile * 8u + (b & 7u);
                     if constexpr (MF) {
                         frame = tile / a.tiles_per_frame;
                         tile -= frame * a.tiles_per_frame;
@@ -1464,16 +1475,29 @@ static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model
     a.n_tiles = frames * a.tiles_per_frame;
     // q -> (q * mult) % n_tiles is a permutation of the tiles when gcd(mult, n_tiles) = 1: consecutive slots land ~1237 tiles apart, so that every
     // workgroup's share (slots b, b + G, ...) is spread over the whole image (equal work without any exchange between workgroups)
+    uint32_t grid = (uint32_t)lp_cu_count();
+    if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
+    if (grid > a.n_tiles) grid = a.n_tiles;
+    // XCD-local ownership (k_head_frame_persist): needs the pixel order of the rays (row_rays), whole tile columns in eights, one workgroup per CU on whole XCDs,
+    // and enough columns per XCD for the comb to balance (8 at 512^2: busiest workgroup 2 % above the mean like before; 4 at 256^2: 12 % instead of 5 %, CPU model in
+    // tests/test_persist_budget_cpu.py -- not taken there)
+    a.xcd_cols8 = 0u;
+    {
+        static int mode = -1;
+        if (mode < 0) { const char *e = getenv("GFPP_PERSIST_XCD"); mode = e ? atoi(e) : 1; }
+        const uint32_t W = ws->row_rays;
+        if (mode != 0 && W != 0u && W % 64u == 0u && W / 64u >= (mode >= 2 ? 1u : 8u) && ws->N % W == 0u && grid % 8u == 0u && grid == (uint32_t)lp_cu_count() &&
+            a.n_tiles / 8u >= grid)
+            a.xcd_cols8 = W / 64u;
+    }
+    const uint32_t nt = a.xcd_cols8 ? a.n_tiles / 8u : a.n_tiles;
     a.tile_mult = 1u;
     for (const uint32_t m : {1237u, 251u, 61u, 7u})
-        if (a.n_tiles % m != 0u && (unsigned long long)a.n_tiles * m < (1ull << 32)) { a.tile_mult = m; break; }
+        if (nt % m != 0u && (unsigned long long)nt * m < (1ull << 32)) { a.tile_mult = m; break; }
     a.step_caps = persist_step_caps();
     a.spin_limit = 0;
     a.stagger = 0;
     if (const char *e = getenv("GFPP_PERSIST_STAGGER")) { const int v = atoi(e); if (v > 0 && v < 64) a.stagger = (uint32_t)v; }
-    uint32_t grid = (uint32_t)lp_cu_count();
-    if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
-    if (grid > a.n_tiles) grid = a.n_tiles;
     return grid;
 }
 

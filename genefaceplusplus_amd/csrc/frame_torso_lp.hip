@@ -684,7 +684,7 @@ static int torso_group_wgs_per_cu() {
     static int n = 0;
     if (n == 0) {
         const char *e = getenv("GFPP_TORSO_GROUP_WGS");            // persistent workgroups per CU (experiments)
-        n = e ? atoi(e) : 3;
+        n = e ? atoi(e) : 2;             // measured (512^2 bf16, frames/s of the clip loop): 2 -> 4 535, 3 -> 4 385, 4 -> 4 216 (the other lane's head launch waits for these workgroups' LDS)
         if (n < 1) n = 1;
         if (n > 4) n = 4;
     }

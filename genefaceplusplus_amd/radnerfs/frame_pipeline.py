@@ -45,7 +45,7 @@ class FrameWs(ctypes.Structure):
                 ("sample_stride", c_u32), ("phase_cycles", c_p), ("separate_trips", c_u32),
                 ("gcounters", c_p), ("N_global", c_u32), ("trip_first", c_u32), ("trip_count", c_u32), ("full_grid_trips", c_u32),
                 ("snapshots", c_p), ("defer_resolve", c_u32), ("resolve_max_steps", c_u32), ("clip_job", c_p), ("clip_lane", c_u32),
-                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("frame_consts_stride", c_u32), ("timeouts", c_p)]
+                ("clip_sub", c_u32), ("clip_advance", c_u32), ("n_frames", c_u32), ("frame_consts_stride", c_u32), ("timeouts", c_p), ("row_rays", c_u32)]
 
 
 class CondModel(ctypes.Structure):
@@ -708,6 +708,7 @@ class FramePipeline:
             ws.snapshots = None
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane = 0, 0, None, 0
             ws.clip_sub, ws.clip_advance, ws.n_frames, ws.frame_consts_stride = 0, 0, 0, 0
+            ws.row_rays = 0
             t["timeouts"] = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: no kernel resets it (gfpp_frame_ws.timeouts)
             ws.timeouts = t["timeouts"].data_ptr()
             ent = (ws, t)
@@ -1007,6 +1008,7 @@ class FramePipeline:
             ws.separate_trips = ws.N_global = ws.trip_first = ws.trip_count = ws.full_grid_trips = 0
             ws.defer_resolve, ws.resolve_max_steps, ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = 0, 0, None, 0, 0, 0
             ws.n_frames, ws.frame_consts_stride, ws.timeouts = n_frames, 0, t["timeouts"].data_ptr()
+            ws.row_rays = 0
             return ws
         ent = (record(0, K), [record(k, 0) for k in range(K)], t)
         self._ws[key] = ent
@@ -1039,9 +1041,11 @@ class FramePipeline:
             if pstep < 16 or any(poses[k].data_ptr() - poses[0].data_ptr() != 4 * pstep * k or poses[k].numel() != 16 for k in range(K)):
                 raise GfppError("render_group_head_torso: the frames' poses must be equally spaced [4, 4] views")
             fx, fy, cx, cy, H, W = camera
+            gws.row_rays = int(W)                  # the rays are generated in pixel order: the head launch may give every XCD its own image columns
             call("gfpp_head_group_begin", ctypes.byref(self.head), ctypes.byref(gws), poses[0].data_ptr(), int(pstep), float(fx), float(fy), float(cx), float(cy), int(H),
                  int(W), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps), st)
         else:
+            gws.row_rays = 0
             for k in range(K):
                 call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
                      float(dt_gamma), int(max_steps), st)

@@ -421,6 +421,11 @@ typedef struct gfpp_frame_ws {
     int32_t *timeouts;        /* optional [1] i32 that NO kernel of this library resets: a device-wide barrier of the multi-trip launch
                                * (gfpp_head_frame_trips_lp) that times out adds 1 -- unlike counters[127], which the next frame's begin kernel zeroes, so a
                                * time-out in the middle of a clip stays visible until the caller has looked (FramePipeline.check_barriers) */
+    uint32_t row_rays;        /* (ABI 7) 0, or W: ray n is pixel (n / W, n % W) of its frame (gfpp_head_group_begin sets up exactly this order).  Known, and a
+                               * multiple of 64 with one workgroup per CU on a multiple of 8 CUs, the persistent head launch gives every XCD its own image COLUMNS
+                               * (8-ray tile column c goes to XCD c % 8, i.e. to the workgroups b with b % 8 == c % 8): the x-y cells of the position grid a
+                               * workgroup gathers -- at the levels whose index drops z, all of them -- then come from 1/8 of the table rows, so that an XCD's 4 MiB
+                               * L2 holds them.  A pure speed choice: which workgroup renders a ray never changes its bits. */
 } gfpp_frame_ws;
 
 /* Starts a frame (replaces renderer.py:302-350 = raymarching.cu:91-145 slab test + the torch.zeros/arange/clone state

@@ -168,6 +168,67 @@ def test_workgroup_shares_are_balanced_on_the_bench_scene(oracle_mod, HW, bar):
     assert strided.max() / strided.mean() > 1.5                                            # what the consecutive slots avoid
 
 
+def _ownership_xcd(N, W, frames, G=256):
+    """XCD-local ownership (round 5; frame_head_lp.hip, gfpp_frame_ws.row_rays): workgroup b belongs to XCD b % 8, which owns the tile columns c with c % 8 == b % 8;
+    the G / 8 workgroups of an XCD share its n_tiles / 8 tiles like all G shared all tiles: consecutive slots of the XCD's own numbering, permuted, and
+    tile = 8 * (XCD's tile number) + XCD.  Returns owner [n_tiles] or None where the library does not take this path."""
+    if W % 64 or W // 64 < 8 or N % W or G % 8:
+        return None
+    n_tiles = frames * (N // TILE)
+    nt, Gs = n_tiles // 8, G // 8
+    if nt < G:
+        return None
+    mult = next((m for m in (1237, 251, 61, 7) if nt % m and nt * m < 2 ** 32), 1)
+    per_wg, extra = divmod(nt, Gs)
+    owner = np.full(n_tiles, -1, np.int64)
+    for b in range(G):
+        bs, x = b >> 3, b & 7
+        my = per_wg + (bs < extra)
+        q0 = bs * per_wg + min(bs, extra)
+        local = (np.arange(q0, q0 + my, dtype=np.uint64) * np.uint64(mult)) % np.uint64(nt)
+        tile = (local * np.uint64(8) + np.uint64(x)).astype(np.int64)
+        assert (owner[tile] == -1).all()
+        owner[tile] = b
+    return owner
+
+
+@pytest.mark.parametrize("HW,frames", [(512, 1), (512, 4), (1024, 2), (640, 3)])
+def test_xcd_local_ownership_covers_every_tile_once_and_keeps_columns_apart(HW, frames):
+    owner = _ownership_xcd(HW * HW, HW, frames)
+    assert owner is not None and (owner >= 0).all()
+    tiles_per_row = HW // TILE
+    col = np.arange(owner.size) % tiles_per_row
+    assert np.array_equal(owner % 8, col % 8)                                             # XCD x renders the tile columns x, x + 8, ...: a comb of 8-pixel columns
+    counts = np.bincount(owner, minlength=256)
+    assert counts.max() - counts.min() <= 1
+    assert _ownership_xcd(256 * 256, 256, 4) is None and _ownership_xcd(37 * 37, 37, 4) is None     # too few columns per XCD / ragged rows: the image-wide permutation
+
+
+def test_xcd_local_shares_are_balanced_on_the_bench_scene(oracle_mod):
+    """The comb gives every XCD the same share of every part of the image: four consecutive 512^2 frames of the bench clip, occupied samples per workgroup -- the
+    busiest workgroup stays within 5 % of the mean (the image-wide permutation: 2 %), the busiest XCD within 2 %."""
+    from helpers import frame_case
+    HW, frames = 512, 4
+    per_tile = []
+    for i in range(frames):
+        case = frame_case("may_torso", HW, frame_idx=i)
+        hp, sd = case["hp"], case["sd"]
+        rays = oracle_mod.get_rays(case["pose"], case["intr"], HW, HW)
+        ro, rd = rays["rays_o"][0], rays["rays_d"][0]
+        N = HW * HW
+        nears, fars = oracle_mod.near_far_from_aabb(ro, rd, sd["aabb_infer"], 0.05)
+        _, _, deltas = oracle_mod.march_rays(N, 23, np.arange(N, dtype=np.int32), nears.copy(), ro, rd, float(hp["bound"]), sd["density_bitfield"], 1, 128, nears, fars,
+                                             -1, False, hp["dt_gamma"], hp["max_steps"])
+        c = (deltas[:N * 23, 0].reshape(N, 23) > 0).sum(1).astype(np.float64)
+        per_tile.append(c.reshape(-1, TILE).sum(1))
+    per_tile = np.concatenate(per_tile)
+    owner = _ownership_xcd(HW * HW, HW, frames)
+    share = np.bincount(owner, weights=per_tile, minlength=256)
+    per_xcd = share.reshape(32, 8).sum(0)
+    assert share.max() / share.mean() <= 1.05, share.max() / share.mean()
+    assert per_xcd.max() / per_xcd.mean() <= 1.02, per_xcd.max() / per_xcd.mean()
+
+
 def test_round_geometry_never_overflows_the_pool():
     for A in range(1, 1025):
         rw = (A + 7) // 8
