@@ -79,6 +79,9 @@ def parse():
                     help="multi-GPU partition: 'frames' = frame-parallel (the default: independent frames, no data-path collective, weak scaling); 'rays' = "
                          "latency mode, ALL ranks render each frame together as ray tiles (one int32 all_reduce per trip for the frame-wide alive count + "
                          "an all_gather of the tiles per frame; strong scaling of one frame)")
+    ap.add_argument("--shard-order", default="contiguous", choices=["contiguous", "interleaved"],
+                    help="multi-GPU frame partition: 'contiguous' = rank r renders the block [r F / G, (r + 1) F / G) of the clip (SURVEY 8e, DESIGN section 6: keeps video order, "
+                         "one gather per chunk reassembles the clip), 'interleaved' = frame i on rank i %% G")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[0] / configs[1] entries")
     ap.add_argument("--long-run-frames", type=int, default=2000, help="frames of modes.long_run (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (control-flow checks of the N>1 path on one GPU)")
@@ -423,9 +426,9 @@ def main():
     model.precision = args.precision
     model.use_graph = not args.no_graph and args.executor == "fused"
 
-    # ---- this rank's frames: global frame index = step * world + rank (frame-parallel sharding) ----------------------------
+    # ---- this rank's frames (frame-parallel sharding): a contiguous block of the clip per rank (--shard-order interleaved: global frame = step * world + rank) ----
     total = K + W
-    my_frames = frames.shard_frames(total * world, rank, world, interleaved=True)
+    my_frames = frames.shard_frames(total * world, rank, world, interleaved=(args.shard_order == "interleaved"))
     intr = syn.intrinsics_for(HW, HW)
     bg_coords = camera.get_bg_coords(HW, HW, "cpu").to(dev)          # host-computed like the reference dataset (dataset_utils.py:240)
     bg_color = torch.full((1, N, 3), 0.5, device=dev)
@@ -587,7 +590,7 @@ def main():
                                          + (" + StyleGAN2 super-resolution to 512x512 (random noise inputs, like the reference)" if args.variant == "may_torso_sr" else "")
                                          + ", max_steps 16, T_thresh 0.01, "
                                          f"random-init weights of the May architecture (seed 9999), ellipsoid occupancy, synthetic poses/landmarks",
-                             "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}" + ((" + RCCL " + ("gather to the writer rank" if args.gather == "writer" else "all_gather")
+                             "frames_per_gpu": K, "shard_order": args.shard_order, "parallelism": f"frame-parallel x{world}" + ((" + RCCL " + ("gather to the writer rank" if args.gather == "writer" else "all_gather")
                                                                            + f" of uint8 frames every {chunk} frames, overlapped with rendering") if world > 1 else ""),
                              "frame_loop": "genefaceplusplus_amd.clip.ClipRenderer: at the start of the timed job the conditioning networks and the constant fold of all its "
                                            "frames (two launches, inside the timed region); then per frame ONE graph launch issued from C (gfpp_graph_replay); inside the "

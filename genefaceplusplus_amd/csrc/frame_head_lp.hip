@@ -26,7 +26,7 @@
 
 // Round 4 (measured on the GPU, then adopted; the A/B numbers are in docs/LAB_NOTEBOOK.md): the two hash grids are read as 16-bit CORNER-BLOCK tables
 // (grid_device.h: one 16-byte gather per z plane of a level, all eight levels of a lane in flight), the three skinny output layers run as MFMA chains on one
-// gathered tile (skinny_mfma), and a block's ray directions are requested before its first grid lookup.  Head pass 0.290 -> 0.240 ms at 512^2.
+// gathered tile (skinny_mfma_fused), and a block's ray directions are requested before its first grid lookup.  Head pass 0.290 -> 0.240 ms at 512^2.
 
 namespace gfpp {
 
@@ -97,7 +97,7 @@ struct LpPoolP {
 
 struct LpShared {
     uint4 w[kLpWeightChunks];      // 126 976 B
-    uint32_t skinny[kSkinnyLds];   //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack
+    uint32_t skinny[kSkinnyLds];   //   1 792 B  skinny output rows as 16-bit pairs, in the operand order of relu_pack_step
     gfpp_grid_level lv[2][16];     //   1 024 B  level descriptors of the position / ambient grid
     float bias[256];               //   1 024 B
     union {
@@ -149,10 +149,20 @@ struct LpTripArgs {
     unsigned long long *phase_cycles;   // optional [trips][8] (k_head_trip_pool<PROF>): cycles summed over wavefronts by phase, see there
 };
 
+// While a wavefront issues a layer's MFMAs it asks for issue priority (s_setprio): of the two wavefronts of a SIMD the one on the matrix pipe goes first and the
+// other fills the remaining issue slots with its vector work, instead of both alternating on every instruction (measured with the fused layers below, same box,
+// 512^2 bf16: 4 473-4 480 -> 4 496-4 522 frames/s).
+constexpr int kMfmaPrio = 2;
 template <typename H, int NS>
 __device__ __forceinline__ void mfma_steps(v16f (&acc)[4], const uint4 *w, int step0, const typename LpTraits<H>::vec (&b)[NS], int lane) {
+    __builtin_amdgcn_s_setprio(kMfmaPrio);
     mfma_layer_lds<H, NS, 4>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(w) + step0 * 256, b, lane);
+    __builtin_amdgcn_s_setprio(0);
 }
+// a 128 -> 128 layer on the previous layer's accumulators, followed by the skinny rows on ITS accumulators: every activation packed under the MFMAs that follow
+// (lp_mfma_device.h: mfma_layer_lds_fused; skinny_mfma_fused below).  keep: the packed hidden state, for a second consumer.
+template <typename H>
+__device__ __forceinline__ void hidden_layer_and_rows(const LpShared &sh, int step0, const v16f (&prev)[4], int lane, v16f &rows, typename LpTraits<H>::vec (*keep)[8]);
 
 // Transcendentals of the 16-bit kernels on the hardware's exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm's range-reduced forms and IEEE
 // divisions: ~100 of a block's ~1 380 vector instructions.  Their inputs carry 8-11 significant bits (16-bit MFMA operands): the forms differ from libm's by a few
@@ -180,11 +190,6 @@ struct LpAmbient<__bf16> {
     typedef _Float16 type;
 };
 
-template <typename H>
-__device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTraits<H>::vec (&b)[8]) {
-    act_pack<H, 4, 1>(acc, b);
-}
-
 // This lane's half of a 16-level, 2-channel grid encoding, packed as MFMA operands.  Half-wave `hi` takes the levels hi, hi+2, ..; value k (= 8 s + e) of the
 // lane is level 2 (k/2) + hi, channel k % 2.
 //   SLOW = false (every level's index is linear modulo a power of two or provably in range -- the tiled grids of every shipped model): the table is the 16-bit
@@ -192,10 +197,9 @@ __device__ __forceinline__ void relu_pack(const v16f (&acc)[4], typename LpTrait
 //     lane are issued before the first is interpolated -- two memory round trips per block and grid.  Measured at 512^2 bf16 (head pass, same box): fp32
 //     tables with two levels in flight 0.290 ms, block tables 0.263, with eight levels in flight 0.249 (with fp32 tables eight levels spill 7 registers).
 //   SLOW = true (hash-addressed or true-modulo levels present): the generic lookup on the fp32 table, level by level.
-// H2: the features a second time as operands of another type (the position features feed ambient_net -- LpAmbient<H> -- and sigma_net); H2 = H: `b2` is not written.
-template <int D, typename H, bool SLOW, typename H2 = H>
+template <int D, typename H, bool SLOW>
 __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid &g, const gfpp_grid_level *lvl, int hi, bool valid,
-                                               typename LpTraits<H>::vec (&b)[2], typename LpTraits<H2>::vec (*b2)[2] = nullptr) {
+                                               typename LpTraits<H>::vec (&b)[2]) {
     bool ok = valid;
     float uc[D];
 #pragma unroll
@@ -258,14 +262,6 @@ __device__ __forceinline__ void encode_half_lp(const float (&u)[D], const LpGrid
             const u32x4 w = __builtin_bit_cast(u32x4, b[s]);
             b[s] = __builtin_bit_cast(typename LpTraits<H>::vec, ok ? w : u32x4{0u, 0u, 0u, 0u});
         }
-        if constexpr (!std::is_same<H2, H>::value) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) (*b2)[s][e] = (H2)f[8 * s + e];
-            if constexpr (!SLOW) {
-                const u32x4 w = __builtin_bit_cast(u32x4, (*b2)[s]);
-                (*b2)[s] = __builtin_bit_cast(typename LpTraits<H2>::vec, ok ? w : u32x4{0u, 0u, 0u, 0u});
-            }
-        }
     }
 }
 
@@ -285,40 +281,53 @@ __device__ __forceinline__ uint32_t skinny_tile_chunk(int lane) {
     const uint32_t q = (h << 3) - h + row;          // (half, row)
     return (q << 3) + q;
 }
+// skinny_mfma with its operands packed from the preceding layer's accumulators UNDER its own MFMAs (lp_mfma_device.h: mfma_layer_lds_fused): the operand of step
+// s + 1 -- eight vector instructions, the duration of one MFMA -- behind the MFMA of step s.  keep: the packed operands for a second consumer (the colour layer).
 template <typename H>
-__device__ __forceinline__ void skinny_mfma(const uint32_t *__restrict__ image, const typename LpTraits<H>::vec (&b)[8], int lane, v16f &acc) {
+__device__ __forceinline__ void skinny_mfma_fused(const uint32_t *__restrict__ image, const v16f (&prev)[4], int lane, v16f &acc, typename LpTraits<H>::vec (*keep)[8]) {
     typedef typename LpTraits<H>::vec vec;
     const vec *p = reinterpret_cast<const vec *>(image) + skinny_tile_chunk(lane);
     vec a[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = p[s];
-    // two independent chains (even / odd steps): a dependent MFMA waits for its predecessor's last pass
     v16f even, odd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) even[r] = odd[r] = 0.0f;
+    vec b = relu_pack_step<H>(prev, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-        even = LpTraits<H>::mfma(a[s], b[s], even);
-        odd = LpTraits<H>::mfma(a[s + 1], b[s + 1], odd);
+    for (int s = 0; s < 8; ++s) {
+        if (keep) (*keep)[s] = b;
+        if (s & 1) odd = LpTraits<H>::mfma(a[s], b, odd);
+        else even = LpTraits<H>::mfma(a[s], b, even);
+        if (s + 1 < 8) {
+            b = relu_pack_step<H>(prev, s + 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = even[r] + odd[r];
+}
+
+template <typename H>
+__device__ __forceinline__ void hidden_layer_and_rows(const LpShared &sh, int step0, const v16f (&prev)[4], int lane, v16f &rows, typename LpTraits<H>::vec (*keep)[8]) {
+    v16f acc[4];
+    __builtin_amdgcn_s_setprio(kMfmaPrio);
+    mfma_layer_lds_fused<H>(acc, reinterpret_cast<const typename LpTraits<H>::vec *>(sh.w) + step0 * 256, prev, lane, nullptr);
+    skinny_mfma_fused<H>(sh.skinny, acc, lane, rows, keep);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // ambient_net on one 32-sample block: pos operand -> ambient coordinates (pre-tanh), replicated in both half-waves
 template <int AMB_D, typename H>
 __device__ __forceinline__ void ambient_block(const LpShared &sh, const float *__restrict__ bias, const typename LpTraits<H>::vec (&bpos)[2], int lane, int hi,
                                               float (&amb)[AMB_D]) {
-    v16f acc[4];
-    typename LpTraits<H>::vec bh[8];
+    v16f acc[4], sk;
     load_bias(acc, bias, hi);
     mfma_steps<H, 2>(acc, sh.w, kStepAmb0, bpos, lane);
-    relu_pack<H>(acc, bh);
-    zero_acc(acc);
-    mfma_steps<H, 8>(acc, sh.w, kStepAmb1, bh, lane);
-    relu_pack<H>(acc, bh);
-    v16f sk;
-    skinny_mfma<H>(sh.skinny, bh, lane, sk);
+    hidden_layer_and_rows<H>(sh, kStepAmb1, acc, lane, sk, nullptr);
 #pragma unroll
     for (int d = 0; d < AMB_D; ++d) amb[d] = sk[d];
 }
@@ -338,14 +347,10 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
     zero_acc(acc);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0, bpos, lane);
     mfma_steps<H, 2>(acc, sh.w, kStepSig0 + 2, bamb, lane);
-    relu_pack<H>(acc, bh);
-    zero_acc(acc);
-    mfma_steps<H, 8>(acc, sh.w, kStepSig1, bh, lane);
-    relu_pack<H>(acc, bh);   // the hidden state feeds both the density row and the (merged) colour layer
     float logit;
     {
         v16f sk;
-        skinny_mfma<H>(sh.skinny, bh, lane, sk);
+        hidden_layer_and_rows<H>(sh, kStepSig1, acc, lane, sk, &bh);   // the hidden state feeds both the density row and the (merged) colour layer
         logit = sk[3];
     }
     const float sigma = a.density_scale * lp_exp(logit);
@@ -360,11 +365,12 @@ __device__ __forceinline__ void radiance_block(const LpTripArgs &a, const LpShar
         load_bias(acc, bias + 128, hi);
         mfma_steps<H, 9>(acc, sh.w, kStepCol, bcol, lane);
     }
-    relu_pack<H>(acc, bh);
     float rgb[3];
     {
         v16f sk;
-        skinny_mfma<H>(sh.skinny, bh, lane, sk);
+        __builtin_amdgcn_s_setprio(kMfmaPrio);
+        skinny_mfma_fused<H>(sh.skinny, acc, lane, sk, nullptr);
+        __builtin_amdgcn_s_setprio(0);
         rgb[0] = sk[4]; rgb[1] = sk[5]; rgb[2] = sk[6];
     }
     if (valid && hi == 0) {
@@ -397,24 +403,31 @@ __device__ __forceinline__ void evaluate_block_lp(const LpTripArgs &a, const LpS
 
     typedef typename LpAmbient<H>::type HA;        // ambient_net's operand type (f16 in the bf16 mode, see LpAmbient)
     vec bpos[2], bamb[2];
-    typename LpTraits<HA>::vec bpos_a[2];
     float dir[3];
     {
         const float *dp = a.rays_d + 3ull * ray;
         dir[0] = dp[0]; dir[1] = dp[1]; dir[2] = dp[2];
     }
     {
-        float u3[3];
+        float amb[AMB_D], ua[AMB_D], u3[3];
         const float b2 = 2.0f * a.mp.bound;
         u3[0] = (wt.px[slot] + a.mp.bound) / b2;
         u3[1] = (wt.py[slot] + a.mp.bound) / b2;
         u3[2] = (wt.pz[slot] + a.mp.bound) / b2;
-        encode_half_lp<3, H, SLOW, HA>(u3, a.pos, lv_pos, hi, valid, bpos, &bpos_a);
-    }
-    {
-        float amb[AMB_D], ua[AMB_D];
-        if constexpr (std::is_same<HA, H>::value) ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
-        else ambient_block<AMB_D, HA>(sh, bias, bpos_a, lane, hi, amb);
+        if constexpr (std::is_same<HA, H>::value) {
+            encode_half_lp<3, H, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos);
+            ambient_block<AMB_D, H>(sh, bias, bpos, lane, hi, amb);
+        } else {
+            // the position features as ambient_net's operands (HA) first; sigma_net's copy (H) is made from them behind ambient_net: both copies alive through its
+            // layers cost the 8 registers that made the bf16 instantiation spill (the features come from 16-bit tables: HA = f16 holds them to 11 bits, H = bf16 keeps 8)
+            typename LpTraits<HA>::vec bpos_a[2];
+            encode_half_lp<3, HA, SLOW>(u3, a.pos, lv_pos, hi, valid, bpos_a);
+            ambient_block<AMB_D, HA>(sh, bias, bpos_a, lane, hi, amb);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bpos[s][e] = (H)(float)bpos_a[s][e];
+        }
 #pragma unroll
         for (int d = 0; d < AMB_D; ++d) {
             const float th = lp_tanh(amb[d]);
@@ -714,7 +727,9 @@ struct PoolViewF32 {
     Dir dx, dy, dz;
 };
 
-template <int AMB_D, typename H, bool SLOW, bool MF>
+// PROF (gfpp_frame_ws.phase_cycles != null; bench.py's roofline section, never the frame loop): thread 0's shader clock by phase, summed over the workgroups into the
+// budget counters [44..49] -- the production instantiation carries no clock reads.
+template <int AMB_D, typename H, bool SLOW, bool MF, bool PROF = false>
 __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_persist(PersistArgs<H> pa) {
     constexpr bool F32 = std::is_same<H, float>::value;
     static_assert(!F32 || (!SLOW && !MF), "the fp32 instantiation: generic lookups are its only ones, one frame per launch");
@@ -745,12 +760,14 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
     if (tid < (int)(32u * kPMaxFrames)) (&pool.hist[0][0])[tid] = 0u;
     const uint32_t cap = a.max_steps + 7u;                        // a ray can never composite more samples than that (k_premarch stores no more)
     uint32_t j_next = 0, A = 0, evaluated = 0, round = 0;
-    unsigned long long t_mark = __builtin_readcyclecounter(), cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
+    unsigned long long t_mark = PROF ? __builtin_readcyclecounter() : 0ull, cyc[4] = {0ull, 0ull, 0ull, 0ull};   // ingest + fetch | compaction | evaluate | composite + list
     unsigned long long cyc_ingest = 0ull;                          // the ingest steps alone (part of cyc[0])
     auto lap = [&](int k) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        cyc[k] += now - t_mark;
-        t_mark = now;
+        if constexpr (PROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            cyc[k] += now - t_mark;
+            t_mark = now;
+        }
     };
     __syncthreads();                                              // weights, descriptors, zeroed histogram
 
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
             A += acc;
             j_next += accepted;
             __syncthreads();
-            cyc_ingest += __builtin_readcyclecounter() - t_mark;
+            if constexpr (PROF) cyc_ingest += __builtin_readcyclecounter() - t_mark;
         }
         if (A == 0u) {
             if (j_next >= my_tiles) break;
@@ -975,10 +992,12 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         atomicAdd(&a.budget[kBudgetRounds], (int)round);
         atomicMax(&a.budget[kBudgetRoundsMax], (int)round);
         atomicMax(&a.budget[kBudgetSamplesMax], (int)evaluated);
-        // where this workgroup's time went (thread 0's clock, units of 1024 shader cycles; sums over the workgroups + the longest workgroup)
-        for (int k = 0; k < 4; ++k) atomicAdd(&a.budget[kBudgetCycles + k], (int)(cyc[k] >> 10));
-        atomicMax(&a.budget[kBudgetCycles + 4], (int)((cyc[0] + cyc[1] + cyc[2] + cyc[3]) >> 10));
-        atomicAdd(&a.budget[kBudgetCycles + 5], (int)(cyc_ingest >> 10));
+        if constexpr (PROF) {
+            // where this workgroup's time went (thread 0's clock, units of 1024 shader cycles; sums over the workgroups + the longest workgroup)
+            for (int k = 0; k < 4; ++k) atomicAdd(&a.budget[kBudgetCycles + k], (int)(cyc[k] >> 10));
+            atomicMax(&a.budget[kBudgetCycles + 4], (int)((cyc[0] + cyc[1] + cyc[2] + cyc[3]) >> 10));
+            atomicAdd(&a.budget[kBudgetCycles + 5], (int)(cyc_ingest >> 10));
+        }
     }
 }
 
@@ -1418,6 +1437,13 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
 template <int AMB_D, typename H, bool SLOW>
 static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
     const PersistArgs<H> pa{a};
+    if constexpr (!SLOW) {
+        if (a.phase_cycles) {          // the profiling instantiation (tiled-grid models only)
+            if (a.n_frames > 1u) hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, true, true>), dim3(grid), dim3(kLpThreads), 0, st, pa);
+            else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false, true>), dim3(grid), dim3(kLpThreads), 0, st, pa);
+            return;
+        }
+    }
     if (a.n_frames > 1u) hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, true>), dim3(grid), dim3(kLpThreads), 0, st, pa);
     else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, pa);
 }
@@ -1484,7 +1510,11 @@ static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model
     a.xcd_cols8 = 0u;
     {
         static int mode = -1;
-        if (mode < 0) { const char *e = getenv("GFPP_PERSIST_XCD"); mode = e ? atoi(e) : 1; }
+        // measured (round 5, 512^2 bf16, four frames per launch, same box): L2 hit rate 80.0 -> 84.4 %, fabric traffic 2.03 -> 1.61 GB per launch, the launch itself
+        // +-0 (808 vs 810-821 us) and the clip loop 1 % slower (4 511-4 515 vs 4 554-4 557 frames/s: the comb's workgroup shares are a little less even) -- the kernel is
+        // bound by issue and gather LATENCY, and the misses that remain are the ambient grid's, whose coordinates are an MLP output (no image locality to keep): off by
+        // default, GFPP_PERSIST_XCD=1 turns it on (2: also with four tile columns per XCD, the 256^2 frames)
+        if (mode < 0) { const char *e = getenv("GFPP_PERSIST_XCD"); mode = e ? atoi(e) : 0; }
         const uint32_t W = ws->row_rays;
         if (mode != 0 && W != 0u && W % 64u == 0u && W / 64u >= (mode >= 2 ? 1u : 8u) && ws->N % W == 0u && grid % 8u == 0u && grid == (uint32_t)lp_cu_count() &&
             a.n_tiles / 8u >= grid)
@@ -1558,6 +1588,7 @@ GFPP_API int gfpp_head_frame_persist_lp(const gfpp_head_model *model, const gfpp
     LpTripArgs a;
     const uint32_t grid = persist_control_args(a, model, ws, rays_o, rays_d, dt_gamma, max_steps, T_thresh, frames);
     { const int rc = lp_model_args("gfpp_head_frame_persist_lp", model, a); if (rc) return rc; }
+    a.phase_cycles = (unsigned long long *)ws->phase_cycles;          // non-null: the instantiation with the phase clocks (k_head_frame_persist<.., PROF>)
     const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
     void (*launch)(uint32_t, hipStream_t, const LpTripArgs &) =
         amb3 ? (bf ? (slow ? launch_persist<3, __bf16, true> : launch_persist<3, __bf16, false>) : (slow ? launch_persist<3, _Float16, true> : launch_persist<3, _Float16, false>))

@@ -19,16 +19,6 @@
 #include "march_device.h"
 #include "sh_device.h"
 
-// experiment builds only (tools/torso_phase.py): every workgroup's first lane stamps the 100 MHz wall clock at its phase boundaries into the buffer whose address the
-// environment variable GFPP_TORSO_PROF_PTR carries ([workgroup][8] uint64)
-#ifndef GFPP_TORSO_PROF
-#define GFPP_TORSO_PROF 0
-#endif
-#if GFPP_TORSO_PROF
-#define GFPP_TORSO_MARK(k) do { if (a.prof && threadIdx.x == 0) a.prof[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define GFPP_TORSO_MARK(k) do { } while (0)
-#endif
 
 namespace gfpp {
 
@@ -62,9 +52,6 @@ struct TorsoLpArgs {
     BudgetView bv;            // hist != null: the head pass was the persistent launch with the resolve deferred to this kernel
     gfpp_clip_job *job;       // != null: also store the frame as uint8 into the clip job's slot of lane `lane` and advance its cursor
     uint32_t lane, sub, advance;   // the frame takes job position cursor[lane] + sub; the launch moves the cursor by `advance` (0: the job's `lanes`; ~0: not at all)
-#if GFPP_TORSO_PROF
-    unsigned long long *prof;
-#endif
 };
 
 template <typename H>
@@ -283,7 +270,6 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- this thread's pixel: occupancy test first (most workgroups of a frame have no torso pixel and skip the weights) ----------
-    GFPP_TORSO_MARK(0);
     const uint32_t n = blockIdx.x * kTlThreads + tid;
     const bool in_frame = n < a.N;
     float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f, hdepth = 0.0f;
@@ -296,14 +282,12 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
     }
     const bool block_has_work = __syncthreads_or(masked ? 1 : 0) != 0;
-    GFPP_TORSO_MARK(1);
     if (in_frame) {
         const RayAccum head = ray_state_final(a.state, a.bv, s_budget, n);
         hr = head.r; hg = head.g; hb = head.b; wsum = head.wsum; hdepth = head.depth;
     }
 
     float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
-    GFPP_TORSO_MARK(2);
     if (block_has_work) {
         // ---- prologue: weights -> LDS, per-frame constant columns folded into biases (same arithmetic as frame_torso.hip) ----------
         for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = reinterpret_cast<const vec *>(a.w16)[i];
@@ -340,7 +324,6 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         // (measured, dropped: the row's weights 32 at a time before the fma chain -- the landmark variant's 134 columns 8.5 -> 7.0 us of prologue, the pose
         // variant's 62 columns 5.0 -> 6.2; tools/torso_phase.py)
         __syncthreads();
-        GFPP_TORSO_MARK(3);
 
         // ---- compaction of the wavefront's masked pixels -------------------------------------------------------------------------
         const unsigned long long ballot = __ballot(masked);
@@ -355,7 +338,6 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        GFPP_TORSO_MARK(4);
         if (masked) {
             const float *r = &sh.res[wave][0][0];
             alpha = r[lane]; tr = r[64 + lane]; tg = r[128 + lane]; tb = r[192 + lane]; ddx = r[256 + lane]; ddy = r[320 + lane];
@@ -381,7 +363,6 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
         a.mask_out[n] = masked ? 1 : 0;
         a.out_depth[n] = fmaxf(hdepth - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
     }
-    GFPP_TORSO_MARK(5);
     if (a.job) {
         // the uint8 frame, fused: four consecutive pixels hold 12 bytes = three dwords, assembled inside the lane quad and written as dwords (a wavefront
         // writes 192 contiguous bytes with ONE store instruction; per-pixel byte stores took 45 us per 512^2 frame, the whole torso pass takes 30)
@@ -633,9 +614,6 @@ static int torso_lp_args(const char *who, const gfpp_torso_model *m, const gfpp_
     a.w16 = m->lp_weights; a.skinny16 = m->lp_skinny;
     a.bv = BudgetView{nullptr, nullptr, 0u, 0u};
     a.job = nullptr; a.lane = 0; a.sub = 0; a.advance = 0;
-#if GFPP_TORSO_PROF
-    a.prof = nullptr;
-#endif
     return 0;
 }
 
@@ -656,9 +634,6 @@ GFPP_API int gfpp_torso_frame_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     }
     a.job = ws->clip_job; a.lane = ws->clip_lane; a.sub = ws->clip_sub; a.advance = ws->clip_advance;
     if (a.job && a.lane >= 8) { set_error("gfpp_torso_frame_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
-#if GFPP_TORSO_PROF
-    if (const char *e = getenv("GFPP_TORSO_PROF_PTR")) a.prof = (unsigned long long *)strtoull(e, nullptr, 0);
-#endif
     const dim3 grid(div_up(ws->N, kTlThreads)), block(kTlThreads);
     if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_lp<__bf16>, grid, block, 0, (hipStream_t)stream, a);
     else if (m->lp_dtype == GFPP_F32) hipLaunchKernelGGL(k_torso_lp<float>, grid, block, 0, (hipStream_t)stream, a);   // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -120,6 +120,94 @@ __device__ __forceinline__ void act_pack(const v16f (&acc)[T], typename LpTraits
     }
 }
 
+// ---- activation packing UNDER the next layer's MFMAs (round 5) -------------------------------------------------------------------------------------------
+// act_pack between two layers is 64 vector instructions (one per value: convert a pair, clamp a pair) that a wavefront ran with its matrix pipe idle, and the next
+// layer's 32 MFMAs (32 cycles each) then ran with its vector ALU idle: in the ISA of a 32-sample block 370 of ~1 300 vector instructions sat in such clusters
+// between the layers (p48 / p40 / p56 in the instruction trace, docs/LAB_NOTEBOOK.md).  A matrix instruction occupies the pipe for 8 passes while the wavefront
+// may issue independent vector instructions, so the operand of step s + 2 is packed -- two vector instructions behind each of the four MFMAs of step s, pinned by
+// sched_group_barrier -- while the pipe works; only the operands of the first two steps are packed up front.  Same conversions and clamps, same order of the
+// MFMAs per accumulator: the same bits as act_pack + mfma_layer_lds.
+template <typename H>
+__device__ __forceinline__ typename LpTraits<H>::pair relu_pair(float a, float b);
+template <>
+__device__ __forceinline__ LpTraits<_Float16>::pair relu_pair<_Float16>(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef LpTraits<_Float16>::pair pair;
+    const pair p = __builtin_convertvector((f32x2){a, b}, pair);
+    return __builtin_elementwise_max(p, (pair)(_Float16)0.0f);
+}
+template <>
+__device__ __forceinline__ LpTraits<__bf16>::pair relu_pair<__bf16>(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef LpTraits<__bf16>::pair pair;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const pair p = __builtin_convertvector((f32x2){a, b}, pair);
+    return __builtin_bit_cast(pair, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2)(short)0));
+}
+
+// relu + round of the eight accumulator values that are operand step s of the next layer: tile s >> 1, registers 8 (s & 1) .. + 7 (act_pack<H, 4, 1>, one vector)
+template <typename H>
+__device__ __forceinline__ typename LpTraits<H>::vec relu_pack_step(const v16f (&acc)[4], int s) {
+    typename LpTraits<H>::vec t;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const typename LpTraits<H>::pair p = relu_pair<H>(acc[s >> 1][8 * (s & 1) + e], acc[s >> 1][8 * (s & 1) + e + 1]);
+        t[e] = p[0];
+        t[e + 1] = p[1];
+    }
+    return t;
+}
+
+// acc[t] = W[32 t.., 16 s..] * relu(prev) over the 8 steps of a 128 -> 128 layer (acc starts at ZERO: the first step's MFMAs take C = 0), the operand of step
+// s + 2 packed from `prev` behind the MFMAs of step s.  keep != nullptr: the eight packed operands are also handed back (the layer's input feeds a second consumer).
+template <typename H>
+__device__ __forceinline__ void mfma_layer_lds_fused(v16f (&acc)[4], const typename LpTraits<H>::vec *__restrict__ wl, const v16f (&prev)[4], int lane,
+                                                     typename LpTraits<H>::vec (*keep)[8]) {
+    typedef typename LpTraits<H>::vec vec;
+    constexpr int NS = 8, T = 4, kAhead = 2;
+    const vec *p = wl + lane;
+    vec ring[kAhead + 1][T];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k)
+#pragma unroll
+        for (int t = 0; t < T; ++t) ring[k][t] = p[(k * T + t) * 64];
+    vec b[3];
+    b[0] = relu_pack_step<H>(prev, 0);
+    b[1] = relu_pack_step<H>(prev, 1);
+    const v16f zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + kAhead < NS) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) ring[(s + kAhead) % (kAhead + 1)][t] = p[((s + kAhead) * T + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const vec bs = b[s % 3];
+        if (keep) (*keep)[s] = bs;
+        vec nb;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[t] = LpTraits<H>::mfma(ring[s % (kAhead + 1)][t], bs, s == 0 ? zero : acc[t]);
+            if (s + 2 < NS) {
+                const int q = s + 2, e = 2 * t;
+                const typename LpTraits<H>::pair pr = relu_pair<H>(prev[q >> 1][8 * (q & 1) + e], prev[q >> 1][8 * (q & 1) + e + 1]);
+                nb[e] = pr[0];
+                nb[e + 1] = pr[1];
+            }
+        }
+        if (s + 2 < NS) {
+            b[(s + 2) % 3] = nb;
+            // one MFMA, then the two vector instructions of one operand pair, four times
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Sum of the two half-waves' values, in every lane: v_permlane32_swap exchanges lanes 32..63 of one register with lanes 0..31 of another
 // (gfx950), no LDS round trip like ds_bpermute (__shfl_xor).  a = b = t  ->  a = {t_lo, t_lo}, b = {t_hi, t_hi}.
 __device__ __forceinline__ float half_wave_sum(float t) {

@@ -27,38 +27,6 @@
 #include "gfpp_common.h"
 #include "lp_mfma_device.h"
 
-// experiment builds only (tools/sr_bench.py; wrong results): 1 = no MFMA loop, 2 = no epilogue stores, 4 = no halo load, 8 = no next-tap weight staging
-#ifndef GFPP_SR_ABLATE
-#define GFPP_SR_ABLATE 0
-#endif
-// experiment builds only (tools/sr_phase.py): every workgroup's first lane stamps the 100 MHz wall clock at its phase boundaries into the buffer whose address
-// the environment variable GFPP_SR_PROF_PTR carries ([layer][workgroup][8] uint64)
-#ifndef GFPP_SR_PROF
-#define GFPP_SR_PROF 0
-#endif
-#if GFPP_SR_PROF
-#define GFPP_SR_MARK(k)                                                                                                                   \
-    do {                                                                                                                                  \
-        if (a.prof && threadIdx.x == 0)                                                                                                   \
-            a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-// accumulated shader-clock cycles of the sections of the tap loop (wavefront 0; summed in registers, stored once: slots 8.. of the workgroup's row)
-#define GFPP_SR_CYC(var) const unsigned long long var = __builtin_readcyclecounter()
-#define GFPP_SR_SUMS unsigned long long sr_sum[4] = {0ull, 0ull, 0ull, 0ull}
-#define GFPP_SR_ACC(k, t0, t1) sr_sum[k] += (t1) - (t0)
-#define GFPP_SR_SUMS_OUT                                                                                                                  \
-    do {                                                                                                                                  \
-        if (a.prof && threadIdx.x == 0)                                                                                                   \
-            for (int k_ = 0; k_ < 4; ++k_)                                                                                                \
-                a.prof[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8 + k_] = sr_sum[k_];              \
-    } while (0)
-#else
-#define GFPP_SR_MARK(k) do { } while (0)
-#define GFPP_SR_CYC(var) do { } while (0)
-#define GFPP_SR_SUMS do { } while (0)
-#define GFPP_SR_ACC(k, t0, t1) do { } while (0)
-#define GFPP_SR_SUMS_OUT do { } while (0)
-#endif
 
 namespace gfpp {
 
@@ -122,9 +90,6 @@ struct SrConvArgs {
     const float *first_noise; // [H][W] or null
     float first_noise_strength;
     SrRng first_rng;
-#if GFPP_SR_PROF
-    unsigned long long *prof;
-#endif
 };
 
 __device__ __forceinline__ float sr_act(float v, float gain, float clamp) {
@@ -297,8 +262,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             int py = y0 - 1 + pp / kSrHalo, px = x0 - 1 + pp % kSrHalo;
             py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
             px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
-            hv[q] = (GFPP_SR_ABLATE & 4) ? make_uint4(py, px, c8, 1)
-                                         : *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + kh * CINH + c8 * 8);
+            hv[q] = *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * CIN + kh * CINH + c8 * 8);
         }
 #pragma unroll
         for (int q = 0; q < HALO_ITERS; ++q) {
@@ -361,7 +325,6 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
         }
     };
-    GFPP_SR_MARK(0);
     sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(0), wbuf[0], tid, lane);
     if constexpr (FIRST) {
         for (int i = tid; i < 2 * 4 * 64; i += kSrThreads) s_wf[i] = a.first_w[i];
@@ -411,7 +374,6 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    GFPP_SR_MARK(1);
 
     v16f acc[NU][NT];
 #pragma unroll
@@ -430,29 +392,24 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
         return sr_lds_addr(&patch[((prow + tap / 3) * kSrHalo + pcol + tap % 3) * PS + (FIRST ? (it2 / 9) * CINH : 0) + 8 * hi]);
     };
     vec Bq[2][NU], Aq[2][NT];
-    GFPP_SR_SUMS;
     auto read_ops = [&](uint32_t b0, uint32_t wl, int s2, vec (&B)[NU], vec (&A)[NT]) {   // (sr_lds_read128: see above)
         sr_lds_read128(B[0], b0 + 32u * (uint32_t)s2);
         if constexpr (NU == 2) sr_lds_read128(B[1], b0 + 2u * kSrHalo * PS * 2u + 32u * (uint32_t)s2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) sr_lds_read128(A[t], wl + (uint32_t)(s2 * NT + t) * 1024u);
     };
-    for (int it = 0; it < ((GFPP_SR_ABLATE & 1) ? 0 : ITERS); ++it) {
-        GFPP_SR_CYC(c_top);
+    for (int it = 0; it < ITERS; ++it) {
         const int tap = it % 9;
         if (KS > 1 && !FIRST && it > 0 && tap == 0) {
             // next K slice: every wavefront is done with the old half patch (barrier at the end of the last iteration); its first weight chunk is
             // already in wbuf[cur]
-            GFPP_SR_MARK(5);
             load_patch(it / 9);
             __syncthreads();
-            GFPP_SR_MARK(6);
         }
         // the next chunk's fragments go global -> LDS directly (no registers, no ds_write: staged through registers they were spilled to scratch and
         // cost half of the tap loop), into the buffer the previous chunk's MFMAs released at the last barrier; they land while this one computes
         const int nxt = cur ^ 1;
-        if (it + 1 < ITERS && !(GFPP_SR_ABLATE & 8)) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[nxt], tid, lane);
-        GFPP_SR_CYC(c_begin);
+        if (it + 1 < ITERS) sr_stage_tap<PER_THREAD, kSrThreads>(chunk_src(it + 1), wbuf[nxt], tid, lane);
         const uint32_t b0 = b_base(it), wl = sr_lds_addr(wbuf[cur]) + (uint32_t)lane * 16u;
         // operands of step s + 1 are read while the NU x NT MFMAs of step s run
         read_ops(b0, wl, 0, Bq[0], Aq[0]);
@@ -467,15 +424,8 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             }
             if (s + 1 < STEPS_H) sr_lds_wait<NT, NU>(Aq[(s + 1) & 1], Bq[(s + 1) & 1]);
         }
-        GFPP_SR_CYC(c_walked);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's part of the chunk being staged has landed in LDS
-        GFPP_SR_CYC(c_landed);
         __syncthreads();
-        GFPP_SR_CYC(c_met);
-        GFPP_SR_ACC(0, c_begin, c_walked);
-        GFPP_SR_ACC(1, c_walked, c_landed);
-        GFPP_SR_ACC(2, c_landed, c_met);
-        GFPP_SR_ACC(3, c_top, c_begin);
         cur = nxt;
     }
 
@@ -483,8 +433,6 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
     // The noise value depends on the output pixel only (for the up-sampling layer: on the pixel and the phase = pair of row tiles), the bias on
     // the channel: both are fetched BEFORE the 2 x NT x 4 store loop (noise: at most 4 loads per lane; bias: LDS).  Inside the loop a
     // conditional global load costs a vmcnt(0) round trip per iteration -- 32 of them were two thirds of this kernel's time in round 1.
-    GFPP_SR_MARK(2);
-    GFPP_SR_SUMS_OUT;
     constexpr int NPH = EPI == kSrUpPhases ? (NT + 1) / 2 : 1;
     const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
     float nzv[NU][NPH];
@@ -522,7 +470,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
                 const float av[4] = {acc[u][t][4 * q], acc[u][t][4 * q + 1], acc[u][t][4 * q + 2], acc[u][t][4 * q + 3]};
                 sr_act4(av, nz, *reinterpret_cast<const float4 *>(&s_bias[n0]), a.act_gain, a.clamp, v);
 
-                if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
+                if constexpr (EPI != kSrFinal) {
                     // into the wavefront's own rows of the staging area (every wavefront is past the last chunk's barrier: patch and weight buffers are free)
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 o;
@@ -548,8 +496,7 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             if (hi == 0) sr_image_out<EPI>(a, rgb, &s_rgb[NT * 32 * 3], Y, X);
         }
     }
-    GFPP_SR_MARK(3);
-    if constexpr (EPI != kSrFinal && !(GFPP_SR_ABLATE & 2)) {
+    if constexpr (EPI != kSrFinal) {
         // the wavefront's 32 NU pixels leave as rows: 16 lanes x 16 B = the 256 contiguous bytes of one input-grid pixel (plain layers: its 128 channels;
         // up-sampling layer: the two output pixels (2Y + pass, 2X) and (2Y + pass, 2X + 1) x 64 channels, adjacent in memory), four pixels per store
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -566,7 +513,6 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
             *reinterpret_cast<uint4 *>(a.y + base + chunk * 8) = row;
         }
     }
-    GFPP_SR_MARK(4);
     if constexpr (EPI == kSrFinal) {
         // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
         if (a.rng_tick) {
@@ -605,7 +551,6 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     const int n_px = (int)a.W / kSrPatch, n_patches = n_px * ((int)a.H / kSrPatch);
-    GFPP_SR_MARK(0);
 
     sr_stage_tap<9 * TAPFRAGS / THREADS, THREADS>(a.w, wall, tid, lane);
     for (int i = tid; i < NT * 32; i += THREADS) s_bias[i] = a.bias[i];
@@ -654,7 +599,6 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
         commit(p);
         if (p + (int)gridDim.x < n_patches) issue(p + (int)gridDim.x);
         __syncthreads();
-        GFPP_SR_MARK(1);
         const int y0 = (p / n_px) * kSrPatch, x0 = (p % n_px) * kSrPatch;
 
         v16f acc[NT];
@@ -682,7 +626,6 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = LpTraits<_Float16>::mfma(Aq[gs % RING][t], Bq[gs % RING][0], acc[t]);
         }
-        GFPP_SR_MARK(2);
 
         // epilogue of k_sr_conv3<64, 2, kSrFinal>: noise + bias, leaky relu * gain, clamp; ToRGB on the f16-rounded activation; image
         const int Y = y0 + prow, X = x0 + pcol;
@@ -707,10 +650,8 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
         if (hi == 0) sr_image_out<kSrFinal>(a, rgb, &s_rgb[NT * 32 * 3], Y, X);
-        GFPP_SR_MARK(3);
         __syncthreads();                 // every wavefront is done with the patch
     }
-    GFPP_SR_MARK(4);
     // the frame's last launch: when its last workgroup is done -- every workgroup of the frame has read the counter by then -- the next frame begins
     if (a.rng_tick && tid == 0) {
         if (atomicAdd(&a.rng_tick[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
@@ -851,13 +792,6 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     // Shapes: 8 wavefronts of 32 pixels (NU = 1), the 128-channel layers in two K slices (KS = 2).  The other shapes the kernel template describes -- 4 wavefronts
     // of 64 pixels, the whole 128-channel patch in LDS -- were the round-2 / round-3 A/B partners (GFPP_SR_TILES, GFPP_SR_KSLICES: measured, docs/LAB_NOTEBOOK.md)
     // and are no longer instantiated.
-#if GFPP_SR_PROF
-    unsigned long long *prof_base = nullptr;
-    if (const char *e = getenv("GFPP_SR_PROF_PTR")) prof_base = (unsigned long long *)strtoull(e, nullptr, 0);
-#define GFPP_SR_PROF_SET(a, layer) (a).prof = prof_base ? prof_base + (size_t)(layer) * 2048 * 16 : nullptr
-#else
-#define GFPP_SR_PROF_SET(a, layer) do { } while (0)
-#endif
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
     bool fuse_first = true;                                         // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, the parity partner)
     if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = atoi(e) != 0;
@@ -873,7 +807,6 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.bias = m->bias[1]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x1; a.H = R; a.W = R;
         a.w_rgb = m->rgb0_w; a.b_rgb = m->rgb0_b; a.img_in = rgb_in; a.img_out = ws->img256;
         a.rng = rng_of(1);
-        GFPP_SR_PROF_SET(a, 0);
         if (fuse_first) {
             a.first_rgb = rgb_in; a.first_w = (const uint4 *)m->w_first; a.first_bias = m->bias[0];
             a.first_noise = noise ? noise[0] : nullptr; a.first_noise_strength = m->noise_strength[0]; a.first_rng = rng_of(0);
@@ -887,7 +820,6 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
         a.rng = rng_of(2);
-        GFPP_SR_PROF_SET(a, 1);
         hipLaunchKernelGGL((k_sr_conv3<128, 4, kSrUpPhases, 1, 2>), dim3(R / kSrPatch, R / kSrPatch, 2), dim3(512), 0, st, a);
         const int rc = check_launch("gfpp_sr_forward(block1.conv0 up)");
         if (rc) return rc;
@@ -901,7 +833,6 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        GFPP_SR_PROF_SET(a, 2);
         bool resident = true;                                       // GFPP_SR_FINAL_RESIDENT=0: one workgroup per patch, weights streamed (A/B runs, parity partner)
         if (const char *e = getenv("GFPP_SR_FINAL_RESIDENT")) resident = atoi(e) != 0;
         if (resident) {

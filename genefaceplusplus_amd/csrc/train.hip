@@ -378,9 +378,6 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_backward_lds(const G *__restr
 // 2^(36 - e) with 2^e > max |grad| of that level (k_grid_grad_levelmax), so one contribution is below 2^36 and 2^27 of them fit (16 M points hitting
 // one entry with all eight corners); what is kept of a contribution reaches 36 bits below the level's largest gradient (fp32 keeps 24 bits below each value; the reference's half accumulators under amp 11,
 // and nothing below 6e-8).  A non-finite gradient anywhere in the level makes the whole level NaN, so that a GradScaler still sees the overflow.
-#ifndef GFPP_RG_ABLATE
-#define GFPP_RG_ABLATE 0
-#endif
 constexpr uint32_t kRgThreads = 1024;
 constexpr uint32_t kRgSlices = kXcds;          // point slices = gradient copies
 constexpr uint32_t kRgValues = kLdsGradFloats * sizeof(float) / sizeof(long long);   // accumulators of one range (16 384)
@@ -455,11 +452,7 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
                 if (r < nrows) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-#if GFPP_RG_ABLATE == 1     // experiment builds (wrong results): plain LDS stores instead of atomics
-                        acc[r * C + c] = (long long)(w * gc[c]);
-#else
                         atomicAdd(reinterpret_cast<unsigned long long *>(&acc[r * C + c]), (unsigned long long)__float2ll_rn(w * gc[c]));
-#endif
                     }
                 }
             }
