@@ -754,6 +754,17 @@ def main():
             one_launch(ev)
         torch.cuda.synchronize()
         t_march = sum(a0.elapsed_time(a1) for a0, a1 in events) * 1e-3
+        if persist and not fp32:
+            # one more launch through the PROFILING instantiation (k_head_frame_persist<.., PROF>: thread 0's shader clock by phase into the budget counters) -- the timed
+            # launches above ran the production instantiation, which carries no clock reads
+            rec = gws if G > 1 else ws
+            flag = torch.zeros(8, dtype=torch.int64, device=dev)
+            rec.phase_cycles = flag.data_ptr()
+            try:
+                one_launch()
+                torch.cuda.synchronize()
+            finally:
+                rec.phase_cycles = None
         if G > 1:
             c = gt["counters"].cpu().numpy()
             per_launch = int(c[0, 168])                              # the launch's evaluated samples (all its frames; kept in the first frame's counters)

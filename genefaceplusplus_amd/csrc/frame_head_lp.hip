@@ -1070,14 +1070,22 @@ __device__ __forceinline__ float march_far_limit(float ox, float oy, float oz, f
     return fminf(far, tf);
 }
 
+// The pre-march of one ray: the t of every occupied sample into out[], the count returned.  One-cascade models with <= 256 cells per axis (every shipped one:
+// wavefront-uniform test) take the marcher's lean probe (march_device.h: ONE_SMALL_SHELL), same bits.
+__device__ __forceinline__ uint32_t premarch_ray(float ox, float oy, float oz, float dx, float dy, float dz, float t, float far_limit, const PremarchArgs &p,
+                                                 float *__restrict__ out) {
+    if (p.mp.C == 1u && p.mp.H <= 256u)
+        return march_one_ray<true>(ox, oy, oz, dx, dy, dz, t, far_limit, p.max_samples, p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+    return march_one_ray<false>(ox, oy, oz, dx, dy, dz, t, far_limit, p.max_samples, p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+}
+
 __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n >= p.N) return;
     const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
     float t = p.nears[n];
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = march_one_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, march_far_limit(o[0], o[1], o[2], d[0], d[1], d[2], p, p.fars[n]), p.max_samples,
-                                    p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+    p.sample_cnt[n] = premarch_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, march_far_limit(o[0], o[1], o[2], d[0], d[1], d[2], p, p.fars[n]), p, out);
 }
 
 // k_frame_begin (frame_head.hip) and k_premarch in one pass: the slab test's near is the marcher's start, so the rays are read once and one
@@ -1095,8 +1103,7 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
-                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p, out);
 }
 
 // The prologue of a frame group as ONE launch: ray generation (k_get_rays' expressions: utils.py:352-363) + slab test + state / counter reset + pre-march
@@ -1132,8 +1139,7 @@ __global__ __launch_bounds__(256) void k_group_begin(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = march_one_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p.max_samples, p.bitfield, p.mp,
-                                    [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
+    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p, out);
 }
 
 // k_head_budget_resolve for the K frames of a group in one launch (each frame against its own histogram / counters)

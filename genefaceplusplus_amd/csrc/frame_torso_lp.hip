@@ -137,129 +137,132 @@ struct TorsoPassCtx {
     uint32_t head_aware, use_head;
 };
 
-// One pass: the compacted masked pixels [first, first + 32) of a wavefront's 64-pixel span (order: compact index -> local pixel) through the head-aware encoder,
-// the deformation MLP, the 2-D grid and the canonical MLP; alpha, r, g, b, dx, dy of each go to res[0..5][local pixel] (the wavefront's own LDS rows).  cx, cy,
-// hr .. wsum: this lane's pixel coordinate and head colour / alpha (the pass fetches its columns' values with lane shuffles).  Shared by k_torso_lp (one frame per
-// launch) and k_torso_group_lp (a frame group per launch): same instructions, same bits.
+// The torso field of 32 pixels (one per column; lane (j, h) supplies column j's pixel coordinate px, py and head colour / alpha hr .. wsum in BOTH half-waves):
+// head-aware encoder, deformation MLP, 2-D grid, canonical MLP -> o4 = pre-sigmoid alpha, r, g, b and dxy = the deformation, valid in the lanes of both halves.
+template <typename H>
+__device__ __forceinline__ void torso_eval_cols(const TorsoPassCtx<H> &c, float px, float py, float hr, float hg, float hb, float wsum, int lane, float (&o4)[4],
+                                                float (&dxy)[2]) {
+    typedef typename LpTraits<H>::vec vec;
+    const int hi = lane >> 5;
+    const vec *W = c.W;
+    const float x0 = px * c.shrink, x1 = py * c.shrink;
+
+    // frequency features of the pixel coordinate, this half-wave's 24 of the 48 operand slots (42 used):
+    // slot k = 16 s + 8 h + e  <->  ex[k] = k < 2 ? x_k : freq_feature(x_{k&1}, k/2 - 1)
+    vec bex[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * s + 8 * hi + e;
+            const float xk = (k & 1) ? x1 : x0;
+            float v = k < 2 ? xk : (k < 42 ? freq_feature(xk, (uint32_t)(k / 2 - 1)) : 0.0f);
+            if constexpr (sizeof(H) == 2) v = k < 2 ? xk : (k < 42 ? freq_feature_fast(xk, (uint32_t)(k / 2 - 1)) : 0.0f);   // (the exact-fp32 instantiation keeps sinf)
+            bex[s][e] = (H)v;
+        }
+
+    // head-aware encoder of (head rgb, head alpha): Linear 4->16, LeakyReLU, 16->32, LeakyReLU, 32->16
+    vec bha[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bha[0][e] = (H)0.0f;
+    if (c.head_aware) {
+        const float i0 = c.use_head ? hr : 0.0f, i1 = c.use_head ? hg : 0.0f;
+        const float i2 = c.use_head ? hb : 0.0f, i3 = c.use_head ? wsum : 0.0f;
+        vec bin[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bin[0][e] = (H)0.0f;
+        if (hi == 0) { bin[0][0] = (H)i0; bin[0][1] = (H)i1; bin[0][2] = (H)i2; bin[0][3] = (H)i3; }
+        v16f acc1[1];
+        vec b2[2];
+        tl_load_bias<1>(acc1, c.bha0, hi);
+        mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa0 * 64, bin, lane);
+        act_pack<H, 1, 2>(acc1, b2);            // rows 0..15 live in b2[0]; b2[1] (rows 16..31) is padding
+        vec b1[1] = {b2[0]};
+        tl_load_bias<1>(acc1, c.bha1, hi);
+        mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa1 * 64, b1, lane);
+        act_pack<H, 1, 2>(acc1, b2);
+        tl_load_bias<1>(acc1, c.bha2, hi);
+        mfma_layer_lds<H, 2, 1>(acc1, W + kTlHa2 * 64, b2, lane);
+        act_pack<H, 1, 0>(acc1, b2);
+        bha[0] = b2[0];
+    }
+
+    // deformation MLP
+    {
+        v16f acc2[2];
+        vec bin[4] = {bex[0], bex[1], bex[2], bha[0]};
+        tl_load_bias<2>(acc2, c.bdef, hi);
+        mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef0 * 64, bin, lane);
+        vec bh[4];
+        act_pack<H, 2, 1>(acc2, bh);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
+        mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef1 * 64, bh, lane);
+        act_pack<H, 2, 1>(acc2, bh);
+        skinny_dot<2, 4, H>(c.skinny + kTlSkinnyDef, 2, bh, hi, dxy);
+    }
+
+    // 2-D tiled grid at the displaced, clamped coordinate; half-wave h encodes the levels h, h+2, ...
+    vec bgrid[2];
+    {
+        float u[2];
+        u[0] = (clampf(x0 + dxy[0], -1.0f, 1.0f) + 1.0f) / 2.0f;
+        u[1] = (clampf(x1 + dxy[1], -1.0f, 1.0f) + 1.0f) / 2.0f;
+        float f[16];
+        TlRows rows[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tl_level2_issue(u, c.table, c.lv[2 * i + hi], rows[i]);
+        __builtin_amdgcn_sched_barrier(0);             // all sixteen rows are requested before the first is used
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float o[2];
+            tl_level2_finish(rows[i], o);
+            f[2 * i] = o[0];
+            f[2 * i + 1] = o[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bgrid[s][e] = (H)f[8 * s + e];
+    }
+
+    // canonical MLP
+    {
+        v16f acc1[1];
+        vec bin[6] = {bgrid[0], bgrid[1], bex[0], bex[1], bex[2], bha[0]};
+        tl_load_bias<1>(acc1, c.bcan, hi);
+        mfma_layer_lds<H, 6, 1>(acc1, W + kTlCan0 * 64, bin, lane);
+        vec bh[2];
+        act_pack<H, 1, 1>(acc1, bh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
+        mfma_layer_lds<H, 2, 1>(acc1, W + kTlCan1 * 64, bh, lane);
+        act_pack<H, 1, 1>(acc1, bh);
+        skinny_dot<4, 2, H>(c.skinny + kTlSkinnyCan, 4, bh, hi, o4);
+    }
+}
+
+// One pass of a wavefront's 64-pixel span: its compacted masked pixels [first, first + 32) (order: compact index -> local pixel) through torso_eval_cols; alpha, r, g,
+// b, dx, dy of each go to res[0..5][local pixel] (the wavefront's own LDS rows).  cx, cy, hr .. wsum: this lane's pixel coordinate and head colour / alpha (the pass
+// fetches its columns' values with lane shuffles).
 template <typename H>
 __device__ __forceinline__ void torso_pass(const TorsoPassCtx<H> &c, float *__restrict__ res, const uint8_t *__restrict__ order, uint32_t first, uint32_t n_m,
                                            float cx, float cy, float hr, float hg, float hb, float wsum, int lane) {
-    typedef typename LpTraits<H>::vec vec;
     const int j = lane & 31, hi = lane >> 5;
-    const vec *W = c.W;
-    {
-        const uint32_t col = first + (uint32_t)j;
-        const bool valid = col < n_m;
-        const int src = valid ? (int)order[col] : 0;   // local pixel this column evaluates
-        const float px = __shfl(cx, src), py = __shfl(cy, src);
-        const float x0 = px * c.shrink, x1 = py * c.shrink;
-
-        // frequency features of the pixel coordinate, this half-wave's 24 of the 48 operand slots (42 used):
-        // slot k = 16 s + 8 h + e  <->  ex[k] = k < 2 ? x_k : freq_feature(x_{k&1}, k/2 - 1)
-        vec bex[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 16 * s + 8 * hi + e;
-                const float xk = (k & 1) ? x1 : x0;
-                float v = k < 2 ? xk : (k < 42 ? freq_feature(xk, (uint32_t)(k / 2 - 1)) : 0.0f);
-                if constexpr (sizeof(H) == 2) v = k < 2 ? xk : (k < 42 ? freq_feature_fast(xk, (uint32_t)(k / 2 - 1)) : 0.0f);   // (the exact-fp32 instantiation keeps sinf)
-                bex[s][e] = (H)v;
-            }
-
-        // head-aware encoder of (head rgb, head alpha): Linear 4->16, LeakyReLU, 16->32, LeakyReLU, 32->16
-        vec bha[1];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bha[0][e] = (H)0.0f;
-        if (c.head_aware) {
-            const float i0 = c.use_head ? __shfl(hr, src) : 0.0f, i1 = c.use_head ? __shfl(hg, src) : 0.0f;
-            const float i2 = c.use_head ? __shfl(hb, src) : 0.0f, i3 = c.use_head ? __shfl(wsum, src) : 0.0f;
-            vec bin[1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bin[0][e] = (H)0.0f;
-            if (hi == 0) { bin[0][0] = (H)i0; bin[0][1] = (H)i1; bin[0][2] = (H)i2; bin[0][3] = (H)i3; }
-            v16f acc1[1];
-            vec b2[2];
-            tl_load_bias<1>(acc1, c.bha0, hi);
-            mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa0 * 64, bin, lane);
-            act_pack<H, 1, 2>(acc1, b2);            // rows 0..15 live in b2[0]; b2[1] (rows 16..31) is padding
-            vec b1[1] = {b2[0]};
-            tl_load_bias<1>(acc1, c.bha1, hi);
-            mfma_layer_lds<H, 1, 1>(acc1, W + kTlHa1 * 64, b1, lane);
-            act_pack<H, 1, 2>(acc1, b2);
-            tl_load_bias<1>(acc1, c.bha2, hi);
-            mfma_layer_lds<H, 2, 1>(acc1, W + kTlHa2 * 64, b2, lane);
-            act_pack<H, 1, 0>(acc1, b2);
-            bha[0] = b2[0];
-        }
-
-        // deformation MLP
-        float dxy[2];
-        {
-            v16f acc2[2];
-            vec bin[4] = {bex[0], bex[1], bex[2], bha[0]};
-            tl_load_bias<2>(acc2, c.bdef, hi);
-            mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef0 * 64, bin, lane);
-            vec bh[4];
-            act_pack<H, 2, 1>(acc2, bh);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
-            mfma_layer_lds<H, 4, 2>(acc2, W + kTlDef1 * 64, bh, lane);
-            act_pack<H, 2, 1>(acc2, bh);
-            skinny_dot<2, 4, H>(c.skinny + kTlSkinnyDef, 2, bh, hi, dxy);
-        }
-
-        // 2-D tiled grid at the displaced, clamped coordinate; half-wave h encodes the levels h, h+2, ...
-        vec bgrid[2];
-        {
-            float u[2];
-            u[0] = (clampf(x0 + dxy[0], -1.0f, 1.0f) + 1.0f) / 2.0f;
-            u[1] = (clampf(x1 + dxy[1], -1.0f, 1.0f) + 1.0f) / 2.0f;
-            float f[16];
-            TlRows rows[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tl_level2_issue(u, c.table, c.lv[2 * i + hi], rows[i]);
-            __builtin_amdgcn_sched_barrier(0);             // all sixteen rows are requested before the first is used
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float o[2];
-                tl_level2_finish(rows[i], o);
-                f[2 * i] = o[0];
-                f[2 * i + 1] = o[1];
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bgrid[s][e] = (H)f[8 * s + e];
-        }
-
-        // canonical MLP
-        float o4[4];
-        {
-            v16f acc1[1];
-            vec bin[6] = {bgrid[0], bgrid[1], bex[0], bex[1], bex[2], bha[0]};
-            tl_load_bias<1>(acc1, c.bcan, hi);
-            mfma_layer_lds<H, 6, 1>(acc1, W + kTlCan0 * 64, bin, lane);
-            vec bh[2];
-            act_pack<H, 1, 1>(acc1, bh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
-            mfma_layer_lds<H, 2, 1>(acc1, W + kTlCan1 * 64, bh, lane);
-            act_pack<H, 1, 1>(acc1, bh);
-            skinny_dot<4, 2, H>(c.skinny + kTlSkinnyCan, 4, bh, hi, o4);
-        }
-        if (valid && hi == 0) {
-            float *r = res;
-            r[0 * 64 + src] = tl_sigmoid(o4[0]);
-            r[1 * 64 + src] = tl_sigmoid(o4[1]);
-            r[2 * 64 + src] = tl_sigmoid(o4[2]);
-            r[3 * 64 + src] = tl_sigmoid(o4[3]);
-            r[4 * 64 + src] = dxy[0];
-            r[5 * 64 + src] = dxy[1];
-        }
+    const uint32_t col = first + (uint32_t)j;
+    const bool valid = col < n_m;
+    const int src = valid ? (int)order[col] : 0;   // local pixel this column evaluates
+    float o4[4], dxy[2];
+    torso_eval_cols<H>(c, __shfl(cx, src), __shfl(cy, src), __shfl(hr, src), __shfl(hg, src), __shfl(hb, src), __shfl(wsum, src), lane, o4, dxy);
+    if (valid && hi == 0) {
+        res[0 * 64 + src] = tl_sigmoid(o4[0]);
+        res[1 * 64 + src] = tl_sigmoid(o4[1]);
+        res[2 * 64 + src] = tl_sigmoid(o4[2]);
+        res[3 * 64 + src] = tl_sigmoid(o4[3]);
+        res[4 * 64 + src] = dxy[0];
+        res[5 * 64 + src] = dxy[1];
     }
 }
 
@@ -395,15 +398,19 @@ __global__ __launch_bounds__(kTlThreads) void k_torso_lp(TorsoLpArgs a) {
 }
 
 
-// ---- a frame GROUP's torso passes as ONE launch (round 5) ---------------------------------------------------------------------------------------------------
+// ---- a frame GROUP's torso passes as TWO launches (round 5) -----------------------------------------------------------------------------------------------
 // k_torso_lp is one workgroup per 256 pixels with every workgroup resident at once: a launch lasts as long as ONE workgroup's dependent chain -- occupancy test,
 // the 28 KB weight image into LDS, the fold of the frame's constant columns (62-134 dependent fmas per bias), two 32-pixel passes -- 27-30 us whatever the frame
-// size, with the device a few per cent busy, and a group of K frames paid it K times plus K uint8 stores, a resolve launch and the gaps between them: 0.055 ms of
-// every 0.24 ms frame period, during which the other lane's head launch cannot start (that launch needs every CU's LDS).  Here the K frames are one launch of
-// persistent workgroups: weights once per workgroup, the constant fold once per FRAME (k_torso_fold, issued ahead of the head launch), and every wavefront walks
-// over 64-pixel spans of all K frames (dealt out through a multiplicative permutation: the masked pixels are the lower image rows) -- resolve (the frame's step
-// budget from its histogram, snapshot selection per ray) and the uint8 store of the clip job included.  Per pixel the same instructions as k_torso_lp
-// (torso_pass): every output is the bits of the per-frame launch.
+// size, with the device a few per cent busy, and a group of K frames paid it K times plus K uint8 stores, a resolve launch and the gaps between them.  Two facts
+// let the group do better.  (1) WHICH pixels the torso field is evaluated at does not depend on the frame: the mask is the occupancy grid sampled at the pixel
+// coordinates (radnerf_torso.py:166-169), both constants of the model and the resolution -- so the masked pixels are listed ONCE (gfpp_torso_mask + a stream
+// compaction on the host side of the ABI) and every 32-pixel pass of every frame is full and known in advance: k_torso_mlp_group deals the K x ceil(M / 32) passes
+// out to persistent wavefronts, weights once per workgroup, no occupancy test, no compaction, no shuffles.  (2) Everything else of the pass -- resolve (the frame's
+// step budget from its histogram, snapshot selection per ray), torso over background, head over torso, depth, the uint8 frame of the clip job and the cursor's
+// advance -- is a stream over all pixels: k_torso_compose_group, one thread per pixel at full occupancy.  The constant fold happens once per FRAME
+// (k_torso_fold, issued ahead of the head launch).  Per pixel the same instructions as k_torso_lp (torso_eval_cols, the compositing expressions): every output is
+// the bits of the per-frame launch.  (A first version -- ONE launch of persistent wavefronts walking over 64-pixel spans with the occupancy test inside -- took
+// 113 us for four 512^2 frames, as long as the four launches it replaced: eight dependent global round trips per span and 0 or 4 masked spans per wavefront.)
 struct TorsoFoldArgs {
     const float *cond_in;       // frame f's lm68 [136] / pose [6] at cond_in + f * cond_stride
     uint32_t cond_stride;
@@ -439,35 +446,41 @@ __global__ __launch_bounds__(128) void k_torso_fold(TorsoFoldArgs f) {
 constexpr uint32_t kTgMaxFrames = 4;      // = kPMaxFrames of the head launch (frame_head_lp.hip)
 constexpr int kTgCounterWords = 192, kTgBudgetBase = 128, kTgBudgetSamples = 40;     // gfpp_frame_ws.counters (head_eval_device.h: kCounterWords, kBudgetBase, kBudgetSamples)
 
+// The torso mask of a resolution: mask[n] = occupancy(bg_coords[n]) > thresh -- k_torso_lp's own test, once per model and resolution.
+__global__ __launch_bounds__(256) void k_torso_mask(const float *__restrict__ bg_coords, const float *__restrict__ density_grid, uint32_t G, float thresh, uint32_t N,
+                                                    uint8_t *__restrict__ mask) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    mask[n] = tl_bilinear_occupancy(density_grid, G, bg_coords[2ull * n], bg_coords[2ull * n + 1]) > thresh ? 1 : 0;
+}
+
 struct TorsoGroupArgs {
     TorsoLpArgs a;              // the frames' shared inputs; every per-ray array is the STACK of the K frames (frame f at + f * N), outputs likewise
     uint32_t frames, max_steps;
     const float *folded;        // [frames, 96] (k_torso_fold)
-    int32_t *counters;          // [frames, 192]: the head launch's histograms; the reconstructed alive counts are written here (workgroup 0)
+    int32_t *counters;          // [frames, 192]: the head launch's histograms; the reconstructed alive counts are written here (compose kernel)
     const float *snaps;         // [frames * N, 7, 5]
-    uint32_t n_spans, spans_per_frame, span_mult;
+    const uint8_t *mask;        // [N] (k_torso_mask)
+    const int32_t *masked;      // [n_masked] pixel indices with mask = 1, ascending
+    uint32_t n_masked, passes_per_frame;
 };
 
 template <typename H>
-struct TorsoGroupShared {
+struct TorsoMlpShared {
     typename LpTraits<H>::vec w[kTlFrags * 64];
     typename LpTraits<H>::vec skinny[kTlSkinnyVecs];
     float bdef[kTgMaxFrames][64], bcan[kTgMaxFrames][32], bha0[32], bha1[32], bha2[32];
     gfpp_grid_level lv[16];
-    float res[kTlWaves][6][64];
-    uint8_t order[kTlWaves][64];
     uint32_t budget[kTgMaxFrames];
-    uint32_t cursor;
 };
 
 template <typename H>
-__global__ __launch_bounds__(kTlThreads, 3) void k_torso_group_lp(TorsoGroupArgs g) {
+__global__ __launch_bounds__(kTlThreads, 3) void k_torso_mlp_group(TorsoGroupArgs g) {
     typedef typename LpTraits<H>::vec vec;
     const TorsoLpArgs &a = g.a;
-    __shared__ TorsoGroupShared<H> sh;
+    __shared__ TorsoMlpShared<H> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // ---- once per workgroup: weights, descriptors, every frame's folded biases and step budget -------------------------------------------------------------
+    const int j = lane & 31, hi = lane >> 5;
     for (int i = tid; i < kTlFrags * 64; i += kTlThreads) sh.w[i] = reinterpret_cast<const vec *>(a.w16)[i];
     for (int i = tid; i < kTlSkinnyVecs; i += kTlThreads) sh.skinny[i] = reinterpret_cast<const vec *>(a.skinny16)[i];
     if (tid < 16 * 8) reinterpret_cast<uint32_t *>(&sh.lv[0])[tid] = reinterpret_cast<const uint32_t *>(a.levels)[tid];
@@ -481,100 +494,108 @@ __global__ __launch_bounds__(kTlThreads, 3) void k_torso_group_lp(TorsoGroupArgs
         const float v = g.folded[i];
         if (k < 64u) sh.bdef[f][k] = v; else sh.bcan[f][k - 64u] = v;
     }
-    if ((uint32_t)tid < g.frames) {
-        // renderer.py:359-364,384 replayed on the frame's histogram (k_group_budget_resolve's header; workgroup 0 also leaves the alive counts the trip launches
-        // would have counted, for FramePipeline.trip_counters)
-        int32_t *c = g.counters + (size_t)tid * kTgCounterWords;
-        sh.budget[tid] = budget_from_hist(c + kTgBudgetBase, a.N, g.max_steps, blockIdx.x == 0 ? c : nullptr);
-        if (blockIdx.x == 0 && tid == 0) c[64] = c[kTgBudgetBase + kTgBudgetSamples];
-    }
-    if (tid == 0) sh.cursor = a.job ? a.job->cursor[a.lane] : 0u;
+    const bool need_head = a.head_aware && a.use_head;           // the head's colour / alpha of the pixel are inputs of the torso field (head-aware encoder)
+    if ((uint32_t)tid < g.frames)
+        sh.budget[tid] = need_head ? budget_from_hist(g.counters + (size_t)tid * kTgCounterWords + kTgBudgetBase, a.N, g.max_steps, nullptr) : 0u;
     __syncthreads();
-    const TorsoPassCtx<H> pc0{sh.w, sh.skinny, nullptr, nullptr, sh.bha0, sh.bha1, sh.bha2, sh.lv, a.table, a.shrink, a.head_aware, a.use_head};
-    const uint32_t job_pos0 = sh.cursor;
-    float *res = &sh.res[wave][0][0];
-
-    // ---- the wavefront's spans ---------------------------------------------------------------------------------------------------------------------------
-    const uint32_t n_waves = gridDim.x * kTlWaves;
-    for (uint32_t i = blockIdx.x * kTlWaves + (uint32_t)wave; i < g.n_spans; i += n_waves) {
-        const uint32_t span = (uint32_t)(((unsigned long long)i * g.span_mult) % g.n_spans);
-        const uint32_t f = span / g.spans_per_frame;
-        const uint32_t n = (span - f * g.spans_per_frame) * 64u + (uint32_t)lane;     // pixel of the frame
-        const bool in_frame = n < a.N;
-        const size_t fn = (size_t)f * a.N + n;                                         // ... and its entry in the stacked per-ray arrays
-        float cx = 0.0f, cy = 0.0f, hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f, hdepth = 0.0f;
-        bool masked = false;
-        if (in_frame) {
-            cx = a.bg_coords[2ull * n]; cy = a.bg_coords[2ull * n + 1];
-            masked = tl_bilinear_occupancy(a.density_grid, a.G, cx, cy) > a.thresh;
+    TorsoPassCtx<H> pc{sh.w, sh.skinny, nullptr, nullptr, sh.bha0, sh.bha1, sh.bha2, sh.lv, a.table, a.shrink, a.head_aware, a.use_head};
+    const uint32_t n_passes = g.frames * g.passes_per_frame, n_waves = gridDim.x * kTlWaves;
+    for (uint32_t p = blockIdx.x * kTlWaves + (uint32_t)wave; p < n_passes; p += n_waves) {
+        const uint32_t f = p / g.passes_per_frame, col = (p - f * g.passes_per_frame) * 32u + (uint32_t)j;
+        const bool valid = col < g.n_masked;
+        const uint32_t n = (uint32_t)g.masked[valid ? col : 0u];
+        const size_t fn = (size_t)f * a.N + n;
+        const float px = a.bg_coords[2ull * n], py = a.bg_coords[2ull * n + 1];
+        float hr = 0.0f, hg = 0.0f, hb = 0.0f, wsum = 0.0f;
+        if (need_head) {
             const BudgetView bv{g.counters + (size_t)f * kTgCounterWords + kTgBudgetBase, g.snaps, a.N, g.max_steps};
             const RayAccum head = ray_state_final(a.state, bv, sh.budget[f], (uint32_t)fn);
-            hr = head.r; hg = head.g; hb = head.b; wsum = head.wsum; hdepth = head.depth;
+            hr = head.r; hg = head.g; hb = head.b; wsum = head.wsum;
         }
-        float alpha = 0.0f, tr = 0.0f, tg = 0.0f, tb = 0.0f, ddx = 0.0f, ddy = 0.0f;
-        const unsigned long long ballot = __ballot(masked);
-        const uint32_t n_m = (uint32_t)__popcll(ballot);
-        if (n_m) {                                               // (wavefront-uniform)
-            if (masked) sh.order[wave][__popcll(ballot & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            TorsoPassCtx<H> pc = pc0;
-            pc.bdef = sh.bdef[f];
-            pc.bcan = sh.bcan[f];
-            for (uint32_t first = 0; first < n_m; first += 32) torso_pass<H>(pc, res, sh.order[wave], first, n_m, cx, cy, hr, hg, hb, wsum, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (masked) { alpha = res[lane]; tr = res[64 + lane]; tg = res[128 + lane]; tb = res[192 + lane]; ddx = res[256 + lane]; ddy = res[320 + lane]; }
-            // (the next span's pass writes res / order again: the reads above are complete before it starts -- same wavefront, program order)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        uint32_t packed = 0;
-        if (in_frame) {
-            // torso over background, head over torso (radnerf_torso.py:186-197) -- k_torso_lp's expressions
-            const float T = 1.0f - wsum;
-            const float tcol[3] = {tr, tg, tb}, hcol[3] = {hr, hg, hb};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float bg = a.bg_color ? a.bg_color[3ull * n + c] : a.bg_scalar;
-                const float tbg = tcol[c] * alpha + bg * (1.0f - alpha);
-                const float v = clampf(hcol[c] + T * tbg, 0.0f, 1.0f);
-                a.torso_bg[3ull * fn + c] = tbg;
-                a.out_image[3ull * fn + c] = v;
-                packed |= (uint32_t)(uint8_t)clampf(v * 255.0f, 0.0f, 255.0f) << (8 * c);
-            }
-            a.torso_alpha[fn] = alpha;
-            a.deform[2ull * fn] = ddx;
-            a.deform[2ull * fn + 1] = ddy;
-            a.mask_out[fn] = masked ? 1 : 0;
-            a.out_depth[fn] = fmaxf(hdepth - a.nears[fn], 0.0f) / (a.fars[fn] - a.nears[fn]);
-        }
-        if (a.job) {
-            const int q0 = lane & ~3, ql = lane & 3;
-            const uint32_t w0 = (uint32_t)__shfl((int)packed, q0), w1 = (uint32_t)__shfl((int)packed, q0 + 1);
-            const uint32_t w2 = (uint32_t)__shfl((int)packed, q0 + 2), w3 = (uint32_t)__shfl((int)packed, q0 + 3);
-            const uint32_t pos = job_pos0 + f;
-            if (in_frame && pos < a.job->n) {
-                uint8_t *frame = a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes;
-                const uint32_t nq = n & ~3u;
-                if (nq + 3u < a.N && (a.job->frame_bytes & 3ull) == 0ull) {
-                    const uint32_t d = ql == 0 ? (w0 | (w1 << 24)) : (ql == 1 ? ((w1 >> 8) | (w2 << 16)) : ((w2 >> 16) | (w3 << 8)));
-                    if (ql < 3) *reinterpret_cast<uint32_t *>(frame + 3ull * nq + 4u * (uint32_t)ql) = d;
-                } else {
-                    frame[3ull * n] = (uint8_t)packed; frame[3ull * n + 1] = (uint8_t)(packed >> 8); frame[3ull * n + 2] = (uint8_t)(packed >> 16);
-                }
-            }
+        pc.bdef = sh.bdef[f];
+        pc.bcan = sh.bcan[f];
+        float o4[4], dxy[2];
+        torso_eval_cols<H>(pc, px, py, hr, hg, hb, wsum, lane, o4, dxy);
+        if (valid && hi == 0) {
+            // alpha, the torso's own colour (k_torso_compose_group blends it over the background in place) and the deformation of the masked pixel
+            a.torso_alpha[fn] = tl_sigmoid(o4[0]);
+            a.torso_bg[3ull * fn] = tl_sigmoid(o4[1]);
+            a.torso_bg[3ull * fn + 1] = tl_sigmoid(o4[2]);
+            a.torso_bg[3ull * fn + 2] = tl_sigmoid(o4[3]);
+            a.deform[2ull * fn] = dxy[0];
+            a.deform[2ull * fn + 1] = dxy[1];
         }
     }
+}
+
+// grid (ceil(N / 256), frames): one thread per pixel of a frame
+__global__ __launch_bounds__(256) void k_torso_compose_group(TorsoGroupArgs g) {
+    const TorsoLpArgs &a = g.a;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, f = blockIdx.y;
+    const uint32_t n = blockIdx.x * 256u + tid;
+    const bool in_frame = n < a.N;
+    const size_t fn = (size_t)f * a.N + n;
+    __shared__ uint32_t s_budget, s_cursor;
+    if (tid == 0) {
+        // renderer.py:359-364,384 replayed on the frame's histogram (k_group_budget_resolve's header; the frame's first workgroup also leaves the alive counts the trip
+        // launches would have counted, for FramePipeline.trip_counters)
+        int32_t *c = g.counters + (size_t)f * kTgCounterWords;
+        s_budget = budget_from_hist(c + kTgBudgetBase, a.N, g.max_steps, blockIdx.x == 0 ? c : nullptr);
+        if (blockIdx.x == 0 && f == 0) c[64] = c[kTgBudgetBase + kTgBudgetSamples];
+        s_cursor = a.job ? a.job->cursor[a.lane] : 0u;
+    }
+    __syncthreads();
+    uint32_t packed = 0;
+    if (in_frame) {
+        const bool masked = g.mask[n] != 0;
+        const BudgetView bv{g.counters + (size_t)f * kTgCounterWords + kTgBudgetBase, g.snaps, a.N, g.max_steps};
+        const RayAccum head = ray_state_final(a.state, bv, s_budget, (uint32_t)fn);
+        float alpha = 0.0f, tcol[3] = {0.0f, 0.0f, 0.0f}, ddx = 0.0f, ddy = 0.0f;
+        if (masked) {
+            alpha = a.torso_alpha[fn];
+            tcol[0] = a.torso_bg[3ull * fn]; tcol[1] = a.torso_bg[3ull * fn + 1]; tcol[2] = a.torso_bg[3ull * fn + 2];
+            ddx = a.deform[2ull * fn]; ddy = a.deform[2ull * fn + 1];
+        }
+        // torso over background, head over torso (radnerf_torso.py:186-197) -- k_torso_lp's expressions
+        const float T = 1.0f - head.wsum;
+        const float hcol[3] = {head.r, head.g, head.b};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float bg = a.bg_color ? a.bg_color[3ull * n + c] : a.bg_scalar;
+            const float tbg = tcol[c] * alpha + bg * (1.0f - alpha);
+            const float v = clampf(hcol[c] + T * tbg, 0.0f, 1.0f);
+            a.torso_bg[3ull * fn + c] = tbg;
+            a.out_image[3ull * fn + c] = v;
+            packed |= (uint32_t)(uint8_t)clampf(v * 255.0f, 0.0f, 255.0f) << (8 * c);
+        }
+        a.torso_alpha[fn] = alpha;
+        a.deform[2ull * fn] = ddx;
+        a.deform[2ull * fn + 1] = ddy;
+        a.mask_out[fn] = masked ? 1 : 0;
+        a.out_depth[fn] = fmaxf(head.depth - a.nears[fn], 0.0f) / (a.fars[fn] - a.nears[fn]);
+    }
     if (a.job) {
+        // the uint8 frame (k_torso_lp's store): four consecutive pixels hold 12 bytes = three dwords, assembled inside the lane quad
+        const int q0 = (int)(lane & ~3u), ql = (int)(lane & 3u);
+        const uint32_t w0 = (uint32_t)__shfl((int)packed, q0), w1 = (uint32_t)__shfl((int)packed, q0 + 1);
+        const uint32_t w2 = (uint32_t)__shfl((int)packed, q0 + 2), w3 = (uint32_t)__shfl((int)packed, q0 + 3);
+        const uint32_t pos = s_cursor + f;
+        if (in_frame && pos < a.job->n) {
+            uint8_t *frame = a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes;
+            const uint32_t nq = n & ~3u;
+            if (nq + 3u < a.N && (a.job->frame_bytes & 3ull) == 0ull) {
+                const uint32_t d = ql == 0 ? (w0 | (w1 << 24)) : (ql == 1 ? ((w1 >> 8) | (w2 << 16)) : ((w2 >> 16) | (w3 << 8)));
+                if (ql < 3) *reinterpret_cast<uint32_t *>(frame + 3ull * nq + 4u * (uint32_t)ql) = d;
+            } else {
+                frame[3ull * n] = (uint8_t)packed; frame[3ull * n + 1] = (uint8_t)(packed >> 8); frame[3ull * n + 2] = (uint8_t)(packed >> 16);
+            }
+        }
         // every workgroup read the lane's cursor in its prologue; the last one to get here moves it on (as k_clip_store_u8 does)
         __syncthreads();
         if (tid == 0 && a.advance != 0xFFFFFFFFu) {
-            if (atomicAdd(&a.job->ticket[a.lane], 1u) == gridDim.x - 1u) {
+            if (atomicAdd(&a.job->ticket[a.lane], 1u) == gridDim.x * gridDim.y - 1u) {
                 a.job->ticket[a.lane] = 0u;
-                a.job->cursor[a.lane] = job_pos0 + (a.advance ? a.advance : a.job->lanes);
+                a.job->cursor[a.lane] = s_cursor + (a.advance ? a.advance : a.job->lanes);
             }
         }
     }
@@ -655,11 +676,18 @@ GFPP_API int gfpp_torso_fold_batch(const gfpp_torso_model *m, const float *cond_
     return check_launch("gfpp_torso_fold_batch");
 }
 
+GFPP_API int gfpp_torso_mask(const gfpp_torso_model *m, const float *bg_coords, uint32_t N, uint8_t *mask, gfpp_stream_t stream) {
+    if (!m || !bg_coords || !mask || !m->density_grid) { set_error("gfpp_torso_mask: null argument"); return GFPP_EINVAL; }
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_torso_mask, dim3(div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, bg_coords, m->density_grid, m->grid_size, m->density_thresh, N, mask);
+    return check_launch("gfpp_torso_mask");
+}
+
 static int torso_group_wgs_per_cu() {
     static int n = 0;
     if (n == 0) {
-        const char *e = getenv("GFPP_TORSO_GROUP_WGS");            // persistent workgroups per CU (experiments)
-        n = e ? atoi(e) : 2;             // measured (512^2 bf16, frames/s of the clip loop): 2 -> 4 535, 3 -> 4 385, 4 -> 4 216 (the other lane's head launch waits for these workgroups' LDS)
+        const char *e = getenv("GFPP_TORSO_GROUP_WGS");            // persistent workgroups of the MLP launch per CU (experiments)
+        n = e ? atoi(e) : 3;
         if (n < 1) n = 1;
         if (n > 4) n = 4;
     }
@@ -667,21 +695,22 @@ static int torso_group_wgs_per_cu() {
 }
 
 GFPP_API int gfpp_torso_group_lp(const gfpp_torso_model *m, const gfpp_frame_ws *ws, const float *bg_coords, const float *folded, const float *code,
-                                 const float *bg_color, float bg_scalar, uint32_t use_head, uint32_t max_steps, float *out_image, float *out_depth,
-                                 float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream) {
-    if (!m || !ws || !bg_coords || !folded || !out_image || !out_depth || !torso_alpha || !torso_bg || !deform || !mask) {
+                                 const uint8_t *mask_static, const int32_t *masked_idx, uint32_t n_masked, const float *bg_color, float bg_scalar, uint32_t use_head,
+                                 uint32_t max_steps, float *out_image, float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask,
+                                 gfpp_stream_t stream) {
+    if (!m || !ws || !bg_coords || !folded || !mask_static || (n_masked && !masked_idx) || !out_image || !out_depth || !torso_alpha || !torso_bg || !deform || !mask) {
         set_error("gfpp_torso_group_lp: null argument");
         return GFPP_EINVAL;
     }
     const uint32_t frames = ws->n_frames > 1u ? ws->n_frames : 1u;
-    if (frames > kTgMaxFrames || ws->N == 0 || !ws->ray_state || !ws->nears || !ws->fars || !ws->counters || !ws->snapshots || ws->gcounters) {
-        set_error("gfpp_torso_group_lp: needs a frame-group workspace (n_frames <= %u; ray_state, nears, fars, counters [n_frames, 192], snapshots)", kTgMaxFrames);
+    if (frames > kTgMaxFrames || ws->N == 0 || n_masked > ws->N || !ws->ray_state || !ws->nears || !ws->fars || !ws->counters || !ws->snapshots || ws->gcounters) {
+        set_error("gfpp_torso_group_lp: needs a frame-group workspace (n_frames <= %u; ray_state, nears, fars, counters [n_frames, 192], snapshots) and n_masked <= N", kTgMaxFrames);
         return GFPP_EINVAL;
     }
     if (max_steps == 0 || max_steps > 24u) { set_error("gfpp_torso_group_lp: max_steps must be in 1..24"); return GFPP_EUNSUPPORTED; }
     if (m->lp_dtype != GFPP_F16 && m->lp_dtype != GFPP_BF16) { set_error("gfpp_torso_group_lp: 16-bit weight images only"); return GFPP_EUNSUPPORTED; }
     TorsoGroupArgs g;
-    // (cond_in is not read by the group kernel: the constant columns arrive folded)
+    // (cond_in is not read by the group kernels: the constant columns arrive folded)
     const int rc = torso_lp_args("gfpp_torso_group_lp", m, ws, bg_coords, nullptr, code, bg_color, bg_scalar, use_head, g.a);
     if (rc) return rc;
     g.a.out_image = out_image; g.a.out_depth = out_depth; g.a.torso_alpha = torso_alpha; g.a.torso_bg = torso_bg; g.a.deform = deform; g.a.mask_out = mask;
@@ -689,17 +718,20 @@ GFPP_API int gfpp_torso_group_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     if (g.a.job && g.a.lane >= 8) { set_error("gfpp_torso_group_lp: clip_lane must be < 8"); return GFPP_EINVAL; }
     g.frames = frames; g.max_steps = max_steps;
     g.folded = folded; g.counters = ws->counters; g.snaps = ws->snapshots;
-    g.spans_per_frame = div_up(ws->N, 64u);
-    g.n_spans = frames * g.spans_per_frame;
-    g.span_mult = 1u;
-    for (const uint32_t mult : {1237u, 251u, 61u, 7u})
-        if (g.n_spans % mult != 0u) { g.span_mult = mult; break; }
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    uint32_t grid = (uint32_t)cus * (uint32_t)torso_group_wgs_per_cu();
-    const uint32_t need = div_up(g.n_spans, (uint32_t)kTlWaves);
-    if (grid > need) grid = need;
-    if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_group_lp<__bf16>, dim3(grid), dim3(kTlThreads), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(k_torso_group_lp<_Float16>, dim3(grid), dim3(kTlThreads), 0, (hipStream_t)stream, g);
+    g.mask = mask_static; g.masked = masked_idx; g.n_masked = n_masked;
+    g.passes_per_frame = div_up(n_masked, 32u);
+    const hipStream_t st = (hipStream_t)stream;
+    if (n_masked) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        uint32_t grid = (uint32_t)cus * (uint32_t)torso_group_wgs_per_cu();
+        const uint32_t need = div_up(frames * g.passes_per_frame, (uint32_t)kTlWaves);
+        if (grid > need) grid = need;
+        if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_mlp_group<__bf16>, dim3(grid), dim3(kTlThreads), 0, st, g);
+        else hipLaunchKernelGGL(k_torso_mlp_group<_Float16>, dim3(grid), dim3(kTlThreads), 0, st, g);
+        const int rc2 = check_launch("gfpp_torso_group_lp (mlp)");
+        if (rc2) return rc2;
+    }
+    hipLaunchKernelGGL(k_torso_compose_group, dim3(div_up(ws->N, 256u), frames), dim3(256), 0, st, g);
     return check_launch("gfpp_torso_group_lp");
 }

@@ -39,6 +39,16 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {
 __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
     return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
 }
+// the same code for coordinates below 256: the 10-bit spread's first stage is the identity (march_device.h: the marcher's probe of one-cascade models)
+__device__ __forceinline__ uint32_t spread3_8(uint32_t v) {
+    v = (v | (v << 8)) & 0x0000F00Fu;
+    v = (v | (v << 4)) & 0x000C30C3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3_8(uint32_t x, uint32_t y, uint32_t z) {
+    return (spread3_8(z) << 2) | ((spread3_8(y) << 1) | spread3_8(x));
+}
 __device__ __forceinline__ uint32_t compact3(uint32_t x) {
     x &= 0x49249249u;
     x = (x | (x >> 2)) & 0xc30c30c3u;

@@ -44,6 +44,7 @@ struct MarchParams {
     uint32_t C, H;
     float half_H;       // 0.5 H
     uint32_t H_pow2;    // H is a power of two: the voxel coordinate's fp64 product is an exact scaling, done in fp32 (same bits)
+    float rbound;       // 1 / bound, correctly rounded (the host's division): what the reference's `1 / mip_bound` gives in the outermost shell
 };
 
 __host__ __device__ inline MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
@@ -61,6 +62,7 @@ __host__ __device__ inline MarchParams make_march_params(float bound, float dt_g
     p.H = H;
     p.half_H = 0.5f * (float)H;
     p.H_pow2 = (H & (H - 1u)) == 0u && H >= 2u ? 1u : 0u;
+    p.rbound = 1.0f / bound;
     return p;
 }
 
@@ -98,9 +100,12 @@ struct Sample {
 
 // Advance one ray from t, emitting up to n_step occupied samples through `emit(step, Sample)`.
 // Returns the number of samples emitted; `t` is left at the position after the last emitted sample (or >= far).
-// (Measured and dropped in round 4: a probe without the IEEE division, the 32-bit multiplies of the Morton spread and the float round trip of the cell
-// index -- 164 -> 125 instructions per probe, same bits -- left the frame rate where it was: the pre-march runs under the other frame's head pass.)
-template <typename Emit>
+// ONE_SMALL_SHELL (the caller has checked p.C == 1 and p.H <= 256: every shipped model): a leaner probe with the same bits -- 1 / mip_bound without the IEEE
+// division sequence (the only shell's bound is the scene bound, whose correctly rounded reciprocal comes from the host), the cell index is the Morton code itself
+// (no float round trip through `level * H^3`), and the 8-bit Morton spread (no 32-bit multiplies): 164 -> 125 instructions per probe.  Measured and dropped in
+// round 4, when the pre-march still ran UNDER the other lane's head launch; since the head launch holds every vector register of a SIMD (2 x 249-251) the frame
+// group's prologue is on the critical path between two head launches (round 5 kernel trace: 71-79 us of every 880 us period) and the probe is what it executes.
+template <bool ONE_SMALL_SHELL = false, typename Emit>
 __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, float dx, float dy, float dz, float &t, float far,
                                                   uint32_t n_step, const uint8_t *__restrict__ bitfield, const MarchParams &p,
                                                   Emit &&emit) {
@@ -111,12 +116,14 @@ __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, 
         const float y = clampf(fmaf(t, dy, oy), -p.bound, p.bound);
         const float z = clampf(fmaf(t, dz, oz), -p.bound, p.bound);
         const float dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
-        const int level = cascade_of(x, y, z, dt, p);
-        const float mip_bound = fminf(scalbnf(1.0f, level), p.bound);
-        const float mip_rbound = 1.0f / mip_bound;
+        const int level = ONE_SMALL_SHELL ? 0 : cascade_of(x, y, z, dt, p);
+        const float mip_bound = ONE_SMALL_SHELL ? fminf(1.0f, p.bound) : fminf(scalbnf(1.0f, level), p.bound);
+        // (one cascade means bound <= 1: the shell's bound is the scene bound)
+        const float mip_rbound = ONE_SMALL_SHELL ? (p.bound <= 1.0f ? p.rbound : 1.0f) : 1.0f / mip_bound;
         const int nx = voxel_of(x, mip_rbound, p), ny = voxel_of(y, mip_rbound, p), nz = voxel_of(z, mip_rbound, p);
-        // the reference forms this index in fp32 (exact below 2^24)
-        const uint32_t cell = (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        // the reference forms this index in fp32 (exact below 2^24); with one cascade the level is 0 and the index is the Morton code itself
+        const uint32_t cell = ONE_SMALL_SHELL ? morton3_8((uint32_t)nx, (uint32_t)ny, (uint32_t)nz)
+                                              : (uint32_t)fmaf((float)level, p.H3, (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
         const bool occupied = (bitfield[cell >> 3] >> (cell & 7u)) & 1u;
         if (occupied) {
             const float t0 = t;

@@ -72,7 +72,8 @@ _lib.register("gfpp_cond_feat_batch", [ctypes.POINTER(CondModel), c_p, c_u32, c_
 _lib.register("gfpp_torso_frame_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_p])
 _lib.register("gfpp_torso_fold_batch", [ctypes.POINTER(TorsoModel), c_p, c_u32, c_p, c_u32, c_p, c_p])
-_lib.register("gfpp_torso_group_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p])
+_lib.register("gfpp_torso_group_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_p, c_u32, c_p, c_f, c_u32, c_u32, c_p, c_p, c_p, c_p, c_p, c_p, c_p])
+_lib.register("gfpp_torso_mask", [ctypes.POINTER(TorsoModel), c_p, c_u32, c_p, c_p])
 _lib.register("gfpp_occupancy_bounds", [c_p, c_u32, c_u32, c_f, c_p, c_p])
 _lib.register("gfpp_grid_level_table", [c_u32, c_f, c_u32, c_p, c_p])
 _lib.register("gfpp_grid_levels_fill", [c_u32, c_u32, c_f, c_u32, c_u32, ctypes.c_int, c_p, c_u32, c_p])
@@ -386,6 +387,7 @@ class FramePipeline:
         self.precision = "fp32"
         self._graphs = {}
         self._side_stream = {}
+        self._torso_pixels = {}
         #: which of several independent workspaces (and side streams) the next frame uses: frames of different lanes may be in flight at
         #: the same time on different streams (clip.ClipRenderer(lanes=2)); weights and tables are shared
         self.lane = 0
@@ -982,6 +984,22 @@ class FramePipeline:
         return (self.precision != "fp32" and self.lp_kernel == "persist" and self.torso is not None and 2 <= int(K) <= self.GROUP_MAX and int(max_steps) <= 24
                 and int(K) * int(N) <= (1 << 22) and bool(self.torso.lp_weights))
 
+    def torso_pixels(self, bg_coords):
+        """(mask [N] uint8, ascending int32 indices of the masked pixels): WHERE the torso field is evaluated -- the occupancy grid sampled at the pixel coordinates
+        (radnerf_torso.py:166-169), constants of the model and the resolution -- computed once per coordinate tensor (gfpp_torso_mask + one compaction; synchronises:
+        the first frame of a resolution, never inside a captured graph because the capture's warm-up frames come first)."""
+        key = (bg_coords.data_ptr(), int(bg_coords.shape[0]), bg_coords._version)
+        hit = self._torso_pixels.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise GfppError("torso_pixels: the masked-pixel list of this resolution must exist before a graph is captured (render one frame group first)")
+            N = int(bg_coords.shape[0])
+            mask = torch.empty(N, dtype=torch.uint8, device=self.device)
+            call("gfpp_torso_mask", ctypes.byref(self.torso), bg_coords.data_ptr(), N, mask.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            idx = torch.nonzero(mask, as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+            hit = self._torso_pixels[key] = (mask, idx, bg_coords)          # (keeps the keyed tensor's address alive)
+        return hit[0], hit[1]
+
     def group_workspace(self, N, K, max_steps):
         """The workspaces of K frames of N rays BEHIND EACH OTHER in every per-ray array (what gfpp_head_frame_persist_lp needs to render them with one
         launch) -> (group record, [the K frames' own records], tensors).  `tensors['rays_o' / 'rays_d']` [K, N, 3] are where the caller puts the rays."""
@@ -1079,7 +1097,9 @@ class FramePipeline:
             stack = {"image": f(K * N, 3), "depth": f(K * N), "torso_alpha": f(K * N, 1), "torso_bg": f(K * N, 3), "deform_dense": f(K * N, 2),
                      "torso_mask": torch.empty(K * N, dtype=torch.uint8, device=dev)}
             try:
+                mask_static, masked_idx = self.torso_pixels(bg_coords)
                 call("gfpp_torso_group_lp", ctypes.byref(self.torso), ctypes.byref(gws), bg_coords.data_ptr(), folded.data_ptr(), code.data_ptr() if code is not None else None,
+                     mask_static.data_ptr(), masked_idx.data_ptr() if masked_idx.numel() else None, int(masked_idx.numel()),
                      bg_ptr, bg_scalar, int(bool(use_head_for_torso)), int(max_steps), stack["image"].data_ptr(), stack["depth"].data_ptr(), stack["torso_alpha"].data_ptr(),
                      stack["torso_bg"].data_ptr(), stack["deform_dense"].data_ptr(), stack["torso_mask"].data_ptr(), st)
             finally:

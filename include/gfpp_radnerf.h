@@ -603,21 +603,27 @@ int gfpp_torso_frame_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, 
                         const float *code, const float *bg_color, float bg_scalar, uint32_t use_head, float *out_image,
                         float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
 
-/* (ABI 7) The torso passes of a frame GROUP as one launch (radnerf_torso.py:156-197 / radnerf_torso_sr.py:186-231 for K consecutive frames of the caller's loop,
- * genefacepp_infer.py:460-469).  gfpp_torso_fold_batch: the per-frame constant columns of torso_deform_net.0 / torso_canonicial_net.0 (frequency-encoded pose or
- * chin landmarks + individual code) folded into bias vectors, one workgroup per frame -- the arithmetic of gfpp_torso_frame_lp's prologue: frame f reads
- * cond_in + f * cond_stride (poses [6] or lm68 [136]) and writes folded[f] = bdef [64] | bcan [32].  It does not depend on the head pass: issue it ahead of it.
+/* (ABI 7) The torso passes of a frame GROUP (radnerf_torso.py:156-197 / radnerf_torso_sr.py:186-231 for K consecutive frames of the caller's loop,
+ * genefacepp_infer.py:460-469) as two launches whatever K is.
+ * gfpp_torso_mask: mask[n] = occupancy grid sampled at bg_coords[n] > density_thresh (radnerf_torso.py:166-169) -- constants of the model and the resolution, so the
+ *   caller computes it ONCE and keeps the ascending list of the masked pixels (`masked_idx`, a stream compaction of `mask`).
+ * gfpp_torso_fold_batch: the per-frame constant columns of torso_deform_net.0 / torso_canonicial_net.0 (frequency-encoded pose or chin landmarks + individual code)
+ *   folded into bias vectors, one workgroup per frame -- the arithmetic of gfpp_torso_frame_lp's prologue: frame f reads cond_in + f * cond_stride (poses [6] or
+ *   lm68 [136]) and writes folded[f] = bdef [64] | bcan [32].  It does not depend on the head pass: issue it ahead of it.
  * gfpp_torso_group_lp: `ws` is a frame-group record (gfpp_frame_ws.n_frames = K, every per-ray array the stack of the K frames) whose head pass was
- * gfpp_head_frame_persist_lp WITHOUT a resolve step; persistent workgroups walk over 64-pixel spans of all K frames: step budget from each frame's histogram and
- * snapshot selection per ray (= gfpp_head_group_resolve; workgroup 0 also writes counters[f][k], the alive counts of the reference's loop), torso field, compositing,
- * depth, and -- when ws->clip_job is set -- the uint8 store of frame f into job position cursor[clip_lane] + f and the cursor's advance by ws->clip_advance
- * (= gfpp_clip_store_u8_at).  Outputs are stacks over the frames: out_image / torso_bg [K N, 3], out_depth / torso_alpha [K N], deform [K N, 2], mask [K N].
- * Every value is the bits of the per-frame entry (same per-pixel code, torso_pass).  16-bit weight images only (model->lp_dtype GFPP_F16 / GFPP_BF16). */
+ *   gfpp_head_frame_persist_lp WITHOUT a resolve step.  Launch 1: the torso field at the listed pixels of all K frames, 32 per pass, dealt out to persistent
+ *   wavefronts (no occupancy test, no compaction: every pass is full and known in advance).  Launch 2, one thread per pixel: step budget from each frame's histogram
+ *   and snapshot selection per ray (= gfpp_head_group_resolve; it also writes counters[f][k], the alive counts of the reference's loop), torso over background,
+ *   head over torso, depth, and -- when ws->clip_job is set -- the uint8 store of frame f into job position cursor[clip_lane] + f and the cursor's advance by
+ *   ws->clip_advance (= gfpp_clip_store_u8_at).  Outputs are stacks over the frames: out_image / torso_bg [K N, 3], out_depth / torso_alpha [K N], deform [K N, 2],
+ *   mask [K N].  Every value is the bits of the per-frame entry (same per-pixel code).  16-bit weight images only (model->lp_dtype GFPP_F16 / GFPP_BF16). */
+int gfpp_torso_mask(const gfpp_torso_model *model, const float *bg_coords, uint32_t N, uint8_t *mask, gfpp_stream_t stream);
 int gfpp_torso_fold_batch(const gfpp_torso_model *model, const float *cond_in, uint32_t cond_stride, const float *code, uint32_t frames, float *folded,
                           gfpp_stream_t stream);
 int gfpp_torso_group_lp(const gfpp_torso_model *model, const gfpp_frame_ws *ws, const float *bg_coords, const float *folded, const float *code,
-                        const float *bg_color, float bg_scalar, uint32_t use_head, uint32_t max_steps, float *out_image, float *out_depth,
-                        float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask, gfpp_stream_t stream);
+                        const uint8_t *mask_static, const int32_t *masked_idx, uint32_t n_masked, const float *bg_color, float bg_scalar, uint32_t use_head,
+                        uint32_t max_steps, float *out_image, float *out_depth, float *torso_alpha, float *torso_bg, float *deform, uint8_t *mask,
+                        gfpp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section A.3 -- training-side entry points of _raymarching_face and _gridencoder.  Same conventions as Section A:

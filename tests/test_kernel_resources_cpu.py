@@ -61,7 +61,7 @@ def test_every_source_has_a_report_and_the_head_kernels_are_in_it():
     assert {r["file"] for r in rep.values()} >= {os.path.basename(h)[:-4] + ".res" for h in glob.glob(os.path.join(CSRC, "*.hip"))}
     persist = [n for n in rep if "k_head_frame_persist" in n]
     assert len(persist) == 26, persist                 # AMB_D 2/3 x {f16, bf16} x SLOW x MF (+ the profiling twin of the tiled-grid ones) + two fp32
-    assert any("k_torso_group_lp" in n for n in rep) and any("k_group_begin" in n for n in rep)
+    assert any("k_torso_mlp_group" in n for n in rep) and any("k_torso_compose_group" in n for n in rep) and any("k_group_begin" in n for n in rep)
 
 
 def test_shipped_may_instantiations_use_no_scratch():
@@ -78,7 +78,7 @@ def test_shipped_may_instantiations_use_no_scratch():
     for n, r in rep.items():
         if "k_torso" in n or "k_group_begin" in n or "k_begin_premarch" in n or "budget_resolve" in n or "k_cond_feat" in n or "k_sr_final" in n or "k_clip" in n:
             assert r["scratch"] == 0, (n, r)
-    group = [r for n, r in rep.items() if "k_torso_group_lp" in n]
+    group = [r for n, r in rep.items() if "k_torso_mlp_group" in n]
     assert group and all(r["vgprs"] <= 168 and r["occupancy"] >= 3 for r in group), group      # three wavefronts per SIMD (launch bounds), no spill
 
 
