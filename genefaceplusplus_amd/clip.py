@@ -348,18 +348,24 @@ class ClipRenderer:
     def _replay_from_c(self):
         return self.replay_mode == "c" and self.use_graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
 
+    @property
+    def chunk_multiple(self):
+        """Frames per graph launch once a job has started (1 before): issue() works in whole multiples of this."""
+        return self.group
+
     def issue(self, count=None):
         """Issue the next `count` frames of the job (all that are left by default): frame k runs on lane k % lanes -- with frame groups (self.group = K > 1)
-        the K frames [g K, g K + K) are one launch on lane g % lanes, `count` must be a multiple of K unless it finishes the job, and a last, partial group
-        renders its missing positions for nothing (they fetch and store nothing).  No host synchronisation."""
+        the K frames [g K, g K + K) are one launch on lane g % lanes, a `count` that is no multiple of K is rounded up to whole groups (the number of frames really
+        issued is returned), and a last, partial group renders its missing positions for nothing (they fetch and store nothing).  No host synchronisation."""
         J = self._job
         count = J["n"] - J["issued"] if count is None else min(int(count), J["n"] - J["issued"])
         if count <= 0:
             return 0
         K = self.group
-        if J["issued"] % K or (count % K and J["issued"] + count < J["n"]):
-            raise GfppError(f"ClipRenderer.issue: with frame groups of {K} frames a chunk must be a multiple of {K} frames (or finish the job)")
+        # whole frame groups only: a count that is no multiple of K is rounded UP (the caller gets at least what it asked for and the return value / the next call
+        # account for the overshoot; `chunk_multiple` tells callers that size their buffers per chunk what to round to)
         launches, first = -(-count // K), (J["issued"] // K) % self.lanes
+        count = min(launches * K, J["n"] - J["issued"])
         if self._replay_from_c():
             execs, streams = self._exec_arrays()
             if self.lanes == 1:
@@ -526,7 +532,7 @@ class ClipRenderer:
         if getattr(self.model, "executor", "fused") != "fused":
             return False
         pipe = self.model.pipeline()
-        return pipe.precision != "fp32" and (pipe.lp_kernel != "persist" or int(self.render_kwargs.get("max_steps", 16)) > 24 or self.rays_per_frame > (1 << 22))
+        return pipe.precision != "fp32" and (pipe.lp_kernel != "persist" or int(self.render_kwargs.get("max_steps", 1024)) > 24 or self.rays_per_frame > (1 << 22))      # (render()'s own default)
 
     def check(self):
         """After the frames of a job have completed: raise GfppError if any of them was rendered by a launch whose device-wide barrier timed out

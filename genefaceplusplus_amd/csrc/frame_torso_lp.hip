@@ -445,6 +445,10 @@ __global__ __launch_bounds__(128) void k_torso_fold(TorsoFoldArgs f) {
 
 constexpr uint32_t kTgMaxFrames = 4;      // = kPMaxFrames of the head launch (frame_head_lp.hip)
 constexpr int kTgCounterWords = 192, kTgBudgetBase = 128, kTgBudgetSamples = 40;     // gfpp_frame_ws.counters (head_eval_device.h: kCounterWords, kBudgetBase, kBudgetSamples)
+// two free words of a frame's budget array (zeroed with it by the group's prologue): the frame's step budget B and the clip job position of the group's first frame,
+// computed / read ONCE by the MLP launch and handed to the compose launch -- a first version computed B (two dozen dependent loads of the histogram) in every one
+// of the compose launch's 4 096 workgroups and took a ticket per workgroup on one word to find the last reader of the cursor: 219 us for four frames
+constexpr int kTgSlotBudget = 56, kTgSlotJobPos = 57;
 
 // The torso mask of a resolution: mask[n] = occupancy(bg_coords[n]) > thresh -- k_torso_lp's own test, once per model and resolution.
 __global__ __launch_bounds__(256) void k_torso_mask(const float *__restrict__ bg_coords, const float *__restrict__ density_grid, uint32_t G, float thresh, uint32_t N,
@@ -495,8 +499,21 @@ __global__ __launch_bounds__(kTlThreads, 3) void k_torso_mlp_group(TorsoGroupArg
         if (k < 64u) sh.bdef[f][k] = v; else sh.bcan[f][k - 64u] = v;
     }
     const bool need_head = a.head_aware && a.use_head;           // the head's colour / alpha of the pixel are inputs of the torso field (head-aware encoder)
-    if ((uint32_t)tid < g.frames)
-        sh.budget[tid] = need_head ? budget_from_hist(g.counters + (size_t)tid * kTgCounterWords + kTgBudgetBase, a.N, g.max_steps, nullptr) : 0u;
+    if ((uint32_t)tid < g.frames) {
+        // renderer.py:359-364,384 replayed on the frame's histogram (k_group_budget_resolve's header).  Workgroup 0 also leaves the alive counts the trip launches would
+        // have counted (FramePipeline.trip_counters), the budget and -- thread 0 -- the lane's job position for the compose launch, which then needs no such chain
+        int32_t *c = g.counters + (size_t)tid * kTgCounterWords;
+        const bool first = blockIdx.x == 0;
+        const uint32_t B = (need_head || first) ? budget_from_hist(c + kTgBudgetBase, a.N, g.max_steps, first ? c : nullptr) : 0u;
+        sh.budget[tid] = B;
+        if (first) {
+            c[kTgBudgetBase + kTgSlotBudget] = (int32_t)B;
+            if (tid == 0) {
+                c[64] = c[kTgBudgetBase + kTgBudgetSamples];
+                c[kTgBudgetBase + kTgSlotJobPos] = a.job ? (int32_t)a.job->cursor[a.lane] : 0;
+            }
+        }
+    }
     __syncthreads();
     TorsoPassCtx<H> pc{sh.w, sh.skinny, nullptr, nullptr, sh.bha0, sh.bha1, sh.bha2, sh.lv, a.table, a.shrink, a.head_aware, a.use_head};
     const uint32_t n_passes = g.frames * g.passes_per_frame, n_waves = gridDim.x * kTlWaves;
@@ -528,28 +545,22 @@ __global__ __launch_bounds__(kTlThreads, 3) void k_torso_mlp_group(TorsoGroupArg
     }
 }
 
-// grid (ceil(N / 256), frames): one thread per pixel of a frame
+// grid (ceil(N / 256), frames): one thread per pixel of a frame; the frame's step budget and the group's job position come from the MLP launch (no per-workgroup
+// chain of dependent loads in front of the stream, no ticket behind it: nobody but this launch's first thread touches the lane's cursor, and the next group's
+// fetch kernel follows in stream order)
 __global__ __launch_bounds__(256) void k_torso_compose_group(TorsoGroupArgs g) {
     const TorsoLpArgs &a = g.a;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, f = blockIdx.y;
     const uint32_t n = blockIdx.x * 256u + tid;
     const bool in_frame = n < a.N;
     const size_t fn = (size_t)f * a.N + n;
-    __shared__ uint32_t s_budget, s_cursor;
-    if (tid == 0) {
-        // renderer.py:359-364,384 replayed on the frame's histogram (k_group_budget_resolve's header; the frame's first workgroup also leaves the alive counts the trip
-        // launches would have counted, for FramePipeline.trip_counters)
-        int32_t *c = g.counters + (size_t)f * kTgCounterWords;
-        s_budget = budget_from_hist(c + kTgBudgetBase, a.N, g.max_steps, blockIdx.x == 0 ? c : nullptr);
-        if (blockIdx.x == 0 && f == 0) c[64] = c[kTgBudgetBase + kTgBudgetSamples];
-        s_cursor = a.job ? a.job->cursor[a.lane] : 0u;
-    }
-    __syncthreads();
+    const uint32_t budget = (uint32_t)g.counters[(size_t)f * kTgCounterWords + kTgBudgetBase + kTgSlotBudget];
+    const uint32_t job_pos0 = (uint32_t)g.counters[kTgBudgetBase + kTgSlotJobPos];
     uint32_t packed = 0;
     if (in_frame) {
         const bool masked = g.mask[n] != 0;
         const BudgetView bv{g.counters + (size_t)f * kTgCounterWords + kTgBudgetBase, g.snaps, a.N, g.max_steps};
-        const RayAccum head = ray_state_final(a.state, bv, s_budget, (uint32_t)fn);
+        const RayAccum head = ray_state_final(a.state, bv, budget, (uint32_t)fn);
         float alpha = 0.0f, tcol[3] = {0.0f, 0.0f, 0.0f}, ddx = 0.0f, ddy = 0.0f;
         if (masked) {
             alpha = a.torso_alpha[fn];
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(256) void k_torso_compose_group(TorsoGroupArgs g) {
         const int q0 = (int)(lane & ~3u), ql = (int)(lane & 3u);
         const uint32_t w0 = (uint32_t)__shfl((int)packed, q0), w1 = (uint32_t)__shfl((int)packed, q0 + 1);
         const uint32_t w2 = (uint32_t)__shfl((int)packed, q0 + 2), w3 = (uint32_t)__shfl((int)packed, q0 + 3);
-        const uint32_t pos = s_cursor + f;
+        const uint32_t pos = job_pos0 + f;
         if (in_frame && pos < a.job->n) {
             uint8_t *frame = a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes;
             const uint32_t nq = n & ~3u;
@@ -590,14 +601,7 @@ __global__ __launch_bounds__(256) void k_torso_compose_group(TorsoGroupArgs g) {
                 frame[3ull * n] = (uint8_t)packed; frame[3ull * n + 1] = (uint8_t)(packed >> 8); frame[3ull * n + 2] = (uint8_t)(packed >> 16);
             }
         }
-        // every workgroup read the lane's cursor in its prologue; the last one to get here moves it on (as k_clip_store_u8 does)
-        __syncthreads();
-        if (tid == 0 && a.advance != 0xFFFFFFFFu) {
-            if (atomicAdd(&a.job->ticket[a.lane], 1u) == gridDim.x * gridDim.y - 1u) {
-                a.job->ticket[a.lane] = 0u;
-                a.job->cursor[a.lane] = s_cursor + (a.advance ? a.advance : a.job->lanes);
-            }
-        }
+        if (blockIdx.x == 0 && f == 0 && tid == 0 && a.advance != 0xFFFFFFFFu) a.job->cursor[a.lane] = job_pos0 + (a.advance ? a.advance : a.job->lanes);
     }
 }
 
@@ -721,12 +725,14 @@ GFPP_API int gfpp_torso_group_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     g.mask = mask_static; g.masked = masked_idx; g.n_masked = n_masked;
     g.passes_per_frame = div_up(n_masked, 32u);
     const hipStream_t st = (hipStream_t)stream;
-    if (n_masked) {
+    {
+        // (always launched, with one workgroup when no pixel is masked: it also computes the frames' step budgets and reads the job position for the compose launch)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         uint32_t grid = (uint32_t)cus * (uint32_t)torso_group_wgs_per_cu();
         const uint32_t need = div_up(frames * g.passes_per_frame, (uint32_t)kTlWaves);
         if (grid > need) grid = need;
+        if (grid == 0u) grid = 1u;
         if (m->lp_dtype == GFPP_BF16) hipLaunchKernelGGL(k_torso_mlp_group<__bf16>, dim3(grid), dim3(kTlThreads), 0, st, g);
         else hipLaunchKernelGGL(k_torso_mlp_group<_Float16>, dim3(grid), dim3(kTlThreads), 0, st, g);
         const int rc2 = check_launch("gfpp_torso_group_lp (mlp)");

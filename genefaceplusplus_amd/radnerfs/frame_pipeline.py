@@ -268,6 +268,10 @@ def corner_block_table(emb, offsets, levels):
     gfpp_grid_levels_fill's `sy` / `mask` give -- as 8 halves: c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1).
     emb [rows, 2] float tensor, offsets [L+1] ints (unpadded), levels: sequence of objects with sy / mask / size.  Returns [rows, 8] float16."""
     parts = []
+    peak = float(emb.abs().max()) if emb.numel() else 0.0
+    if not peak < 65504.0:
+        raise GfppError(f"corner_block_table: the grid table holds |values| up to {peak:g}, beyond the fp16 range of the 16-bit kernels' table copy "
+                        "(render this model with precision='fp32')")
     for l, lv in enumerate(levels):
         T = emb[int(offsets[l]):int(offsets[l + 1])].float()
         size, sy, mask = int(lv.size), int(lv.sy), int(lv.mask)
