@@ -1,0 +1,857 @@
+#!/usr/bin/env python
+"""The sub-benchmarks of bench.py (round 5: split out of its one 1 100-line `main`): everything the JSON line carries besides the timed headline.
+
+bench.py renders the timed frames and assembles the line; what it attaches -- the timed-frames check, the roofline of the dominant launch, the other precision modes and
+BASELINE configurations, the stand-alone grid stage, the CPU baseline -- lives here and is importable on its own:
+
+    from tools import bench_parts
+    parts = bench_parts.build(ctx)          # ctx: the namespace bench.py's main() fills (model, clip renderer, inputs, sizes, args, ...)
+    parts.head_roofline(model, hp, x, N, variant, frames_per_launch=4)
+
+cpu_baseline / cpu_crop_config are the only places that touch oracle/ (test infrastructure), as the checker / baseline, never as the thing measured.
+"""
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 161536          # head MLPs after folding the per-frame-constant input columns
+FLOP_PER_SAMPLE_LP = 128768       # 16-bit kernel: additionally sigma_net.2 (geo rows) x color_net.0 merged into one 128x128 layer
+GATHER_BYTES_PER_SAMPLE = 2060    # fused pipeline: 12 B position + 2 encodes x 16 levels x 8 corners x 8 B: the yardstick's unit in every round
+GATHER_BYTES_PER_SAMPLE_BLOCK = 1036   # what the 16-bit kernels request since round 4: 12 B + 2 encodes x 32 gathers x 16 B (16-bit corner-block tables; SURVEY 8d with s_tab = 2)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense f16 / bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+GRID_BYTES_PER_POINT = 1164       # 3-D, 16 levels x 8 corners x 8 B + 12 B in + 128 B out
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
+PEAK_L2_GBPS = 34500.0          # aggregate L2, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(variant, hw_sample=512, hw_full=512):
+    """Oracle (CPU restatement of the reference path) on one hw_sample^2 frame, scaled to frames/s at hw_full^2."""
+    threads = min(os.cpu_count() or 1, 64)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    from oracle import oracle as orc
+    from tests.helpers import frame_case, oracle_render
+    orc.build()
+    with threadpool_limits(limits=threads):
+        case = frame_case(variant, 64)
+        oracle_render(orc, case)                                  # warm-up (page in tables, spin up thread pools)
+        case = frame_case(variant, hw_sample)
+        t0 = time.perf_counter()
+        trace = []
+        oracle_render(orc, case, trace=trace)
+        dt = time.perf_counter() - t0
+    scale = (hw_full / hw_sample) ** 2
+    return {"value": round(1.0 / (dt * scale), 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 {variant} frame at {hw_sample}x{hw_sample} ({hw_sample * hw_sample} rays) in {dt:.2f} s on {threads} threads "
+                      f"(OpenMP C kernels + BLAS fp32 GEMMs), scaled x1/{scale:.0f} to {hw_full}x{hw_full}",
+            "host_cpus": os.cpu_count()}
+
+
+def cpu_crop_config():
+    """BASELINE configs[0]: "May head-NeRF, 64x64 crop, 1k rays/step, CPU forward of radnerfs (no raymarching ext) -- plumbing/ref".
+    The reference has no CPU path, so this is the oracle: the centre 64x64 crop of a 512x512 May-head frame, rendered in
+    4 steps of 1 024 rays (each step is its own render call: the sample budget depends on the ray set)."""
+    threads = min(os.cpu_count() or 1, 64)
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    from oracle import oracle as orc
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.configs import may_hparams
+    orc.build()
+    hp = may_hparams("may_head")
+    sd = syn.synthetic_state_dict(hp, "may_head")
+    fi = syn.synthetic_frame_inputs(hp, 0)
+    rays = orc.get_rays(syn.synthetic_pose(0)[None], syn.intrinsics_for(512, 512), 512, 512)
+    rows, cols = np.meshgrid(np.arange(224, 288), np.arange(224, 288), indexing="ij")
+    sel = (rows * 512 + cols).reshape(-1)
+    ro, rd = rays["rays_o"][:, sel], rays["rays_d"][:, sel]
+    kw = dict(bg_color=np.full((1, 1024, 3), 0.5, np.float32), dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=0.01)
+    with threadpool_limits(limits=threads):
+        orc.render_head(ro[:, :1024], rd[:, :1024], fi["cond"], sd, hp, **kw)        # warm-up
+        times = []
+        for rep in range(3):
+            for c in range(4):
+                t0 = time.perf_counter()
+                orc.render_head(ro[:, 1024 * c:1024 * (c + 1)], rd[:, 1024 * c:1024 * (c + 1)], fi["cond"], sd, hp, **kw)
+                times.append(time.perf_counter() - t0)
+    times = np.array(times)
+    return {"baseline_config": "configs[0]: May head-NeRF, 64x64 crop, 1k rays/step, CPU forward (no raymarching ext)", "kind": "port (CPU oracle; the reference has no CPU path)",
+            "rays_per_step": 1024, "steps": int(times.size), "ms_per_step_mean": round(1e3 * float(times.mean()), 3), "ms_per_step_min": round(1e3 * float(times.min()), 3),
+            "rays_per_s": round(1024 / float(times.mean()), 1), "crop_ms": round(4e3 * float(times.mean()), 2), "cores": threads, "host_cpus": os.cpu_count()}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (the driver's command shape): start the N ranks ourselves, one process per GPU -- what
+    `torch.distributed.run --standalone --nproc-per-node N` would do, and what the reference's trainer does with mp.spawn
+    (utils/commons/trainer.py:137-141, 587-599).  Rank r gets RANK = LOCAL_RANK = r, a common MASTER_ADDR/PORT on 127.0.0.1; rank 0 inherits our
+    stdout, so the job still prints ONE JSON line.  Returns the exit code of the job (first non-zero child, the others are then stopped)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GFPP_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                     # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dist_evidence(dev, backend):
+    """What the job itself saw of its ranks (so a multi-GPU line is self-evidencing): ranks counted by an all_reduce of ones on the device,
+    every rank's device uuid / name / index by all_gather."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": dist.get_rank(), "device": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name, "pid": os.getpid()}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    uuids = [x["uuid"] for x in seen]
+    return {"backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "launcher": os.environ.get("GFPP_BENCH_LAUNCHER", "external (torch.distributed.run)"),
+            "world_size": world, "ranks_seen": int(ones.item()), "device_uuids": uuids, "distinct_devices": len(set((x["device"], x["uuid"]) for x in seen)),
+            "device_index_per_rank": [x["device"] for x in seen], "device_name": props.name}
+
+
+def run_identities(args, rank, world, dev, dinfo=None):
+    """BASELINE configs[4]: several person-specific models at once (4 identities on 8 GPUs, 2 GPUs each), shared audio2motion.
+
+    The ranks are split into contiguous blocks, one per identity (frames.make_identity_groups); the upstream result -- the driving signals of
+    the clip, which every identity renders with its own weights -- exists on rank 0 only and is broadcast ONCE (frames.share_driving_signals;
+    the reference would run audio2motion per inference call, genefacepp_infer.py:298-431); inside a block the clip is frame-parallel and the
+    finished frames go to the block's writer rank.  With one GPU the identities take turns on it (same code, blocks of size 1 on one rank).
+    value = frames of ALL identities per second; K = frames per rank and identity (weak scaling)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from genefaceplusplus_amd import synthetic as syn, radnerfs, frames
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.clip import ClipRenderer
+    from tests.helpers import CLASSES
+
+    n_id, HW, K, W = args.identities, args.hw, args.steps, args.warmup
+    hp = may_hparams(args.variant)
+    if world > 1:
+        my_ident, group, blocks = frames.make_identity_groups(n_id)
+        mine = [my_ident]
+        block = blocks[my_ident]
+        local_rank, local_world = block.index(rank), len(block)
+    else:
+        mine, group, local_rank, local_world = list(range(n_id)), None, 0, 1
+    F = (K + W) * local_world                                   # frames of one identity's clip
+    # ---- the shared upstream result: made on rank 0, broadcast once ------------------------------------------------------------
+    smo, cwin, cin = hp["smo_win_size"], hp.get("cond_win_size", 1), syn.cond_input_dim(hp)
+    sig = {"cond_wins": torch.zeros(F, smo, cwin, cin, device=dev), "lm68": torch.zeros(F, 136, device=dev),
+           "eye_area_percent": torch.zeros(F, 1, 1, device=dev), "ngp_poses": torch.zeros(F, 4, 4, device=dev)}
+    if rank == 0:
+        fi = [syn.synthetic_frame_inputs(hp, i) for i in range(F)]
+        sig["cond_wins"].copy_(torch.from_numpy(np.stack([f["cond"] for f in fi])))
+        sig["lm68"].copy_(torch.from_numpy(np.stack([f["lm68"] for f in fi])))
+        sig["eye_area_percent"].copy_(torch.from_numpy(np.stack([f["eye_area_percent"] for f in fi])))
+        sig["ngp_poses"].copy_(torch.from_numpy(np.stack([syn.synthetic_pose(i) for i in range(F)]).astype(np.float32)))
+    # landmark-conditioned models: what audio2motion + 3DMM hand over is the clip's predicted landmarks [F, 68, 3]; every identity then projects
+    # them onto ITS person's manifold and normalises with ITS statistics (postnet.IdentityConditioner: LLE + normalise + clamp + windows,
+    # genefacepp_infer.py:335-423) -- per-identity work on the identity's own GPU, after the one broadcast
+    per_identity_cond = cwin == 1 and cin == 68 * 3
+    if per_identity_cond:
+        sig["idexp_lm3d"] = torch.zeros(F, 68, 3, device=dev)
+        if rank == 0:
+            g = torch.Generator().manual_seed(4242)
+            sig["idexp_lm3d"].copy_(0.3 * torch.randn(F, 68, 3, generator=g))
+    frames.share_driving_signals(sig, src=0)
+    lm3d = sig.pop("idexp_lm3d", None)
+    batch = {k: v.cpu().numpy() for k, v in sig.items()}
+    # ---- one model + clip renderer per identity this rank serves ----------------------------------------------------------------
+    bg = torch.full((1, HW * HW, 3), 0.5, device=dev)
+    renderers = []
+    for ident in mine:
+        sd = syn.synthetic_state_dict(hp, args.variant, seed=9999 + ident)
+        m = getattr(radnerfs, CLASSES[args.variant])(hp)
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.to(dev).eval()
+        m.executor, m.precision, m.use_graph = args.executor, args.precision, not args.no_graph
+        cr = ClipRenderer(m, HW, HW, syn.intrinsics_for(HW, HW), bg_img=bg, T_thresh=0.01, use_graph=m.use_graph, lanes=args.lanes)
+        my_batch = batch
+        if per_identity_cond:
+            from genefaceplusplus_amd.postnet import IdentityConditioner
+            g = torch.Generator().manual_seed(777 + ident)                       # this person's training-set landmarks (synthetic)
+            person = IdentityConditioner(0.3 * torch.randn(2000, 68, 3, generator=g), device=dev)
+            my_batch = dict(batch)
+            my_batch["cond_wins"] = person.cond_wins(lm3d, smo, lle_percent=0.2).cpu().numpy()
+        renderers.append((ident, cr, cr.prepare(my_batch, dev)))
+    my_frames = frames.shard_frames(F, local_rank, local_world, interleaved=True)
+    warm, timed = my_frames[:W], my_frames[W:W + K]
+    outs = {ident: torch.empty(K, HW, HW, 3, dtype=torch.uint8, device=dev) for ident in mine}
+    for ident, cr, clip in renderers:
+        cr.render_to_device(clip, warm, out=outs[ident][:len(warm)])
+    if world > 1:
+        frames.gather_identity_clip(outs[mine[0]], K * local_world, group, interleaved=True, dst=0)      # channel set-up outside the timed region
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ident, cr, clip in renderers:
+        cr.render_to_device(clip, timed, out=outs[ident])
+    if world > 1:
+        frames.gather_identity_clip(outs[mine[0]], K * local_world, group, interleaved=True, dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    if rank == 0:
+        total = K * (world if world > 1 else n_id)
+        print(json.dumps({"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(total / elapsed, 3), "unit": "frames/s", "n_gpus": world,
+                          "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[4]: {n_id} person-specific {args.variant} models ({HW}x{HW}), "
+                                                 f"{'ranks in contiguous blocks of ' + str(local_world) if world > 1 else 'taking turns on one GPU'}, driving signals "
+                                                 f"broadcast once (shared audio2motion), frames gathered to each block's writer rank",
+                                     "identities": n_id, "frames_per_rank_and_identity": K, "frames_total": total,
+                                     "parallelism": f"{n_id} identity blocks x frame-parallel x{local_world}", **({"dist": dinfo} if dinfo else {})}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_ray_tiles(args, rank, world, dev, dinfo=None):
+    """--shard rays: every frame is rendered by ALL ranks together (frames.render_frame_tiled): rank r takes the r-th contiguous tile of the rays,
+    the frame-wide alive count is all-reduced once per trip so that every ray gets the single-GPU sample budget (renderer.py:364), the finished
+    tiles are all-gathered.  value = frames/s of the group (strong scaling of one frame: total work fixed); ms_per_step = latency of one frame."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from genefaceplusplus_amd import synthetic as syn, radnerfs, frames
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import camera
+    from tests.helpers import CLASSES
+    HW, K, W = args.hw, args.steps, args.warmup
+    hp = may_hparams(args.variant)
+    sd = syn.synthetic_state_dict(hp, args.variant)
+    model = getattr(radnerfs, CLASSES[args.variant])(hp)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    model.executor, model.precision, model.use_graph = "fused", args.precision, False
+    bg_coords = camera.get_bg_coords(HW, HW, "cpu").to(dev)
+    bg = torch.full((1, HW * HW, 3), 0.5, device=dev)
+    inputs = []
+    for j in range(min(K + W, 8)):
+        pose = torch.from_numpy(syn.synthetic_pose(j)).to(dev)[None]
+        fi = syn.synthetic_frame_inputs(hp, j)
+        r = camera.get_rays(pose, syn.intrinsics_for(HW, HW), HW, HW)
+        inputs.append((r["rays_o"], r["rays_d"], torch.from_numpy(fi["cond"]).to(dev), camera.convert_poses(pose)))
+    kw = dict(index=0, perturb=False, T_thresh=0.01, max_steps=hp["max_steps"], dt_gamma=hp["dt_gamma"])
+
+    def frame(i):
+        ro, rd, cond, pose6 = inputs[i % len(inputs)]
+        return frames.render_frame_tiled(model, ro, rd, cond, bg_coords, pose6, bg_color=bg, **kw)
+    for i in range(W):
+        frame(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        frame(W + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(K / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K,
+                          "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic",
+                          "config": {"workload": f"{args.variant}: ONE {HW}x{HW} frame at a time rendered by all {world} GPUs as ray tiles (latency mode)",
+                                     "parallelism": f"ray tiles x{world}: int32 all_reduce of the alive count per trip + all_gather of the tiles per frame",
+                                     "launch": "eager (collectives between the trip launches)", **({"dist": dinfo} if dinfo else {})}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def build(ctx):
+    """The sub-benchmarks as closures over bench.py's state (ctx: types.SimpleNamespace).  Returns a namespace of functions."""
+    import numpy as np
+    import torch
+    from genefaceplusplus_amd import synthetic as syn
+    from genefaceplusplus_amd.configs import may_hparams
+    from genefaceplusplus_amd.radnerfs import camera
+    from genefaceplusplus_amd import radnerfs, frames
+    from genefaceplusplus_amd.clip import ClipRenderer
+    from tests.helpers import CLASSES
+    args, dev, world, rank = ctx.args, ctx.dev, ctx.world, ctx.rank
+    model, hp, inputs, render = ctx.model, ctx.hp, ctx.inputs, ctx.render
+    HW, HWO, N, K, W = ctx.HW, ctx.HWO, ctx.N, ctx.K, ctx.W
+    cr, clip, out_u8, my_frames = ctx.cr, ctx.clip, ctx.out_u8, ctx.my_frames
+    bg_coords, bg_color, intr, batch, fi_all = ctx.bg_coords, ctx.bg_color, ctx.intr, ctx.batch, ctx.fi_all
+
+    # ---- the timed frames themselves: rendered, and rendered RIGHT (round-4 review: the line must not be able to report black frames) -------------------------
+    # >= 2 of the K timed frames (first, middle, last: different frame groups / lanes) are re-rendered through the per-frame API -- model.render() on
+    # pre-materialised rays, the reference's own call (genefacepp_infer.py:460-469) -- and compared BYTE FOR BYTE with what the timed job left in its output
+    # stack; the same frames in the exact-fp32 mode give the PSNR of the timed bytes.  A failed check sets `value` to null.  (The *_sr models draw fresh
+    # super-resolution noise per launch like the reference: no byte comparison there, PSNR only against the head+torso input of the SR stage is not defined.)
+    def timed_frames_check(result):
+        """>= 2 of the K timed frames against model.render() (bytes) and the exact-fp32 mode (PSNR); a failed check sets `value` to null."""
+        check = {"frames_checked": [], "bytes_equal_per_frame_api": None, "psnr_vs_fp32_mode_db": [], "ok": False}
+        try:
+            def frame_input(j):
+                pose = torch.from_numpy(batch["ngp_poses"][j]).to(dev)[None]
+                rays = camera.get_rays(pose, intr, HW, HW)
+                return {"rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "poses": camera.convert_poses(pose), "cond": torch.from_numpy(fi_all[j]["cond"]).to(dev),
+                        "lm68": torch.from_numpy(fi_all[j]["lm68"]).to(dev), "eye": torch.from_numpy(fi_all[j]["eye_area_percent"]).to(dev)}
+
+            def api_frame(x):
+                with torch.no_grad():
+                    res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=0, staged=False, bg_color=bg_color, lm68=x["lm68"], perturb=False,
+                                       force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
+                return res["rgb_map"].reshape(HW, HW, 3).float().contiguous()
+            picks = sorted({0, K // 2, K - 1})
+            equal, psnrs, spread = [], [], []
+            sr_variant = args.variant == "may_torso_sr"
+            for k in picks:
+                timed = out_u8[k]
+                spread.append(float(timed.float().std().item()))
+                if sr_variant:
+                    continue
+                x = frame_input(W + k)
+                model.precision = args.precision
+                u8 = torch.empty(HW, HW, 3, dtype=torch.uint8, device=dev)
+                frames.to_uint8_hwc(api_frame(x), u8)
+                equal.append(bool(torch.equal(u8, timed)))
+                model.precision = "fp32"
+                ref32 = api_frame(x)
+                mse = float(((timed.float() / 255.0 - ref32) ** 2).mean().item())
+                psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
+            model.precision = args.precision
+            bar = 45.0 if args.precision != "fp32" else 55.0         # SURVEY 8c's 16-bit bar; fp32 frames differ from themselves by the uint8 step only (58.9 dB)
+            check.update({"frames_checked": [W + k for k in picks], "bytes_equal_per_frame_api": (all(equal) if equal else None), "psnr_vs_fp32_mode_db": psnrs,
+                          "uint8_std_per_frame": [round(v, 2) for v in spread], "psnr_bar_db": bar,
+                          "what": "timed frames (output stack of the timed job) vs model.render() on the same inputs: bytes; vs the exact-fp32 mode: PSNR"
+                                  + (" -- *_sr model: fresh SR noise per launch, only the frames' spread is checked" if sr_variant else "")})
+            check["ok"] = bool(all(v > 5.0 for v in spread) and (sr_variant or (all(equal) and all(p >= bar for p in psnrs))))
+        except Exception as exc:
+            check["error"] = f"{type(exc).__name__}: {exc}"
+        result["config"]["timed_frames_check"] = check
+        if not check["ok"]:
+            result["value_unchecked"] = result["value"]
+            result["value"] = None
+
+    # ---- roofline of the dominant kernel: time the trip launches of a few frames with HIP events on the launch stream ------------
+    def head_roofline(model, hp, x, N, variant, frames_per_launch=1, ms_per_frame_period=None, pmc_tag=None):
+        """HIP events around the head-pass launches of 5 frames (frame groups: 5 launches of `frames_per_launch` frames each) issued back to back on the
+        launch stream, production prologue before them.  ms_per_frame_period: the clip loop's measured frame period (several frames in flight), for
+        `effective_frac_per_frame_period`; pmc_tag: name of this workload's committed counter pass (profiles/<round>_pmc_<tag>.json) for the ratios."""
+        pipe = model.pipeline()
+        with torch.no_grad():
+            cond_feat = model.cal_cond_feat(x["cond"]) if variant != "may_torso_sr" else model.cal_cond_feat(x["cond"], eye_area_percent=x["eye"])
+        reps = 5
+        import ctypes
+        from genefaceplusplus_amd._lib import call
+        ro, rd = x["rays_o"].view(-1, 3).contiguous(), x["rays_d"].view(-1, 3).contiguous()
+        max_steps = int(hp["max_steps"])
+        st = torch.cuda.current_stream().cuda_stream
+        ind = model.individual_embeddings[0].detach().float().contiguous()
+        cf = cond_feat.detach().float().contiguous()
+        fp32 = args.precision == "fp32"
+        persist = pipe.lp_kernel == "persist" and (not fp32 or pipe.fp32_kernel == "wave")
+        G = int(frames_per_launch) if (persist and not fp32 and frames_per_launch > 1 and pipe.group_supported(N, frames_per_launch, max_steps)) else 1
+        trips_fn = ("gfpp_head_frame_persist" if persist else "gfpp_head_frame_trips") if fp32 else ("gfpp_head_frame_persist_lp" if persist else "gfpp_head_frame_trips_lp")
+        if G > 1:
+            gws, fws, gt = pipe.group_workspace(N, G, max_steps)
+            for k in range(G):
+                gt["rays_o"][k].copy_(ro)
+                gt["rays_d"][k].copy_(rd)
+            consts = pipe.fold_rows(cf.reshape(1, -1).repeat(G, 1).contiguous(), ind)           # [G, 256]: the production fold, once per clip job
+            gws.frame_consts, gws.frame_consts_stride = consts.data_ptr(), 256
+        else:
+            ws, tbuf = pipe.workspace(N)
+            if ws.sample_stride < max_steps + 7:                      # (a clip that rendered through frame groups never used this workspace)
+                stride = (max_steps + 7 + 7) // 8 * 8
+                tbuf["sample_t"] = torch.empty(N, stride, dtype=torch.float32, device=dev)
+                tbuf["sample_cnt"] = torch.empty(N, dtype=torch.int32, device=dev)
+                ws.sample_t, ws.sample_cnt, ws.sample_stride = tbuf["sample_t"].data_ptr(), tbuf["sample_cnt"].data_ptr(), stride
+            ws.frame_consts = tbuf["frame_consts"].data_ptr()
+            if persist and "snapshots" not in tbuf:
+                tbuf["snapshots"] = torch.empty(N, 7, 5, dtype=torch.float32, device=dev)
+            if persist:
+                ws.snapshots = tbuf["snapshots"].data_ptr()
+            ws.defer_resolve = 0
+
+        def one_launch(ev=None):
+            # the production prologue (slab test + state reset + pre-march in one launch per frame, then the bias fold), then the launch(es) the roofline is about
+            if G > 1:
+                for k in range(G):
+                    call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(fws[k]), gt["rays_o"][k].data_ptr(), gt["rays_d"][k].data_ptr(),
+                         float(hp["dt_gamma"]), max_steps, st)
+                if ev is not None:
+                    ev[0].record()
+                call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(gws), gt["rays_o"].data_ptr(), gt["rays_d"].data_ptr(), float(hp["dt_gamma"]), max_steps, 0.01, st)
+                if ev is not None:
+                    ev[1].record()
+                return
+            call("gfpp_head_frame_begin_premarch", ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), max_steps, st)
+            call("gfpp_head_frame_fold", ctypes.byref(pipe.head), ctypes.byref(ws), cf.data_ptr(), ind.data_ptr(), st)
+            if ev is not None:
+                ev[0].record()
+            call(trips_fn, ctypes.byref(pipe.head), ctypes.byref(ws), ro.data_ptr(), rd.data_ptr(), float(hp["dt_gamma"]), max_steps, 0.01, st)
+            if ev is not None:
+                ev[1].record()
+
+        # the launches are issued back to back (no host synchronisation in between, two untimed ones first): an idle gap lets the GPU clock down
+        # and the next launches would be timed at the low clock
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        # ... and after host-side work (the timed-frames check, model set-up of a sub-benchmark) the part sits in its idle power state: untimed launches until the GPU has
+        # worked for 60 ms, like the warm-up of the timed region (the launches measured 0.80-0.84 ms at ~1.87 GHz without this, 0.73 ms at 2.1 GHz in round 4's
+        # record, whose roofline section ran right behind the timed loop)
+        t_w = time.perf_counter()
+        while True:
+            one_launch()
+            one_launch()
+            torch.cuda.synchronize()
+            if 1e3 * (time.perf_counter() - t_w) >= 60.0:
+                break
+        one_launch()
+        one_launch()
+        for ev in events:
+            one_launch(ev)
+        torch.cuda.synchronize()
+        t_march = sum(a0.elapsed_time(a1) for a0, a1 in events) * 1e-3
+        if persist and not fp32:
+            # one more launch through the PROFILING instantiation (k_head_frame_persist<.., PROF>: thread 0's shader clock by phase into the budget counters) -- the timed
+            # launches above ran the production instantiation, which carries no clock reads
+            rec = gws if G > 1 else ws
+            flag = torch.zeros(8, dtype=torch.int64, device=dev)
+            rec.phase_cycles = flag.data_ptr()
+            try:
+                one_launch()
+                torch.cuda.synchronize()
+            finally:
+                rec.phase_cycles = None
+        if G > 1:
+            c = gt["counters"].cpu().numpy()
+            per_launch = int(c[0, 168])                              # the launch's evaluated samples (all its frames; kept in the first frame's counters)
+            samples = reps * per_launch
+            launches = reps
+            common = {"frames_per_launch": G, "samples_per_launch": per_launch, "samples_per_frame": per_launch // G, "launches_per_frame": round(1.0 / G, 4),
+                      "avg_launch_ms": round(1e3 * t_march / reps, 4), "ms_per_frame_all_trips": round(1e3 * t_march / (reps * G), 4), "traffic": None,
+                      "workgroup_rounds": {"max": int(c[0, 170]), "mean": round(int(c[0, 169]) / max(pipe.cu_count, 1), 2)},
+                      "workgroup_balance": {"samples_busiest": int(c[0, 171]), "samples_mean": round(per_launch / max(pipe.cu_count, 1), 1)},
+                      "workgroup_kcycles": {"fetch": int(c[0, 172]), "compact": int(c[0, 173]), "evaluate": int(c[0, 174]), "composite": int(c[0, 175]), "longest_wg": int(c[0, 176]),
+                                            "ingest_of_fetch": int(c[0, 177])}}
+            frames_timed = reps * G
+        else:
+            alive, smp = pipe.trip_counters(N)                       # the same frame every time: counters of the last one
+            samples = reps * int(smp.sum())
+            launches = reps * (1 if persist else int((smp > 0).sum()))
+            common = {"samples_per_frame": samples // reps, ("launches_per_frame" if persist else "nonempty_trips_per_frame"): launches // reps,
+                      "avg_launch_ms": round(1e3 * t_march / max(launches, 1), 4), "ms_per_frame_all_trips": round(1e3 * t_march / reps, 4),
+                      "alive_per_trip": [int(v) for v in alive[:17] if v > 0], "traffic": None}
+            if persist:
+                b = pipe.budget(N)
+                common["workgroup_rounds"] = {"max": b["rounds_max"], "mean": round(b["rounds_sum"] / max(pipe.cu_count, 1), 2)}
+                common["workgroup_balance"] = {"samples_busiest": b["samples_max_wg"], "samples_mean": round(b["samples"] / max(pipe.cu_count, 1), 1)}
+                common["workgroup_kcycles"] = b["kcycles"]        # thread 0's shader clock by phase, summed over the workgroups (units of 1024 cycles)
+            frames_timed = reps
+        if args.precision == "fp32":
+            achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
+            kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
+                else "k_head_trip_wp<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, workgroup sample pool)"
+            if persist:
+                kname = "k_head_frame_persist<3,float> (the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips; exact-fp32 MFMA MLP)"
+            return {"kernel": kname, "bound": "mfma",
+                                  "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), **common}
+        # the 16-bit kernel is bound by instruction issue / gather latency, not by a memory level.  `achieved` / `frac` = the gather bytes THIS MODE REQUESTS (SURVEY 8d's
+        # formula with the s_tab of the tables the kernel reads: 16-bit corner-block tables since round 4 -> 12 B + 2 grids x 32 gathers x 16 B = 1 036 B per sample;
+        # hash-addressed models keep the fp32 tables -> 2 060 B) against the HBM peak (the north star's yardstick for the hash-grid stage); `frac_fp32_equiv` keeps the
+        # rounds 1-3 unit (2 060 B whatever is read) for continuity and is NOT a hardware quantity
+        blk_tables = bool(pipe.head.pos_grid_blk.table) and bool(pipe.head.amb_grid_blk.table)
+        bytes_read = GATHER_BYTES_PER_SAMPLE_BLOCK if blk_tables else GATHER_BYTES_PER_SAMPLE
+        gbps = samples * bytes_read / t_march / 1e9
+        gbps_eq = samples * GATHER_BYTES_PER_SAMPLE / t_march / 1e9
+        tflops = samples * FLOP_PER_SAMPLE_LP / t_march / 1e12
+        kname = "k_head_frame_persist" if persist else "k_head_trip_pool"
+        what = ("the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips" if persist
+                else "fused march + grid encode + 16-bit MFMA MLP + composite, one launch per trip")
+        if G > 1:
+            what = f"the whole march / evaluate / composite loop of {G} consecutive frames as ONE launch (frame group), workgroup-local trips over the pooled samples"
+        roof = {"kernel": f"{kname}<3,{args.precision}> ({what})", "bound": "hbm",
+                "bound_note": "'hbm' is the north star's yardstick for the hash-grid stage (SURVEY 8d's algorithmic gather bytes at the table precision the kernel reads, vs the "
+                              "8 TB/s HBM peak), not what limits the kernel: the tables are L2 / Infinity-Cache resident and the counters show an issue / latency bound "
+                              "(`limiter`, `pmc`)",
+                "limiter": "instruction issue + LDS-fed MFMA + gather latency (no single saturated unit)",
+                "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                "bytes_per_sample": bytes_read,
+                "bytes_note": ("16-bit corner-block tables: 12 B position + 2 grids x 32 gathers x 16 B (SURVEY 8d's formula with s_tab = 2 B)" if blk_tables
+                               else "fp32 tables through the generic lookup (hash-addressed levels): 12 B + 2 grids x 16 levels x 8 corners x 8 B"),
+                "frac_fp32_equiv": round(gbps_eq / PEAK_HBM_GBPS, 4),
+                "fp32_equiv_note": "the same launches priced at 2 060 B per sample (fp32 tables), the unit of rounds 1-3's fractions -- for continuity only, the kernel does "
+                                   "not move these bytes",
+                "l2": {"achieved": round(gbps, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L2_GBPS, 4),
+                       "what": "the requested gather bytes against the aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s), the level that serves them"},
+                "mfma": {"achieved": round(tflops, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / PEAK_16BIT_MFMA_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE_LP,
+                         "flop_per_sample_note": "128 768 algorithmic (folded, merged) -- the fraction's unit; the launch issues 148 MFMAs per 32-sample block = 151 552 FLOP per "
+                                                 "sample since the skinny rows run as MFMA chains on a gathered tile"}, **common}
+        if ms_per_frame_period:
+            # production overlaps several frames (clip lanes): what the frame PERIOD delivers of the yardstick, next to the one-launch-at-a-time figure above
+            eff = (samples / frames_timed) * bytes_read / (ms_per_frame_period * 1e-3) / 1e9
+            roof["effective_frac_per_frame_period"] = round(eff / PEAK_HBM_GBPS, 4)
+            roof["effective_note"] = (f"requested gather bytes of one frame / the clip loop's frame period ({ms_per_frame_period:.4f} ms, several frames in flight: the period "
+                                      f"also holds the frame's other kernels)")
+        pmc = load_pmc(pmc_tag)
+        if pmc:
+            roof["pmc"] = pmc
+        return roof
+
+    def load_pmc(tag):
+        """The committed counter pass of THIS workload and precision (profiles/<round>_pmc_<tag>.json, written by tools/pmc_summary.py from separate
+        rocprofv3 --pmc runs), or None: ratios are quoted from measurements of the same workload or not at all."""
+        if not tag:
+            return None
+        for rnd in ("r05", "r04"):                # the newest committed pass of this workload (the r04 passes belong to round 4's kernels and say so in `source`)
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.json")
+            if os.path.exists(path):
+                try:
+                    d = json.load(open(path))
+                    d["source"] = os.path.relpath(path, ROOT) + " (committed counter pass of this workload; not measured in this run)"
+                    return d
+                except Exception:
+                    return None
+        return None
+
+    # ---- the other precision modes, briefly (same model, same inputs; graphs are kept per precision) -------------------------------
+    def other_modes(result):
+        """frames/s of the other precision modes, the per-frame API, delivery to host memory, the *_sr model (+ its roofline) and a >= 2 000-frame run."""
+        modes = {}
+        for prec in ("fp32", "fp16", "bf16"):
+            if prec == args.precision:
+                continue
+            model.precision = prec
+            n_m = min(40, K)                          # long enough for the two frames in flight to reach their steady state
+            cr.render_to_device(clip, range(3), out=out_u8[:3] if K >= 3 else None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cr.render_to_device(clip, range(W, W + n_m), out=out_u8[:n_m])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            modes[prec] = {"value": round(n_m / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_m, 4), "steps": n_m}
+        model.precision = args.precision
+        # the reference-shaped call sequence as genefacepp_infer.py issues it today: rays pre-materialised per frame (6.3 MB each), one
+        # model.render() per frame, uint8 conversion as a separate launch
+        for i in range(3):
+            render(i, slot=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(20):
+            render(W + k, slot=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        modes["per_frame_api"] = {"value": round(20 / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / 20, 4), "steps": 20,
+                                  "precision": args.precision, "workload": "model.render(rays_o, rays_d, ...) per frame with pre-materialised rays"}
+        # the caller's whole loop (genefacepp_infer.py:246-269, 460-469) through genefaceplusplus_amd.clip: rays generated on the device from the
+        # pose, uint8 conversion on the device, every frame delivered to HOST memory through the pinned ring -- the PCIe-inclusive rate
+        try:
+            n_c = 64
+            fi_c = [syn.synthetic_frame_inputs(hp, i) for i in range(n_c)]
+            batch_c = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(n_c)]).astype(np.float32),
+                       "cond_wins": np.stack([f["cond"] for f in fi_c]), "lm68": np.stack([f["lm68"] for f in fi_c]),
+                       "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_c])}
+            clip_c = cr.prepare(batch_c, dev)
+            sunk = [0]
+
+            def sink(i, frame):
+                sunk[0] += int(frame[0, 0, 0]) * 0 + 1
+            cr.render_to_host(clip_c, sink=sink, frame_indices=range(4))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cr.render_to_host(clip_c, sink=sink)
+            dt = time.perf_counter() - t1
+            modes["clip_to_host"] = {"value": round(n_c / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_c, 4), "steps": n_c,
+                                     "precision": args.precision, "frames_delivered": sunk[0] - 4,
+                                     "workload": "the headline frame loop + every frame delivered to host memory through the pinned ring (async D2H): "
+                                                 "the PCIe-inclusive rate"}
+        except Exception as exc:
+            modes["clip_to_host"] = {"value": None, "error": str(exc)}
+        if args.variant == "may_torso" and HW == 512:
+            # the released May checkpoint's shape: 256^2 rays, landmark-conditioned head-aware torso, StyleGAN2 super-resolution to 512^2
+            try:
+                hp_sr = may_hparams("may_torso_sr")
+                sd_sr = dict(syn.synthetic_state_dict(hp_sr, "may_torso_sr"))
+                sd_sr.update(syn.synthetic_sr_state())
+                m_sr = getattr(radnerfs, CLASSES["may_torso_sr"])(hp_sr)
+                m_sr.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_sr.items()}, strict=True)
+                m_sr = m_sr.to(dev).eval()
+                m_sr.precision, m_sr.use_graph = args.precision, model.use_graph
+                n_s = 120
+                fi_s = [syn.synthetic_frame_inputs(hp_sr, i) for i in range(n_s)]
+                batch_s = {"ngp_poses": np.stack([syn.synthetic_pose(i) for i in range(n_s)]).astype(np.float32),
+                           "cond_wins": np.stack([f["cond"] for f in fi_s]), "lm68": np.stack([f["lm68"] for f in fi_s]),
+                           "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_s])}
+                cr_sr = ClipRenderer(m_sr, 256, 256, syn.intrinsics_for(256, 256), bg_img=torch.full((1, 256 * 256, 3), 0.5, device=dev), T_thresh=0.01,
+                                     use_graph=model.use_graph, lanes=args.lanes)
+                clip_s = cr_sr.prepare(batch_s, dev)
+                stack = torch.empty(n_s, 512, 512, 3, dtype=torch.uint8, device=dev)
+                cr_sr.render_to_device(clip_s, range(4), out=stack[:4])
+                torch.cuda.synchronize()
+                dt = None
+                for _ in range(2):          # the first pass also pages the second model's tables into the caches
+                    t1 = time.perf_counter()
+                    cr_sr.render_to_device(clip_s, out=stack)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    if os.environ.get("GFPP_BENCH_DEBUG"):
+                        print("sr mode pass", n_s / dt, file=sys.stderr)
+                modes["may_torso_sr"] = {"value": round(n_s / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_s, 4), "steps": n_s,
+                                         "precision": args.precision,
+                                         "workload": "256x256 rays + landmark-conditioned head-aware torso + StyleGAN2 super-resolution -> 512x512 frame"}
+                # the 256^2 geometry of the released checkpoint with its own roofline (the head pass carries a quarter of the 512^2 frame's samples)
+                try:
+                    pose_s = torch.from_numpy(batch_s["ngp_poses"][0]).to(dev)[None]
+                    rays_s = camera.get_rays(pose_s, syn.intrinsics_for(256, 256), 256, 256)
+                    x_s = {"rays_o": rays_s["rays_o"], "rays_d": rays_s["rays_d"], "cond": torch.from_numpy(fi_s[0]["cond"]).to(dev),
+                           "eye": torch.from_numpy(fi_s[0]["eye_area_percent"]).to(dev)}
+                    sr_cfg = {"baseline_config": "the released May checkpoint's class (RADNeRFTorsowithSR): 256x256 rays, landmark-conditioned head-aware torso, "
+                                                 "StyleGAN2 super-resolution to 512x512", "value": modes["may_torso_sr"]["value"], "unit": "frames/s",
+                              "frames_in_flight": cr_sr.lanes, "frames_per_graph_launch": cr_sr.group,
+                              "roofline": head_roofline(m_sr, hp_sr, x_s, 256 * 256, "may_torso_sr", frames_per_launch=cr_sr.group, ms_per_frame_period=1e3 * dt / n_s,
+                                                        pmc_tag=f"may_torso_sr_256_{args.precision}")}
+                    # the super-resolution stage alone (4 launches, 77.3 GFLOP of f16 MFMA work per forward), HIP events on torch's current stream (the one
+                    # Superresolution.forward launches on), noise drawn in the kernels as the frame loop does
+                    try:
+                        x_img = torch.rand(1, 3, 256, 256, device=dev)
+                        for _ in range(5):
+                            m_sr.sr_net(x_img, noise_mode="random", clamp01=True)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        reps = 100
+                        e0.record()
+                        for _ in range(reps):
+                            m_sr.sr_net(x_img, noise_mode="random", clamp01=True)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us = e0.elapsed_time(e1) / reps * 1e3
+                        gflop = 19.327 + 38.655 + 19.327
+                        sr_cfg["sr_stage"] = {"kernels": "k_sr_conv3<128,first fused> + k_sr_conv3<128,up> + k_sr_final_resident (3 launches; genefaceplusplus_amd/csrc/superres.hip)",
+                                              "us_per_forward": round(us, 2), "gflop_per_forward": round(gflop, 2), "bound": "mfma",
+                                              "achieved": round(gflop / us * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gflop / us * 1e3 / 2500.0, 4),
+                                              "sustained_clock_note": "the tap loops of these kernels run at 85-91 % MFMA-pipe occupancy in cycles, at the ~1.4 GHz the part sustains "
+                                                                      "under dense f16 MFMA on all 256 CUs (tools/sr_phase.py, tools/clock_probe_sr.py; docs/LAB_NOTEBOOK.md): "
+                                                                      "the data-sheet peak assumes 2.4 GHz",
+                                              "frac_of_sustained_clock_peak": round(gflop / us * 1e3 / (2500.0 * 1.4 / 2.4), 4)}
+                    except Exception as exc:
+                        sr_cfg["sr_stage"] = {"error": str(exc)}
+                    result.setdefault("configs", {})["may_torso_sr_256"] = sr_cfg
+                except Exception as exc:
+                    result.setdefault("configs", {})["may_torso_sr_256"] = {"error": str(exc)}
+                del cr_sr, m_sr
+            except Exception as exc:
+                modes["may_torso_sr"] = {"value": None, "error": str(exc)}
+        if args.long_run_frames > 0:
+            # a run long enough that clock ramps, the first graph replays and the scheduling of the frames in flight average out:
+            # >= 2 000 frames in blocks of 100 (each block timed on its own), same clip renderer / precision as the headline
+            per = 100
+            n_blocks = max(1, args.long_run_frames // per)
+            reps = (per + len(my_frames) - W - 1) // max(len(my_frames) - W, 1)
+            idx = (list(range(W, len(my_frames))) * reps)[:per]
+            stack = out_u8 if K >= per else torch.empty(per, HWO, HWO, 3, dtype=torch.uint8, device=dev)
+            cr.render_to_device(clip, idx[:8], out=stack[:8])
+            torch.cuda.synchronize()
+            rates = []
+            t_all = time.perf_counter()
+            for _ in range(n_blocks):
+                t1 = time.perf_counter()
+                cr.render_to_device(clip, idx, out=stack[:per])
+                torch.cuda.synchronize()
+                rates.append(per / (time.perf_counter() - t1))
+            t_all = time.perf_counter() - t_all
+            rates = np.array(rates)
+            modes["long_run"] = {"value": round(n_blocks * per / t_all, 2), "unit": "frames/s", "frames": n_blocks * per, "precision": args.precision,
+                                 "block_frames": per, "block_mean": round(float(rates.mean()), 2), "block_std": round(float(rates.std()), 2),
+                                 "block_min": round(float(rates.min()), 2), "block_max": round(float(rates.max()), 2),
+                                 "workload": "the headline configuration, frames cycled through the resident clip"}
+        result["modes"] = modes
+
+    # ---- the other single-GPU BASELINE configurations ---------------------------------------------------------------------------------
+    def baseline_configs(result):
+        """the other single-GPU BASELINE configurations (configs[1] latency, no-termination scene, reference-shaped loop, configs[0] on the CPU oracle)."""
+        cfgs = result.setdefault("configs", {})
+        try:
+            # configs[1]: "May head-NeRF full 512x512, 1 MI355X, fp32, single-frame latency": ONE frame in flight, the caller waits for it
+            hp_h = may_hparams("may_head")
+            m_h = getattr(radnerfs, CLASSES["may_head"])(hp_h)
+            m_h.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synthetic_state_dict(hp_h, "may_head").items()}, strict=True)
+            m_h = m_h.to(dev).eval()
+            m_h.precision, m_h.use_graph, m_h.executor = "fp32", model.use_graph, args.executor
+            lat = []
+            n_lat = 220
+            for i in range(n_lat):
+                x = inputs[i % len(inputs)]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                with torch.no_grad():
+                    r = m_h.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=i, bg_color=bg_color, perturb=False, force_all_rays=False,
+                                   T_thresh=0.01, **hp_h)
+                torch.cuda.synchronize()
+                lat.append(1e3 * (time.perf_counter() - t1))
+            lat = np.array(lat[20:])                     # the first calls capture the graph and warm the caches
+            cfgs["may_head_fp32_latency"] = {"baseline_config": "configs[1]: May head-NeRF full 512x512, 1 MI355X, fp32, single-frame latency",
+                                             "latency_ms_p50": round(float(np.percentile(lat, 50)), 4), "latency_ms_p99": round(float(np.percentile(lat, 99)), 4),
+                                             "latency_ms_mean": round(float(lat.mean()), 4), "frames": int(lat.size), "frames_in_flight": 1, "dtype": "f32",
+                                             "what": "wall time of one model.render() call (rays resident, host-synchronised before and after): exact-fp32 MFMA head "
+                                                     "pass + finish, " + ("hipGraph replay" if m_h.use_graph else "eager launches"),
+                                             "frames_per_s_at_this_latency": round(1e3 / float(lat.mean()), 2)}
+            del m_h
+        except Exception as exc:
+            cfgs["may_head_fp32_latency"] = {"error": str(exc)}
+        try:
+            # "with sigma ~ 1 (alpha 0.03 per step) no ray ever terminates: worst case, report it separately as no-termination" -- 7 trips
+            # (n_step 1,2,2,2,2,3,4), ~1.5 M evaluated slots, rays composite past max_steps: the snapshot path of the persistent launch
+            hp_n = may_hparams("may_torso")
+            m_n = getattr(radnerfs, CLASSES["may_torso"])(hp_n)
+            m_n.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synthetic_state_dict(hp_n, "may_torso", sigma_gain=0.05).items()}, strict=True)
+            m_n = m_n.to(dev).eval()
+            m_n.precision, m_n.use_graph, m_n.executor = args.precision, model.use_graph, args.executor
+            cr_n = ClipRenderer(m_n, HW, HW, intr, bg_img=bg_color, T_thresh=0.01, use_graph=model.use_graph, lanes=args.lanes)
+            n_n = 120
+            stack = out_u8 if K >= n_n else torch.empty(n_n, HWO, HWO, 3, dtype=torch.uint8, device=dev)
+            idx_n = [W + (i % max(len(my_frames) - W, 1)) for i in range(n_n)]
+            cr_n.render_to_device(clip, idx_n[:4], out=stack[:4])
+            torch.cuda.synchronize()
+            dt_n = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                cr_n.render_to_device(clip, idx_n, out=stack[:n_n])
+                torch.cuda.synchronize()
+                dt_n = time.perf_counter() - t1
+            x_n = inputs[W]
+            roof_n = head_roofline(m_n, hp_n, x_n, N, "may_torso", frames_per_launch=cr_n.group, ms_per_frame_period=1e3 * dt_n / n_n, pmc_tag=None)
+            cfgs["may_torso_no_termination"] = {"workload": "the headline model with sigma_net's density row scaled to sigma ~ 1 (alpha ~ 0.03 per step: no ray terminates by "
+                                                            "transmittance; SURVEY 8d 'report separately as no-termination'), 512x512 head+torso, same frame loop",
+                                                "value": round(n_n / dt_n, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_n / n_n, 4), "steps": n_n, "precision": args.precision,
+                                                "frames_in_flight": cr_n.lanes, "roofline": roof_n}
+            del cr_n, m_n
+        except Exception as exc:
+            cfgs["may_torso_no_termination"] = {"error": str(exc)}
+        try:
+            # a second baseline next to cpu_baseline, on the SAME MI355X: the reference-shaped loop (executor 'staged': one C-ABI launch per reference extension
+            # call, torch layers on rocBLAS between them, a device->host synchronisation per loop trip -- renderer.py:354-384 as written), same model and inputs
+            model.executor = "staged"
+            for i in range(2):
+                render(i, slot=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(8):
+                render(W + k, slot=0)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t1
+            cfgs["reference_shaped_loop_same_gpu"] = {"value": round(8 / dt_s, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_s / 8, 3), "steps": 8,
+                                                      "what": "executor='staged': the reference's own loop structure (one launch per extension call, nn.Linear GEMMs in between, a "
+                                                              "host sync per trip) on this MI355X with this package's kernels -- a baseline for what the fused path removes, "
+                                                              "not the reference's CUDA build", "precision": "fp32 torch layers" if args.precision == "fp32" else "torch autocast-free fp32 layers"}
+        except Exception as exc:
+            cfgs["reference_shaped_loop_same_gpu"] = {"error": str(exc)}
+        finally:
+            model.executor = args.executor
+        try:
+            cfgs["crop64_cpu_oracle"] = cpu_crop_config()
+        except Exception as exc:
+            cfgs["crop64_cpu_oracle"] = {"error": str(exc)}
+        result["configs"] = cfgs
+
+    # ---- HBM-side traffic of the dominant launch: from the committed rocprofv3 --pmc pass of this same workload and precision, or null --------
+    def attach_traffic(roof):
+        pmc = roof.get("pmc")
+        if pmc and pmc.get("fabric_bytes_per_launch"):
+            roof["traffic"] = int(pmc["fabric_bytes_per_launch"])
+            roof["traffic_source"] = pmc.get("source")
+            per_launch = roof.get("samples_per_launch") or roof.get("samples_per_frame", 0)
+            roof["requested_bytes_per_launch"] = int(per_launch * roof.get("bytes_per_sample", GATHER_BYTES_PER_SAMPLE))
+        else:
+            roof["traffic_source"] = "no counter pass committed for this workload and precision (profiles/r0N_pmc_<variant>_<hw>_<precision>.json)"
+    def grid_stage(result):
+        """stand-alone hash-grid kernel: 2^22 uniform points and the marcher's real sample stream; measured stream-copy ceiling."""
+        from genefaceplusplus_amd.radnerfs.encoders import grid_encode_raw
+        from genefaceplusplus_amd.radnerfs import raymarching as rm
+        enc = model.position_embedder
+        emb = enc.embeddings.detach()
+
+        def grid_time(u, reps=10):
+            for _ in range(3):
+                grid_encode_raw(u, emb, enc.offsets, enc.per_level_scale, 16, enc.gridtype_id, False, 0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                grid_encode_raw(u, emb, enc.offsets, enc.per_level_scale, 16, enc.gridtype_id, False, 0)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        def grid_entry(u, label, cache_served=False):
+            t = grid_time(u)
+            gbps = u.shape[0] * GRID_BYTES_PER_POINT / t / 1e9
+            ent = {"kernel": "k_grid_encode<3,2,float>", "points": int(u.shape[0]), "achieved": round(gbps, 1), "unit": "GB/s", "ms": round(t * 1e3, 4),
+                   "input": label, "bytes_per_point": GRID_BYTES_PER_POINT}
+            if cache_served:
+                # a ray-ordered stream re-uses table rows from L1 / L2: its algorithmic rate is NOT evidence about HBM, no fraction is quoted
+                ent.update({"bound": "cache (L1/L2 re-use of table rows along rays)", "peak": None, "frac": None})
+            else:
+                ent.update({"bound": "hbm", "peak": PEAK_HBM_GBPS, "frac": round(gbps / PEAK_HBM_GBPS, 4)})
+            return ent
+
+        # measured streaming ceiling of this GPU (SURVEY 8d asks for it next to the nominal 8 TB/s): 1 GiB device-to-device copy, read + write
+        src_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_buf = torch.empty_like(src_buf)
+        for _ in range(2):
+            dst_buf.copy_(src_buf)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst_buf.copy_(src_buf)
+        c1.record()
+        torch.cuda.synchronize()
+        t_copy = c0.elapsed_time(c1) * 1e-3 / 5
+        result["hbm_stream_copy"] = {"achieved": round(2 * src_buf.numel() * 4 / t_copy / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBPS,
+                                     "what": "1 GiB device-to-device copy (read + write bytes / time): the measured streaming ceiling"}
+        del src_buf, dst_buf
+        result["grid_stage"] = grid_entry(torch.rand(1 << 22, 3, device=dev), "2^22 points uniform in [0,1]^3 (cache-hostile)")
+        # (ii) the marcher's real sample stream: every occupied sample of the first 8 steps of one frame
+        x = inputs[W]
+        ro, rd = x["rays_o"].view(-1, 3).contiguous(), x["rays_d"].view(-1, 3).contiguous()
+        nears, fars = rm.near_far_from_aabb(ro, rd, model.aabb_infer, model.min_near)
+        alive = torch.arange(N, dtype=torch.int32, device=dev)
+        xyzs, _, deltas = rm.march_rays(N, 8, alive, nears.clone(), ro, rd, model.bound, model.density_bitfield, model.cascade, model.grid_size,
+                                        nears, fars, -1, False, hp["dt_gamma"], hp["max_steps"])
+        real = ((xyzs[deltas[:, 0] > 0] + model.bound) / (2 * model.bound)).contiguous()
+        if real.shape[0] > 0:
+            result["grid_stage_ray_stream"] = grid_entry(real, "occupied samples of one frame in ray order (what the renderer feeds the grid)", cache_served=True)
+
+    return types.SimpleNamespace(timed_frames_check=timed_frames_check, head_roofline=head_roofline, load_pmc=load_pmc, other_modes=other_modes,
+                                 baseline_configs=baseline_configs, attach_traffic=attach_traffic, grid_stage=grid_stage)
