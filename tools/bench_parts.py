@@ -348,7 +348,9 @@ def build(ctx):
                 equal.append(bool(torch.equal(u8, timed)))
                 model.precision = "fp32"
                 ref32 = api_frame(x)
-                mse = float(((timed.float() / 255.0 - ref32) ** 2).mean().item())
+                # (the stored bytes are truncated like the reference's `(x * 255.).int()`: de-quantised at the middle of their step, so that the floor of this
+                # figure is the 58.9 dB of a uint8 step, not the 52.9 dB of the truncation's bias)
+                mse = float((((timed.float() + 0.5) / 255.0 - ref32) ** 2).mean().item())
                 psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
             model.precision = args.precision
             bar = 45.0 if args.precision != "fp32" else 55.0         # SURVEY 8c's 16-bit bar; fp32 frames differ from themselves by the uint8 step only (58.9 dB)
