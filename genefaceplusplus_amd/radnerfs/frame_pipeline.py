@@ -1001,6 +1001,8 @@ class FramePipeline:
             mask = torch.empty(N, dtype=torch.uint8, device=self.device)
             call("gfpp_torso_mask", ctypes.byref(self.torso), bg_coords.data_ptr(), N, mask.data_ptr(), torch.cuda.current_stream().cuda_stream)
             idx = torch.nonzero(mask, as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+            while len(self._torso_pixels) >= 4:                             # a caller that hands over a fresh coordinate tensor per call must not grow this for ever
+                self._torso_pixels.pop(next(iter(self._torso_pixels)))
             hit = self._torso_pixels[key] = (mask, idx, bg_coords)          # (keeps the keyed tensor's address alive)
         return hit[0], hit[1]
 
