@@ -116,6 +116,7 @@ class ClipRenderer:
         self._job_dev = torch.zeros(ctypes.sizeof(ClipJob), dtype=torch.uint8, device=dev)
         self._job_stage = [torch.zeros(ctypes.sizeof(ClipJob), dtype=torch.uint8).pin_memory() for _ in range(8)]
         self._job_stage_ev = [None] * 8
+        self._order_stage, self._order_stage_ev = [None] * 8, [None] * 8
         self._job_calls = 0
         self._job = None                          # host-side state of the running job
         self._host_bufs = None
@@ -219,6 +220,24 @@ class ClipRenderer:
         ev = self._job_stage_ev[slot] = torch.cuda.Event()
         ev.record()
 
+    def _upload_order(self, idx):
+        """The job's frame order as an int32 device tensor, through a small ring of REUSED pinned staging buffers (a fresh `pin_memory()` per job is a host
+        allocation of pinned memory -- the slowest single step of start() -- and a short job's start-up is a twentieth of the driver's 20-frame line)."""
+        n = len(idx)
+        slot = self._job_calls % len(self._job_stage)
+        st = self._order_stage[slot]
+        if st is None or st.numel() < n:
+            st = self._order_stage[slot] = torch.empty(max(256, 2 * n), dtype=torch.int32).pin_memory()
+        ev = self._order_stage_ev[slot]
+        if ev is not None:
+            ev.synchronize()                         # the asynchronous upload that last read this buffer has completed
+        st[:n] = torch.as_tensor(idx, dtype=torch.int32)
+        order = torch.empty(n, dtype=torch.int32, device=self.device)
+        order.copy_(st[:n], non_blocking=True)
+        ev = self._order_stage_ev[slot] = torch.cuda.Event()
+        ev.record()
+        return order
+
     def _ensure_graphs(self, clip):
         """Capture the lanes' frame graphs (first use, or another clip layout / precision).  The warm-up runs and the capture execute the frame with
         an EMPTY job (n = 0: fetch and store do nothing, the static input keeps a copy of the clip's first row), so they cannot disturb a job."""
@@ -280,7 +299,7 @@ class ClipRenderer:
             self._join(torch.cuda.current_stream())
         clip = self._with_cond_features(clip)
         self._ensure_graphs(clip)
-        order = torch.tensor(idx if idx else [0], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+        order = self._upload_order(idx if idx else [0])
         job = ClipJob()
         job.packed, job.order, job.out = clip["packed"].data_ptr(), order.data_ptr(), out.data_ptr()
         job.frame_bytes = self.out_hw[0] * self.out_hw[1] * 3
