@@ -1515,7 +1515,7 @@ static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model
     // tests/test_persist_budget_cpu.py -- not taken there)
     a.xcd_cols8 = 0u;
     {
-        static int mode = -1;
+        int mode = -1;          // (read at every issue: a captured graph keeps what it was captured with)
         // measured (round 5, 512^2 bf16, four frames per launch, same box): L2 hit rate 80.0 -> 84.4 %, fabric traffic 2.03 -> 1.61 GB per launch, the launch itself
         // +-0 (808 vs 810-821 us) and the clip loop 1 % slower (4 511-4 515 vs 4 554-4 557 frames/s: the comb's workgroup shares are a little less even) -- the kernel is
         // bound by issue and gather LATENCY, and the misses that remain are the ambient grid's, whose coordinates are an MLP output (no image locality to keep): off by

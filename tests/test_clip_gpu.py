@@ -315,3 +315,50 @@ def test_headline_shape_frame_groups_bytes_and_oracle(dev, oracle_mod, precision
     stats = {"psnr": 10.0 * np.log10(1.0 / mse), "max": float(err.max()), "frac_over": float((err > 2e-2 + 1.0 / 255.0).mean())}
     print("headline group frame vs oracle", precision, stats)
     assert stats["psnr"] >= 45.0 and stats["frac_over"] <= 5e-4, stats
+
+
+def test_group_torso_launch_with_an_empty_torso_mask(dev):
+    """No pixel of the frame lies in the torso's occupancy grid (an untrained / cleared torso grid): the MLP launch of gfpp_torso_group_lp has no pass to run -- it
+    still hands the frames' step budgets and the job position to the compose launch -- and the group renders the bytes of the per-frame launches."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    HW, K, F = 64, 4, 6
+    case = frame_case("may_torso", HW)
+    case["sd"] = dict(case["sd"], density_grid_torso=np.zeros_like(case["sd"]["density_grid_torso"]))
+    model = build_model(case, dev, "fused")
+    model.precision = "fp16"
+    kw = dict(case["hp"], use_head_for_torso=True)
+    mk = lambda **o: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, **o)
+    single = mk(group=1, lanes=2)
+    clip = single.prepare(_clip_batch(case["hp"], F), dev)
+    want = single.render_to_device(clip).cpu().numpy()
+    pipe = model.pipeline()
+    grouped = mk(group=K, lanes=2)
+    got = grouped.render_to_device(clip).cpu().numpy()
+    assert grouped.group == K and pipe.group_torso
+    mask, idx = pipe.torso_pixels(grouped.bg_coords)
+    assert idx.numel() == 0 and int(mask.sum()) == 0
+    np.testing.assert_array_equal(got, want)
+    assert want.std() > 5
+
+
+def test_xcd_local_tile_ownership_renders_the_same_bytes(dev, monkeypatch):
+    """GFPP_PERSIST_XCD=1 (tile column c of the image -> the workgroups of XCD c % 8; off by default: less fabric traffic, no time): which workgroup
+    renders a ray never changes its bits -- 512^2, four frames per launch, against the image-wide permutation."""
+    from genefaceplusplus_amd.clip import ClipRenderer
+    HW, F = 512, 8
+    case = frame_case("may_torso", HW)
+    model = build_model(case, dev, "fused")
+    model.precision = "bf16"
+    kw = dict(case["hp"], use_head_for_torso=True)
+    mk = lambda: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, group=4, lanes=2)
+    monkeypatch.delenv("GFPP_PERSIST_XCD", raising=False)
+    a = mk()
+    clip = a.prepare(_clip_batch(case["hp"], F), dev)
+    want = a.render_to_device(clip).cpu().numpy()
+    monkeypatch.setenv("GFPP_PERSIST_XCD", "1")
+    b = mk()                                              # (a new renderer: the lanes' graphs are captured with the switch on)
+    got = b.render_to_device(clip).cpu().numpy()
+    assert a.group == 4 and b.group == 4 and want.std() > 10
+    np.testing.assert_array_equal(got, want)
+    hist = model.pipeline().group_workspace(HW * HW, 4, int(case["hp"]["max_steps"]))[2]["counters"][:, 128:160].cpu().numpy()
+    assert (hist.sum(axis=1) == HW * HW).all()            # every ray of every frame was rendered exactly once
