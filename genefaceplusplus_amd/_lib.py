@@ -8,7 +8,23 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GFPP_LIB_PATH") or os.path.join(_HERE, "libgfpp_radnerf.so")   # (GFPP_LIB_PATH: experiment builds of tools/*, e.g. -DGFPP_SR_ABLATE)
+def _library_path():
+    """The shipped library -- or, for same-box A/B measurements, an experiment build of tools/build_variant.sh: GFPP_LIB_PATH is honoured ONLY for
+    build/variants/lib_<name>.so of this checkout (anything else raises: the package cannot be pointed at an arbitrary library)."""
+    shipped = os.path.join(_HERE, "libgfpp_radnerf.so")
+    override = os.environ.get("GFPP_LIB_PATH")
+    if not override:
+        return shipped
+    real, variants = os.path.realpath(override), os.path.realpath(os.path.join(_HERE, "..", "build", "variants"))
+    name = os.path.basename(real)
+    if real == os.path.realpath(shipped):
+        return shipped
+    if os.path.dirname(real) != variants or not (name.startswith("lib_") and name.endswith(".so")):
+        raise RuntimeError(f"GFPP_LIB_PATH={override}: only experiment builds of tools/build_variant.sh (build/variants/lib_<name>.so) may replace the shipped library")
+    return real
+
+
+LIB_PATH = _library_path()
 ABI_VERSION = 7          # include/gfpp_radnerf.h GFPP_ABI_VERSION (7: gfpp_torso_fold_batch / gfpp_torso_group_lp, f16 ambient_net steps inside the bf16 image; 6: corner-block grid copies, frame groups, sticky barrier word; 5: gfpp_head_model.occ_aabb; 4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
 _lib = None
 

@@ -19,10 +19,10 @@ def pytest_report_header(config):
 
 
 def pytest_sessionstart(session):
+    # (genefaceplusplus_amd/_lib.py itself refuses anything but build/variants/lib_<name>.so of this checkout)
     lib = os.environ.get("GFPP_LIB_PATH")
-    if lib and os.environ.get("GFPP_ALLOW_LIB_OVERRIDE") != "1" and not os.path.basename(lib).startswith("lib_"):
-        raise pytest.UsageError(f"GFPP_LIB_PATH={lib} is neither the shipped library nor a tools/build_variant.sh build (lib_<name>.so); "
-                                "set GFPP_ALLOW_LIB_OVERRIDE=1 to run the suite on it anyway")
+    if lib and not os.path.basename(lib).startswith("lib_"):
+        raise pytest.UsageError(f"GFPP_LIB_PATH={lib} is neither the shipped library nor a tools/build_variant.sh build (lib_<name>.so)")
 
 
 @pytest.fixture(scope="session")
