@@ -297,8 +297,15 @@ class ClipRenderer:
             # frames of the previous job may still be running on the lanes (a caller that never joined): the new job record, its rows and its
             # output ring must not reach the device before they are done.  A stream-level wait, no host synchronisation
             self._join(torch.cuda.current_stream())
-        clip = self._with_cond_features(clip)
-        self._ensure_graphs(clip)
+        target = getattr(self.model, "_orig_mod", self.model)
+        if hasattr(target, "modules"):
+            from .radnerfs.frame_pipeline import fingerprint_memo
+            with fingerprint_memo(target):
+                clip = self._with_cond_features(clip)
+                self._ensure_graphs(clip)
+        else:
+            clip = self._with_cond_features(clip)
+            self._ensure_graphs(clip)
         order = self._upload_order(idx if idx else [0])
         job = ClipJob()
         job.packed, job.order, job.out = clip["packed"].data_ptr(), order.data_ptr(), out.data_ptr()

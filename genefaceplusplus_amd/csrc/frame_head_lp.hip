@@ -143,7 +143,7 @@ struct LpTripArgs {
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
     uint32_t xcd_cols8;                 // != 0: XCD-local ownership (gfpp_frame_ws.row_rays): tile columns per image row / 8; tile_mult then permutes the n_tiles / 8 tiles of ONE XCD
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
-    uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 8 128 cycles late
+    uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 1 024 cycles late
     uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8] (k_head_trip_pool<PROF>): cycles summed over wavefronts by phase, see there
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         // walk the block's phases in step -- both gathering, then both on the matrix pipe; the second one starts a fraction of a block later so that
         // one's gathers run under the other's MFMA layers (it never has more blocks than the first, so the round does not get longer)
         if (wave >= 4)
-            for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+            for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(16);
         if constexpr (F32) {
             PoolViewF32 view{pool.px, pool.py, pool.pz, pool.px, pool.py, pool.pz, pool.cb, pool.order, total,
                              {&pool, a.rays_d}, {&pool, a.rays_d + 1}, {&pool, a.rays_d + 2}};
