@@ -11,6 +11,7 @@
 // staged row-major in LDS (coalesced 16-byte loads, one chunk ahead in registers) and the fragments are read from there transposed (eight 2- or 4-byte
 // LDS reads per fragment; wavefront w owns the output row tiles w and w + 4 and all column tiles, so a k-step is <= 7 fragments for <= 10 MFMAs).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "gfpp_common.h"
 #include "lp_mfma_device.h"
@@ -161,6 +162,138 @@ __global__ __launch_bounds__(kWgThreads) void k_linear_wgrad(WgArgs a) {
     }
 }
 
+// ---- zero-padded half matrices (widths multiples of 32: what the fused MLP launches write, train_mlp_fused.hip) -------------------------------------------------
+// The kernel above gathers a fragment -- one column at 8 consecutive rows -- with eight 2-byte LDS reads, (2 + TI) x 8 of them per 16-row step for <= 10 MFMAs, with
+// one wavefront per SIMD (194 VGPRs + 160 AGPRs): measured 143-146 us per 128 x 128 layer over 3 x 10^5 rows, ~1 TB/s, 22 % of a fused training step's kernel time.
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: the 16 lanes of a quarter wavefront read a 4-row x 16-column block, lane p the four halves at its own
+// address = row p / 4, columns 4 (p % 4) ..; lane l gets column l of the block, rows 0 .. 3) delivers the same fragment in TWO reads, if the rows start on 8-byte
+// boundaries -- true for these matrices.  Chunks of 64 rows are staged row-major with a row pitch = 64 or 192 (mod 256) bytes (the 8 rows x 64 bytes one read
+// instruction touches then fall into distinct banks), double-buffered (one barrier per chunk, the chunk after next in flight in registers), eight wavefronts
+// as 4 row-tile groups x 2 column-tile groups with <= 2 x 3 accumulator tiles each: two wavefronts per SIMD.
+constexpr int kWtThreads = 512, kWtRows = 64;
+__host__ __device__ constexpr int wt_pitch(int C) { return (C * 2) % 128 == 0 ? C * 2 + 64 : C * 2; }
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 wt_fp16x4;
+typedef _Float16 wt_f16x4 __attribute__((ext_vector_type(4)));
+
+// this lane's fragment of the 16-row step whose first row starts at `at` (LDS byte address incl. the lane's own offset): rows +0..3 and +4..7 of its half
+template <int P>
+__device__ __forceinline__ f16x8 wt_fragment(const unsigned char *at) {
+    typedef __attribute__((address_space(3))) wt_fp16x4 *lds_ptr;
+    const wt_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(at));
+    const wt_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(at + 4 * P));
+    return __builtin_shufflevector(__builtin_bit_cast(wt_f16x4, lo), __builtin_bit_cast(wt_f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int TO, int TI>
+__global__ __launch_bounds__(kWtThreads, kWtThreads / 256) void k_linear_wgrad_tr(WgArgs a) {
+    constexpr int CO = 32 * TO, CI = 32 * TI, PY = wt_pitch(CO), PX = wt_pitch(CI);
+    constexpr int RVY = CO / 8, RVX = CI / 8;                                    // 16-byte vectors per row
+    constexpr int NVY = (kWtRows * RVY + kWtThreads - 1) / kWtThreads, NVX = (kWtRows * RVX + kWtThreads - 1) / kWtThreads;
+    constexpr int NRT = (TO + 3) / 4, NCT = (TI + 1) / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char s_y[2][kWtRows * PY], s_x[2][kWtRows * PX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5, p = lane & 15, gi = (lane >> 4) & 1;
+    const int rg = wave & 3, cg = wave >> 2;
+    v16f acc[NRT][NCT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int k = 0; k < NCT; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][k][e] = 0.0f;
+    const uint4 *gy = static_cast<const uint4 *>(a.gy), *gx = static_cast<const uint4 *>(a.x);
+    const uint32_t c0 = blockIdx.x * a.chunks_per_wg, c1 = c0 + a.chunks_per_wg < a.n_chunks ? c0 + a.chunks_per_wg : a.n_chunks;
+    uint4 ry[NVY], rx[NVX];
+    auto load = [&](uint32_t c) {
+        const uint32_t m0 = c * (uint32_t)kWtRows;
+#pragma unroll
+        for (int q = 0; q < NVY; ++q) {
+            const int v = q * kWtThreads + tid;
+            const uint32_t m = m0 + (uint32_t)(v / RVY);
+            ry[q] = (v < kWtRows * RVY && m < a.M) ? gy[(size_t)m * RVY + (uint32_t)(v % RVY)] : uint4{0u, 0u, 0u, 0u};       // rows beyond the matrix: zeros
+        }
+#pragma unroll
+        for (int q = 0; q < NVX; ++q) {
+            const int v = q * kWtThreads + tid;
+            const uint32_t m = m0 + (uint32_t)(v / RVX);
+            rx[q] = (v < kWtRows * RVX && m < a.M) ? gx[(size_t)m * RVX + (uint32_t)(v % RVX)] : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < NVY; ++q) {
+            const int v = q * kWtThreads + tid;
+            if (v < kWtRows * RVY) *reinterpret_cast<uint4 *>(&s_y[b][(v / RVY) * PY + (v % RVY) * 16]) = ry[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NVX; ++q) {
+            const int v = q * kWtThreads + tid;
+            if (v < kWtRows * RVX) *reinterpret_cast<uint4 *>(&s_x[b][(v / RVX) * PX + (v % RVX) * 16]) = rx[q];
+        }
+    };
+    if (c0 < c1) {
+        load(c0);
+        store(0);
+        if (c0 + 1 < c1) load(c0 + 1);
+    }
+    __syncthreads();
+    // the lane's place in a step's block: row 8 h + p / 4, columns 16 gi + 4 (p % 4) .. of a 32-column tile
+    const int off_y = (8 * h + (p >> 2)) * PY + (16 * gi + 4 * (p & 3)) * 2, off_x = (8 * h + (p >> 2)) * PX + (16 * gi + 4 * (p & 3)) * 2;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const int b = (int)((c - c0) & 1u);
+        if (c + 1 < c1) {
+            store(b ^ 1);                                          // chunk c + 1 (requested one iteration ago); its buffer was last read before the previous barrier
+            if (c + 2 < c1) load(c + 2);
+        }
+#pragma unroll
+        for (int s = 0; s < kWtRows / 16; ++s) {
+            f16x8 A[NRT], B[NCT];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r)
+                if (rg + 4 * r < TO) A[r] = wt_fragment<PY>(&s_y[b][0] + off_y + s * 16 * PY + (rg + 4 * r) * 64);
+#pragma unroll
+            for (int k = 0; k < NCT; ++k)
+                if (cg + 2 * k < TI) B[k] = wt_fragment<PX>(&s_x[b][0] + off_x + s * 16 * PX + (cg + 2 * k) * 64);
+#pragma unroll
+            for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                for (int k = 0; k < NCT; ++k)
+                    if (rg + 4 * r < TO && cg + 2 * k < TI) acc[r][k] = LpTraits<_Float16>::mfma(A[r], B[k], acc[r][k]);
+        }
+        __syncthreads();
+    }
+    // lane (j = i, h) holds rows (r & 3) + 8 (r >> 2) + 4 h of column j of every tile
+    float *out = a.partial + (size_t)blockIdx.x * CO * CI;
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) {
+        const int rt = rg + 4 * r;
+        if (rt >= TO) continue;
+#pragma unroll
+        for (int k = 0; k < NCT; ++k) {
+            const int ct = cg + 2 * k;
+            if (ct >= TI) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[(size_t)(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * CI + 32 * ct + i] = acc[r][k][e];
+        }
+    }
+}
+
+template <int TO>
+static bool wt_pick_in(uint32_t ti, const WgArgs &a, uint32_t slices, hipStream_t st) {
+    switch (ti) {
+    case 2: hipLaunchKernelGGL((k_linear_wgrad_tr<TO, 2>), dim3(slices), dim3(kWtThreads), 0, st, a); return true;
+    case 3: hipLaunchKernelGGL((k_linear_wgrad_tr<TO, 3>), dim3(slices), dim3(kWtThreads), 0, st, a); return true;
+    case 4: hipLaunchKernelGGL((k_linear_wgrad_tr<TO, 4>), dim3(slices), dim3(kWtThreads), 0, st, a); return true;
+    case 5: hipLaunchKernelGGL((k_linear_wgrad_tr<TO, 5>), dim3(slices), dim3(kWtThreads), 0, st, a); return true;
+    }
+    return false;
+}
+static bool wt_pick(uint32_t to, uint32_t ti, const WgArgs &a, uint32_t slices, hipStream_t st) {
+    if (to == 1) return wt_pick_in<1>(ti, a, slices, st);
+    if (to == 4) return wt_pick_in<4>(ti, a, slices, st);
+    if (to == 5) return wt_pick_in<5>(ti, a, slices, st);
+    return false;
+}
+
 // grad_weight (zeroed) += the slices, 32 per workgroup row
 constexpr uint32_t kWgReduceGroup = 32;
 __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float *__restrict__ partial, uint32_t slices, uint32_t n, float *__restrict__ gw) {
@@ -185,14 +318,19 @@ GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, ui
     a.gy = grad_out; a.x = input; a.partial = partial; a.M = M; a.O = O; a.I = I;
     a.TO = div_up(O, 32); a.TI = div_up(I, 32);
     if (a.TO > (uint32_t)kWgMaxTO || a.TI > (uint32_t)kWgMaxTI) { set_error("%s: built for out_features <= 256 and in_features <= 160 (got %u, %u)", who, O, I); return GFPP_EUNSUPPORTED; }
-    const uint32_t R = dtype == GFPP_F16 ? (uint32_t)WgCfg<_Float16>::rows : (uint32_t)WgCfg<float>::rows;
-    a.n_chunks = div_up(M, R);
-    a.chunks_per_wg = div_up(a.n_chunks, kWgMaxSlices);
-    const uint32_t slices = div_up(a.n_chunks, a.chunks_per_wg);
     const hipStream_t st = (hipStream_t)stream;
     if (((uintptr_t)grad_out | (uintptr_t)input) & 15u) { set_error("%s: grad_out and input must be 16-byte aligned", who); return GFPP_EINVAL; }
     if (hipMemsetAsync(grad_weight, 0, (size_t)O * I * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear grad_weight", who); return GFPP_EINVAL; }
-    if (dtype == GFPP_F16) hipLaunchKernelGGL(k_linear_wgrad<_Float16>, dim3(slices), dim3(kWgThreads), 0, st, a);
+    // zero-padded half matrices (both widths multiples of 32, the fused MLP's): fragments by transposing LDS reads, one workgroup per CU (GFPP_WGRAD_TR=0: the
+    // generic kernel, its A/B partner)
+    static const bool tr_off = [] { const char *e = getenv("GFPP_WGRAD_TR"); return e && e[0] == '0'; }();
+    const bool tr = dtype == GFPP_F16 && !tr_off && O % 32 == 0 && I % 32 == 0 && (a.TO == 1 || a.TO == 4 || a.TO == 5) && a.TI >= 2;
+    const uint32_t R = tr ? (uint32_t)kWtRows : dtype == GFPP_F16 ? (uint32_t)WgCfg<_Float16>::rows : (uint32_t)WgCfg<float>::rows;
+    a.n_chunks = div_up(M, R);
+    a.chunks_per_wg = div_up(a.n_chunks, kWgMaxSlices);          // (the transposing kernel: 80 KB of LDS and 82 VGPRs, two workgroups per CU)
+    const uint32_t slices = div_up(a.n_chunks, a.chunks_per_wg);
+    if (tr) wt_pick(a.TO, a.TI, a, slices, st);
+    else if (dtype == GFPP_F16) hipLaunchKernelGGL(k_linear_wgrad<_Float16>, dim3(slices), dim3(kWgThreads), 0, st, a);
     else hipLaunchKernelGGL(k_linear_wgrad<float>, dim3(slices), dim3(kWgThreads), 0, st, a);
     int rc = check_launch(who);
     if (rc) return rc;

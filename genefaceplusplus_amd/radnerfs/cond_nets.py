@@ -9,6 +9,7 @@ per-sample MLPs (ambient / sigma / colour / torso) are evaluated by the fused HI
 the MLP containers below; ``MLP.forward`` (plain torch GEMMs) is kept for the stand-alone ``forward()/density()`` API.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -66,6 +67,14 @@ _lib.register("gfpp_linear_weight_grad", [ctypes.c_void_p, ctypes.c_void_p, ctyp
                                           ctypes.c_void_p, ctypes.c_void_p])
 #: rows from which a training-mode Linear layer takes the split-M weight-gradient kernel (below, the BLAS call is fine)
 WGRAD_MIN_ROWS = 8192
+_u32 = ctypes.c_uint32
+_lib.register("gfpp_mlp_train_pack", [ctypes.POINTER(ctypes.c_void_p), _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+_lib.register("gfpp_mlp_train_image_bytes", [_u32, _u32, _u32, ctypes.c_int], restype=ctypes.c_uint32)
+_lib.register("gfpp_mlp_train_forward", [ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+_lib.register("gfpp_mlp_train_backward", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+#: whole-MLP training launches under fp16 autocast (csrc/train_mlp_fused.hip); GFPP_TRAIN_FUSED_MLP=0: layer by layer (the A/B partner, and what other shapes use)
+FUSED_MLP = os.environ.get("GFPP_TRAIN_FUSED_MLP", "1") != "0"
+_FUSED_IN, _FUSED_OUT, _FUSED_HIDDEN = (64, 96, 160), (32, 160), 128
 
 
 class _LinearNoBias(torch.autograd.Function):
@@ -104,6 +113,69 @@ class _LinearNoBias(torch.autograd.Function):
         return gx, gw
 
 
+class _FusedMLP(torch.autograd.Function):
+    """The whole MLP over a training batch under fp16 autocast: one forward launch (hidden activations kept), one backward launch for the input-gradient
+    chain (gfpp_mlp_train_forward / _backward), the layers' weight gradients through the split-M kernel on the matrices those two wrote.  Same arithmetic as
+    autocast's layer-by-layer graph: half operands, fp32 accumulation, every layer output rounded to half, relu's backward on the rounded activation."""
+
+    @staticmethod
+    def forward(ctx, x, in_pad, out_pad, *weights):
+        M, I = x.shape
+        NL, O = len(weights), weights[-1].shape[0]
+        dev, st = x.device, torch.cuda.current_stream().cuda_stream
+        xh = x.to(torch.float16)
+        if I != in_pad:
+            xh = F.pad(xh, (0, in_pad - I))
+        xh = xh.contiguous()
+        if xh.data_ptr() % 16:
+            xh = xh.clone()
+        ws = [w.detach().float().contiguous() for w in weights]
+        ptrs = (ctypes.c_void_p * NL)(*[w.data_ptr() for w in ws])
+        size = [int(_lib.lib().gfpp_mlp_train_image_bytes(NL, in_pad, out_pad, b)) for b in (0, 1)]
+        fwd = torch.empty(size[0] // 2, dtype=torch.float16, device=dev)
+        bwd = torch.empty(size[1] // 2, dtype=torch.float16, device=dev)
+        _lib.call("gfpp_mlp_train_pack", ptrs, NL, I, _FUSED_HIDDEN, O, in_pad, out_pad, fwd.data_ptr(), bwd.data_ptr(), st)
+        acts = torch.empty(NL - 1, M, _FUSED_HIDDEN, dtype=torch.float16, device=dev)
+        out = torch.empty(M, out_pad, dtype=torch.float16, device=dev)
+        _lib.call("gfpp_mlp_train_forward", xh.data_ptr(), fwd.data_ptr(), M, in_pad, _FUSED_HIDDEN, NL, out_pad, acts.data_ptr(), out.data_ptr(), st)
+        ctx.save_for_backward(xh, acts, bwd)
+        ctx.shape = (I, O, in_pad, out_pad, [tuple(w.shape) for w in weights], x.dtype)
+        return out[:, :O]
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, acts, bwd = ctx.saved_tensors
+        I, O, in_pad, out_pad, shapes, x_dtype = ctx.shape
+        NL, M = len(shapes), xh.shape[0]
+        dev, st = xh.device, torch.cuda.current_stream().cuda_stream
+        gyp = gy.to(torch.float16)
+        if O != out_pad:
+            gyp = F.pad(gyp, (0, out_pad - O))
+        gyp = gyp.contiguous()
+        if gyp.data_ptr() % 16:
+            gyp = gyp.clone()
+        G = torch.empty(NL - 1, M, _FUSED_HIDDEN, dtype=torch.float16, device=dev)
+        gx = torch.empty(M, in_pad, dtype=torch.float16, device=dev) if ctx.needs_input_grad[0] else None
+        _lib.call("gfpp_mlp_train_backward", gyp.data_ptr(), acts.data_ptr(), bwd.data_ptr(), M, in_pad, _FUSED_HIDDEN, NL, out_pad, G.data_ptr(),
+                  gx.data_ptr() if gx is not None else None, st)
+        partial = torch.empty(512 * 160 * 160, dtype=torch.float32, device=dev)      # the split-M kernel's slices: one scratch, the launches are stream-ordered
+        gws = []
+        for l in range(NL):
+            if not ctx.needs_input_grad[3 + l]:
+                gws.append(None)
+                continue
+            dy = gyp if l == NL - 1 else G[l]
+            xin = xh if l == 0 else acts[l - 1]
+            gw = torch.empty(dy.shape[1], xin.shape[1], dtype=torch.float32, device=dev)
+            _lib.call("gfpp_linear_weight_grad", dy.data_ptr(), xin.data_ptr(), M, dy.shape[1], xin.shape[1], 1, partial.data_ptr(), gw.data_ptr(), st)
+            o, i = shapes[l]
+            gws.append(gw[:o, :i].contiguous() if (o, i) != tuple(gw.shape) else gw)
+        gxo = None
+        if gx is not None:
+            gxo = (gx[:, :I] if I != in_pad else gx).to(x_dtype)
+        return (gxo, None, None, *gws)
+
+
 class MLP(nn.Module):
     """num_layers bias-free Linear layers, ReLU between them."""
 
@@ -122,6 +194,11 @@ class MLP(nn.Module):
             # the split-M kernel has f16 and f32 operand forms: under bf16 autocast the layers run as nn.Linear does (F.linear casts to the autocast dtype)
             dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
             own = dt == torch.float16
+            if own and FUSED_MLP and self.dim_hidden == _FUSED_HIDDEN and self.num_layers in (2, 3) and self.dim_in <= _FUSED_IN[-1] and self.dim_out <= _FUSED_OUT[-1] \
+                    and all(l.weight.requires_grad for l in self.net):
+                in_pad = next(p for p in _FUSED_IN if self.dim_in <= p)
+                out_pad = next(p for p in _FUSED_OUT if self.dim_out <= p)
+                return _FusedMLP.apply(x, in_pad, out_pad, *[l.weight for l in self.net])
         for i, layer in enumerate(self.net):
             x = _LinearNoBias.apply(x, layer.weight) if own and layer.weight.requires_grad else layer(x)
             if i != last:

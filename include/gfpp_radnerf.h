@@ -677,6 +677,27 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
 int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
                             gfpp_stream_t stream);
 
+/* A whole `MLP` (cond_encoder.py:183-202: bias-free Linear layers, ReLU between them; ambient_net / sigma_net / color_net, radnerf.py:60-100) over a
+ * training batch under `amp: true` as ONE forward and ONE backward launch -- what autograd runs as a BLAS GEMM + relu + cast kernels per layer and
+ * direction (radnerf.py:108-141 under torch.autocast, tasks/radnerfs/radnerf.py:101-176).  Half operands, fp32 accumulation, every layer output rounded
+ * to half (autocast's F.linear), relu's backward on the saved rounded activation.  All matrices are plain row-major half, 16-byte aligned, with the
+ * feature axes zero-padded: input [M, in_pad], hidden [n_layers - 1][M, 128], output [M, out_pad].
+ *   hidden 128; n_layers 2 or 3; in_pad 64 / 96 / 160; out_pad 32 / 160 (GFPP_EUNSUPPORTED otherwise: the caller keeps the per-layer path).
+ *   gfpp_mlp_train_pack      the forward and the transposed (backward) weight images from the fp32 parameters (weights[l]: device pointer to
+ *                            nn.Linear.weight [out_l, in_l]; `weights` itself is a HOST array of n_layers pointers), one launch;
+ *                            gfpp_mlp_train_image_bytes: the size of either image.
+ *   gfpp_mlp_train_forward   x -> hidden_acts (relu(hidden), kept for the backward pass) and out.
+ *   gfpp_mlp_train_backward  grad_out (+ hidden_acts) -> grad_hidden [n_layers - 1][M, 128] (G_l = (W_{l+1}^T G_{l+1}) where the activation passed: the
+ *                            `grad_out` operand of gfpp_linear_weight_grad for layer l) and grad_x [M, in_pad] (may be null).
+ * The weight gradients are gfpp_linear_weight_grad(G_l or grad_out, act_{l-1} or x). */
+int gfpp_mlp_train_pack(const float *const *weights, uint32_t n_layers, uint32_t in_features, uint32_t hidden, uint32_t out_features, uint32_t in_pad,
+                        uint32_t out_pad, void *fwd_image, void *bwd_image, gfpp_stream_t stream);
+uint32_t gfpp_mlp_train_image_bytes(uint32_t n_layers, uint32_t in_pad, uint32_t out_pad, int backward);
+int gfpp_mlp_train_forward(const void *x, const void *fwd_image, uint32_t M, uint32_t in_pad, uint32_t hidden, uint32_t n_layers, uint32_t out_pad,
+                           void *hidden_acts, void *out, gfpp_stream_t stream);
+int gfpp_mlp_train_backward(const void *grad_out, const void *hidden_acts, const void *bwd_image, uint32_t M, uint32_t in_pad, uint32_t hidden,
+                            uint32_t n_layers, uint32_t out_pad, void *grad_hidden, void *grad_x, gfpp_stream_t stream);
+
 /* The input gradient of the lookup without a materialised dy_dx (gridencoder.cu:198-243 kernel_grid's dy_dx branch + gridencoder.cu:342-368
  * kernel_input_backward in one pass): grad [L,B,2] (fp32 or half, grad_dtype) -> grad_inputs [B,D] fp32, the derivative recomputed from the fp32 table.
  * The reference keeps dy_dx [B, L*D*C] from the forward pass (116 MB per May step for the ambient grid); callers that hold one can still pass it to

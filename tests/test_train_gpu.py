@@ -173,13 +173,20 @@ def test_grid_encoder_gradients_under_autocast_use_the_half_kernels(dev, oracle_
     np.testing.assert_array_equal(y32.detach().cpu().numpy(), ref_y)
 
 
-@pytest.mark.parametrize("dims,M", [((96, 3, 128, 3), 10007), ((64, 129, 128, 3), 8192), ((148, 3, 128, 2), 33000)])
-@pytest.mark.parametrize("amp", [False, True])
-def test_mlp_weight_gradients_through_the_split_m_kernel(dev, dims, M, amp):
+@pytest.mark.parametrize("dims,M", [((96, 3, 128, 3), 10007), ((64, 129, 128, 3), 8192), ((148, 3, 128, 2), 33000), ((64, 129, 128, 3), 1029), ((40, 20, 128, 2), 70001)])
+@pytest.mark.parametrize("mode", ["fp32", "amp", "amp_fused"])
+def test_mlp_weight_gradients_through_the_split_m_kernel(dev, dims, M, mode):
     """gfpp_linear_weight_grad (dW = dY^T X with the step's samples as the reduction, split over workgroups, MFMA accumulators) inside the training-mode
     MLP against the same MLP through torch's own Linear backward: the May layer shapes incl. the ragged ones (3, 129 outputs; 96, 148 inputs) and a row
-    count that is no multiple of the chunk.  fp32: exact-fp32 MFMA, another summation order; autocast: half operands, fp32 accumulation."""
+    count that is no multiple of the chunk.  fp32: exact-fp32 MFMA, another summation order; autocast: half operands, fp32 accumulation.
+    amp_fused: the whole MLP as one forward and one backward launch (gfpp_mlp_train_forward / _backward, csrc/train_mlp_fused.hip) -- what a May training
+    step under `amp: true` runs; `amp`: the layer-by-layer partner (GFPP_TRAIN_FUSED_MLP=0)."""
     from genefaceplusplus_amd.radnerfs import cond_nets
+    amp = mode != "fp32"
+    was_fused = cond_nets.FUSED_MLP
+    cond_nets.FUSED_MLP = mode == "amp_fused"
+    launched = []
+    real_call = cond_nets._lib.call
     torch.manual_seed(3)
     ref = cond_nets.MLP(*dims).to(dev)
     own = cond_nets.MLP(*dims).to(dev)
@@ -187,16 +194,28 @@ def test_mlp_weight_gradients_through_the_split_m_kernel(dev, dims, M, amp):
     x = torch.randn(M, dims[0], device=dev)
     gy = torch.randn(M, dims[1], device=dev) * 1e-2
     outs = {}
+    def spy(name, *args):
+        launched.append(name)
+        return real_call(name, *args)
     for name, net, rows in (("ref", ref, 1 << 30), ("own", own, 1024)):
         cond_nets.WGRAD_MIN_ROWS = rows
+        cond_nets._lib.call = spy
         try:
             xin = x.clone().requires_grad_(True)
             with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
                 y = net(xin)
+            assert tuple(y.shape) == (M, dims[1]) and y.dtype == (torch.float16 if amp else torch.float32)
             y.backward(gy.to(y.dtype))
         finally:
             cond_nets.WGRAD_MIN_ROWS = 8192
+            cond_nets._lib.call = real_call
+            if name == "own":
+                cond_nets.FUSED_MLP = was_fused
         outs[name] = (y.detach().float(), xin.grad.float(), [l.weight.grad.float() for l in net.net])
+    # the path under test is the one that ran: one forward + one backward launch for the whole MLP, or none of them
+    want = 1 if mode == "amp_fused" else 0
+    assert launched.count("gfpp_mlp_train_forward") == want and launched.count("gfpp_mlp_train_backward") == want
+    assert launched.count("gfpp_linear_weight_grad") == dims[3]
     tol = 2e-2 if amp else 2e-5
     for a, b in zip(outs["ref"][2], outs["own"][2]):
         assert b.dtype == torch.float32 and torch.isfinite(b).all()

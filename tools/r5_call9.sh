@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 5, GPU call 9: the fused training MLP (csrc/train_mlp_fused.hip): tests, step time A/B against the layer-by-layer path, kernel trace of the fused step
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+L=gpurun_out/r5c9.log
+: > $L
+timeout 600 python -m pytest tests/test_train_gpu.py -q -x -m gpu -k "mlp_weight_gradients" 2>&1 | tail -15 >> $L
+timeout 900 python -m pytest tests/test_train_gpu.py -q -m gpu 2>&1 | tail -15 >> $L
+for rep in 1 2; do
+  ( GFPP_TRAIN_FUSED_MLP=0 timeout 300 python tools/profile_train.py 65536 6 amp 2>&1 | tail -1 | sed 's/^/per-layer: /' ) >> $L
+  ( timeout 300 python tools/profile_train.py 65536 6 amp 2>&1 | tail -1 | sed 's/^/fused:     /' ) >> $L
+done
+for tag in r05_train_amp r05_train_amp_layers; do
+  rm -rf gpurun_out/${tag}_stats
+  if [ $tag = r05_train_amp ]; then export GFPP_TRAIN_FUSED_MLP=1; else export GFPP_TRAIN_FUSED_MLP=0; fi
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o t -- python tools/profile_train.py 65536 6 amp > gpurun_out/${tag}.log 2>&1
+  tail -1 gpurun_out/${tag}.log >> $L
+  python - >> $L <<PY
+import csv
+rows=list(csv.DictReader(open("gpurun_out/${tag}_stats/t_kernel_stats.csv")))
+tot=sum(int(r["TotalDurationNs"]) for r in rows)
+print("${tag}: total kernel ms", tot/1e6, "launches", sum(int(r["Calls"]) for r in rows), "(8 steps)")
+for r in rows[:40]:
+    print(f'{int(r["TotalDurationNs"])/1e6:8.2f} ms {float(r["Percentage"]):5.1f}% {r["Calls"]:>5} calls {float(r["AverageNs"])/1e3:9.1f} us  {r["Name"][:120]}')
+PY
+  rm -f gpurun_out/${tag}_stats/*kernel_trace.csv gpurun_out/${tag}_stats/*/*kernel_trace.csv
+done
+echo done >> $L
