@@ -119,8 +119,8 @@ class _FusedMLP(torch.autograd.Function):
     autocast's layer-by-layer graph: half operands, fp32 accumulation, every layer output rounded to half, relu's backward on the rounded activation."""
 
     @staticmethod
-    def forward(ctx, x, in_pad, out_pad, *weights):
-        M, I = x.shape
+    def forward(ctx, x, in_pad, out_pad, padded_out, *weights):
+        M, I = x.shape                         # I == in_pad: the caller built x with its zero columns already (their gradient comes back as zeros)
         NL, O = len(weights), weights[-1].shape[0]
         dev, st = x.device, torch.cuda.current_stream().cuda_stream
         xh = x.to(torch.float16)
@@ -134,13 +134,13 @@ class _FusedMLP(torch.autograd.Function):
         size = [int(_lib.lib().gfpp_mlp_train_image_bytes(NL, in_pad, out_pad, b)) for b in (0, 1)]
         fwd = torch.empty(size[0] // 2, dtype=torch.float16, device=dev)
         bwd = torch.empty(size[1] // 2, dtype=torch.float16, device=dev)
-        _lib.call("gfpp_mlp_train_pack", ptrs, NL, I, _FUSED_HIDDEN, O, in_pad, out_pad, fwd.data_ptr(), bwd.data_ptr(), st)
+        _lib.call("gfpp_mlp_train_pack", ptrs, NL, int(weights[0].shape[1]), _FUSED_HIDDEN, O, in_pad, out_pad, fwd.data_ptr(), bwd.data_ptr(), st)
         acts = torch.empty(NL - 1, M, _FUSED_HIDDEN, dtype=torch.float16, device=dev)
         out = torch.empty(M, out_pad, dtype=torch.float16, device=dev)
         _lib.call("gfpp_mlp_train_forward", xh.data_ptr(), fwd.data_ptr(), M, in_pad, _FUSED_HIDDEN, NL, out_pad, acts.data_ptr(), out.data_ptr(), st)
         ctx.save_for_backward(xh, acts, bwd)
-        ctx.shape = (I, O, in_pad, out_pad, [tuple(w.shape) for w in weights], x.dtype)
-        return out[:, :O]
+        ctx.shape = (I, O if not padded_out else out_pad, in_pad, out_pad, [tuple(w.shape) for w in weights], x.dtype)
+        return out if padded_out else out[:, :O]
 
     @staticmethod
     def backward(ctx, gy):
@@ -161,7 +161,7 @@ class _FusedMLP(torch.autograd.Function):
         partial = torch.empty(512 * 160 * 160, dtype=torch.float32, device=dev)      # the split-M kernel's slices: one scratch, the launches are stream-ordered
         gws = []
         for l in range(NL):
-            if not ctx.needs_input_grad[3 + l]:
+            if not ctx.needs_input_grad[4 + l]:
                 gws.append(None)
                 continue
             dy = gyp if l == NL - 1 else G[l]
@@ -173,7 +173,29 @@ class _FusedMLP(torch.autograd.Function):
         gxo = None
         if gx is not None:
             gxo = (gx[:, :I] if I != in_pad else gx).to(x_dtype)
-        return (gxo, None, None, *gws)
+        return (gxo, None, None, None, *gws)
+
+
+class SplitFirstColumn(torch.autograd.Function):
+    """(h[:, 0], h[:, 1:1 + n]) of a zero-padded row-major [M, 1 + n + pad] matrix (sigma_net's output: density logit + geo_feat) whose backward assembles the
+    padded gradient in ONE concatenation -- autograd's two slice backwards are two zero fills, two copies and an add over [M, 129], and the fused MLP's backward
+    then pads the sum again."""
+
+    @staticmethod
+    def forward(ctx, h, n):
+        ctx.n, ctx.width, ctx.dtype = n, h.shape[1], h.dtype
+        return h[:, 0], h[:, 1:1 + n]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        M = (g0 if g0 is not None else g1).shape[0]
+        dev = (g0 if g0 is not None else g1).device
+        g0 = torch.zeros(M, 1, dtype=ctx.dtype, device=dev) if g0 is None else g0.to(ctx.dtype).unsqueeze(1)
+        g1 = torch.zeros(M, ctx.n, dtype=ctx.dtype, device=dev) if g1 is None else g1.to(ctx.dtype)
+        parts = [g0, g1]
+        if ctx.width > 1 + ctx.n:
+            parts.append(torch.zeros(M, ctx.width - 1 - ctx.n, dtype=ctx.dtype, device=dev))
+        return torch.cat(parts, dim=1), None
 
 
 class MLP(nn.Module):
@@ -185,6 +207,27 @@ class MLP(nn.Module):
         dims = [dim_in] + [dim_hidden] * (num_layers - 1) + [dim_out]
         self.net = nn.ModuleList(nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:]))
 
+    def fused_widths(self, x, cols=None):
+        """(in_pad, out_pad) if this call runs as the whole-MLP training launches (csrc/train_mlp_fused.hip): gradients on, a CUDA [M, features] batch of at least
+        WGRAD_MIN_ROWS rows under fp16 autocast, hidden 128, 2 or 3 trainable layers; else None.  x may already carry the zero columns up to in_pad.
+        cols: ask for an input that is still to be assembled (x then only lends its rows, device and dtype)."""
+        if not (FUSED_MLP and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_autocast_enabled()
+                and x.dtype in (torch.float32, torch.float16)):
+            return None
+        dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+        if dt != torch.float16 or self.dim_hidden != _FUSED_HIDDEN or self.num_layers not in (2, 3) or self.dim_in > _FUSED_IN[-1] or self.dim_out > _FUSED_OUT[-1] \
+                or not all(l.weight.requires_grad for l in self.net):
+            return None
+        in_pad = next(p for p in _FUSED_IN if self.dim_in <= p)
+        out_pad = next(p for p in _FUSED_OUT if self.dim_out <= p)
+        return (in_pad, out_pad) if (x.shape[1] if cols is None else cols) in (self.dim_in, in_pad) else None
+
+    def forward_padded(self, x):
+        """The fused training launches with the output left zero-padded ([M, out_pad], columns >= dim_out are zeros): the caller slices it (SplitFirstColumn) and
+        the gradient arrives padded too -- no pad / slice copies of [M, 129] matrices.  None when fused_widths() says the call takes the layer-by-layer path."""
+        w = self.fused_widths(x)
+        return None if w is None else _FusedMLP.apply(x, w[0], w[1], True, *[l.weight for l in self.net])
+
     def forward(self, x):
         last = self.num_layers - 1
         # training batches (a step's samples x features): the layers' weight gradients through the split-M kernel
@@ -194,11 +237,9 @@ class MLP(nn.Module):
             # the split-M kernel has f16 and f32 operand forms: under bf16 autocast the layers run as nn.Linear does (F.linear casts to the autocast dtype)
             dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
             own = dt == torch.float16
-            if own and FUSED_MLP and self.dim_hidden == _FUSED_HIDDEN and self.num_layers in (2, 3) and self.dim_in <= _FUSED_IN[-1] and self.dim_out <= _FUSED_OUT[-1] \
-                    and all(l.weight.requires_grad for l in self.net):
-                in_pad = next(p for p in _FUSED_IN if self.dim_in <= p)
-                out_pad = next(p for p in _FUSED_OUT if self.dim_out <= p)
-                return _FusedMLP.apply(x, in_pad, out_pad, *[l.weight for l in self.net])
+            w = self.fused_widths(x) if own else None
+            if w is not None:
+                return _FusedMLP.apply(x, w[0], w[1], False, *[l.weight for l in self.net])
         for i, layer in enumerate(self.net):
             x = _LinearNoBias.apply(x, layer.weight) if own and layer.weight.requires_grad else layer(x)
             if i != last:

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import raymarching
 from .._lib import GfppError
-from .cond_nets import AudioNet, AudioAttNet, MLP
+from .cond_nets import AudioNet, AudioAttNet, MLP, SplitFirstColumn
 from .encoders import get_encoder
 from .camera import trunc_exp, get_audio_features
 
@@ -404,7 +404,12 @@ class RADNeRF(NeRFRenderer):
         ambient_in = torch.cat([pos_feat, cond_feat.reshape(1, -1).expand(n, -1).to(pos_feat.dtype)], dim=1)
         ambient_pos = torch.tanh(self.ambient_net(ambient_in).float())
         ambient_feat = self.ambient_embedder(ambient_pos, bound=1)
-        h = self.sigma_net(torch.cat([pos_feat, ambient_feat], dim=-1))
+        sigma_in = torch.cat([pos_feat, ambient_feat], dim=-1)
+        hp = self.sigma_net.forward_padded(sigma_in)
+        if hp is not None:          # training under amp: the whole MLP as one launch per direction, its output / gradient left zero-padded (no [M, 129] pad and slice copies)
+            logit, geo_feat = SplitFirstColumn.apply(hp, self.geo_feat_dim)
+            return trunc_exp(logit), geo_feat, ambient_pos
+        h = self.sigma_net(sigma_in)
         return trunc_exp(h[..., 0]), h[..., 1:], ambient_pos
 
     def _fused_eval_ok(self, position, cond_mask):
@@ -422,6 +427,11 @@ class RADNeRF(NeRFRenderer):
         parts = [self.direction_embedder(direction).to(geo_feat.dtype), geo_feat]
         if individual_code is not None:
             parts.append(individual_code.reshape(1, -1).expand(position.shape[0], -1).to(geo_feat.dtype))
+        width = sum(int(t.shape[-1]) for t in parts)
+        fused = self.color_net.fused_widths(geo_feat, cols=width) if geo_feat.dim() == 2 else None
+        if fused is not None and fused[0] > width:
+            # the zero columns up to the fused launch's input width join the concatenation that is made anyway (instead of a second pass that pads it)
+            parts.append(torch.zeros(1, 1, dtype=geo_feat.dtype, device=geo_feat.device).expand(position.shape[0], fused[0] - width))
         color = torch.sigmoid(self.color_net(torch.cat(parts, dim=-1)))
         return sigma, color, ambient_pos
 

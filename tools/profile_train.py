@@ -39,9 +39,11 @@ samples = []
 times = []
 scaler = torch.amp.GradScaler("cuda", enabled=amp)
 torch.manual_seed(0)
-for it in range(steps + 2):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+loss = None
+
+
+def one_step():
+    global loss
     rays = camera.get_rays(pose, case["intr"], 512, 512, N=n_rays)
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
         res = model.render(rays["rays_o"], rays["rays_d"], cond, bg_coords, camera.convert_poses(pose), index=0, dt_gamma=hp["dt_gamma"],
@@ -52,10 +54,24 @@ for it in range(steps + 2):
     scaler.scale(loss).backward()
     scaler.step(opt)
     scaler.update()
+
+
+for it in range(steps + 2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    one_step()
     torch.cuda.synchronize()
     if it >= 2:
         times.append(time.perf_counter() - t0)
         samples.append(int(model.step_counter[(model.local_step - 1) % 16, 0]))
 t = float(np.mean(times))
-print(f"profile_train{' [amp]' if amp else ''}: {n_rays} rays/step, {np.mean(samples):.0f} samples/step, {t * 1e3:.2f} ms/step -> {n_rays / t / 1e6:.2f} Mrays/s, {np.mean(samples) / t / 1e6:.2f} Msamples/s "
-      f"(loss {float(loss):.5f})")
+line = (f"profile_train{' [amp]' if amp else ''}: {n_rays} rays/step, {np.mean(samples):.0f} samples/step, {t * 1e3:.2f} ms/step -> {n_rays / t / 1e6:.2f} Mrays/s, {np.mean(samples) / t / 1e6:.2f} Msamples/s "
+        f"(loss {float(loss):.5f})")
+# the same steps as a trainer issues them: back to back, the host running ahead of the GPU (one synchronisation around the lot, none per step)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for it in range(steps):
+    one_step()
+torch.cuda.synchronize()
+tp = (time.perf_counter() - t0) / steps
+print(line + f"; back to back (no synchronisation per step): {tp * 1e3:.2f} ms/step")

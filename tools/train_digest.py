@@ -22,10 +22,11 @@ def name(n):
     return n if len(n) < 100 else n[:97] + "..."
 
 
-out = [f"# rocprofv3 --kernel-trace --stats -- python tools/profile_train.py 65536 6 {'amp' if 'amp' in tag else ''}   ({tag}, MI355X; 8 training steps incl. 2 warm-up)", "",
+out = [f"# rocprofv3 --kernel-trace --stats -- python tools/profile_train.py 65536 6 {'amp' if 'amp' in tag else ''}   ({tag}, MI355X; 14 training steps: 2 warm-up, 6 timed one by one, 6 back to back)", "",
        note, "", "```", line, "```", "", "| total ms | share | calls | avg us | kernel |", "|---|---|---|---|---|"]
 for r in rows[:24]:
     out.append(f"| {int(r['TotalDurationNs']) / 1e6:.2f} | {float(r['Percentage']):.1f}% | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | `{name(r['Name'])}` |")
-out += ["", f"Sum over all kernels: {tot / 1e6:.1f} ms."]
+calls = sum(int(r["Calls"]) for r in rows)
+out += ["", f"Sum over all kernels: {tot / 1e6:.1f} ms = {tot / 14e6:.2f} ms per step; {calls} launches = {calls / 14:.0f} per step."]
 open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:14]))
