@@ -8,6 +8,7 @@ HIP pipeline (frame_pipeline.py: device-side loop control, no host syncs); the r
 the "unfused" baseline for measurements.
 """
 import copy
+import os
 import warnings
 import math
 import random
@@ -298,6 +299,24 @@ class NeRFRenderer(nn.Module):
         return {"depth_map": depth, "rgb_map": image}
 
 
+#: a training step's conditioning networks as graph launches (RADNeRF._graphed_cond_feat); GFPP_TRAIN_COND_GRAPH=0: eager, the A/B partner
+COND_GRAPH = os.environ.get("GFPP_TRAIN_COND_GRAPH", "1") != "0"
+
+
+class _CondFeatModule(nn.Module):
+    """cal_cond_feat's eager body as a module of its own -- torch.cuda.make_graphed_callables graphs a Module's parameters' gradients -- that shares the owner's
+    Parameter objects and is registered nowhere (the owner's state_dict does not change)."""
+
+    def __init__(self, owner, params):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+        for i, p in enumerate(params):
+            self.register_parameter(f"p{i}", p)
+
+    def forward(self, cond, eye=None):
+        return self._owner._cond_feat_eager(cond, eye)
+
+
 class RADNeRF(NeRFRenderer):
     def __init__(self, hparams):
         super().__init__(hparams)
@@ -385,6 +404,13 @@ class RADNeRF(NeRFRenderer):
                 pipe = self.pipeline()
                 if pipe.cond is not None:
                     return pipe.cond_feat(cond, eye_area_percent if hp.get("add_eye_blink_cond", False) else None)
+        graphed = self._graphed_cond_feat(cond, eye_area_percent)
+        if graphed is not None:
+            return graphed
+        return self._cond_feat_eager(cond, eye_area_percent)
+
+    def _cond_feat_eager(self, cond, eye_area_percent=None):
+        hp = self.hparams
         feat = self.cond_prenet(cond)
         if hp.get("add_eye_blink_cond", False):
             if eye_area_percent is None:
@@ -396,6 +422,52 @@ class RADNeRF(NeRFRenderer):
         if self.with_att:
             feat = self.cond_att_net(feat)
         return feat
+
+    def _cond_modules(self):
+        mods = [self.cond_prenet]
+        if self.hparams.get("add_eye_blink_cond", False):
+            mods += [self.blink_embedding, self.blink_encoder]
+        if self.with_att:
+            mods.append(self.cond_att_net)
+        return mods
+
+    def _graphed_cond_feat(self, cond, eye_area_percent):
+        """A training step's cal_cond_feat as two graph launches (forward, backward) instead of ~120 eager ones: the networks see a [<= 8, <= 16, <= 204]
+        window -- microseconds of GPU work -- but every convolution call costs ~0.1 ms of host time in MIOpen, 2.0 of a May step's 5.5 ms
+        (tools/profile_train.py, docs/LAB_NOTEBOOK.md).  torch.cuda.make_graphed_callables captures the eager body below once per (window shape, autocast
+        dtype, parameter storage); the parameters' gradients come out of the backward graph as ordinary autograd results.  None: not a CUDA training call
+        (or GFPP_TRAIN_COND_GRAPH=0) -- the caller runs the eager body."""
+        if not (COND_GRAPH and self.training and torch.is_grad_enabled() and torch.is_tensor(cond) and cond.device.type == "cuda" and not cond.requires_grad
+                and (eye_area_percent is None or (torch.is_tensor(eye_area_percent) and not eye_area_percent.requires_grad))
+                and not torch.cuda.is_current_stream_capturing()):
+            return None
+        params = [p for m in self._cond_modules() for p in m.parameters()]
+        if not params or not all(p.requires_grad and p.device.type == "cuda" for p in params):
+            return None
+        blink = self.hparams.get("add_eye_blink_cond", False)
+        args = [cond.float().contiguous()]
+        if blink:
+            eye = eye_area_percent if eye_area_percent is not None else torch.zeros(1, 1)
+            args.append(eye.reshape(1, 1).to(device=cond.device, dtype=torch.float32))
+        amp = torch.is_autocast_enabled()
+        dt = (torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()) if amp else None
+        key = (tuple(args[0].shape), blink, dt, tuple(p.data_ptr() for p in params))
+        cache = self.__dict__.setdefault("_cond_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 4:
+                cache.clear()
+            try:
+                mod = _CondFeatModule(self, params)
+                with torch.autocast("cuda", dtype=dt or torch.float16, enabled=amp, cache_enabled=False):
+                    ent = torch.cuda.make_graphed_callables(mod, tuple(a.clone() for a in args), allow_unused_input=True)
+            except Exception as e:             # a torch / MIOpen build that cannot capture these layers: say so once, stay eager
+                warnings.warn(f"genefaceplusplus_amd: conditioning networks stay eager in training (graph capture failed: {e})", RuntimeWarning)
+                ent = False
+            cache[key] = ent
+        if ent is False:
+            return None
+        return ent(*args)
 
     # -- per-sample evaluation (stand-alone API; render() uses the fused kernels) ----------------------------
     def _sigma_trunk(self, position, cond_feat):
