@@ -56,6 +56,54 @@ class CondModel(ctypes.Structure):
                 ("center_tap_only", c_u32), ("blob", c_p), ("blob_floats", c_u32)]
 
 
+def cond_train_model(m):
+    """(descriptor, parameters, fill) of cal_cond_feat's networks for the training kernels (gfpp_cond_feat_train_forward / _backward): the descriptor points at
+    the parameters THEMSELVES (fp32, contiguous: an optimiser step is seen without re-packing), `parameters` lists them in the order their gradients come back,
+    fill(addresses) makes the descriptor that says where each gradient goes.  None if the window is outside what the one-workgroup kernels cover."""
+    from .cond_nets import _STRIDES
+    hp, pre = m.hparams, m.cond_prenet
+    dims = (int(m.smo_win_size), int(m.cond_win_size), int(m.cond_in_dim), int(m.cond_out_dim))
+    if dims[3] > 64 or dims[0] > 64 or dims[0] * 64 * dims[1] > 8192 or pre.win_size not in _STRIDES:
+        return None
+    slots, plist = [], []
+
+    def f(name, i, p):
+        slots.append((name, i))
+        plist.append(p)
+
+    for i in range(4):
+        conv = pre.encoder_conv[2 * i]
+        f("conv_w", i, conv.weight), f("conv_b", i, conv.bias)
+    for i, j in enumerate((0, 2)):
+        f("fc_w", i, pre.encoder_fc1[j].weight), f("fc_b", i, pre.encoder_fc1[j].bias)
+    blink = int(hp["eye_blink_dim"]) if hp.get("add_eye_blink_cond", False) else 0
+    if blink:
+        f("blink_emb", None, m.blink_embedding.weight)
+        for i in range(2):
+            f("blink_w", i, m.blink_encoder[i].weight), f("blink_b", i, m.blink_encoder[i].bias)
+    if m.with_att:
+        att = m.cond_att_net
+        for i in range(5):
+            conv = att.attentionConvNet[2 * i]
+            f("att_conv_w", i, conv.weight), f("att_conv_b", i, conv.bias)
+        f("att_fc_w", None, att.attentionNet[0].weight), f("att_fc_b", None, att.attentionNet[0].bias)
+
+    def fill(addresses):
+        cm = CondModel()
+        cm.smo, cm.t_win, cm.c_in, cm.dim_aud = dims
+        for i, s_ in enumerate(_STRIDES[pre.win_size]):
+            cm.strides[i] = s_
+        cm.blink_dim, cm.with_att = blink, int(bool(m.with_att))
+        for (name, i), addr in zip(slots, addresses):
+            if i is None:
+                setattr(cm, name, addr)
+            else:
+                getattr(cm, name)[i] = addr
+        return cm
+
+    return fill([p.data_ptr() for p in plist]), plist, fill
+
+
 class TorsoModel(ctypes.Structure):
     _fields_ = [("density_grid", c_p), ("grid_size", c_u32), ("density_thresh", c_f), ("torso_shrink", c_f), ("variant", c_u32),
                 ("code_dim", c_u32), ("const_dim", c_u32), ("head_aware", c_u32), ("grid", GridDesc),
@@ -69,6 +117,9 @@ _lib.register("gfpp_torso_frame", [ctypes.POINTER(TorsoModel), ctypes.POINTER(Fr
                                    c_p, c_p, c_p])
 _lib.register("gfpp_cond_feat", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p])
 _lib.register("gfpp_cond_feat_batch", [ctypes.POINTER(CondModel), c_p, c_u32, c_p, c_u32, c_p, c_u32, c_u32, c_p])
+_lib.register("gfpp_cond_feat_train_floats", [ctypes.POINTER(CondModel), ctypes.c_int], restype=ctypes.c_uint32)
+_lib.register("gfpp_cond_feat_train_forward", [ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p, c_p])
+_lib.register("gfpp_cond_feat_train_backward", [ctypes.POINTER(CondModel), ctypes.POINTER(CondModel), c_p, c_p, c_p, c_p, c_p, c_p])
 _lib.register("gfpp_torso_frame_lp", [ctypes.POINTER(TorsoModel), ctypes.POINTER(FrameWs), c_p, c_p, c_p, c_p, c_f, c_u32, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_p])
 _lib.register("gfpp_torso_fold_batch", [ctypes.POINTER(TorsoModel), c_p, c_u32, c_p, c_u32, c_p, c_p])

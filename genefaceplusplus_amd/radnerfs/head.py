@@ -8,6 +8,7 @@ HIP pipeline (frame_pipeline.py: device-side loop control, no host syncs); the r
 the "unfused" baseline for measurements.
 """
 import copy
+import ctypes
 import os
 import warnings
 import math
@@ -18,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import raymarching
+from .. import _lib
 from .._lib import GfppError
 from .cond_nets import AudioNet, AudioAttNet, MLP, SplitFirstColumn
 from .encoders import get_encoder
@@ -299,22 +301,41 @@ class NeRFRenderer(nn.Module):
         return {"depth_map": depth, "rgb_map": image}
 
 
-#: a training step's conditioning networks as graph launches (RADNeRF._graphed_cond_feat); GFPP_TRAIN_COND_GRAPH=0: eager, the A/B partner
-COND_GRAPH = os.environ.get("GFPP_TRAIN_COND_GRAPH", "1") != "0"
+#: a training step's conditioning networks: "fused" = one forward and one backward launch of the library's own kernels (RADNeRF._fused_train_cond_feat; shapes
+#: they do not cover stay eager); GFPP_TRAIN_COND=eager: torch's layers, the A/B partner
+COND_TRAIN = os.environ.get("GFPP_TRAIN_COND", "fused")
 
 
-class _CondFeatModule(nn.Module):
-    """cal_cond_feat's eager body as a module of its own -- torch.cuda.make_graphed_callables graphs a Module's parameters' gradients -- that shares the owner's
-    Parameter objects and is registered nowhere (the owner's state_dict does not change)."""
+class _CondFeatTrain(torch.autograd.Function):
+    """cal_cond_feat of a training step through gfpp_cond_feat_train_forward / _backward: (cond, eye, descriptor, *parameters) -> cond_feat; the parameters'
+    gradients come back in the descriptor's order."""
 
-    def __init__(self, owner, params):
-        super().__init__()
-        object.__setattr__(self, "_owner", owner)
-        for i, p in enumerate(params):
-            self.register_parameter(f"p{i}", p)
+    @staticmethod
+    def forward(ctx, cond, eye, desc, *params):
+        cm, plist, fill = desc
+        st = torch.cuda.current_stream().cuda_stream
+        saved = torch.empty(int(_lib.lib().gfpp_cond_feat_train_floats(ctypes.byref(cm), 0)), dtype=torch.float32, device=cond.device)
+        out = torch.empty(cm.dim_aud if cm.with_att else (cm.smo, cm.dim_aud), dtype=torch.float32, device=cond.device)
+        _lib.call("gfpp_cond_feat_train_forward", ctypes.byref(cm), cond.data_ptr(), eye.data_ptr() if eye is not None else None, out.data_ptr(), saved.data_ptr(), st)
+        ctx.save_for_backward(cond, eye, saved)
+        ctx.desc = desc
+        return out
 
-    def forward(self, cond, eye=None):
-        return self._owner._cond_feat_eager(cond, eye)
+    @staticmethod
+    def backward(ctx, gout):
+        cond, eye, saved = ctx.saved_tensors
+        cm, plist, fill = ctx.desc
+        st = torch.cuda.current_stream().cuda_stream
+        flat = torch.empty(sum(p.numel() for p in plist), dtype=torch.float32, device=cond.device)
+        grads, at = [], 0
+        for p in plist:
+            grads.append(flat[at:at + p.numel()].view(p.shape))
+            at += p.numel()
+        gm = fill([g.data_ptr() for g in grads])
+        scratch = torch.empty(int(_lib.lib().gfpp_cond_feat_train_floats(ctypes.byref(cm), 1)), dtype=torch.float32, device=cond.device)
+        _lib.call("gfpp_cond_feat_train_backward", ctypes.byref(cm), ctypes.byref(gm), cond.data_ptr(), eye.data_ptr() if eye is not None else None, saved.data_ptr(),
+                  gout.float().contiguous().data_ptr(), scratch.data_ptr(), st)
+        return (None, None, None, *[g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads)])
 
 
 class RADNeRF(NeRFRenderer):
@@ -404,10 +425,8 @@ class RADNeRF(NeRFRenderer):
                 pipe = self.pipeline()
                 if pipe.cond is not None:
                     return pipe.cond_feat(cond, eye_area_percent if hp.get("add_eye_blink_cond", False) else None)
-        graphed = self._graphed_cond_feat(cond, eye_area_percent)
-        if graphed is not None:
-            return graphed
-        return self._cond_feat_eager(cond, eye_area_percent)
+        feat = self._fused_train_cond_feat(cond, eye_area_percent)
+        return feat if feat is not None else self._cond_feat_eager(cond, eye_area_percent)
 
     def _cond_feat_eager(self, cond, eye_area_percent=None):
         hp = self.hparams
@@ -431,43 +450,33 @@ class RADNeRF(NeRFRenderer):
             mods.append(self.cond_att_net)
         return mods
 
-    def _graphed_cond_feat(self, cond, eye_area_percent):
-        """A training step's cal_cond_feat as two graph launches (forward, backward) instead of ~120 eager ones: the networks see a [<= 8, <= 16, <= 204]
-        window -- microseconds of GPU work -- but every convolution call costs ~0.1 ms of host time in MIOpen, 2.0 of a May step's 5.5 ms
-        (tools/profile_train.py, docs/LAB_NOTEBOOK.md).  torch.cuda.make_graphed_callables captures the eager body below once per (window shape, autocast
-        dtype, parameter storage); the parameters' gradients come out of the backward graph as ordinary autograd results.  None: not a CUDA training call
-        (or GFPP_TRAIN_COND_GRAPH=0) -- the caller runs the eager body."""
-        if not (COND_GRAPH and self.training and torch.is_grad_enabled() and torch.is_tensor(cond) and cond.device.type == "cuda" and not cond.requires_grad
+    def _cond_train_call_ok(self, cond, eye_area_percent):
+        if not (self.training and torch.is_grad_enabled() and torch.is_tensor(cond) and cond.device.type == "cuda" and not cond.requires_grad
                 and (eye_area_percent is None or (torch.is_tensor(eye_area_percent) and not eye_area_percent.requires_grad))
                 and not torch.cuda.is_current_stream_capturing()):
             return None
         params = [p for m in self._cond_modules() for p in m.parameters()]
         if not params or not all(p.requires_grad and p.device.type == "cuda" for p in params):
             return None
-        blink = self.hparams.get("add_eye_blink_cond", False)
-        args = [cond.float().contiguous()]
-        if blink:
-            eye = eye_area_percent if eye_area_percent is not None else torch.zeros(1, 1)
-            args.append(eye.reshape(1, 1).to(device=cond.device, dtype=torch.float32))
-        amp = torch.is_autocast_enabled()
-        dt = (torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()) if amp else None
-        key = (tuple(args[0].shape), blink, dt, tuple(p.data_ptr() for p in params))
-        cache = self.__dict__.setdefault("_cond_graphs", {})
-        ent = cache.get(key)
-        if ent is None:
-            if len(cache) >= 4:
-                cache.clear()
-            try:
-                mod = _CondFeatModule(self, params)
-                with torch.autocast("cuda", dtype=dt or torch.float16, enabled=amp, cache_enabled=False):
-                    ent = torch.cuda.make_graphed_callables(mod, tuple(a.clone() for a in args), allow_unused_input=True)
-            except Exception as e:             # a torch / MIOpen build that cannot capture these layers: say so once, stay eager
-                warnings.warn(f"genefaceplusplus_amd: conditioning networks stay eager in training (graph capture failed: {e})", RuntimeWarning)
-                ent = False
-            cache[key] = ent
-        if ent is False:
+        return params
+
+    def _fused_train_cond_feat(self, cond, eye_area_percent):
+        """A training step's cal_cond_feat as ONE forward and ONE backward launch (gfpp_cond_feat_train_forward / _backward, csrc/cond_nets.hip), fp32.  None:
+        not a CUDA training call, a shape outside the one-workgroup kernels, or GFPP_TRAIN_COND=eager.  (torch's eager layers captured as two graphs --
+        torch.cuda.make_graphed_callables -- were the intermediate step: 5.9 -> 5.55 ms per May step, ~100 kernel nodes still 1.3 ms of GPU time; this path: 4.6 ms.)"""
+        if COND_TRAIN != "fused":
             return None
-        return ent(*args)
+        params = self._cond_train_call_ok(cond, eye_area_percent)
+        if params is None or any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+            return None
+        from .frame_pipeline import cond_train_model
+        desc = cond_train_model(self)
+        if desc is None or tuple(cond.shape) != (desc[0].smo, desc[0].t_win, desc[0].c_in):
+            return None
+        eye = None
+        if desc[0].blink_dim and eye_area_percent is not None:
+            eye = eye_area_percent.reshape(-1)[:1].to(device=cond.device, dtype=torch.float32)
+        return _CondFeatTrain.apply(cond.float().contiguous(), eye, desc, *desc[1])
 
     # -- per-sample evaluation (stand-alone API; render() uses the fused kernels) ----------------------------
     def _sigma_trunk(self, position, cond_feat):

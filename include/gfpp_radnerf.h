@@ -276,6 +276,18 @@ int gfpp_cond_feat(const gfpp_cond_model *model, const float *cond, const float 
 int gfpp_cond_feat_batch(const gfpp_cond_model *model, const float *cond, uint32_t cond_stride, const float *eye_area, uint32_t eye_stride,
                          float *cond_feat, uint32_t out_stride, uint32_t count, gfpp_stream_t stream);
 
+/* RADNeRF.cal_cond_feat (radnerf.py:88-106) inside a TRAINING step (tasks/radnerfs/radnerf.py:101-176 trains AudioNet / AudioAttNet with the field): the same
+ * networks with every activation kept (forward) and their whole backward pass, one launch of one workgroup each -- autograd runs them as ~120 eager launches,
+ * each convolution call ~0.1 ms of host time in MIOpen.  fp32 throughout (autocast would run the layers in half).
+ *   model: the parameters AS THEY ARE (Conv1d weights [out, in, 3], center_tap_only = 0, blob = NULL), fp32 device pointers.
+ *   saved: gfpp_cond_feat_train_floats(model, 0) floats, written by the forward pass, read by the backward pass; scratch: (model, 1) floats.
+ *   grads: a gfpp_cond_model whose pointers say where each parameter's gradient goes (same shapes; the dimensions are taken from `model`); every one is OVERWRITTEN.
+ *   grad_out: [dim_aud] ([smo, dim_aud] without the attention net).  cond itself gets no gradient (a driving signal). */
+uint32_t gfpp_cond_feat_train_floats(const gfpp_cond_model *model, int scratch);
+int gfpp_cond_feat_train_forward(const gfpp_cond_model *model, const float *cond, const float *eye_area, float *cond_feat, float *saved, gfpp_stream_t stream);
+int gfpp_cond_feat_train_backward(const gfpp_cond_model *model, const gfpp_cond_model *grads, const float *cond, const float *eye_area, const float *saved,
+                                  const float *grad_out, float *scratch, gfpp_stream_t stream);
+
 /* MLP weight packing for the MFMA kernels ("fragment order", fp32):
  *   a dense layer out[128] = W[128,K] x  is evaluated as a sequence of K/2 rank-2 updates with
  *   v_mfma_f32_32x32x2_f32; update `s` consumes the input pair (k0[s], k1[s]).  Packed array P[s/4][m][lane][s%4] =

@@ -408,6 +408,53 @@ def test_training_step_under_autocast_follows_the_fp32_step(dev, oracle_mod):
     assert last < 0.9 * first
 
 
+@pytest.mark.parametrize("mode", ["fused"])
+@pytest.mark.parametrize("variant", ["may_head", "may_head_sr", "audio_head"])
+def test_conditioning_networks_in_a_training_step(dev, variant, mode):
+    """cal_cond_feat under autograd: the library's own forward / backward launches (`fused`: gfpp_cond_feat_train_forward / _backward, one workgroup each)
+    against torch's eager layers -- on the lm3d window ([5, 1, 204]: convolutions whose
+    outer taps only see padding), the blink variant ([3, 1, 204] + eye value) and the audio window ([8, 16, 44], strided convolutions): same features, same
+    gradient on every parameter."""
+    from helpers import frame_case, build_model
+    from genefaceplusplus_amd.radnerfs import head as head_mod
+    case = frame_case(variant, 16)
+    model = build_model(case, dev, "fused").train()
+    cond = torch.from_numpy(case["cond"]).to(dev)
+    eye = torch.tensor([[0.37]], device=dev) if case["hp"].get("add_eye_blink_cond", False) else None
+    names = [n for n, _ in model.named_parameters() if n.startswith(("cond_prenet", "cond_att_net", "blink_"))]
+    torch.manual_seed(1)
+    gout = torch.randn(case["hp"]["cond_out_dim"], device=dev)
+    got, launched = {}, []
+    real_call = head_mod._lib.call
+
+    def spy(name, *a):
+        launched.append(name)
+        return real_call(name, *a)
+    was = head_mod.COND_TRAIN
+    try:
+        for m in ("eager", mode, mode):
+            head_mod.COND_TRAIN = m
+            head_mod._lib.call = spy
+            for p in model.parameters():
+                p.grad = None
+            feat = model.cal_cond_feat(cond, eye_area_percent=eye)
+            (feat.float() * gout).sum().backward()
+            torch.cuda.synchronize()
+            got[m] = (feat.detach().float().clone(), {n: model.get_parameter(n).grad.detach().clone() for n in names})
+    finally:
+        head_mod.COND_TRAIN = was
+        head_mod._lib.call = real_call
+    want = 2 if mode == "fused" else 0
+    assert launched.count("gfpp_cond_feat_train_forward") == want and launched.count("gfpp_cond_feat_train_backward") == want
+    ref_f, ref_g = got["eager"]
+    f, g = got[mode]
+    assert float((f - ref_f).abs().max()) <= 2e-5 * float(ref_f.abs().max()) + 1e-7
+    for n in names:
+        assert torch.isfinite(g[n]).all() and g[n].shape == ref_g[n].shape
+        assert float((g[n] - ref_g[n]).abs().max()) <= 1e-4 * float(ref_g[n].abs().max()) + 1e-7, (n, float((g[n] - ref_g[n]).abs().max()), float(ref_g[n].abs().max()))
+    assert any(float(ref_g[n].abs().max()) > 0 for n in names)
+
+
 def test_update_extra_state_and_mark_untrained(dev, oracle_mod):
     orc = oracle_mod
     case = _train_case(32)
