@@ -64,10 +64,10 @@ class ClipRenderer:
         a small grid, because a launch that finds nothing left still needs a whole CU per workgroup (results never depend on it, a later frame that
         needs more trips is rendered by the small grid).
         group: frames per graph launch (round 4).  K > 1: a lane takes K consecutive frames of the clip at a time and renders them with ONE persistent
-        head launch (RADNeRFTorso*.render_group, gfpp_frame_ws.n_frames) -- every frame the bits of its own launch, the fixed costs of a launch paid once
+        head launch (RADNeRF*.render_group, gfpp_frame_ws.n_frames) -- every frame the bits of its own launch, the fixed costs of a launch paid once
         per K frames.  None: 4 (measured, frames/s with K = 1 / 2 / 3 / 4: 256^2 rays + SR 4 806 / 5 107 / 5 205 / 5 286 -- a workgroup's share of ONE
         such frame is ~110 occupied rays, 27 sample blocks for 8 wavefronts --; 512^2 3 684 / 3 778 / 3 861 / 3 846; a 20-frame job 3 090 / - / 2 920 / 3 140);
-        models / precisions without group support (head-only models, fp32, lp_kernel='trips', more than 2^22 rays per group) and clips without precomputed
+        models / precisions without group support (fp32, lp_kernel='trips', more than 2^22 rays per group) and clips without precomputed
         conditioning render frame by frame whatever is asked."""
         dev = model.density_bitfield.device
         if dev.type != "cuda":

@@ -1064,9 +1064,9 @@ class FramePipeline:
     group_torso = os.environ.get("GFPP_GROUP_TORSO", "1") != "0"
 
     def group_supported(self, N, K, max_steps):
-        """Frame groups run on the persistent 16-bit launch with the MFMA torso kernel (what a clip renders with unless told otherwise)."""
-        return (self.precision != "fp32" and self.lp_kernel == "persist" and self.torso is not None and 2 <= int(K) <= self.GROUP_MAX and int(max_steps) <= 24
-                and int(K) * int(N) <= (1 << 22) and bool(self.torso.lp_weights))
+        """Frame groups run on the persistent 16-bit launch (what a clip renders with unless told otherwise); torso models need the MFMA torso kernel's weight images."""
+        return (self.precision != "fp32" and self.lp_kernel == "persist" and 2 <= int(K) <= self.GROUP_MAX and int(max_steps) <= 24
+                and int(K) * int(N) <= (1 << 22) and (self.torso is None or bool(self.torso.lp_weights)))
 
     def torso_pixels(self, bg_coords):
         """(mask [N] uint8, ascending int32 indices of the masked pixels): WHERE the torso field is evaluated -- the occupancy grid sampled at the pixel coordinates
@@ -1118,6 +1118,71 @@ class FramePipeline:
         self._ws[key] = ent
         return ent
 
+    def _group_head_launch(self, consts, N, dt_gamma, max_steps, T_thresh, poses, camera, who):
+        """The two halves of a frame group's head pass as closures: begin() = per frame slab test + pre-march (+ the rays, when `poses` / `camera` are given: ONE
+        prologue launch for the K frames), launch() = the ONE persistent head launch over the rays of all K frames.  (Two halves: the torso's per-frame constant
+        folds are issued between them.)"""
+        K = len(consts)
+        gws, frames, t = self.group_workspace(N, K, max_steps)
+        st = torch.cuda.current_stream().cuda_stream
+        c = [x.consts if isinstance(x, FoldedConsts) else x for x in consts]
+        for x in c:
+            if x.numel() != 256 or x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
+                raise GfppError(f"{who}: every frame needs 256 contiguous float32 folded constants on the GPU")
+        step = (c[1].data_ptr() - c[0].data_ptr()) // 4
+        if step < 256 or any(c[k].data_ptr() - c[0].data_ptr() != 4 * step * k for k in range(K)):
+            raise GfppError(f"{who}: the frames' constants must be equally spaced views (frame_consts_stride)")
+        pstep = 0
+        if poses is not None:
+            pstep = (poses[1].data_ptr() - poses[0].data_ptr()) // 4
+            if pstep < 16 or any(poses[k].data_ptr() - poses[0].data_ptr() != 4 * pstep * k or poses[k].numel() != 16 for k in range(K)):
+                raise GfppError(f"{who}: the frames' poses must be equally spaced [4, 4] views")
+
+        def begin():
+            if poses is not None:
+                fx, fy, cx, cy, H, W = camera
+                gws.row_rays = int(W)                  # the rays are generated in pixel order: the head launch may give every XCD its own image columns
+                call("gfpp_head_group_begin", ctypes.byref(self.head), ctypes.byref(gws), poses[0].data_ptr(), int(pstep), float(fx), float(fy), float(cx), float(cy), int(H),
+                     int(W), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps), st)
+            else:
+                gws.row_rays = 0
+                for k in range(K):
+                    call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
+                         float(dt_gamma), int(max_steps), st)
+
+        def launch():
+            gws.frame_consts, gws.frame_consts_stride = c[0].data_ptr(), step
+            call("gfpp_head_frame_persist_lp", ctypes.byref(self.head), ctypes.byref(gws), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps),
+                 float(T_thresh), st)
+        return begin, launch
+
+    def render_group_head(self, consts, N, dt_gamma, max_steps, T_thresh, bg_color, after_frame=None, poses=None, camera=None):
+        """Head-only models (RADNeRF / RADNeRFwithSR): K = len(consts) frames of N rays through ONE persistent head launch, then one resolve launch for the group and
+        per frame the head-only epilogue (renderer.py:385-397) (+ `after_frame(k, out)`: the SR stage, the uint8 store).  Rays: from `poses` + `camera` inside the
+        prologue launch, or as the caller has put them into group_workspace()['rays_o' / 'rays_d'].  Every frame is the bits of its own render_head.  Returns the K
+        result dicts {'image' [N, 3], 'depth' [N]}."""
+        K = len(consts)
+        if self.torso is not None or not self.group_supported(N, K, max_steps):
+            raise GfppError("render_group_head: needs a head-only model, a 16-bit precision, lp_kernel='persist', 2 <= K <= 4, max_steps <= 24")
+        gws, frames, t = self.group_workspace(N, K, max_steps)
+        st = torch.cuda.current_stream().cuda_stream
+        begin, launch = self._group_head_launch(consts, N, dt_gamma, max_steps, T_thresh, poses, camera, "render_group_head")
+        begin()
+        launch()
+        call("gfpp_head_group_resolve", ctypes.byref(gws), int(max_steps), st)       # every frame against its own histogram, one launch
+        bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
+        outs = []
+        for k in range(K):
+            ws = frames[k]
+            ws.defer_resolve, ws.resolve_max_steps = 0, 0
+            ws.clip_job, ws.clip_lane, ws.clip_sub, ws.clip_advance = None, 0, 0, 0
+            out = {"image": torch.empty(N, 3, dtype=torch.float32, device=self.device), "depth": torch.empty(N, dtype=torch.float32, device=self.device)}
+            call("gfpp_head_frame_finish", ctypes.byref(ws), bg_ptr, bg_scalar, out["image"].data_ptr(), out["depth"].data_ptr(), st)
+            if after_frame is not None:
+                after_frame(k, out)
+            outs.append(out)
+        return outs
+
     def render_group_head_torso(self, consts, ind_code, bg_coords, torso_inputs, torso_code, dt_gamma, max_steps, T_thresh, bg_color, use_head_for_torso,
                                 after_frame=None, poses=None, camera=None):
         """K frames (K = len(consts)) whose rays the caller has put into group_workspace()['rays_o' / 'rays_d']: per frame slab test + pre-march, then ONE
@@ -1128,31 +1193,13 @@ class FramePipeline:
         Every frame is the bits of its own render_head_torso.  Returns the K result dicts."""
         K = len(consts)
         N = int(bg_coords.reshape(-1, 2).shape[0])
-        if not self.group_supported(N, K, max_steps):
+        if self.torso is None or not self.group_supported(N, K, max_steps):
             raise GfppError("render_group_head_torso: needs a 16-bit precision, lp_kernel='persist', a torso model, 2 <= K <= 4, max_steps <= 24")
         gws, frames, t = self.group_workspace(N, K, max_steps)
         st = torch.cuda.current_stream().cuda_stream
         dev = self.device
-        c = [x.consts if isinstance(x, FoldedConsts) else x for x in consts]
-        for x in c:
-            if x.numel() != 256 or x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
-                raise GfppError("render_group_head_torso: every frame needs 256 contiguous float32 folded constants on the GPU")
-        step = (c[1].data_ptr() - c[0].data_ptr()) // 4
-        if step < 256 or any(c[k].data_ptr() - c[0].data_ptr() != 4 * step * k for k in range(K)):
-            raise GfppError("render_group_head_torso: the frames' constants must be equally spaced views (frame_consts_stride)")
-        if poses is not None:
-            pstep = (poses[1].data_ptr() - poses[0].data_ptr()) // 4
-            if pstep < 16 or any(poses[k].data_ptr() - poses[0].data_ptr() != 4 * pstep * k or poses[k].numel() != 16 for k in range(K)):
-                raise GfppError("render_group_head_torso: the frames' poses must be equally spaced [4, 4] views")
-            fx, fy, cx, cy, H, W = camera
-            gws.row_rays = int(W)                  # the rays are generated in pixel order: the head launch may give every XCD its own image columns
-            call("gfpp_head_group_begin", ctypes.byref(self.head), ctypes.byref(gws), poses[0].data_ptr(), int(pstep), float(fx), float(fy), float(cx), float(cy), int(H),
-                 int(W), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps), st)
-        else:
-            gws.row_rays = 0
-            for k in range(K):
-                call("gfpp_head_frame_begin_premarch", ctypes.byref(self.head), ctypes.byref(frames[k]), t["rays_o"][k].data_ptr(), t["rays_d"][k].data_ptr(),
-                     float(dt_gamma), int(max_steps), st)
+        begin, launch = self._group_head_launch(consts, N, dt_gamma, max_steps, T_thresh, poses, camera, "render_group_head_torso")
+        begin()
         code = self._dev_f32(torso_code.reshape(-1), "torso_code") if torso_code is not None else None
         folded = None
         if self.group_torso and self.torso.lp_dtype in (GFPP_F16, GFPP_BF16):
@@ -1167,9 +1214,7 @@ class FramePipeline:
                 tstep = want
             folded = torch.empty(K, 96, dtype=torch.float32, device=dev)
             call("gfpp_torso_fold_batch", ctypes.byref(self.torso), ins[0].data_ptr(), int(tstep), code.data_ptr() if code is not None else None, K, folded.data_ptr(), st)
-        gws.frame_consts, gws.frame_consts_stride = c[0].data_ptr(), step
-        call("gfpp_head_frame_persist_lp", ctypes.byref(self.head), ctypes.byref(gws), t["rays_o"].data_ptr(), t["rays_d"].data_ptr(), float(dt_gamma), int(max_steps),
-             float(T_thresh), st)
+        launch()
         bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)

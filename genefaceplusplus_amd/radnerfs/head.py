@@ -415,6 +415,39 @@ class RADNeRF(NeRFRenderer):
             return None
         return pipe.fold_rows(feats, self._individual_code(index))
 
+    # -- K consecutive frames of a clip through one persistent head launch (clip.ClipRenderer, frame groups): head-only models ----------------------
+    def group_supported(self, N, K, max_steps, perturb=False):
+        return (self.executor == "fused" and not self.training and self._fused_ok(perturb, max_steps) and self.pipeline().group_supported(N, K, max_steps))
+
+    def render_group(self, consts, bg_coords, poses, lm68s=None, index=0, dt_gamma=0, bg_color=None, max_steps=1024, T_thresh=1e-4, sr_noise_mode="random",
+                     after_frame=None, ngp_poses=None, camera=None, **kwargs):
+        """render() for K = len(consts) frames whose conditioning is given as folded constants (consts[k]: 256 values, frame_consts_rows) -- the frame loop of
+        inference/genefacepp_infer.py:460-469 taken K frames at a time with a head-only model (RADNeRF, RADNeRFwithSR).  Rays: generated on the device from
+        ngp_poses (K equally spaced [4, 4] cam2world views) + camera (fx, fy, cx, cy, H, W), or put by the caller into pipeline().group_workspace(N, K, max_steps)
+        [2]['rays_o' / 'rays_d'].  Every frame is the bits of its own render() call (the super-resolution noise of 'random' mode is drawn per launch either way).
+        after_frame(k, result dict of frame k): issued right behind the frame's last kernel.  `poses` / `lm68s` (the torso models' inputs) are not used.
+        Returns the K result dicts with render()'s keys."""
+        K = len(consts)
+        N = int(bg_coords.reshape(-1, 2).shape[0])
+        if not self.group_supported(N, K, max_steps):
+            raise GfppError("render_group: not available for this model / precision / executor (see FramePipeline.group_supported)")
+        sr = getattr(self, "sr_net", None)
+        side = sr.input_resolution if sr is not None else None
+        results = [None] * K
+
+        def finish(k, out):
+            res = {"depth_map": out["depth"].view(1, N), "rgb_map": out["image"].view(1, N, 3)}
+            if sr is not None:
+                rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
+                res["rgb_map"] = rgb
+                if sr.ready:
+                    res["sr_rgb_map"] = sr(rgb.clone(), noise_mode=sr_noise_mode, clamp01=True)
+            results[k] = res
+            if after_frame is not None:
+                after_frame(k, res)
+        self.pipeline().render_group_head(consts, N, dt_gamma, max_steps, T_thresh, bg_color, after_frame=finish, poses=ngp_poses, camera=camera)
+        return results
+
     def cal_cond_feat(self, cond, eye_area_percent=None):
         """cond [smo_win, t_window, cond_in] -> cond_feat [cond_out] (radnerf.py:88-106)."""
         hp = self.hparams

@@ -177,7 +177,8 @@ def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
 
 # ---- frame groups: K consecutive frames through ONE persistent head launch (round 4) ---------------------------------------------------------
 @pytest.mark.parametrize("variant,HW,precision,F", [("may_torso_sr", 256, "fp16", 10), ("may_torso", 96, "bf16", 9), ("may_torso", 37, "fp16", 5),
-                                                    ("may_torso", 8, "fp16", 9)])      # 8 x 8: a group's prologue launch has fewer blocks than frames (counter reset, round-4 advisory)
+                                                    ("may_torso", 8, "fp16", 9),       # 8 x 8: a group's prologue launch has fewer blocks than frames (counter reset, round-4 advisory)
+                                                    ("may_head", 48, "fp16", 9), ("may_head_sr", 256, "bf16", 6)])     # head-only models (round 5): resolve + head epilogue per frame
 @pytest.mark.parametrize("K", [2, 3, 4])
 def test_frame_groups_deliver_the_bytes_of_single_frames(dev, variant, HW, precision, F, K):
     """ClipRenderer(group=K): a lane takes K consecutive frames at a time and renders them with one persistent head launch (gfpp_frame_ws.n_frames: the rays of
@@ -212,9 +213,9 @@ def test_frame_groups_deliver_the_bytes_of_single_frames(dev, variant, HW, preci
 
 
 def test_frame_groups_fall_back_where_they_are_not_supported(dev):
-    """fp32 (trip launches), the trip-launch path of the 16-bit modes and head-only models render frame by frame whatever group size is asked for."""
+    """fp32 (trip launches; torso and head-only models) and the trip-launch path of the 16-bit modes render frame by frame whatever group size is asked for."""
     from genefaceplusplus_amd.clip import ClipRenderer
-    for variant, precision, kernel in (("may_torso", "fp32", None), ("may_torso", "fp16", "trips"), ("may_head", "fp16", None)):
+    for variant, precision, kernel in (("may_torso", "fp32", None), ("may_torso", "fp16", "trips"), ("may_head", "fp32", None)):
         case = frame_case(variant, 48)
         model = build_model(case, dev, "fused")
         model.precision = precision
