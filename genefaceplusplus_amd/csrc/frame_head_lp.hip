@@ -1284,6 +1284,9 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
         const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid;
         for (int l = 0; l < 16; ++l) any_slow |= gd.levels_host[l].flags & GFPP_LEVEL_SLOW;
     }
+    // a model WITHOUT the 16-bit corner-block copies (both descriptors empty: the caller's opt-out, GFPP_LP_BLOCK_TABLE=0 in the Python binding) renders through the
+    // generic lookup on its fp32 tables, like a hash-grid model
+    if (!model->pos_grid_blk.table && !model->amb_grid_blk.table) any_slow |= GFPP_LEVEL_SLOW;
     for (int which = 0; which < 2; ++which) {
         const gfpp_grid_desc &gd = which ? model->amb_grid : model->pos_grid, &gb = which ? model->amb_grid_blk : model->pos_grid_blk;
         LpGrid &g = which ? a.amb : a.pos;

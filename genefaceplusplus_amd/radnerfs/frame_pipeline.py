@@ -546,7 +546,9 @@ class FramePipeline:
         call("gfpp_grid_levels_fill", int(enc.input_dim), L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id),
              int(enc.align_corners), off.ctypes.data, 0, lv)
         d = GridDesc()
-        if any(int(lv[l].flags) & 1 for l in range(L)):                 # GFPP_LEVEL_SLOW
+        # GFPP_LP_BLOCK_TABLE=0 (round-4 advisory: an opt-out for A/B and parity debugging): no 16-bit copy of the tables -- the 16-bit kernels then run their generic
+        # lookup on the fp32 tables (fp32 corner values and weights, 2 060 B per sample), the instantiation hash-grid models use anyway
+        if any(int(lv[l].flags) & 1 for l in range(L)) or os.environ.get("GFPP_LP_BLOCK_TABLE", "1") == "0":                 # GFPP_LEVEL_SLOW
             return d
         levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
         d.table = self._hold(corner_block_table(enc.embeddings.detach(), off, lv))

@@ -355,7 +355,8 @@ typedef struct gfpp_head_model {
      *     c0(x,y) c0(x+1,y) | c1(x,y) c1(x+1,y) | c0(x,y+1) c0(x+1,y+1) | c1(x,y+1) c1(x+1,y+1)
      * so that a level costs one 16-byte gather per z plane (32 gathers from <= 25 cache lines per sample and 3-D grid instead of 64 from 64) and the
      * interpolation is four packed dot products per plane (v_dot2_f32_f16: fp16 corner weights, fp32 accumulation).  The reference's autocast inference reads
-     * a half table too (grid.py:43-47).  The exact-fp32 kernels never read these. */
+     * a half table too (grid.py:43-47).  The exact-fp32 kernels never read these.  BOTH left empty (table == NULL): the caller's opt-out -- the 16-bit kernels then
+     * read pos_grid / amb_grid through the generic lookup (fp32 corner values and weights, 2 060 B per sample), as for hash-grid models. */
     gfpp_grid_desc pos_grid_blk;
     gfpp_grid_desc amb_grid_blk;
 } gfpp_head_model;

@@ -64,6 +64,25 @@ def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, 
     assert stats["frac_over_tol"] <= 5e-4, stats
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_16bit_mode_on_the_fp32_tables(dev, oracle_mod, monkeypatch, precision):
+    """GFPP_LP_BLOCK_TABLE=0: the 16-bit head kernels without the 16-bit corner-block copies of the grids (generic lookup on the fp32 tables, fp32 corner weights) --
+    the opt-out for A/B and parity debugging.  Same tolerance against the oracle as the default path, and close to it."""
+    case = frame_case("may_torso", 96)
+    ref = oracle_render(oracle_mod, case)["rgb_map"].reshape(-1, 3)
+    frames = {}
+    for switch in ("1", "0"):
+        monkeypatch.setenv("GFPP_LP_BLOCK_TABLE", switch)
+        model = build_model(case, dev, "fused")
+        model.precision = precision
+        frames[switch] = product_render(model, case, dev, "oracle", oracle_mod)["rgb_map"].float().cpu().numpy().reshape(-1, 3)
+        blk = model.pipeline().head.pos_grid_blk
+        assert bool(blk.table) == (switch == "1")
+        err = np.abs(frames[switch] - ref).max(axis=1)
+        assert _psnr(frames[switch], ref) >= 45.0 and (err > 2e-2).mean() <= 5e-4, (switch, _psnr(frames[switch], ref), float(err.max()))
+    assert _psnr(frames["0"], frames["1"]) >= 45.0
+
+
 def test_autocast_selects_the_16bit_path(dev):
     """precision='auto' follows torch.autocast like nn.Linear does in the reference."""
     case = frame_case("may_head", 64)
