@@ -4,7 +4,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 r=$1
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -4 > gpurun_out/${r}_gpu_suite.log
+ulimit -c 0
+timeout 1500 python -X faulthandler -m pytest tests -q -x -m gpu > gpurun_out/${r}_gpu_suite_full.log 2>&1; grep -v '^  File "/usr' gpurun_out/${r}_gpu_suite_full.log | tail -25 > gpurun_out/${r}_gpu_suite.log
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${r}_bench_final.json 2> gpurun_out/${r}_bench_final.err
 timeout 300 python bench.py --variant may_torso_sr --hw 256 --precision fp16 --no-modes --no-configs --no-cpu-baseline --no-grid-stage > gpurun_out/${r}_bench_sr.json 2>/dev/null
 timeout 300 python bench.py --precision fp32 --steps 60 --no-modes --no-configs --no-cpu-baseline --no-grid-stage > gpurun_out/${r}_bench_fp32.json 2>/dev/null
@@ -15,8 +16,10 @@ if [ "$2" != "nopmc" ]; then
   bash tools/pmc_workload.sh ${r}_pmc_may_torso_512_bf16 may_torso 512 bf16 4
   bash tools/pmc_workload.sh ${r}_pmc_may_torso_sr_256_bf16 may_torso_sr 256 bf16 4
 fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${r}_smoke.log 2>&1; tail -1 gpurun_out/${r}_smoke.log
+for mode in amp ""; do timeout 300 python tools/profile_train.py 65536 6 $mode 2>&1 | tail -1; done > gpurun_out/${r}_train_steps.log
 timeout 120 python tools/sr_bench.py 200 random > gpurun_out/${r}_sr_bench_stage.log 2>&1
 timeout 120 python tools/clock_probe_sr.py > gpurun_out/${r}_clock_probe_sr.log 2>&1
 cat gpurun_out/${r}_gpu_suite.log; for f in final sr fp32; do python -c "
 import json; d=json.loads(open('gpurun_out/${r}_bench_$f.json').readlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'])"; done
-tail -1 gpurun_out/${r}_sr_bench_stage.log; tail -3 gpurun_out/${r}_clock_probe_sr.log
+cat gpurun_out/${r}_train_steps.log; tail -1 gpurun_out/${r}_sr_bench_stage.log; tail -3 gpurun_out/${r}_clock_probe_sr.log
