@@ -449,6 +449,18 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
+    // The level's index arithmetic resolved once per workgroup (what gfpp_grid_levels_fill does on the host for the frame kernels): the loop of get_grid_index
+    // (gridencoder.cu:66-83) keeps a dimension while stride <= size, and `index % size` is an AND for a power-of-two size and nothing at all where every index
+    // provably stays below the size.  grid_row per corner -- three multiplies, the dimension tests and a 32-bit modulo by a run-time value, eight times per point and
+    // level, in every one of a level's eight range workgroups -- was most of the kernel's ~200 instructions per point; hash-addressed / true-modulo levels keep it.
+    const uint32_t r1 = align_corners ? res : res + 1u;
+    uint32_t stride = 1, st[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (stride <= size) { st[d] = stride; stride *= r1; }
+    const bool pow2 = size != 0u && (size & (size - 1u)) == 0u, hashed = gridtype == 0u && stride > size, exact = stride <= size;
+    const bool slow = hashed || (!pow2 && (!exact || align_corners));
+    const uint32_t mask = pow2 ? size - 1u : 0xFFFFFFFFu;
     if (finite) {
         for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
             float pos[D], deriv[D];
@@ -457,17 +469,28 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
 #pragma unroll
             for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c] * to_fixed_a;   // (in flight together with the coordinates)
             if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
+            uint32_t base = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) base += pg[d] * st[d];
 #pragma unroll
             for (int idx = 0; idx < (1 << D); ++idx) {
-                float w = to_fixed_b;
-                uint32_t pl[D];
+                uint32_t r;
+                if (!slow) {                                       // workgroup-uniform
+                    uint32_t row = base;
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    if ((idx & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+                    for (int d = 0; d < D; ++d)
+                        if (idx & (1 << d)) row += st[d];
+                    r = (row & mask) - row0;                       // (wraps for rows below the range)
+                } else {
+                    uint32_t pl[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) pl[d] = pg[d] + ((idx >> d) & 1u);
+                    r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;
                 }
-                const uint32_t r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;   // (wraps for rows below the range)
                 if (r < nrows) {
+                    float w = to_fixed_b;                           // the corner's weight: the same products in the same order as before (same bits)
+#pragma unroll
+                    for (int d = 0; d < D; ++d) w *= (idx & (1 << d)) ? pos[d] : 1.0f - pos[d];
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         atomicAdd(reinterpret_cast<unsigned long long *>(&acc[r * C + c]), (unsigned long long)__float2ll_rn(w * gc[c]));
