@@ -225,6 +225,52 @@ __device__ __forceinline__ bool tr_locate(const float *__restrict__ in, float sc
     return true;
 }
 
+// A level's index arithmetic resolved once (what gfpp_grid_levels_fill does on the host for the frame kernels): the loop of get_grid_index (gridencoder.cu:66-83)
+// keeps a dimension while stride <= size, and `index % size` is an AND for a power-of-two size and nothing at all where every index provably stays below the size.
+// grid_row per corner -- three multiplies, the dimension tests and a 32-bit modulo by a run-time value, eight times per point and level -- was most of the training
+// kernels' per-point instructions; hash-addressed / true-modulo levels (slow) keep it.  Wave-uniform: the fields live in scalar registers.
+struct TrIndex {
+    uint32_t st[3], mask;
+    bool slow;
+};
+template <int D>
+__device__ __forceinline__ TrIndex tr_index(uint32_t size, uint32_t res, uint32_t gridtype, bool align_corners) {
+    TrIndex ix;
+    const uint32_t r1 = align_corners ? res : res + 1u;
+    uint32_t stride = 1;
+    ix.st[0] = ix.st[1] = ix.st[2] = 0u;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (stride <= size) { ix.st[d] = stride; stride *= r1; }
+    const bool pow2 = size != 0u && (size & (size - 1u)) == 0u, hashed = gridtype == 0u && stride > size, exact = stride <= size;
+    ix.slow = hashed || (!pow2 && (!exact || align_corners));
+    ix.mask = pow2 ? size - 1u : 0xFFFFFFFFu;
+    return ix;
+}
+template <int D>
+__device__ __forceinline__ uint32_t tr_base_row(const TrIndex &ix, const uint32_t (&pg)[D]) {
+    uint32_t base = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) base += pg[d] * ix.st[d];
+    return base;
+}
+// row of corner idx (bit d set: the +1 neighbour along d) of the cell at pg -- the value grid_row returns for it
+template <int D>
+__device__ __forceinline__ uint32_t tr_corner_row(const TrIndex &ix, uint32_t base, const uint32_t (&pg)[D], int idx, uint32_t gridtype, bool align_corners, uint32_t size,
+                                                  uint32_t res) {
+    if (!ix.slow) {
+        uint32_t row = base;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (idx & (1 << d)) row += ix.st[d];
+        return row & ix.mask;
+    }
+    uint32_t pl[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) pl[d] = pg[d] + ((idx >> d) & 1u);
+    return grid_row<D>(pl, gridtype, align_corners, size, res);
+}
+
 // dy_dx [B, L, D, C] (gridencoder.cu:198-243)
 template <int D, int C>
 __global__ __launch_bounds__(kTrBlock) void k_grid_dydx(const float *__restrict__ inputs, const float *__restrict__ table, const int32_t *__restrict__ offsets,
@@ -415,7 +461,15 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_grad_levelmax(const G *__rest
         const uint32_t other = (uint32_t)__shfl_xor((int)m, o);
         m = other > m ? other : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&out[level], m);
+    // one atomic per WORKGROUP: the levels' maxima share a cache line, and an atomic per wavefront (4 096 of them on one L2 line) was most of this kernel's 50 us
+    __shared__ uint32_t wave_max[kTrBlock / 64];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (uint32_t w = 1; w < kTrBlock / 64; ++w) m = wave_max[w] > m ? wave_max[w] : m;
+        if (m) atomicMax(&out[level], m);
+    }
 }
 
 template <int D, int C, typename G>
@@ -449,18 +503,7 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
-    // The level's index arithmetic resolved once per workgroup (what gfpp_grid_levels_fill does on the host for the frame kernels): the loop of get_grid_index
-    // (gridencoder.cu:66-83) keeps a dimension while stride <= size, and `index % size` is an AND for a power-of-two size and nothing at all where every index
-    // provably stays below the size.  grid_row per corner -- three multiplies, the dimension tests and a 32-bit modulo by a run-time value, eight times per point and
-    // level, in every one of a level's eight range workgroups -- was most of the kernel's ~200 instructions per point; hash-addressed / true-modulo levels keep it.
-    const uint32_t r1 = align_corners ? res : res + 1u;
-    uint32_t stride = 1, st[3] = {0u, 0u, 0u};
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (stride <= size) { st[d] = stride; stride *= r1; }
-    const bool pow2 = size != 0u && (size & (size - 1u)) == 0u, hashed = gridtype == 0u && stride > size, exact = stride <= size;
-    const bool slow = hashed || (!pow2 && (!exact || align_corners));
-    const uint32_t mask = pow2 ? size - 1u : 0xFFFFFFFFu;
+    const TrIndex ix = tr_index<D>(size, res, gridtype, align_corners);          // resolved once per workgroup
     if (finite) {
         for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
             float pos[D], deriv[D];
@@ -469,24 +512,10 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
 #pragma unroll
             for (int c = 0; c < C; ++c) gc[c] = (float)grad[((size_t)level * B + b) * C + c] * to_fixed_a;   // (in flight together with the coordinates)
             if (!tr_locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, pos, deriv, pg)) continue;
-            uint32_t base = 0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) base += pg[d] * st[d];
+            const uint32_t base = tr_base_row<D>(ix, pg);
 #pragma unroll
             for (int idx = 0; idx < (1 << D); ++idx) {
-                uint32_t r;
-                if (!slow) {                                       // workgroup-uniform
-                    uint32_t row = base;
-#pragma unroll
-                    for (int d = 0; d < D; ++d)
-                        if (idx & (1 << d)) row += st[d];
-                    r = (row & mask) - row0;                       // (wraps for rows below the range)
-                } else {
-                    uint32_t pl[D];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) pl[d] = pg[d] + ((idx >> d) & 1u);
-                    r = grid_row<D>(pl, gridtype, align_corners, size, res) - row0;
-                }
+                const uint32_t r = tr_corner_row<D>(ix, base, pg, idx, gridtype, align_corners, size, res) - row0;      // (wraps for rows below the range)
                 if (r < nrows) {
                     float w = to_fixed_b;                           // the corner's weight: the same products in the same order as before (same bits)
 #pragma unroll
@@ -540,12 +569,11 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_input_grad(const G *__restric
         const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
         const float *grid = table + (size_t)off * C;
         float v[1 << D][C];
+        const TrIndex ix = tr_index<D>(size, res, gridtype, align_corners);      // level-uniform (scalar registers)
+        const uint32_t base = tr_base_row<D>(ix, pg);
 #pragma unroll
         for (int idx = 0; idx < (1 << D); ++idx) {
-            uint32_t pl[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) pl[d] = pg[d] + ((idx >> d) & 1u);
-            const uint32_t row = grid_row<D>(pl, gridtype, align_corners, size, res);
+            const uint32_t row = tr_corner_row<D>(ix, base, pg, idx, gridtype, align_corners, size, res);
 #pragma unroll
             for (int c = 0; c < C; ++c) v[idx][c] = grid[(size_t)row * C + c];
         }
@@ -753,7 +781,7 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
         // per-level max |grad| -> the levels' fixed-point scales (kept behind the eight copies: the scratch has 64 spare words)
         uint32_t *levelmax = reinterpret_cast<uint32_t *>(xcd_copies + (size_t)kXcds * total_floats);
         if (hipMemsetAsync(levelmax, 0, 64 * sizeof(uint32_t), st) != hipSuccess) { set_error("%s: cannot clear the level maxima", who); return GFPP_EINVAL; }
-        hipLaunchKernelGGL((k_grid_grad_levelmax<G>), dim3(64, L), dim3(kTrBlock), 0, st, grad, B * (uint32_t)C, levelmax);
+        hipLaunchKernelGGL((k_grid_grad_levelmax<G>), dim3(32, L), dim3(kTrBlock), 0, st, grad, B * (uint32_t)C, levelmax);
         rc = check_launch(who);
         if (rc) return rc;
         // sum over levels of ceil(size C / V) <= total / V + L: workgroups beyond the actual ranges return at once
