@@ -294,15 +294,28 @@ static bool wt_pick(uint32_t to, uint32_t ti, const WgArgs &a, uint32_t slices, 
     return false;
 }
 
-// grad_weight (zeroed) += the slices, 32 per workgroup row
-constexpr uint32_t kWgReduceGroup = 32;
+// grad_weight = the sum of the slices, in a FIXED order (a quarter of the slices per wavefront in four chains, the quarters added through LDS): no atomics, no
+// zero fill in front of it, and the weight gradient of a step is reproducible bit for bit (round 4 added 32-slice groups into a cleared matrix with device atomics)
 __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float *__restrict__ partial, uint32_t slices, uint32_t n, float *__restrict__ gw) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const uint32_t w0 = blockIdx.y * kWgReduceGroup, w1 = w0 + kWgReduceGroup < slices ? w0 + kWgReduceGroup : slices;
-    float s = 0.0f;
-    for (uint32_t w = w0; w < w1; ++w) s += partial[(size_t)w * n + e];
-    atomicAdd(&gw[e], s);
+    __shared__ float part[4][64];
+    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const uint32_t e = blockIdx.x * 64u + lane;
+    const uint32_t per = (slices + 3u) / 4u, w0 = q * per < slices ? q * per : slices, w1 = w0 + per < slices ? w0 + per : slices;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (e < n) {
+        const float *p = partial + e;
+        uint32_t w = w0;
+        for (; w + 3u < w1; w += 4u) {
+            s0 += p[(size_t)w * n];
+            s1 += p[(size_t)(w + 1u) * n];
+            s2 += p[(size_t)(w + 2u) * n];
+            s3 += p[(size_t)(w + 3u) * n];
+        }
+        for (; w < w1; ++w) s0 += p[(size_t)w * n];
+    }
+    part[q][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && e < n) gw[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 }  // namespace gfpp
@@ -320,7 +333,6 @@ GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, ui
     if (a.TO > (uint32_t)kWgMaxTO || a.TI > (uint32_t)kWgMaxTI) { set_error("%s: built for out_features <= 256 and in_features <= 160 (got %u, %u)", who, O, I); return GFPP_EUNSUPPORTED; }
     const hipStream_t st = (hipStream_t)stream;
     if (((uintptr_t)grad_out | (uintptr_t)input) & 15u) { set_error("%s: grad_out and input must be 16-byte aligned", who); return GFPP_EINVAL; }
-    if (hipMemsetAsync(grad_weight, 0, (size_t)O * I * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear grad_weight", who); return GFPP_EINVAL; }
     // zero-padded half matrices (both widths multiples of 32, the fused MLP's): fragments by transposing LDS reads, one workgroup per CU (GFPP_WGRAD_TR=0: the
     // generic kernel, its A/B partner)
     static const bool tr_off = [] { const char *e = getenv("GFPP_WGRAD_TR"); return e && e[0] == '0'; }();
@@ -334,6 +346,6 @@ GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, ui
     else hipLaunchKernelGGL(k_linear_wgrad<float>, dim3(slices), dim3(kWgThreads), 0, st, a);
     int rc = check_launch(who);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3(div_up(O * I, 256), div_up(slices, kWgReduceGroup)), dim3(256), 0, st, partial, slices, O * I, grad_weight);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3(div_up(O * I, 64)), dim3(256), 0, st, partial, slices, O * I, grad_weight);
     return check_launch(who);
 }
