@@ -53,3 +53,26 @@ def test_conditioning_descriptor_points_at_the_parameters_in_gradient_order():
         fake = [0x1000 * (i + 1) for i in range(len(plist))]
         gm = fill(fake)
         assert gm.conv_w[0] == fake[0] and gm.att_fc_b == fake[-1] and ctypes.sizeof(gm) == ctypes.sizeof(cm)
+
+
+def test_swap23_row_order_makes_operand_quads_natural_feature_order():
+    """The layout invariant csrc/train_mlp_fused.hip is built on (lp_mfma_device.h's 32x32x16 conventions): after a layer, lane (j, h) holds in acc[t][r] the MFMA row
+    32 t + (r & 3) + 8 (r >> 2) + 4 h of column j, and packs acc[s >> 1][8 (s & 1) + e] into operand (step s, element e).  With the weight image putting MFMA row i of
+    tile t on feature 32 t + swap23(i), that operand element IS feature 16 s + 8 h + e: an operand register quad = 16 contiguous bytes of a row-major [M, features] matrix."""
+    swap23 = lambda i: (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+    assert sorted(swap23(i) for i in range(32)) == list(range(32))
+    for s in range(8):
+        for h in range(2):
+            for e in range(8):
+                t, r = s >> 1, 8 * (s & 1) + e
+                mfma_row = (r & 3) + 8 * (r >> 2) + 4 * h                # row of tile t this lane's acc[t][r] holds
+                assert 32 * t + swap23(mfma_row) == 16 * s + 8 * h + e
+    # and the transposing-read kernel's pitch rule: the 8 rows x 64 bytes one ds_read_b64_tr_b16 instruction touches fall into distinct banks
+    for C in (32, 64, 96, 128, 160):
+        pitch = C * 2 + 64 if (C * 2) % 128 == 0 else C * 2
+        assert pitch % 256 in (64, 192) and pitch % 16 == 0
+        banks = set()
+        for row in list(range(4)) + list(range(8, 12)):
+            for word in range(16):                                       # 64 bytes = 16 banks per row
+                banks.add(((row * pitch) // 4 + word) % 64)
+        assert len(banks) == 64
