@@ -116,7 +116,7 @@ def main():
     from genefaceplusplus_amd.configs import may_hparams
     from genefaceplusplus_amd.radnerfs import camera
     from genefaceplusplus_amd import radnerfs, frames
-    from tests.helpers import CLASSES
+    from genefaceplusplus_amd.configs import CLASSES
 
     if args.identities > 1:
         return run_identities(args, rank, world, dev, dinfo)

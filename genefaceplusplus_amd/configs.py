@@ -74,6 +74,10 @@ _AUDIO = {"cond_type": "esperanto", "cond_win_size": 16, "smo_win_size": 8, "amb
 _VARIANTS["audio_head"] = dict(_AUDIO)
 _VARIANTS["audio_torso"] = dict(_AUDIO)
 
+#: model class (genefaceplusplus_amd.radnerfs.<name> = the reference's modules.radnerfs class of the same name) of each variant
+CLASSES = {"may_head": "RADNeRF", "may_torso": "RADNeRFTorso", "may_torso_sr": "RADNeRFTorsowithSR", "may_head_sr": "RADNeRFwithSR",
+           "audio_head": "RADNeRF", "audio_torso": "RADNeRFTorso"}
+
 #: reference yaml each variant was derived from (relative to the reference root)
 VARIANT_YAML = {
     "may_head": "egs/datasets/May/lm3d_radnerf.yaml",

@@ -3,6 +3,7 @@ from .head import NeRFRenderer, RADNeRF
 from .torso import RADNeRFTorso, RADNeRFTorsowithSR, RADNeRFwithSR
 from .cond_nets import AudioNet, AudioAttNet, MLP
 from .encoders import GridEncoder, SHEncoder, FreqEncoder, get_encoder
+from ..configs import CLASSES
 
 _RUNTIME_HPARAMS = {}
 

@@ -224,6 +224,21 @@ def synthetic_frame_inputs(hp, frame_idx=0, seed=0):
     return {"cond": cond, "lm68": lm68, "eye_area_percent": eye}
 
 
+#: the state-dict family a variant's parameters follow (synthetic_state_dict's own variant switch)
+SD_FAMILY = {"audio_head": "may_head", "audio_torso": "may_torso"}
+
+
+def frame_case(variant, HW, frame_idx=0, hp_over=None, **sd_kw):
+    """One synthetic model + one frame of driving inputs as numpy arrays: what the parity tests hand to the CPU oracle and to the product alike."""
+    hp = may_hparams(variant)
+    hp.update(hp_over or {})
+    sd = synthetic_state_dict(hp, SD_FAMILY.get(variant, variant), **sd_kw)
+    fi = synthetic_frame_inputs(hp, frame_idx)
+    pose = synthetic_pose(frame_idx)[None]
+    return {"variant": variant, "hp": hp, "sd": sd, "HW": HW, "pose": pose, "intr": intrinsics_for(HW, HW), **fi,
+            "bg_color": np.full((1, HW * HW, 3), 0.5, np.float32), "T_thresh": 0.01}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # super-resolution net of the *_sr models (radnerf_sr.py:14-43): same key names / shapes / dtypes as the reference's
 # Superresolution(channels=3).state_dict(), deterministic values.  Kept apart from synthetic_state_dict so that the NeRF
@@ -326,3 +341,36 @@ def read_checkpoint(work_dir_or_file, model_name="model", steps=None):
     else:
         sd = sd[model_name]
     return sd, path
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compact state files: a state_dict as one .npz whose grid tables / occupancy grids are stored as float16
+# (tools/make_trained_checkpoint.py rounds those arrays to float16-representable values BEFORE its final evaluation, so the
+# file is lossless for them) -- the form in which the trained procedural field travels as a test fixture (tests/golden/trained/)
+# ---------------------------------------------------------------------------------------------------------------------
+COMPACT_F16_SUFFIXES = (".embeddings", "density_grid", "density_grid_torso", ".noise_const", "individual_embeddings", "torso_individual_codes")
+
+
+def compact_f16_key(key):
+    return key.endswith(COMPACT_F16_SUFFIXES)
+
+
+def save_compact_state(path, state_dict):
+    """state_dict (tensors or arrays) -> np.savez_compressed; keys of COMPACT_F16_SUFFIXES as float16 (must already be representable)."""
+    import torch
+    arrs = {}
+    for k, v in state_dict.items():
+        a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        if compact_f16_key(k) and a.dtype == np.float32:
+            h = a.astype(np.float16)
+            if not np.array_equal(h.astype(f32), a):
+                raise ValueError(f"save_compact_state: {k} is not float16-representable (round it before the final evaluation)")
+            a = h
+        arrs[k] = a
+    np.savez_compressed(path, **arrs)
+
+
+def load_compact_state(path):
+    """-> {key: numpy array} with the float16-stored arrays widened back to float32 (exact)."""
+    with np.load(path) as z:
+        return {k: (z[k].astype(f32) if z[k].dtype == np.float16 else z[k]) for k in z.files}

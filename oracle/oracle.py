@@ -817,3 +817,16 @@ def freq_encode_backward(grad, outputs, D, degree):
         s = D + 2 * D * k
         res = res + f32(2.0 ** k) * (g[:, s:s + D] * o[:, s + D:s + 2 * D] - g[:, s + D:s + 2 * D] * o[:, s:s + D])
     return res.astype(f32)
+
+
+def render_case(case, trace=None):
+    """A whole frame of a test case (genefaceplusplus_amd.synthetic.frame_case and its relatives: variant, hp, sd, HW, pose, intr, cond, lm68,
+    eye_area_percent, bg_color, T_thresh) through render_head / render_torso, rays from this module's get_rays."""
+    hp, sd, HW = case["hp"], case["sd"], case["HW"]
+    rays = get_rays(case["pose"], case["intr"], HW, HW)
+    kw = dict(bg_color=case["bg_color"], dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=case["T_thresh"],
+              eye_area_percent=case["eye_area_percent"], trace=trace)
+    if case["variant"] in ("may_head", "may_head_sr", "audio_head"):
+        return render_head(rays["rays_o"], rays["rays_d"], case["cond"], sd, hp, **kw)
+    return render_torso(rays["rays_o"], rays["rays_d"], case["cond"], get_bg_coords(HW, HW), convert_poses(case["pose"]),
+                        sd, hp, lm68=case["lm68"], sr_variant=(case["variant"] == "may_torso_sr"), **kw)

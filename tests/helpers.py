@@ -1,25 +1,47 @@
 """Shared scaffolding for frame-level parity tests: one synthetic May-shaped model + one frame of driving inputs,
 rendered by the CPU oracle and by the product on the GPU from identical numpy arrays."""
+import os
+
 import numpy as np
 import torch
 
 from genefaceplusplus_amd import synthetic as syn
-from genefaceplusplus_amd.configs import may_hparams
+from genefaceplusplus_amd.configs import may_hparams, CLASSES
 
-CLASSES = {"may_head": "RADNeRF", "may_torso": "RADNeRFTorso", "may_torso_sr": "RADNeRFTorsowithSR", "may_head_sr": "RADNeRFwithSR",
-           "audio_head": "RADNeRF", "audio_torso": "RADNeRFTorso"}
-# the state-dict family a variant's parameters follow (synthetic_state_dict's own variant switch)
-SD_FAMILY = {"audio_head": "may_head", "audio_torso": "may_torso"}
+from genefaceplusplus_amd.synthetic import frame_case, SD_FAMILY      # noqa: F401  (the case builder lives with the other synthetic inputs)
 
 
-def frame_case(variant, HW, frame_idx=0, hp_over=None, **sd_kw):
+TRAINED_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained")
+_TRAINED_CLIP = {}
+
+
+def trained_case(variant, HW, frame_idx=7):
+    """A frame of the TRAINED procedural field (tools/make_trained_checkpoint.py -> tests/golden/trained/<torso variant>.npz, fit curves in fit_log.json beside
+    it): the package's own training path fitted the May architecture to genefaceplusplus_amd.procedural.ProceduralClip; this is that checkpoint with the
+    clip's own driving signals and background for frame `frame_idx` (7 = a held-out frame).  Head-only variants take the head part of the torso file."""
+    from genefaceplusplus_amd.procedural import ProceduralClip, head_only_state
+    sr = variant.endswith("_sr")
+    torso_variant = "may_torso_sr" if sr else "may_torso"
+    sd = syn.load_compact_state(os.path.join(TRAINED_DIR, torso_variant + ".npz"))
     hp = may_hparams(variant)
-    hp.update(hp_over or {})
-    sd = syn.synthetic_state_dict(hp, SD_FAMILY.get(variant, variant), **sd_kw)
-    fi = syn.synthetic_frame_inputs(hp, frame_idx)
-    pose = syn.synthetic_pose(frame_idx)[None]
-    return {"variant": variant, "hp": hp, "sd": sd, "HW": HW, "pose": pose, "intr": syn.intrinsics_for(HW, HW), **fi,
-            "bg_color": np.full((1, HW * HW, 3), 0.5, np.float32), "T_thresh": 0.01}
+    head_only = variant.startswith("may_head")
+    if head_only:
+        sd = head_only_state(sd)
+        hp["eye_blink_dim"] = may_hparams(torso_variant).get("eye_blink_dim", hp.get("eye_blink_dim"))      # the head a torso model was built on (see the tool)
+        if sr:
+            sd["lambda_ambient"] = np.array([1.0], np.float32)
+    clip = _TRAINED_CLIP.setdefault(256, ProceduralClip(T=256, seed=0))
+    k = frame_idx
+    bg = clip.background_image(HW).numpy()
+    if head_only:        # the head stage's background is the torso layer over the static background (tasks/radnerfs/radnerf.py:117)
+        rows = torch.arange(HW) / (HW - 1) * 2 - 1
+        vv, uu = torch.meshgrid(rows, rows, indexing="ij")
+        trgb, ta = clip.torso(k, uu.reshape(-1), vv.reshape(-1))
+        bg = (trgb * ta[:, None] + torch.from_numpy(bg[0]) * (1 - ta[:, None])).numpy()[None]
+    return {"variant": variant, "hp": hp, "sd": sd, "HW": HW, "pose": clip.ngp_poses[k:k + 1].copy(), "intr": syn.intrinsics_for(HW, HW),
+            "cond": clip.cond_window(k, hp["smo_win_size"]).numpy(), "lm68": clip.lm68s[k].reshape(-1).numpy(),
+            "eye_area_percent": clip.eye_area_percents[k].reshape(1, 1).numpy(), "bg_color": np.ascontiguousarray(bg, np.float32), "T_thresh": 0.01,
+            "clip": clip, "frame_idx": k}
 
 
 def nonconvex_occupancy(case, kind, seed=7):
@@ -72,14 +94,7 @@ def pose_at(distance=4.0, yaw_deg=0.0, shift=(0.0, 0.0, 0.0), away=False):
 
 
 def oracle_render(orc, case, trace=None):
-    hp, sd, HW = case["hp"], case["sd"], case["HW"]
-    rays = orc.get_rays(case["pose"], case["intr"], HW, HW)
-    kw = dict(bg_color=case["bg_color"], dt_gamma=hp["dt_gamma"], max_steps=hp["max_steps"], T_thresh=case["T_thresh"],
-              eye_area_percent=case["eye_area_percent"], trace=trace)
-    if case["variant"] in ("may_head", "may_head_sr", "audio_head"):
-        return orc.render_head(rays["rays_o"], rays["rays_d"], case["cond"], sd, hp, **kw)
-    return orc.render_torso(rays["rays_o"], rays["rays_d"], case["cond"], orc.get_bg_coords(HW, HW), orc.convert_poses(case["pose"]),
-                            sd, hp, lm68=case["lm68"], sr_variant=(case["variant"] == "may_torso_sr"), **kw)
+    return orc.render_case(case, trace=trace)
 
 
 def build_model(case, device, executor):
@@ -87,7 +102,8 @@ def build_model(case, device, executor):
     model = getattr(radnerfs, CLASSES[case["variant"]])(case["hp"])
     sd = dict(case["sd"])
     if hasattr(model, "sr_net"):
-        sd.update(syn.synthetic_sr_state())           # sr_net.* with the reference's layout (tests/golden/sr_state_manifest.json)
+        for k, v in syn.synthetic_sr_state().items():  # sr_net.* with the reference's layout (tests/golden/sr_state_manifest.json) unless the case brings its own
+            sd.setdefault(k, v)
     model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(device).eval()
     model.executor = executor

@@ -38,15 +38,15 @@ def cpu_baseline(variant, hw_sample=512, hw_full=512):
     import numpy as np
     from threadpoolctl import threadpool_limits
     from oracle import oracle as orc
-    from tests.helpers import frame_case, oracle_render
+    from genefaceplusplus_amd.synthetic import frame_case
     orc.build()
     with threadpool_limits(limits=threads):
         case = frame_case(variant, 64)
-        oracle_render(orc, case)                                  # warm-up (page in tables, spin up thread pools)
+        orc.render_case(case)                                  # warm-up (page in tables, spin up thread pools)
         case = frame_case(variant, hw_sample)
         t0 = time.perf_counter()
         trace = []
-        oracle_render(orc, case, trace=trace)
+        orc.render_case(case, trace=trace)
         dt = time.perf_counter() - t0
     scale = (hw_full / hw_sample) ** 2
     return {"value": round(1.0 / (dt * scale), 4), "unit": "frames/s", "cores": threads, "kind": "port",
@@ -152,7 +152,7 @@ def run_identities(args, rank, world, dev, dinfo=None):
     from genefaceplusplus_amd import synthetic as syn, radnerfs, frames
     from genefaceplusplus_amd.configs import may_hparams
     from genefaceplusplus_amd.clip import ClipRenderer
-    from tests.helpers import CLASSES
+    from genefaceplusplus_amd.configs import CLASSES
 
     n_id, HW, K, W = args.identities, args.hw, args.steps, args.warmup
     hp = may_hparams(args.variant)
@@ -251,7 +251,7 @@ def run_ray_tiles(args, rank, world, dev, dinfo=None):
     from genefaceplusplus_amd import synthetic as syn, radnerfs, frames
     from genefaceplusplus_amd.configs import may_hparams
     from genefaceplusplus_amd.radnerfs import camera
-    from tests.helpers import CLASSES
+    from genefaceplusplus_amd.configs import CLASSES
     HW, K, W = args.hw, args.steps, args.warmup
     hp = may_hparams(args.variant)
     sd = syn.synthetic_state_dict(hp, args.variant)
@@ -306,7 +306,7 @@ def build(ctx):
     from genefaceplusplus_amd.radnerfs import camera
     from genefaceplusplus_amd import radnerfs, frames
     from genefaceplusplus_amd.clip import ClipRenderer
-    from tests.helpers import CLASSES
+    from genefaceplusplus_amd.configs import CLASSES
     args, dev, world, rank = ctx.args, ctx.dev, ctx.world, ctx.rank
     model, hp, inputs, render = ctx.model, ctx.hp, ctx.inputs, ctx.render
     HW, HWO, N, K, W = ctx.HW, ctx.HWO, ctx.N, ctx.K, ctx.W
