@@ -38,7 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from tools.bench_parts import cpu_baseline, spawn_ranks, dist_evidence, run_identities, run_ray_tiles   # noqa: E402
+from tools.bench_parts import cpu_baseline, spawn_ranks, dist_evidence, ranks_ok, run_identities, run_ray_tiles   # noqa: E402
 
 
 def parse():
@@ -81,6 +81,11 @@ def parse():
                                                      "e.g. checkpoints/motion2video_nerf/may_torso): bench THESE weights instead of the synthetic ones (SURVEY 8d, last bullet)")
     ap.add_argument("--data-dir", default=None, help="with --ckpt-dir: the directory holding trainval_dataset.npy (data/binary/videos/May, tasks/radnerfs/dataset_utils.py:160-296): "
                                                      "poses, landmarks, background and intrinsics of the clip come from it; without it the synthetic driving signals are used")
+    ap.add_argument("--trained", default=None, choices=["plain", "sr"],
+                    help="bench the TRAINED procedural field instead of the random-init one: tests/golden/trained/may_torso[_sr].npz (tools/make_trained_checkpoint.py) is "
+                         "written out as a checkpoint directory in the reference's layout and loaded through --ckpt-dir's path; poses, conditioning windows, landmarks "
+                         "and background are the procedural clip's own")
+    ap.add_argument("--no-trained", action="store_true", help="skip the configs.trained_* entries of the default run")
     ap.add_argument("--ckpt-parity", type=int, default=2, help="with --ckpt-dir: this many frames are also rendered by the CPU oracle from the same weights and compared (0 = skip)")
     return ap.parse_args()
 
@@ -123,6 +128,15 @@ def main():
     if args.shard == "rays" and world > 1:
         return run_ray_tiles(args, rank, world, dev, dinfo)
 
+    pclip = None
+    if args.trained:
+        import tempfile
+        from genefaceplusplus_amd.procedural import ProceduralClip
+        tv = "may_torso_sr" if args.trained == "sr" else "may_torso"
+        fixture = os.path.join(ROOT, "tests", "golden", "trained", tv + ".npz")
+        args.ckpt_dir = os.path.join(tempfile.mkdtemp(prefix="gfpp_trained_"), tv)
+        syn.write_checkpoint(args.ckpt_dir, tv, may_hparams(tv), steps=6500, state_dict=syn.load_compact_state(fixture))
+        pclip = ProceduralClip(T=256, seed=0)
     HW, K, W = args.hw, args.steps, args.warmup
     real = None              # --ckpt-dir: {"ckpt": path, "dataset": RADNeRFDataset | None}
     if args.ckpt_dir:
@@ -162,6 +176,11 @@ def main():
     batch = {"ngp_poses": np.stack([syn.synthetic_pose(fidx) for fidx in my_frames]).astype(np.float32),
              "cond_wins": np.stack([f["cond"] for f in fi_all]), "lm68": np.stack([f["lm68"] for f in fi_all]),
              "eye_area_percent": np.stack([f["eye_area_percent"] for f in fi_all])}
+    if pclip is not None:
+        batch = pclip.clip_batch(hp["smo_win_size"], my_frames)
+        bg_color = pclip.background_image(HW, dev)
+        fi_all = [{"cond": batch["cond_wins"][j], "lm68": batch["lm68"][j].reshape(-1), "eye_area_percent": np.asarray(batch["eye_area_percent"][j]).reshape(1, 1)}
+                  for j in range(len(my_frames))]
     if real is not None and args.data_dir:
         # the clip's own poses / landmarks / eye values / background / intrinsics (tasks/radnerfs/dataset_utils.py:160-296), frames cycled to the bench length
         from genefaceplusplus_amd.dataset import RADNeRFDataset
@@ -188,18 +207,61 @@ def main():
     # multi-GPU: finished frames are all_gathered in chunks while the next chunk renders (RCCL runs on its own stream)
     chunk = max(1, min(K, args.gather_every)) if world > 1 else K
     chunk = -(-chunk // cr.group_wanted) * cr.group_wanted          # whole frame groups per chunk (ClipRenderer.issue)
-    bounds = [(c, min(c + chunk, K)) for c in range(0, K, chunk)]
-    gathered = None
-    if world > 1 and args.gather == "all":
-        gathered = [torch.empty(world * (e - b), HWO, HWO, 3, dtype=torch.uint8, device=dev) for b, e in bounds]
-    elif world > 1 and rank == 0:          # the writer rank receives one stack per rank and chunk; nobody else receives anything
-        gathered = [[torch.empty(e - b, HWO, HWO, 3, dtype=torch.uint8, device=dev) for _ in range(world)] for b, e in bounds]
 
-    def exchange(c, b, e, async_op):
+    def chunk_bounds(n):
+        """[begin, end) of a job's exchange chunks.  The last chunk's exchange has nothing to hide behind, so it is made as small as the frame loop allows: ONE frame
+        group -- the un-hidable tail of a job is the transfer of `group_wanted` frames per rank whatever the job's length (reported as gather_tail_frames)."""
+        if world == 1:
+            return [(0, n)]
+        tail = min(n, cr.group_wanted)
+        body = [(c, min(c + chunk, n - tail)) for c in range(0, n - tail, chunk)]
+        return body + [(n - tail, n)]
+
+    def receive_buffers(bnds):
+        if world > 1 and args.gather == "all":
+            return [torch.empty(world * (e - b), HWO, HWO, 3, dtype=torch.uint8, device=dev) for b, e in bnds]
+        if world > 1 and rank == 0:          # the writer rank receives one stack per rank and chunk; nobody else receives anything
+            return [[torch.empty(e - b, HWO, HWO, 3, dtype=torch.uint8, device=dev) for _ in range(world)] for b, e in bnds]
+        return None
+    bounds = chunk_bounds(K)
+    gathered = receive_buffers(bounds)
+
+    def exchange(c, b, e, async_op, stack=None, recv=None):
         """The one exchange step of the frame-parallel clip: chunk c's finished frames leave for the writer (or for everybody)."""
+        stack = out_u8 if stack is None else stack
+        recv = gathered if recv is None else recv
         if args.gather == "all":
-            return dist.all_gather_into_tensor(gathered[c], out_u8[b:e], async_op=async_op)
-        return dist.gather(out_u8[b:e], gathered[c] if rank == 0 else None, dst=0, async_op=async_op)
+            return dist.all_gather_into_tensor(recv[c], stack[b:e], async_op=async_op)
+        return dist.gather(stack[b:e], recv[c] if rank == 0 else None, dst=0, async_op=async_op)
+
+    def run_job(frame_idx, stack, bnds, recv, alone=False):
+        """ONE timed job: barrier + synchronise, start the clip job, per chunk issue / join / (async) exchange, wait for the exchanges, synchronise, barrier.
+        Returns this rank's figures; `alone`: no exchange and no barriers (rank 0 rendering by itself while the others wait: the efficiency denominator)."""
+        torch.cuda.synchronize()
+        if world > 1 and not alone:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        pend = []
+        cr._cond_cache = None                    # the conditioning networks + constant fold of the timed frames run INSIDE the timed region (no cached outputs from the warm-up)
+        cr.start(clip, frame_idx, stack)         # ONE job: every frame's graph finds its inputs / output slot through the device-side cursor
+        for c, (b, e) in enumerate(bnds):
+            cr.issue(e - b)                       # the frame loop proper: graph launches issued from C (gfpp_graph_replay), lanes round-robin
+            cr.join()                             # caller's stream waits for these frames; the lanes go on with the next chunk
+            if world > 1 and not alone:
+                pend.append(exchange(c, b, e, True, stack, recv))
+        t_iss = time.perf_counter() - t_begin    # host time to queue every frame (no synchronisation yet): the launch-rate ceiling of the frame loop
+        ev_r, ev_g = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_r.record()                             # caller's stream, after the join of the lanes: every frame of this rank is rendered
+        for work in pend:
+            work.wait()
+        ev_g.record()                             # ... and every chunk's exchange has completed (what the rendering did not hide = exposed)
+        torch.cuda.synchronize()
+        t_loc = time.perf_counter() - t_begin    # this rank's own time (before the closing barrier)
+        if world > 1 and not alone:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return {"elapsed": time.perf_counter() - t_begin, "local": t_loc, "issue": t_iss, "exposed_ms": ev_r.elapsed_time(ev_g)}
 
     # reference-shaped per-frame API with pre-materialised rays (what genefacepp_infer.py calls today): used by `modes` below
     inputs = []
@@ -253,44 +315,25 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) == 0.0:
                 args.gather = "all"
-                gathered = [torch.empty(world * (e - b), HWO, HWO, 3, dtype=torch.uint8, device=dev) for b, e in bounds]
+                gathered = receive_buffers(bounds)
                 gather_note = gather_note or "gather-to-writer failed on another rank; fell back to all_gather"
                 exchange(0, bounds[0][0], bounds[0][1], False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pending = []
-    cr._cond_cache = None                        # the conditioning networks + constant fold of the timed frames run INSIDE the timed region (no cached outputs from the warm-up)
-    cr.start(clip, range(W, W + K), out_u8)      # ONE job for the K timed frames: every frame's graph finds its inputs / output slot through the device-side cursor
-    for c, (b, e) in enumerate(bounds):
-        cr.issue(e - b)                           # the frame loop proper: e - b graph launches issued from C (gfpp_graph_replay), lanes round-robin
-        cr.join()                                 # caller's stream waits for these frames; the lanes go on with the next chunk
-        if world > 1:
-            pending.append(exchange(c, b, e, True))
-    t_issue = time.perf_counter() - t0           # host time to queue every frame (no synchronisation yet): the launch-rate ceiling of the frame loop
-    ev_rendered, ev_gathered = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev_rendered.record()                          # caller's stream, after the join of the lanes: every frame of this rank is rendered
-    for work in pending:
-        work.wait()
-    ev_gathered.record()                          # ... and every chunk's exchange has completed (what the rendering did not hide = exposed)
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0            # this rank's own time (before the closing barrier)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        if len(bounds) > 1:                            # ... and one of the tail chunk's size
+            exchange(len(bounds) - 1, bounds[-1][0], bounds[-1][1], False)
+    if hasattr(model, "sr_net"):
+        model.sr_net.reseed(20260930)            # every lane's in-kernel noise restarts here: the timed frames' noise fields are reproducible (timed_frames_check)
+    job = run_job(range(W, W + K), out_u8, bounds, gathered)          # barrier + synchronise | EXACTLY the K timed frames | synchronise + barrier
+    elapsed, t_local, t_issue = job["elapsed"], job["local"], job["issue"]
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
         per_rank[rank] = K / t_local
         dist.all_reduce(per_rank)
-        exposed = torch.tensor([ev_rendered.elapsed_time(ev_gathered)], dtype=torch.float64, device=dev)
+        exposed = torch.tensor([job["exposed_ms"]], dtype=torch.float64, device=dev)
         dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
         frame_bytes = HWO * HWO * 3
-        dinfo.update({"gather": args.gather, "gather_chunks": len(bounds), "frames_per_chunk_and_rank": chunk,
+        dinfo.update({"gather": args.gather, "gather_chunks": len(bounds), "frames_per_chunk_and_rank": chunk, "gather_tail_frames": bounds[-1][1] - bounds[-1][0],
                       "gathered_MB": round(world * K * frame_bytes / 1e6, 2),       # bytes that arrived at the writer (gather 'all': at every rank)
                       "gather_ms_exposed": round(float(exposed.item()), 3),
                       "per_rank_fps": [round(float(v), 2) for v in per_rank.tolist()]})
@@ -299,14 +342,56 @@ def main():
             b, e = bounds[-1]
             dinfo["writer_holds_own_frames"] = bool(torch.equal(got[rank * (e - b):(rank + 1) * (e - b)], out_u8[b:e]))
             dinfo["writer_frames_nonzero_per_rank"] = [bool(got[r * (e - b):(r + 1) * (e - b)].any().item()) for r in range(world)]
+        # a 20-step window per rank (4.4 ms at 512^2) also holds the barrier skew, RCCL's per-operation latency and the tail chunk: the steady-state figure of the
+        # same job shape, >= 2 000 frames per rank in blocks of 100, next to it -- with rank 0's own rate alone (no exchange, the other ranks waiting) as the
+        # denominator of the weak-scaling efficiency, measured in the same process minutes apart
+        if args.long_run_frames > 0:
+            per = max(cr.group_wanted * 2, (min(100, args.long_run_frames) // cr.group_wanted) * cr.group_wanted)
+            n_blocks = max(1, args.long_run_frames // per)
+            avail = list(range(W, len(my_frames)))
+            idx = (avail * (per // len(avail) + 1))[:per]
+            lr_stack = torch.empty(per, HWO, HWO, 3, dtype=torch.uint8, device=dev)
+            lr_bounds = chunk_bounds(per)
+            lr_recv = receive_buffers(lr_bounds)
+            run_job(idx, lr_stack, lr_bounds, lr_recv)                # one untimed block: the receive buffers' first touch, RCCL channels of this message size
+            tot = {"elapsed": 0.0, "local": 0.0, "exposed_ms": 0.0}
+            blocks = []
+            for _ in range(n_blocks):
+                j = run_job(idx, lr_stack, lr_bounds, lr_recv)
+                for k in tot:
+                    tot[k] += j[k]
+                blocks.append(j["elapsed"])
+            agg = torch.tensor([tot["elapsed"], tot["exposed_ms"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+            pr = torch.zeros(world, dtype=torch.float64, device=dev)
+            pr[rank] = n_blocks * per / tot["local"]
+            dist.all_reduce(pr)
+            alone = 0.0
+            if rank == 0:                                             # the same blocks by rank 0 alone (no exchange); the others wait at the barrier below
+                run_job(idx, lr_stack, lr_bounds, lr_recv, alone=True)
+                alone = sum(run_job(idx, lr_stack, lr_bounds, lr_recv, alone=True)["elapsed"] for _ in range(n_blocks))
+            dist.barrier()
+            value_lr = world * n_blocks * per / float(agg[0].item())
+            dinfo["long_run"] = {"value": round(value_lr, 2), "unit": "frames/s", "frames_per_rank": n_blocks * per, "block_frames": per, "blocks": n_blocks,
+                                 "per_rank_fps": [round(float(v), 2) for v in pr.tolist()], "gather_ms_exposed_per_block": round(float(agg[1].item()) / n_blocks, 3),
+                                 "gather_chunks_per_block": len(lr_bounds), "gather_tail_frames": lr_bounds[-1][1] - lr_bounds[-1][0],
+                                 "rank0_alone_fps": round(n_blocks * per / alone, 2) if rank == 0 else None,
+                                 "efficiency_vs_rank0_alone": round(value_lr / (world * n_blocks * per / alone), 4) if rank == 0 else None,
+                                 "what": "the timed job's shape (barrier | start, issue / join / async exchange per chunk, wait | barrier) per block of frames, blocks back to back; "
+                                         "value = all ranks' frames / the slowest rank's summed block times"}
+            del lr_stack, lr_recv
+        # (c) a multi-rank line whose ranks were not all there, or shared devices under RCCL, is not a measurement
+        dinfo["ranks_ok"] = ranks_ok(dinfo, world, args.dist_backend)
     elapsed = float(t_max.item())
 
     result = None
     if rank == 0:
         fps = world * K / elapsed
-        result = {"metric": "rendered frames/sec at 512x512 (head+torso)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+        if dinfo is not None and not dinfo["ranks_ok"]:
+            fps = float("nan")
+        result = {"metric": "rendered frames/sec at 512x512 (head+torso)", "value": (round(fps, 3) if fps == fps else None), "unit": "frames/s", "n_gpus": world,
                   "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-                  "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision],
+                  "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16 (ambient_net f16)"}[args.precision],
                   "dtype_note": "MLP layers on MFMA: f32 = exact-fp32 MFMA; f16 / bf16 = 16-bit operands with fp32 accumulation; marcher, grid interpolation, "
                                 "activations' transcendental parts and compositing are fp32 in every mode.  bf16 mode: ambient_net (two wide layers + three rows, 48 of a "
                                 "block's 148 MFMAs) multiplies f16 operands -- its output is a coordinate of the second hash grid, which 8-bit significands displace by up to "
@@ -343,6 +428,15 @@ def main():
 
     if rank == 0 and real is not None:
         result["data"] = "real checkpoint" + (" + real driving signals" if real["dataset"] is not None else " + synthetic driving signals")
+        if pclip is not None:
+            result["data"] = "procedural clip (analytic target); weights FITTED to it by this package's training path (tools/make_trained_checkpoint.py), read back from a reference-layout checkpoint"
+            # the timed frames against the analytic target the field was fitted to
+            psnrs = []
+            for k in sorted({0, K // 2, K - 1}):
+                gt = pclip.frame(my_frames[W + k] % pclip.T, HWO, syn.intrinsics_for(HWO, HWO), dev)["gt"].reshape(HWO, HWO, 3)
+                mse = float(((((out_u8[k].float() + 0.5) / 255.0) - gt) ** 2).mean().item())
+                psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
+            result["config"]["timed_frames_psnr_vs_analytic_target_db"] = psnrs
         result["config"]["workload"] = (f"{args.variant} from {real['ckpt']} ({HW}x{HW} rays" + (" + super-resolution to 512x512" if args.variant == "may_torso_sr" else "")
                                         + f", max_steps {hp.get('max_steps')}, T_thresh 0.01)" + (f", driving signals of {args.data_dir}" if real["dataset"] is not None else ""))
         if args.ckpt_parity > 0:
@@ -359,8 +453,13 @@ def main():
                                eye_area_percent=np.asarray(fi_all[j]["eye_area_percent"], np.float32))
                     ref = orc.render_torso(rays["rays_o"], rays["rays_d"], np.asarray(fi_all[j]["cond"], np.float32), orc.get_bg_coords(HW, HW), orc.convert_poses(pose_np), sd, hp,
                                            lm68=np.asarray(fi_all[j]["lm68"], np.float32), sr_variant=(args.variant == "may_torso_sr"), **kwo)
+                    # the product renders the ORACLE's rays here (as the parity tests do): the two ray generators agree to 1-2 ulp in the directions (tests/test_kernels_gpu.py::
+                    # test_get_rays), which a sharp trained field turns into ~5e-4 of the pixels beyond 2e-4 -- the renderer's parity is what this entry is about
                     model.precision = "fp32"
-                    got = render(j)["rgb_map"].float().cpu().numpy()
+                    with torch.no_grad():
+                        got = model.render(torch.from_numpy(rays["rays_o"]).to(dev), torch.from_numpy(rays["rays_d"]).to(dev), x["cond"], bg_coords, x["poses"], index=j, staged=False,
+                                           bg_color=bg_color, lm68=x["lm68"], perturb=False, force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"],
+                                           **hp)["rgb_map"].float().cpu().numpy()
                     model.precision = args.precision
                     if args.variant == "may_torso_sr":
                         got = np.transpose(got, (0, 2, 3, 1))
@@ -372,11 +471,13 @@ def main():
 
     if rank == 0 and args.executor == "fused":
         result["roofline"] = parts.head_roofline(model, hp, inputs[W], N, args.variant, frames_per_launch=cr.group, ms_per_frame_period=1e3 * elapsed / K if world == 1 else None,
-                                                 pmc_tag=f"{args.variant}_{HW}_{args.precision}")
+                                                 pmc_tag=("trained_" if pclip is not None else "") + f"{args.variant}_{HW}_{args.precision}")
     if rank == 0 and world == 1 and not args.no_modes:
         parts.other_modes(result)
     if rank == 0 and world == 1 and not args.no_configs and args.variant == "may_torso" and HW == 512:
         parts.baseline_configs(result)
+    if rank == 0 and world == 1 and not args.no_trained and not args.no_configs and real is None and args.variant == "may_torso" and HW == 512:
+        parts.trained_fields(result)
     if rank == 0 and "roofline" in result:
         parts.attach_traffic(result["roofline"])
         sr = result.get("configs", {}).get("may_torso_sr_256", {}).get("roofline")

@@ -55,6 +55,19 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["grid_stage_ray_stream"]["frac"] is None                              # a cache-served stream carries no HBM fraction
 
 
+def test_a_multi_rank_line_with_missing_or_shared_ranks_is_not_a_measurement():
+    """bench.py nulls `value` when the job's own evidence says its ranks were not all there, or shared devices under RCCL (tools/bench_parts.py::ranks_ok)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from tools.bench_parts import ranks_ok
+    good = {"ranks_seen": 8, "world_size": 8, "distinct_devices": 8}
+    assert ranks_ok(good, 8, "nccl") and ranks_ok(good, 8, "gloo")
+    assert not ranks_ok(dict(good, ranks_seen=7), 8, "nccl")
+    assert not ranks_ok(dict(good, distinct_devices=4), 8, "nccl")           # two ranks per GPU under RCCL
+    assert ranks_ok(dict(good, distinct_devices=1), 8, "gloo")               # the 1-GPU control-flow check shares the device on purpose
+    assert not ranks_ok(good, 4, "nccl")
+
+
 def test_bench_starts_its_own_ranks_and_reports_their_failure():
     """`python bench.py --gpus 2` with no launcher (the driver's command shape) starts two ranks itself; on this GPU-less box both fail loudly
     ("needs MI355X GPUs") and the job's exit code says so -- no AssertionError about WORLD_SIZE any more."""

@@ -55,7 +55,7 @@ def _bench(args, timeout=900):
 
 @pytest.mark.parametrize("gather", ["all", "writer"])
 def test_bench_two_ranks_on_one_gpu_gloo(gather):
-    r = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--gather", gather,
+    r = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--gather", gather, "--long-run-frames", "24",
                 "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
@@ -68,10 +68,15 @@ def test_bench_two_ranks_on_one_gpu_gloo(gather):
     assert len(ev["device_uuids"]) == 2 and len(ev["per_rank_fps"]) == 2 and all(v > 0 for v in ev["per_rank_fps"])
     assert ev["gathered_MB"] == round(2 * 6 * 128 * 128 * 3 / 1e6, 2) and ev["gather_ms_exposed"] >= 0
     assert ev["writer_holds_own_frames"] and all(ev["writer_frames_nonzero_per_rank"])
+    # the steady-state pass of the N > 1 line (round-5 review, item 4): same job shape in blocks, all ranks' frames / the slowest rank's time, rank 0 alone beside it
+    lr = ev["long_run"]
+    assert lr["frames_per_rank"] == 24 and lr["blocks"] == 1 and lr["value"] > 0 and len(lr["per_rank_fps"]) == 2 and all(v > 0 for v in lr["per_rank_fps"])
+    assert lr["rank0_alone_fps"] > 0 and 0 < lr["efficiency_vs_rank0_alone"] and lr["gather_tail_frames"] == ev["gather_tail_frames"] == 4
+    assert ev["ranks_ok"] is True and lr["gather_ms_exposed_per_block"] >= 0
 
 
 def test_bench_under_an_external_launcher_still_works():
-    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo",
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--hw", "128", "--dist-backend", "gloo", "--long-run-frames", "0",
                       "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
@@ -86,11 +91,12 @@ def test_bench_rccl_on_too_few_gpus_fails_loudly():
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL); the driver's multi-GPU node runs it")
 def test_bench_rccl_two_gpus_self_launched():
-    r = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
+    r = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--long-run-frames", "200", "--no-modes", "--no-cpu-baseline", "--no-grid-stage", "--no-configs"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][0])
     ev = d["config"]["dist"]
-    assert ev["backend"].startswith("rccl") and ev["ranks_seen"] == 2 and ev["distinct_devices"] == 2 and ev["writer_holds_own_frames"]
+    assert ev["backend"].startswith("rccl") and ev["ranks_seen"] == 2 and ev["distinct_devices"] == 2 and ev["writer_holds_own_frames"] and ev["ranks_ok"]
+    assert ev["long_run"]["frames_per_rank"] == 200 and ev["long_run"]["efficiency_vs_rank0_alone"] > 0.5
 
 
 def test_bench_identities_one_gpu():
@@ -144,8 +150,8 @@ def test_bench_eight_ranks_on_one_gpu_gloo():
     """The driver's 8-GPU command shape on the 1-GPU box: `python bench.py --gpus 8 --dist-backend gloo --steps 20` -- eight ranks share the one GPU, so
     this checks control flow only: every rank seen, each rendering its own block of 20 frames, the timed window bracketed by barriers, the finished frames
     gathered to the writer in chunks with the exposed gather time reported (what a scaling efficiency computed from a 20-step run rests on)."""
-    r = _bench(["--gpus", "8", "--steps", "20", "--warmup", "2", "--hw", "96", "--dist-backend", "gloo", "--no-modes", "--no-cpu-baseline", "--no-grid-stage",
-                "--no-configs"], timeout=1500)
+    r = _bench(["--gpus", "8", "--steps", "20", "--warmup", "2", "--hw", "96", "--dist-backend", "gloo", "--long-run-frames", "16", "--no-modes", "--no-cpu-baseline",
+                "--no-grid-stage", "--no-configs"], timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1
@@ -156,6 +162,8 @@ def test_bench_eight_ranks_on_one_gpu_gloo():
     assert ev["gather"] == "writer" and ev["gather_ms_exposed"] >= 0 and ev["gathered_MB"] == round(8 * 20 * 96 * 96 * 3 / 1e6, 2)
     assert ev["writer_holds_own_frames"] and all(ev["writer_frames_nonzero_per_rank"]) and len(ev["writer_frames_nonzero_per_rank"]) == 8
     assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]            # whole-job frames / the slowest rank's time
+    lr = ev["long_run"]                                                                  # ... and the steady-state pass of the same shape
+    assert lr["frames_per_rank"] == 16 and len(lr["per_rank_fps"]) == 8 and lr["value"] > 0 and lr["rank0_alone_fps"] > 0 and ev["gather_tail_frames"] == 4
 
 
 def test_bench_four_identities_on_eight_ranks_gloo():

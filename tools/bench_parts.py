@@ -138,6 +138,13 @@ def dist_evidence(dev, backend):
             "device_index_per_rank": [x["device"] for x in seen], "device_name": props.name}
 
 
+def ranks_ok(dinfo, world, backend):
+    """Is a multi-rank line a measurement at all?  Every rank must have been counted by the job's own all_reduce, and under RCCL ('nccl') every rank must sit on
+    a device of its own (ranks sharing a GPU -- a mis-set LOCAL_RANK, a node with fewer devices -- would time N copies of a fraction of one GPU).  A line that
+    fails this carries `value: null` (bench.py)."""
+    return bool(dinfo.get("ranks_seen") == world and dinfo.get("world_size") == world and (backend != "nccl" or dinfo.get("distinct_devices") == world))
+
+
 def run_identities(args, rank, world, dev, dinfo=None):
     """BASELINE configs[4]: several person-specific models at once (4 identities on 8 GPUs, 2 GPUs each), shared audio2motion.
 
@@ -339,9 +346,38 @@ def build(ctx):
             for k in picks:
                 timed = out_u8[k]
                 spread.append(float(timed.float().std().item()))
-                if sr_variant:
-                    continue
                 x = frame_input(W + k)
+                if sr_variant:
+                    # the in-kernel noise of a frame is a function of (seed, lane, launches of that lane since the reseed): bench.py reseeded every lane right before the
+                    # timed job, frame k was launch (g // L) * G + k % G of lane g % L (g = k // G) -- the per-frame API on that lane with the counter put there draws
+                    # the same field, so the BYTES must agree (round-5 review, Missing 5)
+                    G, L = cr.group, cr.lanes
+                    g = k // G
+                    sr = model.sr_net
+                    state = sr._packed["ws"][g % L][1]["rng_state"]
+                    keep, graph = state.clone(), model.use_graph
+                    try:
+                        state[0], state[1] = (g // L) * G + k % G, 0
+                        sr.lane, model.use_graph = g % L, False
+                        model.precision = args.precision
+                        with torch.no_grad():
+                            res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=0, staged=False, bg_color=bg_color, lm68=x["lm68"], perturb=False,
+                                               force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
+                        u8 = torch.empty(HWO, HWO, 3, dtype=torch.uint8, device=dev)
+                        frames.to_uint8_hwc(res["sr_rgb_map"].permute(0, 2, 3, 1).reshape(HWO, HWO, 3).float().contiguous(), u8)
+                        equal.append(bool(torch.equal(u8, timed)))
+                        model.precision = "fp32"
+                        state[0], state[1] = (g // L) * G + k % G, 0
+                        with torch.no_grad():
+                            res = model.render(x["rays_o"], x["rays_d"], x["cond"], bg_coords, x["poses"], index=0, staged=False, bg_color=bg_color, lm68=x["lm68"], perturb=False,
+                                               force_all_rays=False, T_thresh=0.01, eye_area_percent=x["eye"], **hp)
+                        ref32 = res["sr_rgb_map"].permute(0, 2, 3, 1).reshape(HWO, HWO, 3).float()
+                        mse = float((((timed.float() + 0.5) / 255.0 - ref32) ** 2).mean().item())
+                        psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
+                    finally:
+                        state.copy_(keep)
+                        sr.lane, model.use_graph = 0, graph
+                    continue
                 model.precision = args.precision
                 u8 = torch.empty(HW, HW, 3, dtype=torch.uint8, device=dev)
                 frames.to_uint8_hwc(api_frame(x), u8)
@@ -357,8 +393,11 @@ def build(ctx):
             check.update({"frames_checked": [W + k for k in picks], "bytes_equal_per_frame_api": (all(equal) if equal else None), "psnr_vs_fp32_mode_db": psnrs,
                           "uint8_std_per_frame": [round(v, 2) for v in spread], "psnr_bar_db": bar,
                           "what": "timed frames (output stack of the timed job) vs model.render() on the same inputs: bytes; vs the exact-fp32 mode: PSNR"
-                                  + (" -- *_sr model: fresh SR noise per launch, only the frames' spread is checked" if sr_variant else "")})
-            check["ok"] = bool(all(v > 5.0 for v in spread) and (sr_variant or (all(equal) and all(p >= bar for p in psnrs))))
+                                  + (" -- *_sr model: the in-kernel noise of each checked frame reproduced from (seed, lane, launch counter)" if sr_variant else "")})
+            if sr_variant:
+                bar = 38.0         # the SR stage amplifies the 16-bit rounding of its 256^2 input through four random-weight layers; its own f16 activations are common to both
+                check["psnr_bar_db"] = bar
+            check["ok"] = bool(all(v > 5.0 for v in spread) and all(equal) and all(p >= bar for p in psnrs))
         except Exception as exc:
             check["error"] = f"{type(exc).__name__}: {exc}"
         result["config"]["timed_frames_check"] = check
@@ -539,7 +578,7 @@ def build(ctx):
         rocprofv3 --pmc runs), or None: ratios are quoted from measurements of the same workload or not at all."""
         if not tag:
             return None
-        for rnd in ("r05", "r04"):                # the newest committed pass of this workload (the r04 passes belong to round 4's kernels and say so in `source`)
+        for rnd in ("r06", "r05", "r04"):                # the newest committed pass of this workload (the r04 passes belong to round 4's kernels and say so in `source`)
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.json")
             if os.path.exists(path):
                 try:
@@ -788,6 +827,68 @@ def build(ctx):
             cfgs["crop64_cpu_oracle"] = {"error": str(exc)}
         result["configs"] = cfgs
 
+    # ---- the TRAINED procedural field (tests/golden/trained/, tools/make_trained_checkpoint.py): the same frame loop on weights that are not random -----------
+    def trained_fields(result):
+        """Both fitted checkpoints (512^2 RADNeRFTorso; 256^2 + SR RADNeRFTorsowithSR) through the clip renderer with the procedural clip's own driving signals and
+        background: frames/s, the head launch's roofline, samples per frame and the PSNR of rendered frames against the ANALYTIC target the field was fitted to."""
+        from genefaceplusplus_amd.procedural import ProceduralClip
+        cfgs = result.setdefault("configs", {})
+        pclip = ProceduralClip(T=256, seed=0)
+        for tv, hw in (("may_torso", 512), ("may_torso_sr", 256)):
+            key = f"trained_{tv}_{hw}"
+            try:
+                path = os.path.join(ROOT, "tests", "golden", "trained", tv + ".npz")
+                if not os.path.exists(path):
+                    cfgs[key] = {"error": "fixture missing: " + os.path.relpath(path, ROOT)}
+                    continue
+                hp_t = may_hparams(tv)
+                m_t = getattr(radnerfs, CLASSES[tv])(hp_t)
+                m_t.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.load_compact_state(path).items()}, strict=True)
+                m_t = m_t.to(dev).eval()
+                m_t.precision, m_t.use_graph, m_t.executor = args.precision, model.use_graph, args.executor
+                n_t = 128
+                batch_t = pclip.clip_batch(hp_t["smo_win_size"], range(n_t))
+                intr_t = syn.intrinsics_for(hw, hw)
+                bg_t = pclip.background_image(hw, dev)
+                cr_t = ClipRenderer(m_t, hw, hw, intr_t, bg_img=bg_t, T_thresh=0.01, use_graph=model.use_graph, lanes=args.lanes)
+                clip_t = cr_t.prepare(batch_t, dev)
+                hwo = cr_t.out_hw[0]
+                stack = torch.empty(n_t, hwo, hwo, 3, dtype=torch.uint8, device=dev)
+                if hasattr(m_t, "sr_net"):
+                    m_t.sr_net.reseed(1234)
+                cr_t.render_to_device(clip_t, range(4), out=stack[:4])
+                torch.cuda.synchronize()
+                dt = None
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    cr_t.render_to_device(clip_t, out=stack)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                # rendered frames against the analytic target (uint8 bytes de-quantised at the middle of their step)
+                psnrs = []
+                for k in (7, 63, 127):
+                    gt = pclip.frame(k, hwo, syn.intrinsics_for(hwo, hwo), dev)["gt"].reshape(hwo, hwo, 3)
+                    mse = float(((((stack[k].float() + 0.5) / 255.0) - gt) ** 2).mean().item())
+                    psnrs.append(round(10.0 * float(np.log10(1.0 / max(mse, 1e-20))), 2))
+                pose_t = torch.from_numpy(batch_t["ngp_poses"][7]).to(dev)[None]
+                rays_t = camera.get_rays(pose_t, intr_t, hw, hw)
+                x_t = {"rays_o": rays_t["rays_o"], "rays_d": rays_t["rays_d"], "cond": torch.from_numpy(batch_t["cond_wins"][7]).to(dev),
+                       "eye": torch.from_numpy(batch_t["eye_area_percent"][7]).to(dev)}
+                cfgs[key] = {"workload": f"{tv} FITTED to the procedural talking-head clip by the package's own training path (tools/make_trained_checkpoint.py; fixture "
+                                         f"tests/golden/trained/{tv}.npz), {hw}x{hw} rays" + (" + super-resolution to 512x512" if hwo != hw else "")
+                                         + ", the clip's own poses / landmark conditioning / background, same frame loop as the headline",
+                             "value": round(n_t / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_t, 4), "steps": n_t, "precision": args.precision,
+                             "frames_in_flight": cr_t.lanes, "frames_per_graph_launch": cr_t.group,
+                             "psnr_vs_analytic_target_db": psnrs, "psnr_frames": [7, 63, 127],
+                             "torso_mask_share": round(float((m_t.density_grid_torso > 0).float().mean().item()), 4),
+                             "occupied_cells": int(np.unpackbits(m_t.density_bitfield.cpu().numpy()).sum()),
+                             "roofline": head_roofline(m_t, hp_t, x_t, hw * hw, tv, frames_per_launch=cr_t.group, ms_per_frame_period=1e3 * dt / n_t,
+                                                       pmc_tag=f"trained_{tv}_{hw}_{args.precision}")}
+                attach_traffic(cfgs[key]["roofline"])
+                del cr_t, m_t
+            except Exception as exc:
+                cfgs[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- HBM-side traffic of the dominant launch: from the committed rocprofv3 --pmc pass of this same workload and precision, or null --------
     def attach_traffic(roof):
         pmc = roof.get("pmc")
@@ -855,5 +956,5 @@ def build(ctx):
         if real.shape[0] > 0:
             result["grid_stage_ray_stream"] = grid_entry(real, "occupied samples of one frame in ray order (what the renderer feeds the grid)", cache_served=True)
 
-    return types.SimpleNamespace(timed_frames_check=timed_frames_check, head_roofline=head_roofline, load_pmc=load_pmc, other_modes=other_modes,
+    return types.SimpleNamespace(trained_fields=trained_fields, timed_frames_check=timed_frames_check, head_roofline=head_roofline, load_pmc=load_pmc, other_modes=other_modes,
                                  baseline_configs=baseline_configs, attach_traffic=attach_traffic, grid_stage=grid_stage)
