@@ -25,7 +25,7 @@ def _library_path():
 
 
 LIB_PATH = _library_path()
-ABI_VERSION = 7          # include/gfpp_radnerf.h GFPP_ABI_VERSION (7: gfpp_torso_fold_batch / gfpp_torso_group_lp, f16 ambient_net steps inside the bf16 image; 6: corner-block grid copies, frame groups, sticky barrier word; 5: gfpp_head_model.occ_aabb; 4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
+ABI_VERSION = 8          # include/gfpp_radnerf.h GFPP_ABI_VERSION (7: gfpp_torso_fold_batch / gfpp_torso_group_lp, f16 ambient_net steps inside the bf16 image; 6: corner-block grid copies, frame groups, sticky barrier word; 5: gfpp_head_model.occ_aabb; 4: gfpp_frame_ws.counters [192], .snapshots, the persistent 16-bit launch)
 _lib = None
 
 c_u32 = ctypes.c_uint32
@@ -38,6 +38,8 @@ _SIGNATURES = {
     "gfpp_abi_version": [],
     "gfpp_last_error": [],
     "gfpp_struct_size": [ctypes.c_char_p],
+    "gfpp_set_tuning": [c_p],
+    "gfpp_get_tuning": [c_p],
     "gfpp_near_far_from_aabb": [c_p, c_p, c_p, c_u32, c_f, c_p, c_p, c_p],
     "gfpp_morton3D": [c_p, c_u32, c_p, c_p],
     "gfpp_morton3D_invert": [c_p, c_u32, c_p, c_p],
@@ -112,7 +114,21 @@ def lib():
         if got != ABI_VERSION:
             raise GfppError(f"libgfpp_radnerf.so ABI version {got}, expected {ABI_VERSION} (rebuild: make -C genefaceplusplus_amd/csrc)")
         _lib = handle
+        push_tuning()
     return _lib
+
+
+def push_tuning():
+    """Hand tuning.LIB to the loaded library (gfpp_set_tuning); a library that is not loaded yet gets it when it loads."""
+    if _lib is None:
+        return
+    from . import tuning
+    check_struct("tuning", tuning.GfppTuning)
+    rec = tuning.record()
+    rc = _lib.gfpp_set_tuning(ctypes.byref(rec))
+    if rc != 0:
+        msg = _lib.gfpp_last_error()
+        raise GfppError(f"gfpp_set_tuning failed (code {rc}): {msg.decode() if msg else ''}")
 
 
 def check_struct(name, mirror):

@@ -22,7 +22,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, frames
+from . import _lib, frames, tuning
 from ._lib import GfppError, call
 from .radnerfs import camera
 from .radnerfs.frame_pipeline import GraphedFrame, shared_stream
@@ -105,7 +105,7 @@ class ClipRenderer:
                        "stream": shared_stream(dev, "lane", _i) if self.lanes > 1 else None,
                        "graph": None, "key": None, "static_in": None} for _i in range(self.lanes)]
         if group is None:
-            group = int(os.environ.get("GFPP_CLIP_GROUP", "0")) or 4
+            group = tuning.HOST["clip_group"]
         self.group_wanted = max(1, min(int(group), 4)) if fused else 1
         self.group = 1                                       # what the captured graphs render with (decided with the first clip: _ensure_graphs)
         self.ring = max(2, int(ring), self.lanes)
@@ -321,7 +321,7 @@ class ClipRenderer:
         return self
 
     #: conditioning features of all frames in one launch at the start of a job instead of 16 dependent layers inside every frame (GFPP_CLIP_PRECOND=0: per frame)
-    precompute_cond = os.environ.get("GFPP_CLIP_PRECOND", "1") != "0"
+    precompute_cond = tuning.HOST["clip_precond"]
 
     def _with_cond_features(self, clip):
         """The clip with one more field per row: the 256 per-frame constants the head pass gets from the frame's conditioning window (cal_cond_feat +
@@ -368,8 +368,8 @@ class ClipRenderer:
 
     #: (the SR stage's random noise is drawn inside its kernels since round 3: no graph of this renderer uses torch's generator, so every graph can be
     #: launched from C -- torch's own replay() would only add the generator bookkeeping)
-    replay_mode = os.environ.get("GFPP_CLIP_REPLAY", "c")        # 'c' | 'python' (experiments)
-    max_ahead = int(os.environ.get("GFPP_CLIP_MAX_AHEAD", "0"))   # frames per lane the issuing thread may queue ahead of the GPU (0: no limit)
+    replay_mode = tuning.HOST["clip_replay"]        # 'c' | 'python' (experiments)
+    max_ahead = tuning.HOST["clip_max_ahead"]   # frames per lane the issuing thread may queue ahead of the GPU (0: no limit)
 
     def _replay_from_c(self):
         return self.replay_mode == "c" and self.use_graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")

@@ -674,8 +674,7 @@ GFPP_API int gfpp_head_frame_trips(const gfpp_head_model *model, const gfpp_fram
         a.alive_in = ws->alive[trip & 1];
         a.alive_out = ws->alive[(trip + 1) & 1];
         const uint32_t g = ws->full_grid_trips && trip >= ws->full_grid_trips ? late_grid : grid;
-        const char *pool_env = getenv("GFPP_TRIP_POOL");   // 0 = the tile-per-wavefront kernel (A/B runs)
-        if (pool_env && atoi(pool_env) == 0) {
+        if (!tuning().trip_pool) {                          // gfpp_tuning.trip_pool = 0: the tile-per-wavefront kernel (A/B runs)
             if (model->amb_grid.D == 3) hipLaunchKernelGGL(k_head_trip_w<3>, dim3(g), dim3(kThreads), 0, st, a);
             else hipLaunchKernelGGL(k_head_trip_w<2>, dim3(g), dim3(kThreads), 0, st, a);
         } else {

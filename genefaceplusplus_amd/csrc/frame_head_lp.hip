@@ -143,7 +143,6 @@ struct LpTripArgs {
     uint32_t n_tiles, tile_mult;        // ownership tiles of kPTile rays; tile of slot q = (q * tile_mult) % n_tiles
     uint32_t xcd_cols8;                 // != 0: XCD-local ownership (gfpp_frame_ws.row_rays): tile columns per image row / 8; tile_mult then permutes the n_tiles / 8 tiles of ONE XCD
     uint32_t step_caps;                 // 4 bits per round (rounds >= 7 use the last): upper bound of the local n_step
-    uint32_t stagger;                   // persistent launch: the second wavefront of every SIMD starts a round's blocks this many x 1 024 cycles late
     uint32_t spin_limit;                // multi-trip launches: polls of the barrier word before a workgroup gives up and poisons it (GFPP_BARRIER_SPINS, tests)
     float *dbg_ambient;                 // per-sample evaluation entry only (k_head_eval_lp): tanh(ambient_net) of compact sample c -> [c * AMB_D ...]
     unsigned long long *phase_cycles;   // optional [trips][8] (k_head_trip_pool<PROF>): cycles summed over wavefronts by phase, see there
@@ -906,11 +905,8 @@ __global__ __launch_bounds__(kLpThreads, kLpThreads / 256) void k_head_frame_per
         __syncthreads();
         lap(1);
 
-        // phase 2: the pooled 32-sample blocks, dealt out round-robin.  The two wavefronts of a SIMD (w and w + 4) leave the barrier together and would
-        // walk the block's phases in step -- both gathering, then both on the matrix pipe; the second one starts a fraction of a block later so that
-        // one's gathers run under the other's MFMA layers (it never has more blocks than the first, so the round does not get longer)
-        if (wave >= 4)
-            for (uint32_t k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+        // phase 2: the pooled 32-sample blocks, dealt out round-robin (a start offset between the two wavefronts of a SIMD was measured in round 5 and dropped:
+        // docs/LAB_NOTEBOOK.md, "Fine stagger")
         if constexpr (F32) {
             PoolViewF32 view{pool.px, pool.py, pool.pz, pool.px, pool.py, pool.pz, pool.cb, pool.order, total,
                              {&pool, a.rays_d}, {&pool, a.rays_d + 1}, {&pool, a.rays_d + 2}};
@@ -1228,18 +1224,13 @@ static bool lp_block_grid_ok(const gfpp_grid_desc &b, const gfpp_grid_desc &g) {
            b.dtype == GFPP_F16 && b.row_padded == 2u;
 }
 
-// How many trips get a launch of their own before the multi-trip launch takes over (GFPP_LP_SEPARATE_TRIPS overrides, for experiments).
+// How many trips get a launch of their own before the multi-trip launch takes over (gfpp_tuning.lp_separate_trips overrides, for experiments).
 // 5: with the shipped schedule (n_step 1, 2, 2, 2, 4, 8 against max_steps 16) trip 5 uses up the step budget, so the multi-trip launch that
 // starts with it runs that trip and returns without a barrier -- no launch is spent on finding nothing left (6 would: +4 us per frame).
 // Frames that go on pay a device-wide barrier (~17 us) per further trip instead of a launch (~9 us).
 static uint32_t lp_separate_trips() {
-    static int n = -1;
-    if (n < 0) {
-        const char *e = getenv("GFPP_LP_SEPARATE_TRIPS");
-        n = e ? atoi(e) : 5;
-        if (n < 0) n = 0;
-    }
-    return (uint32_t)n;
+    const int n = tuning().lp_separate_trips;
+    return n < 0 ? 5u : (uint32_t)n;
 }
 
 static int lp_cu_count() {
@@ -1314,8 +1305,7 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
 }
 
 static void premarch_occupancy(PremarchArgs &p, const gfpp_head_model *model) {
-    const char *e = getenv("GFPP_OCC_CLIP");          // A/B switch (0 = off), read at every issue (a captured graph keeps what it was captured with)
-    const uint32_t mode = e && atoi(e) == 0 ? 0u : 1u;
+    const uint32_t mode = tuning().occ_clip ? 1u : 0u;          // A/B switch, read at every issue (a captured graph keeps what it was captured with)
     p.occ_valid = 0u;
     for (int i = 0; i < 6; ++i) p.occ[i] = model->occ_aabb[i];
     if (model->occ_aabb[3] > model->occ_aabb[0] && model->occ_aabb[4] > model->occ_aabb[1] && model->occ_aabb[5] > model->occ_aabb[2]) p.occ_valid = mode;
@@ -1422,7 +1412,7 @@ GFPP_API int gfpp_head_frame_trips_lp(const gfpp_head_model *model, const gfpp_f
     a.sync = ws->counters + 127;
     a.timeouts = ws->timeouts;
     a.spin_limit = 1u << 22;
-    if (const char *e = getenv("GFPP_BARRIER_SPINS")) { const long v = atol(e); if (v > 0) a.spin_limit = (uint32_t)v; }   // (tests force a timeout)
+    if (tuning().barrier_spins) a.spin_limit = tuning().barrier_spins;   // (tests force a timeout)
     // the first trips one launch each; everything after (rarely reached: the frame-wide n_step doubles as rays die) as one multi-trip launch
     const uint32_t want_separate = ws->separate_trips ? ws->separate_trips : lp_separate_trips();
     // a ray tile of a shared frame: the caller all-reduces the alive counts between trips, so every trip is a launch of its own
@@ -1457,26 +1447,15 @@ static void launch_persist(uint32_t grid, hipStream_t st, const LpTripArgs &a) {
     else hipLaunchKernelGGL((k_head_frame_persist<AMB_D, H, SLOW, false>), dim3(grid), dim3(kLpThreads), 0, st, pa);
 }
 
-// upper bounds of the local n_step by workgroup round, 4 bits each (GFPP_PERSIST_CAPS="2,2,2,4,8" overrides, experiments).  The take is
+// upper bounds of the local n_step by workgroup round, 4 bits each (gfpp_tuning.persist_caps overrides, experiments).  The take is
 // min(128 / rays per wavefront, cap): at 512^2 a workgroup holds ~440 occupied rays and the pool limits it to 2 whatever the cap; the cap matters for
 // small shares (256^2: ~110 rays per workgroup), where every round costs a whole block time however few blocks it has -- 4,4,4,8 needs 4 rounds
 // instead of 5 there (head pass 0.133 -> 0.122 ms, 1 % more samples evaluated behind rays' ends); 8,8 evaluates 11 % more for nothing
 static uint32_t persist_step_caps() {
-    static uint32_t caps = 0;
-    if (caps == 0) {
-        uint32_t v[8] = {4, 4, 4, 8, 8, 8, 8, 8};
-        if (const char *e = getenv("GFPP_PERSIST_CAPS")) {
-            int k = 0;
-            for (const char *p = e; *p && k < 8; ++k) {
-                const int x = atoi(p);
-                v[k] = (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x));
-                while (*p && *p != ',') ++p;
-                if (*p == ',') ++p;
-            }
-            for (; k > 0 && k < 8; ++k) v[k] = v[k - 1];
-        }
-        for (int k = 0; k < 8; ++k) caps |= v[k] << (4 * k);
-    }
+    if (tuning().persist_caps) return tuning().persist_caps;
+    const uint32_t v[8] = {4, 4, 4, 8, 8, 8, 8, 8};
+    uint32_t caps = 0;
+    for (int k = 0; k < 8; ++k) caps |= v[k] << (4 * k);
     return caps;
 }
 
@@ -1511,19 +1490,17 @@ static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model
     // q -> (q * mult) % n_tiles is a permutation of the tiles when gcd(mult, n_tiles) = 1: consecutive slots land ~1237 tiles apart, so that every
     // workgroup's share (slots b, b + G, ...) is spread over the whole image (equal work without any exchange between workgroups)
     uint32_t grid = (uint32_t)lp_cu_count();
-    if (const char *e = getenv("GFPP_PERSIST_GRID")) { const int v = atoi(e); if (v > 0) grid = (uint32_t)v; }   // experiments: more workgroups than CUs = smaller shares, dealt out as CUs free up
     if (grid > a.n_tiles) grid = a.n_tiles;
     // XCD-local ownership (k_head_frame_persist): needs the pixel order of the rays (row_rays), whole tile columns in eights, one workgroup per CU on whole XCDs,
     // and enough columns per XCD for the comb to balance (8 at 512^2: busiest workgroup 2 % above the mean like before; 4 at 256^2: 12 % instead of 5 %, CPU model in
     // tests/test_persist_budget_cpu.py -- not taken there)
     a.xcd_cols8 = 0u;
     {
-        int mode = -1;          // (read at every issue: a captured graph keeps what it was captured with)
+        const int mode = tuning().persist_xcd;          // (read at every issue: a captured graph keeps what it was captured with)
         // measured (round 5, 512^2 bf16, four frames per launch, same box): L2 hit rate 80.0 -> 84.4 %, fabric traffic 2.03 -> 1.61 GB per launch, the launch itself
         // +-0 (808 vs 810-821 us) and the clip loop 1 % slower (4 511-4 515 vs 4 554-4 557 frames/s: the comb's workgroup shares are a little less even) -- the kernel is
         // bound by issue and gather LATENCY, and the misses that remain are the ambient grid's, whose coordinates are an MLP output (no image locality to keep): off by
-        // default, GFPP_PERSIST_XCD=1 turns it on (2: also with four tile columns per XCD, the 256^2 frames)
-        if (mode < 0) { const char *e = getenv("GFPP_PERSIST_XCD"); mode = e ? atoi(e) : 0; }
+        // default, gfpp_tuning.persist_xcd = 1 turns it on (2: also with four tile columns per XCD, the 256^2 frames)
         const uint32_t W = ws->row_rays;
         if (mode != 0 && W != 0u && W % 64u == 0u && W / 64u >= (mode >= 2 ? 1u : 8u) && ws->N % W == 0u && grid % 8u == 0u && grid == (uint32_t)lp_cu_count() &&
             a.n_tiles / 8u >= grid)
@@ -1535,8 +1512,6 @@ static uint32_t persist_control_args(LpTripArgs &a, const gfpp_head_model *model
         if (nt % m != 0u && (unsigned long long)nt * m < (1ull << 32)) { a.tile_mult = m; break; }
     a.step_caps = persist_step_caps();
     a.spin_limit = 0;
-    a.stagger = 0;
-    if (const char *e = getenv("GFPP_PERSIST_STAGGER")) { const int v = atoi(e); if (v > 0 && v < 64) a.stagger = (uint32_t)v; }
     return grid;
 }
 
@@ -1626,8 +1601,6 @@ GFPP_API int gfpp_head_eval_samples_lp(const gfpp_head_model *model, const gfpp_
     const uint32_t cus = (uint32_t)lp_cu_count();
     if (grid > cus) grid = cus;
     e.waves = kLpWaves;
-    if (const char *g = getenv("GFPP_EVAL_GRID")) { const int v = atoi(g); if (v > 0 && (uint32_t)v < grid) grid = (uint32_t)v; }     // occupancy experiments (tools/eval_bench.py)
-    if (const char *w = getenv("GFPP_EVAL_WAVES")) { const int v = atoi(w); if (v > 0 && v < kLpWaves) e.waves = (uint32_t)v; }
     const bool bf = model->lp_dtype == GFPP_BF16, slow = (a.pos.any_slow | a.amb.any_slow) != 0, amb3 = model->amb_grid.D == 3;
     void (*launch)(uint32_t, hipStream_t, const LpEvalArgs &) =
         amb3 ? (bf ? (slow ? launch_eval_lp<3, __bf16, true> : launch_eval_lp<3, __bf16, false>) : (slow ? launch_eval_lp<3, _Float16, true> : launch_eval_lp<3, _Float16, false>))

@@ -688,14 +688,8 @@ GFPP_API int gfpp_torso_mask(const gfpp_torso_model *m, const float *bg_coords, 
 }
 
 static int torso_group_wgs_per_cu() {
-    static int n = 0;
-    if (n == 0) {
-        const char *e = getenv("GFPP_TORSO_GROUP_WGS");            // persistent workgroups of the MLP launch per CU (experiments)
-        n = e ? atoi(e) : 3;
-        if (n < 1) n = 1;
-        if (n > 4) n = 4;
-    }
-    return n;
+    const int n = tuning().torso_group_wgs;                     // persistent workgroups of the MLP launch per CU (0 = default; experiments)
+    return n <= 0 ? 3 : (n > 4 ? 4 : n);
 }
 
 GFPP_API int gfpp_torso_group_lp(const gfpp_torso_model *m, const gfpp_frame_ws *ws, const float *bg_coords, const float *folded, const float *code,

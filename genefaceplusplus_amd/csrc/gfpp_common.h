@@ -16,6 +16,8 @@
 namespace gfpp {
 
 void set_error(const char *fmt, ...);
+// the launch tuning of the library (gfpp_set_tuning, raymarch.hip): read at every issue, never getenv()
+const gfpp_tuning &tuning();
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -254,6 +254,30 @@ GFPP_API int gfpp_graph_replay(void *const *execs, void *const *streams, uint32_
     return rc;
 }
 
+namespace gfpp {
+static gfpp_tuning default_tuning() {
+    gfpp_tuning t{};
+    t.size = (uint32_t)sizeof(gfpp_tuning);
+    t.trip_pool = 1; t.lp_separate_trips = -1; t.occ_clip = 1; t.barrier_spins = 0; t.persist_caps = 0; t.persist_xcd = 0; t.torso_group_wgs = 0;
+    t.sr_fuse_first = 1; t.sr_final_resident = 1; t.grid_bwd_scatter = 0; t.wgrad_tr = 1;
+    return t;
+}
+static gfpp_tuning g_tuning = default_tuning();
+const gfpp_tuning &tuning() { return g_tuning; }
+}  // namespace gfpp
+
+GFPP_API int gfpp_set_tuning(const gfpp_tuning *t) {
+    if (!t) { gfpp::g_tuning = gfpp::default_tuning(); return 0; }
+    if (t->size != sizeof(gfpp_tuning)) { gfpp::set_error("gfpp_set_tuning: record of %u bytes, this library's gfpp_tuning has %u", t->size, (unsigned)sizeof(gfpp_tuning)); return GFPP_EINVAL; }
+    gfpp::g_tuning = *t;
+    return 0;
+}
+GFPP_API int gfpp_get_tuning(gfpp_tuning *out) {
+    if (!out || out->size != sizeof(gfpp_tuning)) { gfpp::set_error("gfpp_get_tuning: out->size must be sizeof(gfpp_tuning)"); return GFPP_EINVAL; }
+    *out = gfpp::g_tuning;
+    return 0;
+}
+
 GFPP_API int gfpp_abi_version(void) { return GFPP_ABI_VERSION; }
 GFPP_API const char *gfpp_last_error(void) { return gfpp::g_err; }
 GFPP_API unsigned gfpp_struct_size(const char *name) {
@@ -262,6 +286,7 @@ GFPP_API unsigned gfpp_struct_size(const char *name) {
         {"frame_ws", (unsigned)sizeof(gfpp_frame_ws)},       {"head_model", (unsigned)sizeof(gfpp_head_model)}, {"torso_model", (unsigned)sizeof(gfpp_torso_model)},
         {"cond_model", (unsigned)sizeof(gfpp_cond_model)},   {"grid_desc", (unsigned)sizeof(gfpp_grid_desc)},   {"grid_level", (unsigned)sizeof(gfpp_grid_level)},
         {"sr_model", (unsigned)sizeof(gfpp_sr_model)},       {"sr_ws", (unsigned)sizeof(gfpp_sr_ws)},         {"clip_job", (unsigned)sizeof(gfpp_clip_job)},
+        {"tuning", (unsigned)sizeof(gfpp_tuning)},
     };
     for (const auto &e : table)
         if (strcmp(e.n, name) == 0) return e.s;

@@ -793,8 +793,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
     // of 64 pixels, the whole 128-channel patch in LDS -- were the round-2 / round-3 A/B partners (GFPP_SR_TILES, GFPP_SR_KSLICES: measured, docs/LAB_NOTEBOOK.md)
     // and are no longer instantiated.
     auto rng_of = [&](uint32_t layer) { return SrRng{draw ? (const unsigned long long *)ws->rng_state : nullptr, (unsigned long long)ws->rng_seed, layer}; };
-    bool fuse_first = true;                                         // block 0's first convolution inside the second one's halo load (GFPP_SR_FUSE_FIRST=0: its own launch, the parity partner)
-    if (const char *e = getenv("GFPP_SR_FUSE_FIRST")) fuse_first = atoi(e) != 0;
+    const bool fuse_first = tuning().sr_fuse_first != 0;            // block 0's first convolution inside the second one's halo load (gfpp_tuning.sr_fuse_first = 0: its own launch, the parity partner)
     if (!fuse_first) {
         SrFirstArgs a{rgb_in, (const uint4 *)m->w_first, noise ? noise[0] : nullptr, m->noise_strength[0], m->bias[0], gain, clamp, (_Float16 *)ws->x0, R, R, rng_of(0)};
         hipLaunchKernelGGL(k_sr_first, dim3(R / kSrPatch, R / kSrPatch), dim3(kSrThreads), 0, st, a);
@@ -833,8 +832,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng = rng_of(3);
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
-        bool resident = true;                                       // GFPP_SR_FINAL_RESIDENT=0: one workgroup per patch, weights streamed (A/B runs, parity partner)
-        if (const char *e = getenv("GFPP_SR_FINAL_RESIDENT")) resident = atoi(e) != 0;
+        const bool resident = tuning().sr_final_resident != 0;      // gfpp_tuning.sr_final_resident = 0: one workgroup per patch, weights streamed (A/B runs, parity partner)
         if (resident) {
             static int cus = 0;
             if (cus == 0) {

@@ -764,10 +764,7 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
     // per call, not once per process: the attribute is per device and a process may train on several (it costs a table write)
     bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_backward_lds<D, C, G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     bool ranges = lds_ok && xcd_copies != nullptr;
-    if (ranges) {
-        const char *e = getenv("GFPP_GRID_BWD");                   // A/B: "scatter" = device atomics for the levels beyond the LDS (the round-2 path)
-        if (e && e[0] == 's') ranges = false;
-    }
+    if (ranges && tuning().grid_bwd_scatter) ranges = false;       // A/B: device atomics for the levels beyond the LDS (the round-2 path)
     if (ranges) ranges = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_backward_ranges<D, C, G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     if (!lds_ok) (void)hipGetLastError();
     int rc = 0;

@@ -333,9 +333,9 @@ GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, ui
     if (a.TO > (uint32_t)kWgMaxTO || a.TI > (uint32_t)kWgMaxTI) { set_error("%s: built for out_features <= 256 and in_features <= 160 (got %u, %u)", who, O, I); return GFPP_EUNSUPPORTED; }
     const hipStream_t st = (hipStream_t)stream;
     if (((uintptr_t)grad_out | (uintptr_t)input) & 15u) { set_error("%s: grad_out and input must be 16-byte aligned", who); return GFPP_EINVAL; }
-    // zero-padded half matrices (both widths multiples of 32, the fused MLP's): fragments by transposing LDS reads, one workgroup per CU (GFPP_WGRAD_TR=0: the
+    // zero-padded half matrices (both widths multiples of 32, the fused MLP's): fragments by transposing LDS reads, one workgroup per CU (gfpp_tuning.wgrad_tr = 0: the
     // generic kernel, its A/B partner)
-    static const bool tr_off = [] { const char *e = getenv("GFPP_WGRAD_TR"); return e && e[0] == '0'; }();
+    const bool tr_off = tuning().wgrad_tr == 0;
     const bool tr = dtype == GFPP_F16 && !tr_off && O % 32 == 0 && I % 32 == 0 && (a.TO == 1 || a.TO == 4 || a.TO == 5) && a.TI >= 2;
     const uint32_t R = tr ? (uint32_t)kWtRows : dtype == GFPP_F16 ? (uint32_t)WgCfg<_Float16>::rows : (uint32_t)WgCfg<float>::rows;
     a.n_chunks = div_up(M, R);

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, tuning
 
 _SLOPE = 0.02
 # window length -> strides of the four k=3 convolutions (the table of cond_encoder.py:103-114, whose `== [5, 8]` branch
@@ -73,7 +73,7 @@ _lib.register("gfpp_mlp_train_image_bytes", [_u32, _u32, _u32, ctypes.c_int], re
 _lib.register("gfpp_mlp_train_forward", [ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
 _lib.register("gfpp_mlp_train_backward", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
 #: whole-MLP training launches under fp16 autocast (csrc/train_mlp_fused.hip); GFPP_TRAIN_FUSED_MLP=0: layer by layer (the A/B partner, and what other shapes use)
-FUSED_MLP = os.environ.get("GFPP_TRAIN_FUSED_MLP", "1") != "0"
+FUSED_MLP = tuning.HOST["train_fused_mlp"]
 _FUSED_IN, _FUSED_OUT, _FUSED_HIDDEN = (64, 96, 160), (32, 160), 128
 
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, tuning
 from .._lib import call, GfppError
 
 c_p = ctypes.c_void_p
@@ -548,7 +548,7 @@ class FramePipeline:
         d = GridDesc()
         # GFPP_LP_BLOCK_TABLE=0 (round-4 advisory: an opt-out for A/B and parity debugging): no 16-bit copy of the tables -- the 16-bit kernels then run their generic
         # lookup on the fp32 tables (fp32 corner values and weights, 2 060 B per sample), the instantiation hash-grid models use anyway
-        if any(int(lv[l].flags) & 1 for l in range(L)) or os.environ.get("GFPP_LP_BLOCK_TABLE", "1") == "0":                 # GFPP_LEVEL_SLOW
+        if any(int(lv[l].flags) & 1 for l in range(L)) or not tuning.HOST["lp_block_table"]:                 # GFPP_LEVEL_SLOW
             return d
         levels = torch.from_numpy(np.frombuffer(lv, dtype=np.uint8).reshape(L, ctypes.sizeof(GridLevel)).copy()).to(self.device)
         d.table = self._hold(corner_block_table(enc.embeddings.detach(), off, lv))
@@ -819,7 +819,7 @@ class FramePipeline:
     def cu_count(self):
         return torch.cuda.get_device_properties(self.device).multi_processor_count
 
-    def calibrate_trip_launches(self, N, margin=int(os.environ.get("GFPP_TRIP_MARGIN", "1"))):
+    def calibrate_trip_launches(self, N, margin=tuning.HOST["trip_margin"]):
         """Several frames in flight issue every possible trip as a launch of its own (16 for the shipped max_steps); most of them find nothing left
         (the step budget of renderer.py:364 is used up after ~6 trips) and cost ~2 us each of every frame.  Call this after a frame of the clip has
         been rendered on this lane (synchronises): the trips beyond the ones that frame used (+ margin) then become ONE multi-trip launch on a small
@@ -840,10 +840,10 @@ class FramePipeline:
 
     #: exact-fp32 mode, torso pass: 'mfma' = the MFMA kernel with fp32 fragments (gfpp_torso_frame_lp, lp_dtype GFPP_F32; round 3), 'valu' = one
     #: thread per pixel on the vector ALU (gfpp_torso_frame, 170 us per 512^2 frame; the A/B partner)
-    fp32_torso = os.environ.get("GFPP_FP32_TORSO", "mfma")
+    fp32_torso = tuning.HOST["fp32_torso"]
 
     #: slab test + state reset + pre-march as one launch (gfpp_head_frame_begin_premarch); False = the two separate launches (tests compare them)
-    fuse_begin = os.environ.get("GFPP_FUSE_BEGIN", "1") != "0"
+    fuse_begin = tuning.HOST["fuse_begin"]
 
     #: 16-bit kernel: trips with a launch of their own before the multi-trip launch (None / 0 = the library default, 6); tests vary it
     separate_trips = None
@@ -851,7 +851,7 @@ class FramePipeline:
     #: 'persist' = the whole loop as ONE launch with workgroup-local trips (gfpp_head_frame_persist_lp, the production path of the 16-bit modes since
     #: round 3; gfpp_head_frame_persist for the exact-fp32 mode since round 4), 'trips' = one launch per trip (gfpp_head_frame_trips_lp / _trips, the A/B
     #: partners; also taken for max_steps > 24 or more than 2^22 rays)
-    lp_kernel = os.environ.get("GFPP_LP_KERNEL", "persist")
+    lp_kernel = tuning.HOST["lp_kernel"]
 
     #: set > 1 by a caller that keeps frames of several lanes in flight at once (ClipRenderer)
     frames_in_flight = 1
@@ -870,7 +870,7 @@ class FramePipeline:
     #: resolve-in-consumer and uint8-store-in-torso (GFPP_FUSE_TAIL: "0" none, "1" both, "resolve" / "store" one of them).  Measured same-box (round 3,
     #: 512^2 bf16, two frames in flight): none 2 860-2 906 frames/s, resolve only 2 830-2 883 (neutral: the 6 us launch it saves is hidden by the other
     #: frame in flight), store fused 2 640-2 660 (the torso kernel itself gets 45 us longer) -- so the default keeps the two small launches
-    fuse_tail = os.environ.get("GFPP_FUSE_TAIL", "0")
+    fuse_tail = tuning.HOST["fuse_tail"]
 
     def head_pass(self, rays_o, rays_d, cond_feat, ind_code, dt_gamma, max_steps, T_thresh, shard=None, defer_resolve=False):
         """near/far + constant folding + the whole march/evaluate/composite loop; leaves the result in the workspace.
@@ -1063,7 +1063,7 @@ class FramePipeline:
     GROUP_MAX = 4           # kPMaxFrames of csrc/frame_head_lp.hip
     #: the K torso passes of a group (+ resolve + the clip job's uint8 stores) as ONE launch of persistent workgroups (gfpp_torso_group_lp, round 5);
     #: GFPP_GROUP_TORSO=0: one gfpp_torso_frame_lp (+ store) per frame behind a resolve launch, the A/B partner (same bits)
-    group_torso = os.environ.get("GFPP_GROUP_TORSO", "1") != "0"
+    group_torso = tuning.HOST["group_torso"]
 
     def group_supported(self, N, K, max_steps):
         """Frame groups run on the persistent 16-bit launch (what a clip renders with unless told otherwise); torso models need the MFMA torso kernel's weight images."""

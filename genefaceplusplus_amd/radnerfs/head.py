@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import raymarching
-from .. import _lib
+from .. import _lib, tuning
 from .._lib import GfppError
 from .cond_nets import AudioNet, AudioAttNet, MLP, SplitFirstColumn
 from .encoders import get_encoder
@@ -303,7 +303,7 @@ class NeRFRenderer(nn.Module):
 
 #: a training step's conditioning networks: "fused" = one forward and one backward launch of the library's own kernels (RADNeRF._fused_train_cond_feat; shapes
 #: they do not cover stay eager); GFPP_TRAIN_COND=eager: torch's layers, the A/B partner
-COND_TRAIN = os.environ.get("GFPP_TRAIN_COND", "fused")
+COND_TRAIN = tuning.HOST["train_cond"]
 
 
 class _CondFeatTrain(torch.autograd.Function):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFPP_ABI_VERSION 7
+#define GFPP_ABI_VERSION 8
 
 #define GFPP_EINVAL (-1)       /* bad argument (null pointer, zero size where not allowed, ...) */
 #define GFPP_EUNSUPPORTED (-2) /* unsupported D / C / degree / dtype combination (reference: std::runtime_error) */
@@ -49,6 +49,26 @@ const char *gfpp_last_error(void);
  * "cond_model", "grid_desc", "grid_level", "sr_model", "sr_ws"); 0 for an unknown name.  A binding that mirrors the structs (ctypes, cgo, JNI)
  * checks its own layout against this at load time instead of corrupting memory on a mismatch. */
 unsigned gfpp_struct_size(const char *name);
+
+/* Launch tuning of the whole library: ONE record, set once by the host (genefaceplusplus_amd/_lib.py::set_tuning; before round 6 these were getenv() reads
+ * inside the launch paths).  Every field's 0 / default is the shipped, measured optimum; the other values are the A/B partners the tests and tools use.
+ * gfpp_set_tuning copies the record (size-checked); it is read at every issue -- a captured graph keeps what it was captured with. */
+typedef struct gfpp_tuning {
+    uint32_t size;               /* sizeof(gfpp_tuning) of the caller */
+    int32_t trip_pool;           /* fp32 trip kernel: 1 = workgroup sample pool (default), 0 = one tile per wavefront */
+    int32_t lp_separate_trips;   /* 16-bit trip launches before the multi-trip launch takes over: -1 = default (5) */
+    int32_t occ_clip;            /* pre-march stops at the occupancy bounds: 1 (default) / 0 */
+    uint32_t barrier_spins;      /* multi-trip launch's barrier time-out in spins: 0 = default (1 << 22); tests force a time-out with a small value */
+    uint32_t persist_caps;       /* local n_step caps of the persistent launch by workgroup round, 4 bits each: 0 = default (4,4,4,8,8,8,8,8) */
+    int32_t persist_xcd;         /* XCD-local tile ownership of the persistent launch: 0 = off (default; measured: traffic down, time unchanged), 1, 2 */
+    int32_t torso_group_wgs;     /* persistent workgroups per CU of the torso MLP group launch: 0 = default */
+    int32_t sr_fuse_first;       /* block 0's first SR convolution inside the second one's halo load: 1 (default) / 0 */
+    int32_t sr_final_resident;   /* last SR layer with LDS-resident weights: 1 (default) / 0 = one workgroup per patch */
+    int32_t grid_bwd_scatter;    /* table gradient: 0 = LDS ranges (default), 1 = device atomics (the round-2 path) */
+    int32_t wgrad_tr;            /* transposing-read weight gradients: 1 (default) / 0 */
+} gfpp_tuning;
+int gfpp_set_tuning(const gfpp_tuning *t);   /* NULL restores the defaults */
+int gfpp_get_tuning(gfpp_tuning *out);       /* out->size must be set */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Section A.1 -- _raymarching_face
@@ -735,7 +755,7 @@ int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const i
  * recomputes the corners of its points, adds those that fall into its range into LDS accumulators and stores the range into the eighth's copy -- a
  * 2^16-row level is located eight times, which is ~10x cheaper than the 67 M device atomics of a May grid were (4.6 ms per call, 45 % of a training step
  * in round 2).  The LDS accumulators are 64-bit fixed point scaled by the level's largest |grad| (float LDS atomics run ~50x slower than integer ones
- * on gfx950): a contribution is kept down to 2^-36 of that maximum; a non-finite grad makes its level's gradient NaN.  GFPP_GRID_BWD=scatter selects the
+ * on gfx950): a contribution is kept down to 2^-36 of that maximum; a non-finite grad makes its level's gradient NaN.  gfpp_tuning.grid_bwd_scatter selects the
  * round-2 path (LDS-privatised coarse levels + XCD-private device atomics).  rows_total = embeddings.shape[0]. */
 int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,

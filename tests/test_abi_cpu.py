@@ -32,15 +32,16 @@ def test_library_exports_every_declared_symbol(built_lib):
     # and the ctypes table binds exactly the declared set
     assert set(built_lib.declared_symbols()) <= set(names)
     lib = built_lib.lib()
-    assert lib.gfpp_abi_version() == 7
+    assert lib.gfpp_abi_version() == 8
 
 
 def test_ctypes_mirrors_have_the_librarys_struct_sizes(built_lib):
     """Every struct of the header that the Python binding mirrors must have the size the library was compiled with
     (gfpp_struct_size): a field added on one side only would otherwise corrupt memory silently."""
     from genefaceplusplus_amd.radnerfs import frame_pipeline, superres
-    from genefaceplusplus_amd import clip
+    from genefaceplusplus_amd import clip, tuning
     mirrors = dict(frame_pipeline.STRUCT_MIRRORS)
+    mirrors["tuning"] = tuning.GfppTuning
     mirrors.update(superres.STRUCT_MIRRORS)
     mirrors.update(clip.STRUCT_MIRRORS)
     text = open(os.path.join(ROOT, "include", "gfpp_radnerf.h")).read()
@@ -59,7 +60,7 @@ def test_ctypes_mirrors_have_the_librarys_struct_sizes(built_lib):
 def test_every_declaration_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "gfpp_radnerf.h")).read()
     for n in _declared_in_header():
-        if n in ("gfpp_abi_version", "gfpp_last_error", "gfpp_struct_size"):
+        if n in ("gfpp_abi_version", "gfpp_last_error", "gfpp_struct_size", "gfpp_set_tuning", "gfpp_get_tuning"):       # library housekeeping: no reference counterpart
             continue
         i = text.index(n + "(")
         comment = text[text.rfind("/*", 0, i):i]
@@ -137,3 +138,26 @@ print("ok", len(names))
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+
+
+def test_tuning_record_round_trips_and_no_launch_path_reads_the_environment(built_lib):
+    """ONE gfpp_tuning record, set from Python (round-5 review, hygiene): the library takes it, hands it back, refuses a record of another size -- and no source of
+    the library calls getenv()."""
+    import glob
+    from genefaceplusplus_amd import tuning
+    lib = built_lib.lib()
+    got = tuning.GfppTuning()
+    got.size = ctypes.sizeof(tuning.GfppTuning)
+    assert lib.gfpp_get_tuning(ctypes.byref(got)) == 0
+    for k, v in tuning.LIB.items():
+        assert getattr(got, k) == v, k
+    with tuning.tuned(sr_fuse_first=0, persist_caps="2,2,4"):
+        assert lib.gfpp_get_tuning(ctypes.byref(got)) == 0
+        assert got.sr_fuse_first == 0 and got.persist_caps == 0x44444422
+    assert lib.gfpp_get_tuning(ctypes.byref(got)) == 0 and got.sr_fuse_first == 1 and got.persist_caps == 0
+    bad = tuning.GfppTuning()
+    bad.size = 8
+    assert lib.gfpp_set_tuning(ctypes.byref(bad)) != 0 and b"gfpp_set_tuning" in lib.gfpp_last_error()
+    for f in glob.glob(os.path.join(ROOT, "genefaceplusplus_amd", "csrc", "*.h*")):
+        text = re.sub(r"//[^\n]*", "", open(f).read())
+        assert "getenv" not in text, f

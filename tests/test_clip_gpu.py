@@ -137,29 +137,25 @@ def test_timed_out_barrier_is_reported_not_delivered(dev, monkeypatch):
                       lanes=1, group=1)
     clip = cr.prepare(batch, dev)
     cr.render_to_host(clip)                                       # healthy: no error
-    monkeypatch.setenv("GFPP_BARRIER_SPINS", "1")
-    with pytest.raises(GfppError, match="barrier"):
-        cr.render_to_host(clip)
-    monkeypatch.delenv("GFPP_BARRIER_SPINS")
+    from genefaceplusplus_amd import tuning
+    with tuning.tuned(barrier_spins=1):
+        with pytest.raises(GfppError, match="barrier"):
+            cr.render_to_host(clip)
     cr.render_to_host(clip)                                       # the next frame resets the word (gfpp_head_frame_begin_premarch)
     # a time-out in the MIDDLE of a clip (round-3 advisory): the frames after it zero counters[127] again, only the sticky word (gfpp_frame_ws.timeouts) still
     # knows -- and the chunk must be refused BEFORE it reaches the sink.  Chunks of one frame; the sink of frame 0 arms the time-out for the frames issued
     # next, the sink of frame 1 disarms it again
-    import os
     long_clip = cr.prepare(_clip_batch(case["hp"], 8), dev)
     seen = []
 
     def sink(k, arr):
         seen.append(k)
-        if k == 0:
-            os.environ["GFPP_BARRIER_SPINS"] = "1"
-        else:
-            os.environ.pop("GFPP_BARRIER_SPINS", None)
+        tuning.set_tuning(barrier_spins=1 if k == 0 else 0)
     try:
         with pytest.raises(GfppError, match="barrier"):
             cr.render_to_host(long_clip, sink=sink, chunk=1)
     finally:
-        os.environ.pop("GFPP_BARRIER_SPINS", None)
+        tuning.set_tuning(barrier_spins=0)
     torch.cuda.synchronize()
     assert seen and seen == list(range(len(seen))) and len(seen) < 8, seen      # delivery stopped at the damaged frame
     # frames issued while the time-out was armed may have finished after the check that raised: their marks are reported by the next check, once
@@ -343,7 +339,7 @@ def test_group_torso_launch_with_an_empty_torso_mask(dev):
 
 
 def test_xcd_local_tile_ownership_renders_the_same_bytes(dev, monkeypatch):
-    """GFPP_PERSIST_XCD=1 (tile column c of the image -> the workgroups of XCD c % 8; off by default: less fabric traffic, no time): which workgroup
+    """gfpp_tuning.persist_xcd = 1 (tile column c of the image -> the workgroups of XCD c % 8; off by default: less fabric traffic, no time): which workgroup
     renders a ray never changes its bits -- 512^2, four frames per launch, against the image-wide permutation."""
     from genefaceplusplus_amd.clip import ClipRenderer
     HW, F = 512, 8
@@ -352,13 +348,14 @@ def test_xcd_local_tile_ownership_renders_the_same_bytes(dev, monkeypatch):
     model.precision = "bf16"
     kw = dict(case["hp"], use_head_for_torso=True)
     mk = lambda: ClipRenderer(model, HW, HW, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, group=4, lanes=2)
-    monkeypatch.delenv("GFPP_PERSIST_XCD", raising=False)
-    a = mk()
-    clip = a.prepare(_clip_batch(case["hp"], F), dev)
-    want = a.render_to_device(clip).cpu().numpy()
-    monkeypatch.setenv("GFPP_PERSIST_XCD", "1")
-    b = mk()                                              # (a new renderer: the lanes' graphs are captured with the switch on)
-    got = b.render_to_device(clip).cpu().numpy()
+    from genefaceplusplus_amd import tuning
+    with tuning.tuned(persist_xcd=0):
+        a = mk()
+        clip = a.prepare(_clip_batch(case["hp"], F), dev)
+        want = a.render_to_device(clip).cpu().numpy()
+    with tuning.tuned(persist_xcd=1):
+        b = mk()                                          # (a new renderer: the lanes' graphs are captured with the switch on)
+        got = b.render_to_device(clip).cpu().numpy()
     assert a.group == 4 and b.group == 4 and want.std() > 10
     np.testing.assert_array_equal(got, want)
     hist = model.pipeline().group_workspace(HW * HW, 4, int(case["hp"]["max_steps"]))[2]["counters"][:, 128:160].cpu().numpy()

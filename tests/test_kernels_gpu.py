@@ -401,19 +401,19 @@ def test_superresolution_random_noise_is_drawn_in_the_kernels(dev):
 @pytest.mark.parametrize("noise_mode", ["const", "random", "none"])
 def test_superresolution_first_layer_inside_the_second_equals_its_own_launch(dev, monkeypatch, noise_mode):
     """Block 0's first convolution computed into the halo patch of the second one (k_sr_conv3<..., FIRST>) against its own launch (k_sr_first,
-    GFPP_SR_FUSE_FIRST=0): same fragments, same MFMA order, same epilogue -- the 512^2 image bit for bit, image borders included."""
+    gfpp_tuning.sr_fuse_first = 0): same fragments, same MFMA order, same epilogue -- the 512^2 image bit for bit, image borders included."""
     from genefaceplusplus_amd import synthetic as syn
     from genefaceplusplus_amd.radnerfs.superres import Superresolution
     sd = syn.synthetic_sr_state(prefix="")
     rng = np.random.default_rng(11)
     x = torch.from_numpy(rng.random((1, 3, 256, 256)).astype(np.float32)).to(dev)
     outs = []
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("GFPP_SR_FUSE_FIRST", fuse)
+    from genefaceplusplus_amd import tuning
+    for fuse in (0, 1):
         net = Superresolution(channels=3)
         net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
         net = net.to(dev).eval()
-        with torch.no_grad():
+        with torch.no_grad(), tuning.tuned(sr_fuse_first=fuse):
             net.reseed(77)
             outs.append([net(x, noise_mode=noise_mode).cpu().numpy() for _ in range(2)])
     for a, b in zip(*outs):
@@ -424,7 +424,7 @@ def test_superresolution_first_layer_inside_the_second_equals_its_own_launch(dev
 @pytest.mark.parametrize("noise_mode", ["const", "random", "none"])
 def test_superresolution_last_layer_with_resident_weights_equals_the_per_patch_launch(dev, monkeypatch, noise_mode):
     """Block 1's last convolution as one workgroup per CU walking over its patches with the layer's 72 KB of weights resident in LDS (k_sr_final_resident)
-    against one workgroup per patch with streamed weight chunks (k_sr_conv3<64, 2, final>, GFPP_SR_FINAL_RESIDENT=0): same fragments, same tap and step order,
+    against one workgroup per patch with streamed weight chunks (k_sr_conv3<64, 2, final>, gfpp_tuning.sr_final_resident = 0): same fragments, same tap and step order,
     same epilogue -- the 512^2 image bit for bit over two frames (the frame counter advances the same way), image borders included."""
     from genefaceplusplus_amd import synthetic as syn
     from genefaceplusplus_amd.radnerfs.superres import Superresolution
@@ -432,12 +432,12 @@ def test_superresolution_last_layer_with_resident_weights_equals_the_per_patch_l
     rng = np.random.default_rng(13)
     x = torch.from_numpy(rng.random((1, 3, 256, 256)).astype(np.float32)).to(dev)
     outs = []
-    for resident in ("0", "1"):
-        monkeypatch.setenv("GFPP_SR_FINAL_RESIDENT", resident)
+    from genefaceplusplus_amd import tuning
+    for resident in (0, 1):
         net = Superresolution(channels=3)
         net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
         net = net.to(dev).eval()
-        with torch.no_grad():
+        with torch.no_grad(), tuning.tuned(sr_final_resident=resident):
             net.reseed(78)
             outs.append([net(x, noise_mode=noise_mode).cpu().numpy() for _ in range(3)])
     for a, b in zip(*outs):

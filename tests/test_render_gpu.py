@@ -140,13 +140,14 @@ def test_graph_replay_equals_eager(dev, oracle_mod, variant, HW):
                                                         ("may_head", 640, "fp32", None)])
 def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, variant, HW, precision, over):
     """k_head_trip_wp (workgroup-wide sample pool, the production kernel of the fp32 mode) against k_head_trip_w (one tile per wavefront,
-    GFPP_TRIP_POOL=0): the same samples through the same evaluate_block, only grouped into blocks differently, so every output must be equal bit
+    gfpp_tuning.trip_pool = 0): the same samples through the same evaluate_block, only grouped into blocks differently, so every output must be equal bit
     for bit -- also in the thin scene.  (The 16-bit modes' tile-per-wavefront kernel was removed in round 4: their pooled trip launches are pinned
     against the persistent launch, test_persistent_launch_equals_trip_launches, and both against the oracle.)"""
     import numpy as np
     outs = {}
+    from genefaceplusplus_amd import tuning
     for pool in ("1", "0"):
-        monkeypatch.setenv("GFPP_TRIP_POOL", pool)
+        tuning.set_tuning(trip_pool=int(pool))
         case = frame_case(variant, HW, **(over or {}))
         model = build_model(case, dev, "fused")
         model.precision = precision
@@ -156,6 +157,7 @@ def test_pooled_trips_equal_per_wavefront_trips(dev, oracle_mod, monkeypatch, va
         torch.cuda.synchronize()
         outs[pool] = {k: v.detach().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)}
         outs[pool]["_counters"] = np.concatenate(model.pipeline().trip_counters(HW * HW))   # alive per trip | samples evaluated per trip
+    tuning.set_tuning(trip_pool=1)
     for k in outs["1"]:
         np.testing.assert_array_equal(outs["1"][k], outs["0"][k], err_msg=k)
     assert outs["1"]["_counters"][64] > 0
@@ -364,10 +366,11 @@ def test_empty_and_full_occupancy(dev, oracle_mod, precision):
 @pytest.mark.parametrize("variant,HW,over", [("may_torso", 256, None), ("may_head", 96, {"bound": 2}), ("may_head", 64, {"min_near": 0.6})])
 def test_premarch_stops_at_the_occupancy_bounds_with_the_same_samples(dev, oracle_mod, monkeypatch, variant, HW, over):
     """gfpp_head_model.occ_aabb: the pre-march ends a ray where it leaves the bounds of the occupied cells and skips rays that miss them.  The samples
-    -- count and every t, a chain of fp32 additions that starts at `near` -- are the bits of the march to `far` (GFPP_OCC_CLIP=0), and so is the frame."""
+    -- count and every t, a chain of fp32 additions that starts at `near` -- are the bits of the march to `far` (gfpp_tuning.occ_clip = 0), and so is the frame."""
     got = {}
+    from genefaceplusplus_amd import tuning
     for clip in ("0", "1"):
-        monkeypatch.setenv("GFPP_OCC_CLIP", clip)
+        tuning.set_tuning(occ_clip=int(clip))
         case = frame_case(variant, HW, hp_over=over)
         model = build_model(case, dev, "fused")
         model.precision = "fp16"

@@ -523,7 +523,7 @@ def build(ctx):
             frames_timed = reps
         if args.precision == "fp32":
             achieved = samples * FLOP_PER_SAMPLE / t_march / 1e12
-            kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if os.environ.get("GFPP_TRIP_POOL", "1") == "0" \
+            kname = "k_head_trip_w<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, autonomous wavefronts)" if not __import__("genefaceplusplus_amd.tuning", fromlist=["LIB"]).LIB["trip_pool"] \
                 else "k_head_trip_wp<3> (sample fetch + grid encode + exact-fp32 MFMA MLP + composite, workgroup sample pool)"
             if persist:
                 kname = "k_head_frame_persist<3,float> (the whole march / evaluate / composite loop of a frame as ONE launch with workgroup-local trips; exact-fp32 MFMA MLP)"

@@ -26,7 +26,7 @@ if precision != "fp32" and os.environ.get("GFPP_PHASES"):
     product_render(model, case, dev, "hip")
     torch.cuda.synchronize()
     pc = pc.cpu().numpy()
-    if os.environ.get("GFPP_TRIP_POOL", "1") != "0":
+    if __import__("genefaceplusplus_amd.tuning", fromlist=["LIB"]).LIB["trip_pool"]:
         print("trip: k-cycles summed over wavefronts: gather / compaction barriers / evaluate / wait for last block / composite | wavefront rounds, blocks, "
               "longest workgroup round (cycles); per block = evaluate / blocks")
         for k in range(16):
