@@ -151,6 +151,9 @@ class ClipRenderer:
         pipe = self.model.pipeline() if getattr(self.model, "executor", "fused") == "fused" else None
         if pipe is not None and not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane), False       # the torso kernel stores the uint8 frame itself when it can
+        sr = getattr(getattr(self.model, "_orig_mod", self.model), "sr_net", None) if self.with_sr else None
+        if sr is not None:
+            sr.clip_store, sr.clip_consumed = (self._job_dev.data_ptr(), lane, 1, self.lanes), False   # ... and so does the SR stage's last layer
         target = getattr(self.model, "_orig_mod", self.model)     # (a torch.compile wrapper keeps attributes set on it to itself)
         target._clip_cond_feat = cond_feat
         try:
@@ -160,6 +163,9 @@ class ClipRenderer:
             stored = pipe is not None and pipe.clip_job_consumed
             if pipe is not None:
                 pipe.clip_job, pipe.clip_job_consumed = None, False
+            if sr is not None:
+                stored = stored or sr.clip_consumed
+                sr.clip_store, sr.clip_consumed = None, False
         if stored:
             return {}
         if self.with_sr:
@@ -190,8 +196,12 @@ class ClipRenderer:
         if not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane, self.lanes), False      # (GFPP_FUSE_TAIL: the torso kernel may store the uint8 frames itself)
 
+        sr = getattr(model, "sr_net", None) if self.with_sr else None
+        if sr is not None:
+            sr.clip_store, sr.clip_consumed = (self._job_dev.data_ptr(), lane, K, self.lanes), False
+
         def store(k, res):
-            if pipe.clip_job_consumed:
+            if pipe.clip_job_consumed or (sr is not None and sr.clip_consumed):
                 return
             rgb = res["sr_rgb_map"].permute(0, 2, 3, 1) if self.with_sr else res["rgb_map"]
             rgb = rgb.reshape(*self.out_hw, 3)
@@ -206,6 +216,8 @@ class ClipRenderer:
                                ngp_poses=[v["pose"] for v in rows], camera=(fx, fy, cx, cy, self.H, self.W), **kw)
         finally:
             pipe.clip_job, pipe.clip_job_consumed = None, False
+            if sr is not None:
+                sr.clip_store, sr.clip_consumed = None, False
         return {}
 
     # -- the job: which frames, where to ----------------------------------------------------------------------------------------------------------

@@ -83,6 +83,9 @@ struct SrConvArgs {
     SrRng rng;                // noise == null and rng.state != null: unit normals drawn here
     unsigned long long *rng_tick;   // kSrFinal: the last launch of a frame advances the frame counter ([0] counter, [1] ticket)
     uint32_t clamp01;         // kSrFinal: clamp the image to [0, 1]
+    uint8_t *u8_out;          // kSrFinal, set inside the kernel from the clip job (k_sr_final_resident): the frame's uint8 slot INSTEAD of img_out, or null
+    gfpp_clip_job *job;       // kSrFinal: the clip job (null: none); job_lane's cursor + job_sub = the frame's position, the last workgroup advances the cursor
+    uint32_t job_lane, job_sub, job_advance;
     // FIRST (block 0's first convolution computed into the halo patch instead of being read from x): its operands
     const float *first_rgb;   // [H][W][3] fp32, the NeRF image
     const uint4 *first_w;     // [2 steps][4 tiles][64] fragments (SrFirstArgs.w)
@@ -182,7 +185,8 @@ __device__ __forceinline__ void sr_image_out(const Args &a, const float (&rgb)[3
         const float t = fminf(fmaxf(rgb[k] + b_rgb[k], -a.clamp), a.clamp);
         float o = base[k] + t;
         if (EPI == kSrFinal && a.clamp01) o = fminf(fmaxf(o, 0.0f), 1.0f);
-        a.img_out[((size_t)Y * a.W + X) * 3 + k] = o;
+        if (EPI == kSrFinal && a.u8_out) a.u8_out[((size_t)Y * a.W + X) * 3 + k] = (uint8_t)fminf(fmaxf(o * 255.0f, 0.0f), 255.0f);   // k_clip_store_u8's expression
+        else a.img_out[((size_t)Y * a.W + X) * 3 + k] = o;
     }
 }
 
@@ -542,6 +546,12 @@ __global__ __launch_bounds__(512 / NU, (NU == 1 ? 2 : 1) * (FIRST ? 1 : KS)) voi
 // GFPP_SR_FINAL_RESIDENT=0; tests/test_kernels_gpu.py compares the two).
 __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
     typedef LpTraits<_Float16>::vec vec;
+    if (a.job) {
+        // the frame's slot in the clip job's output ring (every workgroup reads the cursor before the launch's LAST workgroup moves it, below); a position beyond
+        // the job (the dry runs of a graph capture, the padding frames of a last group) renders for nothing: its stores go to the fp32 image as without a job
+        const uint32_t pos = a.job->cursor[a.job_lane] + a.job_sub;
+        a.u8_out = pos < a.job->n ? a.job->out + (size_t)(pos % a.job->ring_frames) * a.job->frame_bytes : nullptr;
+    }
     constexpr int CIN = 64, NT = 2, STEPS = CIN / 16, PS = CIN + 8, TAPFRAGS = STEPS * NT * 64, THREADS = 512;
     constexpr int HALO_CHUNKS = kSrHalo * kSrHalo * (CIN / 8), HALO_ITERS = (HALO_CHUNKS + THREADS - 1) / THREADS;
     __shared__ __attribute__((aligned(16))) uint4 wall[9 * TAPFRAGS];
@@ -659,6 +669,11 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
             __threadfence();
             atomicAdd(&a.rng_tick[0], 1ull);
         }
+    }
+    // ... and the clip job's cursor of this lane moves on (k_clip_store_u8's hand-over, raymarch.hip)
+    if (a.job && a.job_advance != 0xFFFFFFFFu && tid == 0 && atomicAdd(&a.job->ticket[a.job_lane], 1u) == gridDim.x - 1u) {
+        a.job->ticket[a.job_lane] = 0u;
+        a.job->cursor[a.job_lane] = a.job->cursor[a.job_lane] + (a.job_advance ? a.job_advance : a.job->lanes);
     }
 }
 
@@ -833,6 +848,8 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         a.rng_tick = draw ? (unsigned long long *)ws->rng_state : nullptr;
         a.clamp01 = ws->clamp01;
         const bool resident = tuning().sr_final_resident != 0;      // gfpp_tuning.sr_final_resident = 0: one workgroup per patch, weights streamed (A/B runs, parity partner)
+        if (ws->clip_job && !resident) { set_error("gfpp_sr_forward: the uint8 store into a clip job needs the resident last layer (gfpp_tuning.sr_final_resident)"); return GFPP_EUNSUPPORTED; }
+        a.job = ws->clip_job; a.job_lane = ws->clip_lane; a.job_sub = ws->clip_sub; a.job_advance = ws->clip_advance;
         if (resident) {
             static int cus = 0;
             if (cus == 0) {

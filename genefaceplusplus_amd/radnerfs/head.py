@@ -441,7 +441,7 @@ class RADNeRF(NeRFRenderer):
                 rgb = out["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2)
                 res["rgb_map"] = rgb
                 if sr.ready:
-                    res["sr_rgb_map"] = sr(rgb.clone(), noise_mode=sr_noise_mode, clamp01=True)
+                    res["sr_rgb_map"] = sr(rgb.clone(), noise_mode=sr_noise_mode, clamp01=True, clip_sub=k)
             results[k] = res
             if after_frame is not None:
                 after_frame(k, res)

@@ -35,7 +35,8 @@ class SrModel(ctypes.Structure):
 
 
 class SrWs(ctypes.Structure):
-    _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p), ("rng_state", c_p), ("rng_seed", ctypes.c_uint64), ("clamp01", ctypes.c_uint32)]
+    _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p), ("rng_state", c_p), ("rng_seed", ctypes.c_uint64), ("clamp01", ctypes.c_uint32),
+                ("clip_job", c_p), ("clip_lane", ctypes.c_uint32), ("clip_sub", ctypes.c_uint32), ("clip_advance", ctypes.c_uint32)]
 
 
 _lib.register("gfpp_sr_forward", [ctypes.POINTER(SrModel), ctypes.POINTER(SrWs), c_p, c_p, c_p, c_p])
@@ -240,6 +241,10 @@ class Superresolution(nn.Module):
 
     #: which activation workspace forward() uses; frames of different lanes may be in flight on different streams (clip.ClipRenderer)
     lane = 0
+    #: set by clip.ClipRenderer around a frame (group): (device pointer of the gfpp_clip_job, lane, frames of the group, lanes).  A forward(clip_sub=k) then leaves frame
+    #: k of the group as uint8 in the job's output slot from inside the last layer's epilogue (no fp32 image, no store launch) and sets `clip_consumed`
+    clip_store = None
+    clip_consumed = False
 
     def _workspace(self, P):
         ent = P["ws"].get(self.lane)
@@ -302,7 +307,7 @@ class Superresolution(nn.Module):
         return up + self.block1.torgb.forward_autograd(x, c)
 
     # -- forward ------------------------------------------------------------------------------------------------------------------
-    def forward(self, rgb, noise_mode="random", clamp01=False, **block_kwargs):
+    def forward(self, rgb, noise_mode="random", clamp01=False, clip_sub=None, **block_kwargs):
         """rgb [1,3,256,256] in [0,1] -> [1,3,512,512] fp32 (radnerf_sr.py:30-43).  noise_mode: 'random' (the reference's default: a fresh
         unit normal field per layer, scaled by the learned noise_strength), 'const' (the stored noise_const buffers) or 'none'.
         clamp01 (not a reference argument): clamp the result to [0, 1] inside the last kernel -- what the callers do next (radnerf_torso_sr.py:221,231)."""
@@ -334,6 +339,14 @@ class Superresolution(nn.Module):
         ws.rng_state = bufs["rng_state"].data_ptr() if noise_mode == "random" else None
         ws.rng_seed = bufs["rng_seed"]
         ws.clamp01 = 1 if clamp01 else 0
+        ws.clip_job = None
+        if self.clip_store is not None and clip_sub is not None and clamp01:
+            from .. import tuning
+            if tuning.LIB["sr_final_resident"]:
+                job, lane, frames, lanes = self.clip_store
+                ws.clip_job, ws.clip_lane, ws.clip_sub = job, lane, int(clip_sub)
+                ws.clip_advance = (frames * lanes if frames > 1 else 0) if clip_sub == frames - 1 else 0xFFFFFFFF
+                self.clip_consumed = True
         out = torch.empty(512, 512, 3, dtype=torch.float32, device=x.device)
         call("gfpp_sr_forward", ctypes.byref(P["model"]), ctypes.byref(ws), x.data_ptr(), arr, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return out.permute(2, 0, 1).unsqueeze(0)                                # [1,3,512,512] view

@@ -232,7 +232,7 @@ class _TorsoBase(RADNeRF):
                 res = {"torso_alpha_map": out["torso_alpha"], "torso_rgb_map": out["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2),
                        "depth_map": out["depth"].view(1, N), "rgb_map": rgb}
                 if sr.ready:
-                    res["sr_rgb_map"] = sr(rgb, noise_mode=sr_noise_mode, clamp01=True)
+                    res["sr_rgb_map"] = sr(rgb, noise_mode=sr_noise_mode, clamp01=True, clip_sub=k)
                     if upscale_torso:
                         res["sr_torso_rgb_map"] = sr(res["torso_rgb_map"], noise_mode=sr_noise_mode, clamp01=True)
             else:
@@ -342,7 +342,7 @@ class RADNeRFTorsowithSR(_TorsoBase):
 
         def superresolve(o):
             if self.sr_net.ready:
-                o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise, clamp01=True)
+                o["sr_rgb"] = self.sr_net(o["image"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise, clamp01=True, clip_sub=0)
                 if upscale_torso:
                     o["sr_torso_rgb"] = self.sr_net(o["torso_bg"].reshape(1, side, side, 3).permute(0, 3, 1, 2), noise_mode=sr_noise, clamp01=True)
 
@@ -393,5 +393,5 @@ class RADNeRFwithSR(RADNeRF):
         res["rgb_map"] = rgb
         if self.sr_net.ready:
             # the reference always renders with the layers' default noise ('random', radnerf_sr.py:30-43); `sr_noise_mode` is our test hook
-            res["sr_rgb_map"] = self.sr_net(rgb.clone(), noise_mode=kwargs.get("sr_noise_mode", "random"), clamp01=True)
+            res["sr_rgb_map"] = self.sr_net(rgb.clone(), noise_mode=kwargs.get("sr_noise_mode", "random"), clamp01=True, clip_sub=0)
         return res

@@ -798,6 +798,12 @@ typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
     uint64_t *rng_state; /* [3] u64, or NULL */
     uint64_t rng_seed;
     uint32_t clamp01;    /* 1: rgb_out = clamp(result, 0, 1) (the caller's `.clamp(0, 1)` of radnerf_torso_sr.py:221,231 folded in) */
+    /* ABI 8: the clip job this forward belongs to (DEVICE pointer, or NULL).  The last layer's epilogue then writes the frame as uint8 -- `(x * 255.).int()` of
+     * genefacepp_infer.py:468, clamped -- straight into the job's output slot of position cursor[clip_lane] + clip_sub instead of writing rgb_out as fp32, and the
+     * launch's last workgroup advances the lane's cursor by clip_advance (0: by job->lanes; 0xFFFFFFFF: not at all -- the earlier frames of a group): no
+     * gfpp_clip_store_u8 launch behind the frame.  Needs the resident last layer (gfpp_tuning.sr_final_resident). */
+    gfpp_clip_job *clip_job;
+    uint32_t clip_lane, clip_sub, clip_advance;
 } gfpp_sr_ws;
 
 /* replaces Superresolution.forward (radnerf_sr.py:30-43).  rgb_in [256][256][3] f32 (NHWC, values in [0,1]) -> rgb_out [512][512][3] f32.  noise: 4 device pointers to

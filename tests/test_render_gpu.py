@@ -66,13 +66,14 @@ def test_16bit_mfma_frame_within_stated_tolerance(dev, oracle_mod, variant, HW, 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_16bit_mode_on_the_fp32_tables(dev, oracle_mod, monkeypatch, precision):
-    """GFPP_LP_BLOCK_TABLE=0: the 16-bit head kernels without the 16-bit corner-block copies of the grids (generic lookup on the fp32 tables, fp32 corner weights) --
+    """tuning.HOST["lp_block_table"] = False (GFPP_LP_BLOCK_TABLE=0 in the environment at import): the 16-bit head kernels without the 16-bit corner-block copies of the grids (generic lookup on the fp32 tables, fp32 corner weights) --
     the opt-out for A/B and parity debugging.  Same tolerance against the oracle as the default path, and close to it."""
     case = frame_case("may_torso", 96)
     ref = oracle_render(oracle_mod, case)["rgb_map"].reshape(-1, 3)
     frames = {}
+    from genefaceplusplus_amd import tuning
     for switch in ("1", "0"):
-        monkeypatch.setenv("GFPP_LP_BLOCK_TABLE", switch)
+        monkeypatch.setitem(tuning.HOST, "lp_block_table", switch == "1")
         model = build_model(case, dev, "fused")
         model.precision = precision
         frames[switch] = product_render(model, case, dev, "oracle", oracle_mod)["rgb_map"].float().cpu().numpy().reshape(-1, 3)
