@@ -151,7 +151,7 @@ class ClipRenderer:
         pipe = self.model.pipeline() if getattr(self.model, "executor", "fused") == "fused" else None
         if pipe is not None and not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane), False       # the torso kernel stores the uint8 frame itself when it can
-        sr = getattr(getattr(self.model, "_orig_mod", self.model), "sr_net", None) if self.with_sr else None
+        sr = getattr(getattr(self.model, "_orig_mod", self.model), "sr_net", None) if self.with_sr and tuning.HOST["sr_store_u8"] else None
         if sr is not None:
             sr.clip_store, sr.clip_consumed = (self._job_dev.data_ptr(), lane, 1, self.lanes), False   # ... and so does the SR stage's last layer
         target = getattr(self.model, "_orig_mod", self.model)     # (a torch.compile wrapper keeps attributes set on it to itself)
@@ -196,7 +196,7 @@ class ClipRenderer:
         if not self.with_sr:
             pipe.clip_job, pipe.clip_job_consumed = (self._job_dev.data_ptr(), lane, self.lanes), False      # (GFPP_FUSE_TAIL: the torso kernel may store the uint8 frames itself)
 
-        sr = getattr(model, "sr_net", None) if self.with_sr else None
+        sr = getattr(model, "sr_net", None) if self.with_sr and tuning.HOST["sr_store_u8"] else None
         if sr is not None:
             sr.clip_store, sr.clip_consumed = (self._job_dev.data_ptr(), lane, K, self.lanes), False
 
@@ -302,6 +302,7 @@ class ClipRenderer:
         idx = list(frame_indices)
         if out.dtype != torch.uint8 or not out.is_contiguous() or tuple(out.shape[1:]) != (*self.out_hw, 3):
             raise GfppError(f"ClipRenderer.start: out must be a contiguous uint8 [F, {self.out_hw[0]}, {self.out_hw[1]}, 3] stack")
+        ring_given = ring_frames is not None and int(ring_frames) < len(idx)
         ring_frames = len(idx) if ring_frames is None else int(ring_frames)
         if out.shape[0] < min(ring_frames, max(len(idx), 1)):
             raise GfppError("ClipRenderer.start: out is smaller than the job's ring")
@@ -329,7 +330,7 @@ class ClipRenderer:
             job.cursor[l] = l * self.group                  # groups of `group` consecutive positions are dealt to the lanes round-robin
         self._upload_job(job)
         main = self._fork()
-        self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip}       # (keeps the extended rows alive)
+        self._job = {"n": len(idx), "issued": 0, "order": order, "out": out, "main": main, "clip": clip, "ring_given": ring_given}       # (keeps the extended rows alive)
         return self
 
     #: conditioning features of all frames in one launch at the start of a job instead of 16 dependent layers inside every frame (GFPP_CLIP_PRECOND=0: per frame)
@@ -386,6 +387,8 @@ class ClipRenderer:
     def _replay_from_c(self):
         return self.replay_mode == "c" and self.use_graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
 
+    _warned_round_up = False
+
     @property
     def chunk_multiple(self):
         """Frames per graph launch once a job has started (1 before): issue() works in whole multiples of this."""
@@ -403,7 +406,13 @@ class ClipRenderer:
         # whole frame groups only: a count that is no multiple of K is rounded UP (the caller gets at least what it asked for and the return value / the next call
         # account for the overshoot; `chunk_multiple` tells callers that size their buffers per chunk what to round to)
         launches, first = -(-count // K), (J["issued"] // K) % self.lanes
-        count = min(launches * K, J["n"] - J["issued"])
+        asked, count = count, min(launches * K, J["n"] - J["issued"])
+        if count != asked and J.get("ring_given") and not ClipRenderer._warned_round_up:
+            # (round-5 advisory) a caller that sized its own ring to its chunks gets up to K - 1 more frames stored per call than it asked for
+            import warnings
+            ClipRenderer._warned_round_up = True
+            warnings.warn(f"ClipRenderer.issue({asked}): rounded up to {count} (whole groups of {K} frames per launch); a job started with its own ring_frames must "
+                          f"leave room for the extra frames or issue multiples of chunk_multiple = {K}", RuntimeWarning, stacklevel=2)
         if self._replay_from_c():
             execs, streams = self._exec_arrays()
             if self.lanes == 1:

@@ -322,6 +322,11 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float *__rest
 
 using namespace gfpp;
 
+GFPP_API unsigned long long gfpp_linear_weight_grad_scratch_floats(uint32_t O, uint32_t I) {
+    if (O == 0 || I == 0 || div_up(O, 32) > (uint32_t)kWgMaxTO || div_up(I, 32) > (uint32_t)kWgMaxTI) return 0ull;
+    return (unsigned long long)kWgMaxSlices * O * I;
+}
+
 GFPP_API int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
                                      gfpp_stream_t stream) {
     const char *who = "gfpp_linear_weight_grad";

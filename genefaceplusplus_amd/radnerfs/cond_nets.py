@@ -69,6 +69,7 @@ _lib.register("gfpp_linear_weight_grad", [ctypes.c_void_p, ctypes.c_void_p, ctyp
 WGRAD_MIN_ROWS = 8192
 _u32 = ctypes.c_uint32
 _lib.register("gfpp_mlp_train_pack", [ctypes.POINTER(ctypes.c_void_p), _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+_lib.register("gfpp_linear_weight_grad_scratch_floats", [ctypes.c_uint32, ctypes.c_uint32], restype=ctypes.c_uint64)
 _lib.register("gfpp_mlp_train_image_bytes", [_u32, _u32, _u32, ctypes.c_int], restype=ctypes.c_uint32)
 _lib.register("gfpp_mlp_train_forward", [ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
 _lib.register("gfpp_mlp_train_backward", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u32, _u32, _u32, _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
@@ -107,7 +108,7 @@ class _LinearNoBias(torch.autograd.Function):
             if gy.data_ptr() % 16:
                 gy = gy.clone()
             gw = torch.empty(O, I, dtype=torch.float32, device=x.device)
-            partial = torch.empty(512, O, I, dtype=torch.float32, device=x.device)
+            partial = torch.empty(int(_lib.lib().gfpp_linear_weight_grad_scratch_floats(O, I)), dtype=torch.float32, device=x.device)
             _lib.call("gfpp_linear_weight_grad", gy.data_ptr(), x.data_ptr(), M, O, I, 1 if x.dtype == torch.float16 else 0, partial.data_ptr(), gw.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
         return gx, gw
@@ -158,7 +159,10 @@ class _FusedMLP(torch.autograd.Function):
         gx = torch.empty(M, in_pad, dtype=torch.float16, device=dev) if ctx.needs_input_grad[0] else None
         _lib.call("gfpp_mlp_train_backward", gyp.data_ptr(), acts.data_ptr(), bwd.data_ptr(), M, in_pad, _FUSED_HIDDEN, NL, out_pad, G.data_ptr(),
                   gx.data_ptr() if gx is not None else None, st)
-        partial = torch.empty(512 * 160 * 160, dtype=torch.float32, device=dev)      # the split-M kernel's slices: one scratch, the launches are stream-ordered
+        # the split-M kernel's slices: ONE scratch for the layers (the launches are stream-ordered), sized by the library for the largest of them
+        widths = [in_pad] + [_FUSED_HIDDEN] * (NL - 1)
+        outs_w = [_FUSED_HIDDEN] * (NL - 1) + [out_pad]
+        partial = torch.empty(max(int(_lib.lib().gfpp_linear_weight_grad_scratch_floats(o, i)) for o, i in zip(outs_w, widths)), dtype=torch.float32, device=dev)
         gws = []
         for l in range(NL):
             if not ctx.needs_input_grad[4 + l]:

@@ -1074,19 +1074,23 @@ class FramePipeline:
         """(mask [N] uint8, ascending int32 indices of the masked pixels): WHERE the torso field is evaluated -- the occupancy grid sampled at the pixel coordinates
         (radnerf_torso.py:166-169), constants of the model and the resolution -- computed once per coordinate tensor (gfpp_torso_mask + one compaction; synchronises:
         the first frame of a resolution, never inside a captured graph because the capture's warm-up frames come first)."""
-        key = (bg_coords.data_ptr(), int(bg_coords.shape[0]), bg_coords._version)
+        # keyed on the CALLER's tensor (address, version, dtype, strides): a half or strided coordinate tensor is converted once and the fp32 copy kept with the
+        # entry -- keyed on the converted tensor, every call of such a caller made a fresh copy, missed, synchronised and churned the four entries (round-5 advisory)
+        key = (bg_coords.data_ptr(), int(bg_coords.numel()), bg_coords._version, bg_coords.dtype, tuple(bg_coords.stride()))
         hit = self._torso_pixels.get(key)
         if hit is None:
             if torch.cuda.is_current_stream_capturing():
                 raise GfppError("torso_pixels: the masked-pixel list of this resolution must exist before a graph is captured (render one frame group first)")
+            caller = bg_coords
+            bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
             N = int(bg_coords.shape[0])
             mask = torch.empty(N, dtype=torch.uint8, device=self.device)
             call("gfpp_torso_mask", ctypes.byref(self.torso), bg_coords.data_ptr(), N, mask.data_ptr(), torch.cuda.current_stream().cuda_stream)
             idx = torch.nonzero(mask, as_tuple=False).reshape(-1).to(torch.int32).contiguous()
             while len(self._torso_pixels) >= 4:                             # a caller that hands over a fresh coordinate tensor per call must not grow this for ever
                 self._torso_pixels.pop(next(iter(self._torso_pixels)))
-            hit = self._torso_pixels[key] = (mask, idx, bg_coords)          # (keeps the keyed tensor's address alive)
-        return hit[0], hit[1]
+            hit = self._torso_pixels[key] = (mask, idx, bg_coords, caller)  # (keeps the keyed tensor's address alive; [2] = its contiguous fp32 form)
+        return hit[0], hit[1], hit[2]
 
     def group_workspace(self, N, K, max_steps):
         """The workspaces of K frames of N rays BEHIND EACH OTHER in every per-ray array (what gfpp_head_frame_persist_lp needs to render them with one
@@ -1217,7 +1221,9 @@ class FramePipeline:
             folded = torch.empty(K, 96, dtype=torch.float32, device=dev)
             call("gfpp_torso_fold_batch", ctypes.byref(self.torso), ins[0].data_ptr(), int(tstep), code.data_ptr() if code is not None else None, K, folded.data_ptr(), st)
         launch()
-        bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
+        bg_caller = bg_coords
+        if folded is None:
+            bg_coords = self._dev_f32(bg_coords, "bg_coords").reshape(-1, 2)
         bg_ptr, bg_scalar, _bg_keep = self._bg(bg_color, N)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         if folded is not None:
@@ -1230,7 +1236,7 @@ class FramePipeline:
             stack = {"image": f(K * N, 3), "depth": f(K * N), "torso_alpha": f(K * N, 1), "torso_bg": f(K * N, 3), "deform_dense": f(K * N, 2),
                      "torso_mask": torch.empty(K * N, dtype=torch.uint8, device=dev)}
             try:
-                mask_static, masked_idx = self.torso_pixels(bg_coords)
+                mask_static, masked_idx, bg_coords = self.torso_pixels(bg_caller)
                 call("gfpp_torso_group_lp", ctypes.byref(self.torso), ctypes.byref(gws), bg_coords.data_ptr(), folded.data_ptr(), code.data_ptr() if code is not None else None,
                      mask_static.data_ptr(), masked_idx.data_ptr() if masked_idx.numel() else None, int(masked_idx.numel()),
                      bg_ptr, bg_scalar, int(bool(use_head_for_torso)), int(max_steps), stack["image"].data_ptr(), stack["depth"].data_ptr(), stack["torso_alpha"].data_ptr(),

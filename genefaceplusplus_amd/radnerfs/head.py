@@ -335,7 +335,9 @@ class _CondFeatTrain(torch.autograd.Function):
         scratch = torch.empty(int(_lib.lib().gfpp_cond_feat_train_floats(ctypes.byref(cm), 1)), dtype=torch.float32, device=cond.device)
         _lib.call("gfpp_cond_feat_train_backward", ctypes.byref(cm), ctypes.byref(gm), cond.data_ptr(), eye.data_ptr() if eye is not None else None, saved.data_ptr(),
                   gout.float().contiguous().data_ptr(), scratch.data_ptr(), st)
-        return (None, None, None, *[g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads)])
+        # (one storage per gradient: AccumulateGrad may keep what it is handed as p.grad, and views of one flat buffer would alias every conditioning-net
+        # gradient to a single allocation at unaligned offsets -- a few hundred KB of copies per step)
+        return (None, None, None, *[g.clone() if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads)])
 
 
 class RADNeRF(NeRFRenderer):
@@ -489,7 +491,7 @@ class RADNeRF(NeRFRenderer):
                 and not torch.cuda.is_current_stream_capturing()):
             return None
         params = [p for m in self._cond_modules() for p in m.parameters()]
-        if not params or not all(p.requires_grad and p.device.type == "cuda" for p in params):
+        if not params or not all(p.requires_grad and p.device == cond.device for p in params):        # (the launches run on cond's device: same device index, not only "cuda")
             return None
         return params
 

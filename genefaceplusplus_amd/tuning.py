@@ -64,6 +64,7 @@ HOST = {
     "clip_precond": _env("GFPP_CLIP_PRECOND", "1") != "0",          # ClipRenderer.precompute_cond
     "clip_replay": _env("GFPP_CLIP_REPLAY", "c"),                   # ClipRenderer.replay_mode: 'c' | 'python'
     "clip_max_ahead": _env("GFPP_CLIP_MAX_AHEAD", 0, int),          # ClipRenderer.max_ahead
+    "sr_store_u8": _env("GFPP_SR_STORE_U8", "1") != "0",            # ClipRenderer: the SR stage's last layer stores the clip frame as uint8 itself (0: a store launch per frame)
     "train_fused_mlp": _env("GFPP_TRAIN_FUSED_MLP", "1") != "0",    # cond_nets.FUSED_MLP
     "train_cond": _env("GFPP_TRAIN_COND", "fused"),                 # head.COND_TRAIN: 'fused' | 'eager'
 }

@@ -709,6 +709,9 @@ int gfpp_grid_encode_backward(const float *grad, const float *inputs, const floa
  * nothing is read past their last element (the vector that straddles the end is assembled element by element). */
 int gfpp_linear_weight_grad(const void *grad_out, const void *input, uint32_t M, uint32_t O, uint32_t I, int dtype, float *partial, float *grad_weight,
                             gfpp_stream_t stream);
+/* floats of the `partial` scratch gfpp_linear_weight_grad needs for an O x I layer (cond_encoder.py:183-202's layers): the slice count is the library's, not the
+ * binding's, to know; 0 for a shape the kernels do not cover. */
+unsigned long long gfpp_linear_weight_grad_scratch_floats(uint32_t O, uint32_t I);
 
 /* A whole `MLP` (cond_encoder.py:183-202: bias-free Linear layers, ReLU between them; ambient_net / sigma_net / color_net, radnerf.py:60-100) over a
  * training batch under `amp: true` as ONE forward and ONE backward launch -- what autograd runs as a BLAS GEMM + relu + cast kernels per layer and

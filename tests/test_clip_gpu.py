@@ -332,7 +332,7 @@ def test_group_torso_launch_with_an_empty_torso_mask(dev):
     grouped = mk(group=K, lanes=2)
     got = grouped.render_to_device(clip).cpu().numpy()
     assert grouped.group == K and pipe.group_torso
-    mask, idx = pipe.torso_pixels(grouped.bg_coords)
+    mask, idx, _coords = pipe.torso_pixels(grouped.bg_coords)
     assert idx.numel() == 0 and int(mask.sum()) == 0
     np.testing.assert_array_equal(got, want)
     assert want.std() > 5
