@@ -1035,6 +1035,7 @@ struct PremarchArgs {
     uint32_t occ_valid;
     // a frame GROUP (k_group_begin): `frames` frames of N rays behind each other in every array, counters [frames, kCounterWords]; the rays are generated here
     // from each frame's pose (the arithmetic of k_get_rays, raymarch.hip) and stored for the head launch
+    uint32_t fixed_step;           // gfpp_tuning.march_fixed_step (1: rays that qualify take march_one_ray_fixed_step; 0: the A/B and parity partner)
     uint32_t frames;
     const float *poses;            // frame f's cam2world [4,4] (ngp convention) at poses + f * pose_stride
     uint32_t pose_stride, W;
@@ -1046,7 +1047,9 @@ struct PremarchArgs {
 // march_one_ray would only skip empty cells until `far` and emit nothing more -- the emitted samples (and their t, a chain of fp32 additions from
 // `near` on: the walk BEFORE the bounds cannot be skipped, and skipping only the bitfield reads there measured slower, a divergent branch per
 // cell) are the same bits.  A ray that misses the bounds has no sample at all (-1).
-__device__ __forceinline__ float march_far_limit(float ox, float oy, float oz, float dx, float dy, float dz, const PremarchArgs &p, float far) {
+__device__ __forceinline__ float march_far_limit(float ox, float oy, float oz, float dx, float dy, float dz, const PremarchArgs &p, float far,
+                                                 float *t_enter = nullptr) {
+    if (t_enter) *t_enter = -FLT_MAX;           // (where the ray ENTERS the bounds: before it no cell is occupied either -- the fixed-step walk probes from there on)
     if (!p.occ_valid) return far;
     const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
     float tn = -FLT_MAX, tf = FLT_MAX;
@@ -1063,13 +1066,53 @@ __device__ __forceinline__ float march_far_limit(float ox, float oy, float oz, f
         }
     }
     if (tn > tf) return -1.0f;
+    if (t_enter) *t_enter = tn;
     return fminf(far, tf);
 }
 
 // The pre-march of one ray: the t of every occupied sample into out[], the count returned.  One-cascade models with <= 256 cells per axis (every shipped one:
 // wavefront-uniform test) take the marcher's lean probe (march_device.h: ONE_SMALL_SHELL), same bits.
+// The fixed-step walk of the pre-march (march_device.h::march_one_ray_fixed_step: ONE chain t_k+1 = t_k + dt_max, every point probed, same bits as the general walk),
+// shaped for what bounds this kernel -- not vector instructions but a chain of DEPENDENT bitfield reads per ray (~27 from the box face to the far side of the
+// occupied cells, each an L2 round trip): (1) no probe before the ray enters the bounds of the occupied cells (they carry a whole cell of margin, k_occupancy_bounds:
+// a chain point outside them lies in an empty cell) -- the chain itself is still walked addition by addition, it is what fixes the later t; (2) the probes of four
+// consecutive chain points are independent of each other, so their reads are issued together and the results consumed in order.
+__device__ __forceinline__ uint32_t premarch_fixed(float ox, float oy, float oz, float dx, float dy, float dz, float t, float far, float t_enter, const PremarchArgs &p,
+                                                   float *__restrict__ out) {
+    const MarchParams &mp = p.mp;
+    const float dt = mp.dt_max, mip_rbound = mp.bound <= 1.0f ? mp.rbound : 1.0f;
+    while (t < far && t + dt < t_enter) t += dt;           // (the next point is still outside: this one cannot be inside either)
+    uint32_t step = 0;
+    while (t < far && step < p.max_samples) {
+        float tk[4];
+        uint32_t cell[4];
+        tk[0] = t;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) tk[i] = tk[i - 1] + dt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = clampf(fmaf(tk[i], dx, ox), -mp.bound, mp.bound);
+            const float y = clampf(fmaf(tk[i], dy, oy), -mp.bound, mp.bound);
+            const float z = clampf(fmaf(tk[i], dz, oz), -mp.bound, mp.bound);
+            cell[i] = morton3_8((uint32_t)voxel_of(x, mip_rbound, mp), (uint32_t)voxel_of(y, mip_rbound, mp), (uint32_t)voxel_of(z, mip_rbound, mp));
+        }
+        uint32_t byte[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) byte[i] = p.bitfield[cell[i] >> 3];      // (positions are clamped into the box: every address is valid, also beyond `far`)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (tk[i] < far && step < p.max_samples && ((byte[i] >> (cell[i] & 7u)) & 1u)) out[step++] = tk[i];
+        }
+        t = tk[3] + dt;
+    }
+    return step;
+}
+
+__device__ __forceinline__ bool tuning_fixed_step(const PremarchArgs &p) { return p.fixed_step != 0u; }
 __device__ __forceinline__ uint32_t premarch_ray(float ox, float oy, float oz, float dx, float dy, float dz, float t, float far_limit, const PremarchArgs &p,
-                                                 float *__restrict__ out) {
+                                                 float *__restrict__ out, float t_enter = -FLT_MAX) {
+    if (march_fixed_step_ok(dx, dy, dz, p.mp) && tuning_fixed_step(p))          // (per ray; every ray of a camera that does not look along a voxel diagonal)
+        return premarch_fixed(ox, oy, oz, dx, dy, dz, t, far_limit, t_enter, p, out);
     if (p.mp.C == 1u && p.mp.H <= 256u)
         return march_one_ray<true>(ox, oy, oz, dx, dy, dz, t, far_limit, p.max_samples, p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
     return march_one_ray<false>(ox, oy, oz, dx, dy, dz, t, far_limit, p.max_samples, p.bitfield, p.mp, [&](uint32_t s, const Sample &smp) { out[s] = smp.t0; });
@@ -1081,7 +1124,9 @@ __global__ __launch_bounds__(256) void k_premarch(PremarchArgs p) {
     const float *o = p.rays_o + 3ull * n, *d = p.rays_d + 3ull * n;
     float t = p.nears[n];
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = premarch_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, march_far_limit(o[0], o[1], o[2], d[0], d[1], d[2], p, p.fars[n]), p, out);
+    float t_enter;
+    const float far_limit = march_far_limit(o[0], o[1], o[2], d[0], d[1], d[2], p, p.fars[n], &t_enter);
+    p.sample_cnt[n] = premarch_ray(o[0], o[1], o[2], d[0], d[1], d[2], t, far_limit, p, out, t_enter);
 }
 
 // k_frame_begin (frame_head.hip) and k_premarch in one pass: the slab test's near is the marcher's start, so the rays are read once and one
@@ -1099,7 +1144,9 @@ __global__ __launch_bounds__(256) void k_begin_premarch(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p, out);
+    float t_enter;
+    const float far_limit = march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far, &t_enter);
+    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, far_limit, p, out, t_enter);
 }
 
 // The prologue of a frame group as ONE launch: ray generation (k_get_rays' expressions: utils.py:352-363) + slab test + state / counter reset + pre-march
@@ -1135,7 +1182,9 @@ __global__ __launch_bounds__(256) void k_group_begin(PremarchArgs p) {
     *reinterpret_cast<float4 *>(p.state + (size_t)kRayRec * n + 4) = float4{0.0f, rb.near, rb.near, 0.0f};
     float t = rb.near;
     float *out = p.sample_t + (size_t)n * p.stride;
-    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far), p, out);
+    float t_enter;
+    const float far_limit = march_far_limit(ox, oy, oz, dx, dy, dz, p, rb.far, &t_enter);
+    p.sample_cnt[n] = premarch_ray(ox, oy, oz, dx, dy, dz, t, far_limit, p, out, t_enter);
 }
 
 // k_head_budget_resolve for the K frames of a group in one launch (each frame against its own histogram / counters)
@@ -1306,6 +1355,7 @@ static int lp_model_args(const char *who, const gfpp_head_model *model, LpTripAr
 
 static void premarch_occupancy(PremarchArgs &p, const gfpp_head_model *model) {
     const uint32_t mode = tuning().occ_clip ? 1u : 0u;          // A/B switch, read at every issue (a captured graph keeps what it was captured with)
+    p.fixed_step = tuning().march_fixed_step ? 1u : 0u;
     p.occ_valid = 0u;
     for (int i = 0; i < 6; ++i) p.occ[i] = model->occ_aabb[i];
     if (model->occ_aabb[3] > model->occ_aabb[0] && model->occ_aabb[4] > model->occ_aabb[1] && model->occ_aabb[5] > model->occ_aabb[2]) p.occ_valid = mode;

@@ -144,6 +144,42 @@ __device__ __forceinline__ uint32_t march_one_ray(float ox, float oy, float oz, 
     return step;
 }
 
+// The same walk when the step is a CONSTANT and longer than a voxel can hold a ray: every chain point is probed, nothing else is computed.
+//
+// With dt_min == dt_max (make_march_params: max_steps <= H / 2^(C-1) -- the shipped max_steps 16 against H = 128) the marcher's `clamp(t dt_gamma, dt_min, dt_max)`
+// is the constant dt_max whatever t is, so t walks ONE chain t_{k+1} = t_k + dt_max (the same fp32 addition in the occupied branch and in the empty branch's
+// skip loop, raymarching.cu:873-912): which points of the chain are emitted depends on the grid, the chain does not.  The empty branch skips the chain points
+// with t < tt = t_k + e, e = the distance to the voxel's exit face.  dt_max is DEFINED as the voxel diagonal (2 sqrt(3) 2^(C-1) / H), and e <= h / max_a |d_a|
+// (h = the voxel's side, one axis at least has |d_a| >= the largest component), so with max_a |d_a| > (1 + 1e-4) / sqrt(3) the exit lies more than 1e-4 dt
+// before the next chain point -- orders of magnitude beyond the rounding of the reference's fp32 expressions for e and tt (a few ulp of t): the skip loop runs
+// exactly once, i.e. the reference probes every chain point too.  (Rays inside that margin of an exact voxel diagonal take the general walk.)  What is left of a
+// probe is position, voxel, Morton code, bit: ~40 vector instructions instead of 125 -- k_group_begin is vector-ALU bound on exactly this loop.
+__device__ __forceinline__ bool march_fixed_step_ok(float dx, float dy, float dz, const MarchParams &p) {
+    return p.C == 1u && p.H <= 256u && p.dt_min == p.dt_max && fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) > 0.57741f;
+}
+template <typename Emit>
+__device__ __forceinline__ uint32_t march_one_ray_fixed_step(float ox, float oy, float oz, float dx, float dy, float dz, float &t, float far, uint32_t n_step,
+                                                             const uint8_t *__restrict__ bitfield, const MarchParams &p, Emit &&emit) {
+    const float dt = p.dt_max;                          // == clampf(t * p.dt_gamma, p.dt_min, p.dt_max) for every t
+    const float mip_rbound = p.bound <= 1.0f ? p.rbound : 1.0f;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        const float x = clampf(fmaf(t, dx, ox), -p.bound, p.bound);
+        const float y = clampf(fmaf(t, dy, oy), -p.bound, p.bound);
+        const float z = clampf(fmaf(t, dz, oz), -p.bound, p.bound);
+        const int nx = voxel_of(x, mip_rbound, p), ny = voxel_of(y, mip_rbound, p), nz = voxel_of(z, mip_rbound, p);
+        const uint32_t cell = morton3_8((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        const float t0 = t;
+        t += dt;
+        if ((bitfield[cell >> 3] >> (cell & 7u)) & 1u) {
+            Sample s{x, y, z, dt, t, t0};
+            emit(step, s);
+            ++step;
+        }
+    }
+    return step;
+}
+
 // Running compositing state of one ray.
 struct RayAccum {
     float wsum, depth, r, g, b;

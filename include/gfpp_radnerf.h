@@ -66,6 +66,8 @@ typedef struct gfpp_tuning {
     int32_t sr_final_resident;   /* last SR layer with LDS-resident weights: 1 (default) / 0 = one workgroup per patch */
     int32_t grid_bwd_scatter;    /* table gradient: 0 = LDS ranges (default), 1 = device atomics (the round-2 path) */
     int32_t wgrad_tr;            /* transposing-read weight gradients: 1 (default) / 0 */
+    int32_t march_fixed_step;    /* pre-march: rays whose step is constant and longer than a voxel probe every chain point without the exit-face arithmetic
+                                  * (march_device.h::march_one_ray_fixed_step, same bits): 1 (default) / 0 = the general walk for every ray */
 } gfpp_tuning;
 int gfpp_set_tuning(const gfpp_tuning *t);   /* NULL restores the defaults */
 int gfpp_get_tuning(gfpp_tuning *out);       /* out->size must be set */

@@ -537,3 +537,50 @@ def test_other_hidden_widths_render_on_the_staged_executor(dev, oracle_mod, vari
     psnr = _psnr(rgb16, ref["rgb_map"].reshape(-1, 3))
     print(variant, hidden, "autocast staged psnr", psnr)
     assert psnr >= 40.0
+
+
+@pytest.mark.parametrize("variant,HW,kind,cam", [("may_torso", 256, None, None), ("may_torso", 128, "speckle", dict(distance=0.9, yaw_deg=12.0)),
+                                                 ("may_head", 96, "shell", dict(distance=4.0, yaw_deg=40.0)), ("may_head", 64, "speckle", "diagonal")])
+def test_fixed_step_premarch_probes_the_same_samples(dev, oracle_mod, variant, HW, kind, cam):
+    """march_one_ray_fixed_step (march_device.h; round 6): with the shipped max_steps the marcher's step is the constant dt_max = one voxel diagonal, so the reference
+    probes every point of ONE chain t_k+1 = t_k + dt_max and the exit-face arithmetic of its empty branch never changes what is probed.  The pre-march with and
+    without that shortcut (gfpp_tuning.march_fixed_step): sample counts, every sample's t (bits) and the frame (bits) -- convex and holey occupancy, a close and a
+    turned camera, and a camera that looks ALONG a voxel diagonal (those rays take the general walk: the shortcut's own precondition)."""
+    from genefaceplusplus_amd import tuning
+    from helpers import nonconvex_occupancy, pose_at
+    got = {}
+    for fixed in (0, 1):
+        case = frame_case(variant, HW)
+        if kind:
+            case = nonconvex_occupancy(case, kind)
+        if cam == "diagonal":
+            # camera on the (1, 1, 1) diagonal looking at the origin: the central rays have |d_x| = |d_y| = |d_z| = 1 / sqrt(3)
+            eye = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0) * 3.0
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+            down = np.cross(fwd, right)
+            pose = np.eye(4)
+            pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, down, fwd, eye
+            case["pose"] = pose.astype(np.float32)[None]
+            case["intr"] = np.array([case["intr"][0], case["intr"][1], HW / 2 - 0.5, HW / 2 - 0.5], np.float32)     # a pixel centre ON the optical axis
+        elif cam:
+            case["pose"] = pose_at(**cam)
+        with tuning.tuned(march_fixed_step=fixed):
+            model = build_model(case, dev, "fused")
+            model.precision = "fp16"
+            model.use_graph = False
+            r = product_render(model, case, dev, "oracle", oracle_mod)
+            torch.cuda.synchronize()
+        t = model.pipeline().workspace(HW * HW)[1]
+        cnt = t["sample_cnt"].cpu().numpy().astype(np.int64)
+        ts = t["sample_t"].cpu().numpy()
+        valid = np.arange(ts.shape[1])[None, :] < cnt[:, None]
+        got[fixed] = (cnt, np.where(valid, ts, 0.0), {k: v.detach().float().cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)})
+    assert got[1][0].sum() > 0
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+    for k in got[0][2]:
+        np.testing.assert_array_equal(got[0][2][k], got[1][2][k], err_msg=k)
+    if cam == "diagonal":
+        d = oracle_mod.get_rays(case["pose"], case["intr"], HW, HW)["rays_d"][0]
+        assert int((np.abs(d).max(axis=1) <= 0.57741).sum()) >= 1           # the axis ray really is inside the margin of the diagonal (the general walk's share)
