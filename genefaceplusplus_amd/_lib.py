@@ -59,15 +59,16 @@ _SIGNATURES = {
     "gfpp_sph_from_ray": [c_p, c_p, c_f, c_u32, c_p, c_p],
     "gfpp_grid_encode_dydx": [c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_u32, c_p],
     "gfpp_grid_encode_backward": [c_p, c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
-    "gfpp_grid_encode_backward_xcd": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
+    "gfpp_grid_encode_backward_xcd": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p, c_p, ctypes.c_uint64],
+    "gfpp_grid_backward_bins_bytes": [c_u32, c_u32, c_u32, c_u32],
     "gfpp_grid_encode_input_backward": [c_p, c_i, c_p, c_p, c_p, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_u32, c_p],
-    "gfpp_grid_encode_backward_f16": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p],
+    "gfpp_grid_encode_backward_f16": [c_p, c_p, c_p, c_p, c_u32, c_p, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_p, c_p, c_u32, c_i, c_u32, c_p, c_p, ctypes.c_uint64],
     "gfpp_grad_total_variation": [c_p, c_p, c_p, c_p, c_f, c_u32, c_u32, c_u32, c_u32, c_f, c_u32, c_u32, c_i, c_p],
     "gfpp_get_rays": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_p, c_p],
     "gfpp_get_rays_at": [c_p, c_f, c_f, c_f, c_f, c_u32, c_u32, c_p, c_u32, c_p, c_p, c_p],
     "gfpp_rgb_to_u8": [c_p, ctypes.c_uint64, c_p, c_p],
 }
-_RESTYPES = {"gfpp_last_error": ctypes.c_char_p, "gfpp_struct_size": ctypes.c_uint}
+_RESTYPES = {"gfpp_last_error": ctypes.c_char_p, "gfpp_struct_size": ctypes.c_uint, "gfpp_grid_backward_bins_bytes": ctypes.c_uint64}
 
 
 class GfppError(RuntimeError):

@@ -97,7 +97,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
             copies = torch.empty(8 * rows * 2 + 64, device=grad_embeddings.device, dtype=torch.float32)
             dy32 = dy_dx.float().contiguous() if dy_dx is not None else None
             call("gfpp_grid_encode_backward_f16", _p(grad.contiguous()), _p(inputs), _p(offsets), _p(ge32), rows, _p(copies), int(B), int(D), 2, int(L), float(S),
-                 int(H), _p(dy32), _p(gi32), int(gridtype), int(bool(align_corners)), int(interp), _st())
+                 int(H), _p(dy32), _p(gi32), int(gridtype), int(bool(align_corners)), int(interp), _st(), None, 0)
         else:
             # other level_dims: fp32 accumulation (more accurate than the reference's half atomics, same interface)
             grid_encode_backward(grad.float(), inputs, embeddings.float(), offsets, ge32, B, D, C, L, S, H, dy_dx.float() if dy_dx is not None else None, gi32,
@@ -109,7 +109,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     rows = int(embeddings.shape[0])
     copies = torch.empty(8 * rows * int(C) + 64, device=grad_embeddings.device, dtype=torch.float32)       # gradient copies + level maxima, see gfpp_grid_encode_backward_xcd
     call("gfpp_grid_encode_backward_xcd", _p(grad), _p(inputs), _p(offsets), _p(grad_embeddings), rows, _p(copies), int(B), int(D), int(C), int(L), float(S), int(H),
-         _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st())
+         _p(dy_dx), _p(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp), _st(), None, 0)
 
 
 def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):   # gridencoder.h:15

@@ -472,13 +472,78 @@ __global__ __launch_bounds__(kTrBlock) void k_grid_grad_levelmax(const G *__rest
     }
 }
 
+// ---- which points a range needs: per level, every point is put on the list of each range that one of its corners falls into (round 6) ---------------------------
+// The range kernel below walks, per (level, range), ALL points and keeps the corners that land in its range: a 2^16-row level is eight ranges, so a point's cell is
+// located eight times there although its eight corners touch two or three of them (rows r, r + 1, r + sy, r + sy + 1 of one z plane are at most a row stride apart,
+// the other plane is sz rows further, modulo the level size).  One pass per level finds the ranges of a point's corners once (a bit mask of <= 32 ranges) and appends
+// the point's index to those ranges' lists; the range kernel then walks its list.  Lists have room for every point (a point is on a list at most once) and are
+// filled through one LDS counter per range and workgroup and one device atomic per range and workgroup; their order is whatever the atomics give -- the range
+// kernel's accumulators are integers, the sums do not depend on it.  Levels of more than 32 ranges (tables beyond 2^18 rows at level_dim 2) are marked
+// "no list" (count 0xFFFFFFFF) and walked the old way.
+constexpr uint32_t kBinMaxRanges = 32;
+template <int D, int C>
+__global__ __launch_bounds__(1024) void k_grid_bin_points(const float *__restrict__ inputs, const int32_t *__restrict__ offsets, uint32_t B, TrLevels lv, uint32_t gridtype,
+                                                          bool align_corners, uint32_t *__restrict__ counts, uint32_t *__restrict__ lists) {
+    __shared__ uint32_t s_cnt[kBinMaxRanges], s_base[kBinMaxRanges];
+    const uint32_t level = blockIdx.y, b = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off, res = lv.resolution[level];
+    constexpr uint32_t rows_per = kLdsGradFloats * (uint32_t)sizeof(float) / (uint32_t)sizeof(long long) / C;
+    const uint32_t nr = (size + rows_per - 1u) / rows_per;
+    if (nr > kBinMaxRanges) {
+        if (blockIdx.x == 0 && threadIdx.x < kBinMaxRanges) counts[level * kBinMaxRanges + threadIdx.x] = 0xFFFFFFFFu;
+        return;
+    }
+    uint32_t item0 = 0;                                            // the level's first range among all ranges (the range kernel's item numbering); scalar loop
+    for (uint32_t l = 0; l < level; ++l) item0 += ((uint32_t)(offsets[l + 1] - offsets[l]) + rows_per - 1u) / rows_per;
+    if (threadIdx.x < kBinMaxRanges) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t mask = 0u, rank[1 << D];
+    if (b < B) {
+        float pos[D], deriv[D];
+        uint32_t pg[D];
+        if (tr_locate<D>(inputs + (size_t)b * D, lv.scale[level], align_corners, 0u, pos, deriv, pg)) {      // (the cell does not depend on the interpolation)
+            const TrIndex ix = tr_index<D>(size, res, gridtype, align_corners);
+            const uint32_t base = tr_base_row<D>(ix, pg);
+#pragma unroll
+            for (int idx = 0; idx < (1 << D); ++idx) mask |= 1u << (tr_corner_row<D>(ix, base, pg, idx, gridtype, align_corners, size, res) / rows_per);
+        }
+    }
+    {
+        uint32_t m = mask;
+#pragma unroll
+        for (int k = 0; k < (1 << D); ++k) {
+            if (m) {
+                const uint32_t r = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                rank[k] = atomicAdd(&s_cnt[r], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nr && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[level * kBinMaxRanges + threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    {
+        uint32_t m = mask;
+#pragma unroll
+        for (int k = 0; k < (1 << D); ++k) {
+            if (m) {
+                const uint32_t r = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                lists[(size_t)(item0 + r) * B + s_base[r] + rank[k]] = b;
+            }
+        }
+    }
+}
+
 template <int D, int C, typename G>
 __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
                                                                      uint32_t B, uint32_t L, TrLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
-                                                                     float *__restrict__ copies, uint32_t total_floats, const uint32_t *__restrict__ levelmax) {
+                                                                     float *__restrict__ copies, uint32_t total_floats, const uint32_t *__restrict__ levelmax,
+                                                                     const uint32_t *__restrict__ bin_counts, const uint32_t *__restrict__ bin_lists) {
     extern __shared__ long long rg_acc[];
     long long *acc = rg_acc;
     uint32_t item = blockIdx.x / kRgSlices;
+    const uint32_t item_global = item;
     const uint32_t slice = blockIdx.x % kRgSlices;
     uint32_t level = 0, range = 0, off = 0, size = 0;
     bool found = false;
@@ -500,12 +565,18 @@ __global__ __launch_bounds__(kRgThreads) void k_grid_backward_ranges(const G *__
     int e = maxbits ? (int)(maxbits >> 23) - 126 : 0;                // 2^e > max |g|
     e = e > 100 ? 100 : (e < -100 ? -100 : e);                       // (keeps both scale factors inside fp32's range; gradients below 2^-100 round to zero)
     const float to_fixed_a = ldexpf(1.0f, 16 - e), to_fixed_b = 1048576.0f;   // two exact power-of-two factors (their product can exceed fp32's range)
-    const uint32_t per = (B + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < B ? first + per : B;
+    // the points of this workgroup: its eighth of the range's LIST (k_grid_bin_points), or of all points where there is none
+    const uint32_t listed = bin_counts ? bin_counts[level * kBinMaxRanges + (range < kBinMaxRanges ? range : 0u)] : 0xFFFFFFFFu;
+    const bool by_list = listed != 0xFFFFFFFFu;
+    const uint32_t n_pts = by_list ? listed : B;
+    const uint32_t *list = by_list ? bin_lists + (size_t)item_global * B : nullptr;
+    const uint32_t per = (n_pts + kRgSlices - 1u) / kRgSlices, first = slice * per, last = first + per < n_pts ? first + per : n_pts;
     const float scale = lv.scale[level];
     const uint32_t res = lv.resolution[level];
     const TrIndex ix = tr_index<D>(size, res, gridtype, align_corners);          // resolved once per workgroup
     if (finite) {
-        for (uint32_t b = first + threadIdx.x; b < last; b += kRgThreads) {
+        for (uint32_t i = first + threadIdx.x; i < last; i += kRgThreads) {
+            const uint32_t b = by_list ? list[i] : i;
             float pos[D], deriv[D];
             uint32_t pg[D];
             float gc[C];
@@ -757,7 +828,8 @@ GFPP_API int gfpp_grid_encode_dydx(const float *inputs, const float *embeddings,
 // One (D, C) instantiation of the three table-gradient kernels for grad type G
 template <int D, int C, typename G>
 static int grid_backward_launch(const char *who, const G *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, float *xcd_copies,
-                                uint32_t total_floats, uint32_t B, uint32_t L, const TrLevels &lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+                                uint32_t total_floats, uint32_t B, uint32_t L, const TrLevels &lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st,
+                                void *bins, unsigned long long bins_bytes) {
     // levels whose table fits kLdsGradFloats go through the LDS-privatised kernel (128 KiB of dynamic LDS); a device that cannot reserve that much
     // (64 KiB parts) scatters every level directly instead (lds_floats = 0) -- slower, same result
     const int lds_bytes = (int)(kLdsGradFloats * sizeof(float));
@@ -774,6 +846,8 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
         rc = check_launch(who);
         if (rc) return rc;
     }
+    // (the range passes store every value of every copy; only the scatter path adds into them)
+    if (!ranges && xcd_copies && hipMemsetAsync(xcd_copies, 0, (size_t)kXcds * total_floats * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear the gradient copies", who); return GFPP_EINVAL; }
     if (ranges) {
         // per-level max |grad| -> the levels' fixed-point scales (kept behind the eight copies: the scratch has 64 spare words)
         uint32_t *levelmax = reinterpret_cast<uint32_t *>(xcd_copies + (size_t)kXcds * total_floats);
@@ -783,8 +857,18 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
         if (rc) return rc;
         // sum over levels of ceil(size C / V) <= total / V + L: workgroups beyond the actual ranges return at once
         const uint32_t items = total_floats / kRgValues + L;
+        // the points of every range as lists (k_grid_bin_points), when the caller brought the scratch for them: [L][32] counters, then `items` lists of B indices
+        uint32_t *bin_counts = nullptr, *bin_lists = nullptr;
+        if (bins && tuning().grid_bwd_bins && L <= (uint32_t)kMaxLevels && bins_bytes >= gfpp_grid_backward_bins_bytes(total_floats / (uint32_t)C, (uint32_t)C, L, B)) {
+            bin_counts = static_cast<uint32_t *>(bins);
+            bin_lists = bin_counts + (size_t)kMaxLevels * kBinMaxRanges;
+            if (hipMemsetAsync(bin_counts, 0, (size_t)kMaxLevels * kBinMaxRanges * sizeof(uint32_t), st) != hipSuccess) { set_error("%s: cannot clear the list counters", who); return GFPP_EINVAL; }
+            hipLaunchKernelGGL((k_grid_bin_points<D, C>), dim3(div_up(B, 1024u), L), dim3(1024), 0, st, inputs, offsets, B, lv, gridtype, ac, bin_counts, bin_lists);
+            rc = check_launch(who);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL((k_grid_backward_ranges<D, C, G>), dim3(items * kRgSlices), dim3(kRgThreads), (size_t)lds_bytes, st, grad, inputs, offsets, B, L, lv,
-                           gridtype, ac, interp, xcd_copies, total_floats, levelmax);
+                           gridtype, ac, interp, xcd_copies, total_floats, levelmax, bin_counts, bin_lists);
     } else {
         hipLaunchKernelGGL((k_grid_backward<D, C, G>), dim3(div_up(B, kTrBlock), L), dim3(kTrBlock), 0, st, grad, inputs, offsets, grad_embeddings, B, L, lv,
                            gridtype, ac, interp, lds_ok ? kLdsGradFloats : 0u, xcd_copies, total_floats);
@@ -794,7 +878,8 @@ static int grid_backward_launch(const char *who, const G *grad, const float *inp
 
 static int grid_backward_impl(const char *who, const void *grad, int grad_dtype, const float *inputs, const int32_t *offsets, float *grad_embeddings,
                               uint32_t rows_total, float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
-                              float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+                              float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream, void *bins = nullptr,
+                              unsigned long long bins_bytes = 0) {
     if (B == 0) return 0;
     if (!grad || !inputs || !offsets || !grad_embeddings || gridtype > 1 || interp > 1 || ((dy_dx == nullptr) != (grad_inputs == nullptr))) {
         set_error("%s: bad arguments (dy_dx and grad_inputs go together)", who);
@@ -804,17 +889,16 @@ static int grid_backward_impl(const char *who, const void *grad, int grad_dtype,
     if (tr_levels(lv, L, S, H)) { set_error("%s: 1 <= L <= 32", who); return GFPP_EINVAL; }
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t total_floats = rows_total * C;
-    if (xcd_copies && hipMemsetAsync(xcd_copies, 0, (size_t)kXcds * total_floats * sizeof(float), st) != hipSuccess) { set_error("%s: cannot clear the gradient copies", who); return GFPP_EINVAL; }
     const bool ac = align_corners != 0;
     int rc;
     if (grad_dtype == GFPP_F16) {
         const _Float16 *g = static_cast<const _Float16 *>(grad);
         if (C != 2 || (D != 2 && D != 3)) { set_error("%s: half gradients are built for level_dim 2, input_dim 2 or 3 (got %u, %u)", who, C, D); return GFPP_EUNSUPPORTED; }
-        rc = D == 2 ? grid_backward_launch<2, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st)
-                    : grid_backward_launch<3, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st);
+        rc = D == 2 ? grid_backward_launch<2, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st, bins, bins_bytes)
+                    : grid_backward_launch<3, 2, _Float16>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st, bins, bins_bytes);
     } else {
         const float *g = static_cast<const float *>(grad);
-#define GFPP_BWD_ONE(DD, CC) rc = grid_backward_launch<DD, CC, float>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st)
+#define GFPP_BWD_ONE(DD, CC) rc = grid_backward_launch<DD, CC, float>(who, g, inputs, offsets, grad_embeddings, xcd_copies, total_floats, B, L, lv, gridtype, ac, interp, st, bins, bins_bytes)
         if (D == 2 && C == 2) GFPP_BWD_ONE(2, 2);
         else if (D == 3 && C == 2) GFPP_BWD_ONE(3, 2);
         else if (D == 2 && C == 1) GFPP_BWD_ONE(2, 1);
@@ -838,12 +922,18 @@ static int grid_backward_impl(const char *who, const void *grad, int grad_dtype,
     return check_launch(who);
 }
 
+GFPP_API unsigned long long gfpp_grid_backward_bins_bytes(uint32_t rows_total, uint32_t C, uint32_t L, uint32_t B) {
+    const unsigned long long items = (unsigned long long)rows_total * C / kRgValues + L;
+    return ((unsigned long long)kMaxLevels * kBinMaxRanges + items * B) * sizeof(uint32_t);
+}
+
 GFPP_API int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                            float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
-                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream, void *bins,
+                                           unsigned long long bins_bytes) {
     if (!xcd_copies || rows_total == 0) { set_error("gfpp_grid_encode_backward_f16: needs the [8, rows_total * C] fp32 scratch"); return GFPP_EINVAL; }
     return grid_backward_impl("gfpp_grid_encode_backward_f16", grad, GFPP_F16, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx,
-                              grad_inputs, gridtype, align_corners, interp, stream);
+                              grad_inputs, gridtype, align_corners, interp, stream, bins, bins_bytes);
 }
 
 GFPP_API int gfpp_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, float *grad_embeddings, uint32_t B,
@@ -856,10 +946,11 @@ GFPP_API int gfpp_grid_encode_backward(const float *grad, const float *inputs, c
 
 GFPP_API int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                            float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
-                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream) {
+                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream, void *bins,
+                                           unsigned long long bins_bytes) {
     if (!xcd_copies || rows_total == 0) { set_error("gfpp_grid_encode_backward_xcd: needs the [8, rows_total * C] scratch"); return GFPP_EINVAL; }
     return grid_backward_impl("gfpp_grid_encode_backward_xcd", grad, GFPP_F32, inputs, offsets, grad_embeddings, rows_total, xcd_copies, B, D, C, L, S, H, dy_dx, grad_inputs,
-                              gridtype, align_corners, interp, stream);
+                              gridtype, align_corners, interp, stream, bins, bins_bytes);
 }
 
 GFPP_API int gfpp_grid_encode_input_backward(const void *grad, int grad_dtype, const float *inputs, const float *embeddings, const int32_t *offsets,

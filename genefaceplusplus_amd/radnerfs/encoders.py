@@ -83,14 +83,28 @@ class _GridEncodeFn(torch.autograd.Function):
         grad_inputs = torch.zeros_like(inputs01) if want_dx else None
         # eight scratch copies of the table gradient (gfpp_grid_encode_backward_xcd: LDS accumulation per level range, no device atomic per corner)
         copies = torch.empty(8 * rows * C + 64, device=grad.device, dtype=torch.float32)     # (+ 64 words: the levels' gradient maxima)
+        bins, bins_bytes = table_gradient_bins(rows, C, L, B, grad.device)                   # per-range point lists (round 6)
         grad = grad.to(torch.half if half else torch.float32).contiguous()
         call("gfpp_grid_encode_backward_f16" if half else "gfpp_grid_encode_backward_xcd", grad.data_ptr(), inputs01.data_ptr(), offsets.data_ptr(),
              grad_emb.data_ptr(), rows, copies.data_ptr(), B, D, C, L, S, H, dy_dx.data_ptr() if dy_dx is not None else None,
-             grad_inputs.data_ptr() if dy_dx is not None else None, gridtype, ac, interp, _stream())
+             grad_inputs.data_ptr() if dy_dx is not None else None, gridtype, ac, interp, _stream(), bins.data_ptr() if bins is not None else None, bins_bytes)
         if want_dx and dy_dx is None:
             call("gfpp_grid_encode_input_backward", grad.data_ptr(), 1 if half else 0, inputs01.data_ptr(), emb.data_ptr(), offsets.data_ptr(), grad_inputs.data_ptr(),
                  B, D, C, L, S, H, gridtype, ac, interp, _stream())
         return grad_inputs, grad_emb, None, None, None, None, None, None
+
+
+def table_gradient_bins(rows, C, L, B, device):
+    """The `bins` scratch of gfpp_grid_encode_backward_xcd / _f16 (per-range point lists: one uint32 per point and range of every level), or (None, 0) when the
+    lists would not pay or not fit: below ~32 k points a range's walk over all of them is short anyway, and the lists of a table with very many ranges
+    (a 2^19-row hash grid: 1 000+ ranges) would take gigabytes."""
+    from .._lib import lib
+    if B < 32768:
+        return None, 0
+    n = int(lib().gfpp_grid_backward_bins_bytes(int(rows), int(C), int(L), int(B)))
+    if n > (1 << 30):
+        return None, 0
+    return torch.empty(n // 4, dtype=torch.int32, device=device), n
 
 
 class GridEncoder(nn.Module):

@@ -66,6 +66,7 @@ typedef struct gfpp_tuning {
     int32_t sr_final_resident;   /* last SR layer with LDS-resident weights: 1 (default) / 0 = one workgroup per patch */
     int32_t grid_bwd_scatter;    /* table gradient: 0 = LDS ranges (default), 1 = device atomics (the round-2 path) */
     int32_t wgrad_tr;            /* transposing-read weight gradients: 1 (default) / 0 */
+    int32_t grid_bwd_bins;       /* table gradient: ranges walk per-range point lists when the caller brings the `bins` scratch: 1 (default) / 0 = all points per range */
     int32_t march_fixed_step;    /* pre-march: rays whose step is constant and longer than a voxel probe every chain point without the exit-face arithmetic
                                   * (march_device.h::march_one_ray_fixed_step, same bits): 1 (default) / 0 = the general walk for every ray */
 } gfpp_tuning;
@@ -752,7 +753,8 @@ int gfpp_grid_encode_input_backward(const void *grad, int grad_dtype, const floa
  * level_dim too). */
 int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
-                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
+                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream, void *bins,
+                                  unsigned long long bins_bytes);
 
 /* The same gradient (gridencoder.cu:247-368) without a device atomic per corner (no reference counterpart).  `xcd_copies` is caller-provided scratch of
  * 8 x rows_total x C + 64 floats (cleared by the call): eight private copies of the table gradient that are summed into grad_embeddings (+=) at the
@@ -761,10 +763,17 @@ int gfpp_grid_encode_backward_f16(const void *grad, const float *inputs, const i
  * 2^16-row level is located eight times, which is ~10x cheaper than the 67 M device atomics of a May grid were (4.6 ms per call, 45 % of a training step
  * in round 2).  The LDS accumulators are 64-bit fixed point scaled by the level's largest |grad| (float LDS atomics run ~50x slower than integer ones
  * on gfx950): a contribution is kept down to 2^-36 of that maximum; a non-finite grad makes its level's gradient NaN.  gfpp_tuning.grid_bwd_scatter selects the
- * round-2 path (LDS-privatised coarse levels + XCD-private device atomics).  rows_total = embeddings.shape[0]. */
+ * round-2 path (LDS-privatised coarse levels + XCD-private device atomics).  rows_total = embeddings.shape[0].
+ * `bins` (ABI 8; may be NULL): gfpp_grid_backward_bins_bytes(rows_total, C, L, B) bytes of scratch.  With it one pass per level first puts every point on the LIST
+ * of each range that one of its corners falls into (a point's eight corners touch two or three of a fine level's eight ranges), and a range's workgroups walk
+ * their list instead of all points: a 2^16-row level's cells are located ~2.3 times instead of eight.  Same accumulators, same sums (integer adds: the order
+ * the lists come out in does not matter).  gfpp_tuning.grid_bwd_bins = 0 ignores the scratch (the A/B partner). */
 int gfpp_grid_encode_backward_xcd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t rows_total,
                                   float *xcd_copies, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
-                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream);
+                                  float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, gfpp_stream_t stream, void *bins,
+                                  unsigned long long bins_bytes);
+/* bytes of the `bins` scratch of the two calls above (gridencoder.cu:247-339 has no counterpart: its scatter needs none) */
+unsigned long long gfpp_grid_backward_bins_bytes(uint32_t rows_total, uint32_t C, uint32_t L, uint32_t B);
 
 /* replaces grad_total_variation (gridencoder.h:15; gridencoder.cu:505-609): TV gradient of the cells visited by `inputs`, grad (+=, atomics). */
 int gfpp_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t D,

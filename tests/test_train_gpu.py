@@ -683,3 +683,35 @@ def test_training_step_matches_reference_python_golden(dev):
             name = key[8:]
             got = named[name].grad.detach().cpu().numpy()
             assert abs(float(np.abs(got).astype(np.float64).sum()) - g[key][1]) <= 0.05 * g[key][1], name
+
+
+@pytest.mark.parametrize("D,gridtype,log2_size,half", [(3, "tiled", 16, True), (3, "tiled", 16, False), (2, "tiled", 16, True), (3, "hash", 14, False), (3, "hash", 19, True)])
+def test_table_gradient_by_range_lists_equals_the_walk_over_all_points(dev, D, gridtype, log2_size, half):
+    """Round 6: the table gradient's range workgroups walk per-range point LISTS (k_grid_bin_points) instead of all points.  Inside a workgroup the accumulators are
+    64-bit integers (order-free), but a range's eight workgroups each leave an fp32 partial sum and WHICH points a workgroup gets now depends on the list order:
+    the gradient with the lists (gfpp_tuning.grid_bwd_bins = 1) is the gradient without them up to the rounding of that 8-term fp32 sum (measured: 4e-6 absolute
+    on values up to 0.3) -- May's tiled 2^16-row grids (fp32 and half grads), the torso's 2-D grid, hash-addressed levels, and a 2^19-row hash grid whose 64
+    ranges per level are beyond the list kernel's 32 (those levels keep the walk over all points inside the same launch)."""
+    from genefaceplusplus_amd import tuning
+    from genefaceplusplus_amd.radnerfs.encoders import GridEncoder
+    rng = np.random.default_rng(21)
+    enc = GridEncoder(input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=log2_size, desired_resolution=2048, gridtype=gridtype).to(dev)
+    with torch.no_grad():
+        enc.embeddings.copy_(torch.from_numpy(rng.standard_normal(tuple(enc.embeddings.shape)).astype(f32)).to(dev))
+    B = 70001
+    # clustered like a step's samples (a head in the middle of the box) + a uniform share + rows outside [-1, 1]
+    x = np.concatenate([rng.normal(0.0, 0.15, (B - 20000, D)), rng.uniform(-1, 1, (19989, D)), np.full((11, D), 1.7)]).astype(f32)
+    g = rng.standard_normal((B, 32)).astype(f32)
+    got = {}
+    for bins in (0, 1):
+        with tuning.tuned(grid_bwd_bins=bins):
+            enc.embeddings.grad = None
+            xt = _t(x, dev)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                y = enc(xt, bound=1)
+            assert y.dtype == (torch.float16 if half else torch.float32)
+            y.backward(_t(g, dev).to(y.dtype))
+            got[bins] = enc.embeddings.grad.cpu().numpy().copy()
+    assert np.isfinite(got[1]).all() and float(np.abs(got[1]).max()) > 0
+    np.testing.assert_allclose(got[0], got[1], rtol=0, atol=3e-5 * float(np.abs(got[0]).max()))
+    assert float(np.abs(got[0] - got[1]).mean()) <= 1e-6 * float(np.abs(got[0]).max())
