@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(HERE, "..", "profiles", "r05_bench_final.json")))
+    d = json.load(open(os.path.join(HERE, "..", "profiles", "r06_bench_final.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -40,11 +40,26 @@ def test_committed_bench_line_has_the_contract_fields():
     assert {"may_torso_sr_256", "may_torso_no_termination"} <= set(cfg)
     sr = cfg["may_torso_sr_256"]
     assert sr["roofline"]["frames_per_launch"] == 4 and sr["roofline"]["bytes_per_sample"] == 1036
-    assert sr["roofline"]["frac"] >= 0.55                              # the released checkpoint's geometry, on the bytes as read (round 4: 0.53; measured 0.606-0.609 in round 5, target 0.60)
+    # the released checkpoint's geometry on RANDOM-INIT weights sits on the 0.60 line (0.598-0.608 over round 6's boxes; round 4: 0.53) -- the bar says what is measured,
+    # not the target; the same geometry on the FITTED field is asserted below
+    assert sr["roofline"]["frac"] >= 0.59
     st = sr["sr_stage"]
     assert abs(st["achieved"] - st["gflop_per_forward"] / st["us_per_forward"] * 1e3) / st["achieved"] < 2e-3 and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-3
     assert d["modes"]["may_torso_sr"]["value"] >= 4000.0
-    assert d["unit"] == "frames/s" and d["data"] == "synthetic" and d["dtype"] == "bf16" and "bf16" not in d["modes"]   # BASELINE configs[2] literally is the headline
+    assert d["unit"] == "frames/s" and d["data"] == "synthetic" and "bf16" not in d["modes"]   # BASELINE configs[2] literally is the headline ...
+    assert d["dtype"] == "bf16 (ambient_net f16)"                                              # ... and the field the driver parses names the mixed mode (round-5 review)
+    # round 6: the same frame loop on the FITTED procedural field (tools/make_trained_checkpoint.py, tests/golden/trained/), both model classes
+    for key, hw, frac_bar in (("trained_may_torso_512", 512, 0.68), ("trained_may_torso_sr_256", 256, 0.63)):
+        t = cfg[key]
+        assert t["value"] > 0 and t["torso_mask_share"] == 1.0 and 30000 < t["occupied_cells"] < 120000
+        assert min(t["psnr_vs_analytic_target_db"]) >= (36.0 if hw == 512 else 31.0)       # rendered bytes against the analytic target (the SR output: 33 dB after 400 SR steps)
+        tr = t["roofline"]
+        assert tr["frac"] >= frac_bar and tr["frames_per_launch"] == 4 and tr["bytes_per_sample"] == 1036
+        assert tr["pmc"]["workload"].startswith(f"{key.rsplit('_', 1)[0]} {hw}x{hw} bf16, 4 frame(s) per head launch")      # its OWN counter pass
+        assert abs(tr["traffic"] - tr["pmc"]["fabric_bytes_per_launch"]) <= 1
+    # a fitted ambient_net keeps the second grid's lookups local: fabric bytes per evaluated sample well below the random-init field's
+    per_sample = lambda rr: rr["traffic"] / rr["samples_per_launch"]
+    assert per_sample(cfg["trained_may_torso_512"]["roofline"]) < 0.6 * per_sample(r)
     assert "limiter" in r and r["l2"]["peak"] > r["peak"]                          # the level that serves the stream is labelled
     assert d["config"]["host_issue_ms_per_frame"] <= 0.05                          # the frame loop is issued from C
     assert d["modes"]["long_run"]["frames"] >= 2000 and d["modes"]["long_run"]["block_std"] >= 0
