@@ -174,8 +174,10 @@ def test_T_thresh_values(dev, oracle_mod, variant, HW, kind, T_thresh):
     case["T_thresh"] = T_thresh
     # T = 0.5: a ray whose transmittance passes 0.5 within the 16-bit rounding of sigma ends one sample earlier or later and that sample carries up to half
     # the pixel: the per-pixel bars hold for all but a few rays per thousand, the PSNR bar for the frame
+    # (round 6: the frame bar at T = 0.5 is the survey's 45 dB too -- measured 53-58 dB --; what cannot hold there is the share of pixels beyond 2e-2: 0.09-0.22 % measured
+    # against the survey's 0.05 %, the rays whose transmittance passes 0.5 within the rounding; bar 0.3 %)
     loose = T_thresh >= 0.5
-    check_all_modes(dev, oracle_mod, case, f"T{T_thresh}/{variant}/{HW}/{kind}", frac16=1e-2 if loose else None, psnr16=38.0 if loose else None,
+    check_all_modes(dev, oracle_mod, case, f"T{T_thresh}/{variant}/{HW}/{kind}", frac16=3e-3 if loose else None, psnr16=45.0 if loose else None,
                     alive16_rel=1e-2 if loose else 2e-3)
 
 
