@@ -1282,15 +1282,7 @@ static uint32_t lp_separate_trips() {
     return n < 0 ? 5u : (uint32_t)n;
 }
 
-static int lp_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    return cus;
-}
+static int lp_cu_count() { return cu_count(); }
 
 }  // namespace gfpp
 

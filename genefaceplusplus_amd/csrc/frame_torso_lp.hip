@@ -721,8 +721,7 @@ GFPP_API int gfpp_torso_group_lp(const gfpp_torso_model *m, const gfpp_frame_ws 
     const hipStream_t st = (hipStream_t)stream;
     {
         // (always launched, with one workgroup when no pixel is masked: it also computes the frames' step budgets and reads the job position for the compose launch)
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const int cus = cu_count();
         uint32_t grid = (uint32_t)cus * (uint32_t)torso_group_wgs_per_cu();
         const uint32_t need = div_up(frames * g.passes_per_frame, (uint32_t)kTlWaves);
         if (grid > need) grid = need;

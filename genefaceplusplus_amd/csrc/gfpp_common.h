@@ -18,6 +18,16 @@ namespace gfpp {
 void set_error(const char *fmt, ...);
 // the launch tuning of the library (gfpp_set_tuning, raymarch.hip): read at every issue, never getenv()
 const gfpp_tuning &tuning();
+// compute units of the current device, asked for once per process (round-5 advisory: several launch paths queried the runtime at every launch)
+inline int cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -851,12 +851,7 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         if (ws->clip_job && !resident) { set_error("gfpp_sr_forward: the uint8 store into a clip job needs the resident last layer (gfpp_tuning.sr_final_resident)"); return GFPP_EUNSUPPORTED; }
         a.job = ws->clip_job; a.job_lane = ws->clip_lane; a.job_sub = ws->clip_sub; a.job_advance = ws->clip_advance;
         if (resident) {
-            static int cus = 0;
-            if (cus == 0) {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                cus = n;
-            }
+            const int cus = cu_count();
             const int patches = (int)(2 * R / kSrPatch) * (int)(2 * R / kSrPatch);
             hipLaunchKernelGGL(k_sr_final_resident, dim3(cus < patches ? cus : patches), dim3(512), 0, st, a);
         } else hipLaunchKernelGGL((k_sr_conv3<64, 2, kSrFinal, 1, 1>), dim3(2 * R / kSrPatch, 2 * R / kSrPatch, 1), dim3(512), 0, st, a);

@@ -291,8 +291,7 @@ static int fm_shape_ok(const char *who, uint32_t in_pad, uint32_t hidden, uint32
 }
 
 static uint32_t fm_grid(uint32_t n_blocks) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int cus = cu_count();
     const uint32_t want = div_up(n_blocks, kFmThreads / 64);
     return want < (uint32_t)cus ? want : (uint32_t)cus;
 }
