@@ -259,7 +259,7 @@ static gfpp_tuning default_tuning() {
     gfpp_tuning t{};
     t.size = (uint32_t)sizeof(gfpp_tuning);
     t.trip_pool = 1; t.lp_separate_trips = -1; t.occ_clip = 1; t.barrier_spins = 0; t.persist_caps = 0; t.persist_xcd = 0; t.torso_group_wgs = 0;
-    t.sr_fuse_first = 1; t.sr_final_resident = 1; t.grid_bwd_scatter = 0; t.wgrad_tr = 1; t.grid_bwd_bins = 1; t.march_fixed_step = 1;
+    t.sr_fuse_first = 1; t.sr_final_resident = 1; t.sr_up_poly = 0; t.grid_bwd_scatter = 0; t.wgrad_tr = 1; t.grid_bwd_bins = 1; t.march_fixed_step = 1;
     return t;
 }
 static gfpp_tuning g_tuning = default_tuning();

@@ -21,6 +21,7 @@
 // sustains under dense MFMA (tools/clock_probe_sr.py) -- : DESIGN.md 2.2, docs/LAB_NOTEBOOK.md.  Measured and dropped: 8 x 16 patches for co-residency, the
 // 4 x 2 register tile, a three-chunk weight ring with deeper operand prefetch, the last layer's wavefronts in two opposite-phase groups.
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -677,6 +678,283 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
     }
 }
 
+// ---- block 1's up-sampling layer (128 -> 64, 256^2 -> 512^2) in POLYPHASE form (round 6) -----------------------------------------------------------------------
+// conv2d_resample(up = 2) is a stride-2 transposed 3 x 3 convolution followed by the [1,3,3,1] x [1,3,3,1] FIR (conv2d_resample.py:117-133).  k_sr_conv3<128, up>
+// composes both into ONE 3 x 3 convolution with 4 x 64 output channels: one implicit GEMM, but 36 tap matrices per low-resolution pixel where the transposed
+// convolution has 9 (38.6 of the stage's 77.3 GFLOP).  Here the two operations stay apart and BOTH run on the matrix pipe:
+//   (1) T = the transposed convolution in polyphase form on the (PW + 2) x (PH + 2) grid of low-resolution positions m of a PW x PH patch (T_hi[2 m + p] = T_p[m] per
+//       axis; T_e[m] = x[m] w[0] + x[m - 1] w[2], T_o[m] = x[m] w[1]): four accumulators per position tile -- ee (4 taps), eo (2), oe (2), oo (1) -- fed from four
+//       SHIFTED reads of the halo patch, 9 tap matrices in all.  Operands swapped with respect to the other layers (A = positions x channels from the patch, B = the
+//       weight fragments, same packing): D = positions x output channels, i.e. a lane holds ONE output channel at 16 positions and can write T channel-major;
+//   (2) T goes to LDS as f16 -- the reference's own intermediate is an fp16 tensor (x stays fp16 through conv_transpose2d and upfirdn2d) -- laid out
+//       [channel][py][my][px][mx] over the memory the halo patch and the weight chunks no longer need;
+//   (3) the FIR is a second GEMM: for one high-resolution output row, out[channel][column] = sum_k T[channel][k] G[k][column] over the two runs of two T rows
+//       (2 x (72 + 8 pad) entries) the row's four y taps touch; G holds the products of the taps {1/4, 3/4}^2 (exact in f16) and is built per lane in registers.
+//       A = T (a lane reads 8 consecutive entries of its channel: two ds_read_b64), B = G: D = channels x 32 output columns -- a lane holds one output pixel's 16
+//       channels, which is the layout the activation epilogue of the other layers works on.
+// MFMAs per low-resolution pixel: (9 x 8 x 8 tiles + 24 rows x 10) x 2 channel halves / 192 = 8.5 instead of 18; one workgroup = one 16 x 12 patch x 32 output
+// channels, 66 KB of LDS: two per CU.  Same noise / bias / activation / clamp expressions as k_sr_conv3's epilogue; not the same bits as the composed layer (T is
+// rounded to f16 here, and the sums associate differently): compared with it and with the oracle by tolerance (tests/test_kernels_gpu.py).
+constexpr int kUpPW = 16, kUpPH = 12, kUpGW = kUpPW + 2, kUpGH = kUpPH + 2, kUpPos = kUpGW * kUpGH;      // 18 x 14 = 252 positions = 8 tiles of 32 (4 idle rows)
+constexpr int kUpRow = 2 * kUpGW;                        // one T row of a channel: [px][mx] = 36 entries
+constexpr int kUpChStride = 2056;                        // bytes between channels of T: 2 x 14 x 36 x 2 = 2016, padded so that 32 lanes' 8-byte reads hit 64 distinct banks
+
+struct SrUpArgs {
+    const _Float16 *x;        // [H][W][128] f16
+    const uint4 *w;           // [2 channel halves][2 K slices][9 taps in chunk order][4 steps][64] fragments
+    const float *noise;       // [2H][2W] or null
+    float noise_strength;
+    const float *bias;        // [64]
+    float act_gain, clamp;
+    _Float16 *y;              // [2H][2W][64] f16
+    uint32_t H, W;
+    const _Float16 *g;        // the FIR as a GEMM operand (gfpp_sr_model.up_fir_g)
+    SrRng rng;
+    unsigned long long *prof; // PROF instantiation only (tools/sr_up_phases.py): [workgroup][8] shader-clock stamps of thread 0 at the phase boundaries
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(512, 4) void k_sr_up_poly(SrUpArgs a) {
+    auto stamp = [&](int k) {
+        if constexpr (PROF) {
+            if (threadIdx.x == 0) a.prof[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k] = __builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
+    typedef LpTraits<_Float16>::vec vec;
+    constexpr int PS = 64 + 8;                                           // halves per position in the patch (one 64-channel K slice + 16 B of padding)
+    constexpr int PATCH_BYTES = 256 * PS * 2, WBUF_BYTES = 9 * 4 * 64 * 16, T_BYTES = 32 * kUpChStride + 32;      // all nine taps of one K slice resident (36 KB)
+    constexpr int LDS_BYTES = PATCH_BYTES + WBUF_BYTES > T_BYTES ? PATCH_BYTES + WBUF_BYTES : T_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_bias[32];
+    _Float16 *patch = reinterpret_cast<_Float16 *>(lds_raw);
+    uint4 *wall = reinterpret_cast<uint4 *>(lds_raw + PATCH_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+    const int x0 = (int)blockIdx.x * kUpPW, y0 = (int)blockIdx.y * kUpPH;
+    const int nt = (int)blockIdx.z;                                      // which 32 of the 64 output channels
+    // The weights of a K slice are its nine tap matrices (4 steps x 64 fragments each), grouped by the input shift they multiply: taps 0-3 (shift 0,0), 4-5 (x - 1),
+    // 6-7 (y - 1), 8 (both).  ALL nine of the current slice are resident; the group a wavefront has finished with is overwritten by the same group of the NEXT
+    // slice right behind the barrier that ends it, so that nobody ever waits for a weight transfer in flight: the first cut of this kernel streamed one group
+    // at a time through a ring of two and spent its time there -- a group is 4-16 MFMAs per wavefront, an L2 -> LDS transfer 1-2 us (k_sr_up_poly 37 us against the
+    // composed layer's 39-41 with HALF the MFMAs).
+    auto stage_taps = [&](int ks, int tap0, int ntap) {
+        const uint4 *src = a.w + ((size_t)(nt * 2 + ks) * 9 + tap0) * 4 * 64;
+        uint4 *dst = wall + tap0 * 4 * 64;
+        for (int i = tid; i < ntap * 256; i += 512)                      // (whole wavefronts: 256 fragments per tap)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i), (__attribute__((address_space(3))) void *)(dst + (i - lane)), 16, 0, 0);
+    };
+    auto load_patch = [&](int ks, int tid) {                             // the halo of one K slice: unconditional loads from clamped coordinates, zero padding by select
+        constexpr int CH = kUpPos * 8, IT = (CH + 511) / 512;
+        uint4 hv[IT];
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * 512 + tid, ic = i < CH ? i : CH - 1;
+            const int pp = ic >> 3, c8 = ic & 7;
+            int py = y0 - 1 + pp / kUpGW, px = x0 - 1 + pp % kUpGW;
+            py = py < 0 ? 0 : (py >= (int)a.H ? (int)a.H - 1 : py);
+            px = px < 0 ? 0 : (px >= (int)a.W ? (int)a.W - 1 : px);
+            hv[q] = *reinterpret_cast<const uint4 *>(a.x + ((size_t)py * a.W + px) * 128 + ks * 64 + c8 * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int i = q * 512 + tid;
+            if (i < CH) {
+                const int pp = i >> 3, c8 = i & 7;
+                const int py = y0 - 1 + pp / kUpGW, px = x0 - 1 + pp % kUpGW;
+                const bool in = py >= 0 && py < (int)a.H && px >= 0 && px < (int)a.W;
+                *reinterpret_cast<uint4 *>(&patch[pp * PS + c8 * 8]) = in ? hv[q] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    stage_taps(0, 0, 9);
+    load_patch(0, tid);
+    if (tid < 32) s_bias[tid] = a.bias[nt * 32 + tid];
+    if (tid < 4 * PS * 2 / 16) reinterpret_cast<uint4 *>(&patch[kUpPos * PS])[tid] = make_uint4(0, 0, 0, 0);      // the four idle rows of the last tile read something finite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stamp(1);                                                            // first patch slice + all nine taps of slice 0 have arrived
+
+    // ---- (1) the polyphase products: wavefront w owns the positions [32 w, 32 w + 32) ------------------------------------------------------------------------
+    v16f acc[4];                                                         // ee, eo, oe, oo
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    const int pos = 32 * wave + j;                                       // this lane's row of the A operand
+    // which accumulator a chunk's tap feeds: shift (0,0): w[0][0] ee, w[0][1] eo, w[1][0] oe, w[1][1] oo; shift x-1: w[0][2] ee, w[1][2] oe; shift y-1: w[2][0] ee, w[2][1] eo;
+    // shift (y-1, x-1): w[2][2] ee
+    constexpr int kShift[4] = {0, -1, -kUpGW, -kUpGW - 1};
+    // one group = one shift of the patch (compile-time: tap count and accumulators), K steps of 16 channels
+    auto run_group = [&](auto shc) {
+        constexpr int SH = decltype(shc)::value, NTAP = SH == 0 ? 4 : (SH == 3 ? 1 : 2), TB = SH == 0 ? 0 : (SH == 1 ? 4 : (SH == 2 ? 6 : 8));
+        int ps = pos + kShift[SH];
+        ps = ps < 0 ? 0 : ps;                                            // (only positions whose T entries nobody reads)
+        const uint32_t a0 = sr_lds_addr(&patch[ps * PS + 8 * hi]), wl = sr_lds_addr(wall + TB * 4 * 64) + (uint32_t)lane * 16u;
+        // operands of step s + 1 are read while the MFMAs of step s run (the reads are inline assembly -- see sr_lds_read128 --: a wait names the registers it guards)
+        vec A[2], B[2][NTAP];
+        auto read_ops = [&](int s, vec &Aq, vec (&Bq)[NTAP]) {
+            sr_lds_read128(Aq, a0 + 32u * (uint32_t)s);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) sr_lds_read128(Bq[t], wl + (uint32_t)(t * 4 + s) * 1024u);
+        };
+        auto wait_ops = [&](vec &Aq, vec (&Bq)[NTAP]) {
+            if constexpr (NTAP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq), "+v"(Bq[0]), "+v"(Bq[1]), "+v"(Bq[2]), "+v"(Bq[3])::"memory");
+            else if constexpr (NTAP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq), "+v"(Bq[0]), "+v"(Bq[1])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq), "+v"(Bq[0])::"memory");
+        };
+        // (the four-tap group reads a step's operands and multiplies them: with its 20 operand registers double-buffered next to the 64 accumulators the kernel
+        // spilled at the 128 registers that two workgroups per CU allow; the other wavefronts of the SIMD cover the LDS latency there)
+        constexpr bool AHEAD = NTAP < 4;
+        read_ops(0, A[0], B[0]);
+        wait_ops(A[0], B[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = AHEAD ? (s & 1) : 0, nxt = AHEAD ? ((s + 1) & 1) : 0;
+            if (AHEAD && s + 1 < 4) read_ops(s + 1, A[nxt], B[nxt]);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                constexpr int kPh[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0};
+                const int ph = kPh[TB + t];                              // (folds: TB and t are constants after unrolling)
+                if (ph == 0) acc[0] = LpTraits<_Float16>::mfma(A[cur], B[cur][t], acc[0]);
+                else if (ph == 1) acc[1] = LpTraits<_Float16>::mfma(A[cur], B[cur][t], acc[1]);
+                else if (ph == 2) acc[2] = LpTraits<_Float16>::mfma(A[cur], B[cur][t], acc[2]);
+                else acc[3] = LpTraits<_Float16>::mfma(A[cur], B[cur][t], acc[3]);
+            }
+            if (s + 1 < 4) {
+                if (!AHEAD) read_ops(s + 1, A[0], B[0]);
+                wait_ops(A[nxt], B[nxt]);
+            }
+        }
+    };
+    // K slice 0; behind every group the same group of slice 1 starts to arrive in its place
+    run_group(std::integral_constant<int, 0>{});
+    __syncthreads();
+    stage_taps(1, 0, 4);
+    run_group(std::integral_constant<int, 1>{});
+    __syncthreads();
+    stage_taps(1, 4, 2);
+    run_group(std::integral_constant<int, 2>{});
+    __syncthreads();
+    stage_taps(1, 6, 2);
+    run_group(std::integral_constant<int, 3>{});
+    __syncthreads();                                                     // everybody is done with slice 0's patch too
+    stamp(2);
+    stage_taps(1, 8, 1);
+    load_patch(1, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stamp(3);
+    run_group(std::integral_constant<int, 0>{});
+    run_group(std::integral_constant<int, 1>{});
+    run_group(std::integral_constant<int, 2>{});
+    run_group(std::integral_constant<int, 3>{});
+    __syncthreads();                                                     // patch and weights are dead from here on
+    stamp(4);
+
+    // ---- (2) T -> LDS, channel-major f16 (the patch and the weight buffers are dead: every wavefront is past the last barrier) -----------------------------------
+    // lane (channel j, hi) holds, in register 4 q + e of accumulator (py, px), position 32 w + 8 q + 4 hi + e
+    {
+        unsigned char *tch = lds_raw + j * kUpChStride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p = 32 * wave + 8 * q + 4 * hi + e;
+                if (p < kUpPos) {
+                    const int my = p / kUpGW, mx = p - my * kUpGW;
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const int py = ph >> 1, px = ph & 1;
+                        *reinterpret_cast<_Float16 *>(tch + ((py * kUpGH + my) * kUpRow + px * kUpGW + mx) * 2) = (_Float16)acc[ph][4 * q + e];
+                    }
+                }
+            }
+        // a run's eight padding entries are the next row's first eight -- or, behind a channel's last row, the channel's own padding: zero, so that 0 x it is 0
+        if (wave == 0 && hi == 0)
+#pragma unroll
+            for (int k = 0; k < (kUpChStride - 2 * kUpGH * kUpRow * 2) / 4; ++k) reinterpret_cast<uint32_t *>(tch + 2 * kUpGH * kUpRow * 2)[k] = 0u;
+    }
+    __syncthreads();
+    stamp(5);
+
+    // ---- (3) FIR as a GEMM + the activation epilogue: wavefront w owns the high-resolution rows 3 w .. 3 w + 2 of the patch's 24 ---------------------------------
+    // G for output column j of the patch (cell X = j / 2, parity b): x taps at T columns 2 X + b - 1 .. + 2, i.e. [px][mx] entries
+    //   b = 0: (1, X) g0, (0, X + 1) g1, (1, X + 1) g2, (0, X + 2) g3        b = 1: (0, X + 1) g0, (1, X + 1) g1, (0, X + 2) g2, (1, X + 2) g3
+    // (mx counts from the patch's halo column: cell X is mx = X + 1).  A run = two T rows (72 entries) + 8 entries of padding with coefficient 0.
+    // G comes from the host (gfpp_sr_model.up_fir_g: [2 pairs][5 steps][64 lanes][8] f16): entry k = 16 s + 8 hi + e of a run is T row r = k / 36 (2 = padding,
+    // coefficient 0), [px][mx] = k % 36; its coefficient is (row tap of the pair: pair 0 = (g1, g3), pair 1 = (g0, g2)) x (column tap of output column j), see
+    // radnerfs/superres.py::_fir_gemm_table.  Loaded here, behind the products, so that its 40 registers are not live under the 64 accumulators.
+    {
+    vec G[2][5];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int s = 0; s < 5; ++s) G[pr][s] = *reinterpret_cast<const vec *>(a.g + ((size_t)(pr * 5 + s) * 64 + lane) * 8);
+    stamp(6);
+    const unsigned long long frame_ctr = a.rng.state ? a.rng.state[0] : 0ull;
+    const unsigned char *tA = lds_raw + j * kUpChStride + 16 * hi;       // this lane's row of the A operand: channel j, entries 8 hi .. of a step
+    // the noise of this lane's three output pixels (rows 3 w .. 3 w + 2, column j): a pixel's value is needed by both lane halves, so each half draws what the other
+    // does not -- half 0 rows 0 and 2, half 1 row 1 and (again) 2 -- and they swap: two Philox + Box-Muller evaluations per lane instead of three (a third of this
+    // phase's vector instructions)
+    float nzr[3];
+    {
+        const int Xo = 2 * x0 + j;
+        auto noise_at = [&](int il) -> float {
+            const int Yo = 2 * y0 + il;
+            const bool in = Yo < 2 * (int)a.H && Xo < 2 * (int)a.W;
+            const size_t at = in ? (size_t)Yo * (2 * a.W) + Xo : 0;
+            return a.noise ? a.noise[at] * a.noise_strength : (a.rng.state ? sr_randn(a.rng, frame_ctr, (uint32_t)at) * a.noise_strength : 0.0f);
+        };
+        const float mine = noise_at(3 * wave + hi), last = noise_at(3 * wave + 2);
+        const float other = __shfl_xor(mine, 32);
+        nzr[0] = hi ? other : mine;
+        nzr[1] = hi ? mine : other;
+        nzr[2] = last;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int il = 3 * wave + rr, Y = il >> 1, av = il & 1, my = Y + 1;
+        // rows of the two runs: parity 0: py = 0 rows (my, my + 1) with (g1, g3), py = 1 rows (my - 1, my) with (g0, g2); parity 1: py = 0 rows (my, my + 1) with (g0, g2),
+        // py = 1 rows (my, my + 1) with (g1, g3)
+        const int run0 = (0 * kUpGH + my) * kUpRow * 2, run1 = (1 * kUpGH + (av ? my : my - 1)) * kUpRow * 2;
+        v16f d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 lo0 = *reinterpret_cast<const h4 *>(tA + run0 + 32 * s), hi0 = *reinterpret_cast<const h4 *>(tA + run0 + 32 * s + 8);
+            const h4 lo1 = *reinterpret_cast<const h4 *>(tA + run1 + 32 * s), hi1 = *reinterpret_cast<const h4 *>(tA + run1 + 32 * s + 8);
+            const vec A0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7), A1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+            d = LpTraits<_Float16>::mfma(A0, av ? G[1][s] : G[0][s], d);
+            d = LpTraits<_Float16>::mfma(A1, av ? G[0][s] : G[1][s], d);
+        }
+        // epilogue: lane (output column j, hi) holds channels 8 q + 4 hi + e in register 4 q + e
+        const int Yo = 2 * y0 + il, Xo = 2 * x0 + j;
+        if (Yo < 2 * (int)a.H && Xo < 2 * (int)a.W) {
+            const size_t at = (size_t)Yo * (2 * a.W) + Xo;
+            const float nz = nzr[rr];
+            _Float16 *dst = a.y + at * 64 + nt * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = 8 * q + 4 * hi;
+                const float av4[4] = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+                float v[4];
+                sr_act4(av4, nz, *reinterpret_cast<const float4 *>(&s_bias[n0]), a.act_gain, a.clamp, v);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                *reinterpret_cast<h4 *>(dst + n0) = o;
+            }
+        }
+    }
+    }
+    stamp(7);
+}
+
 // ---- first layer: 3 -> 128, K = 27 padded to 32 --------------------------------------------------------------------------------------
 struct SrFirstArgs {
     const float *rgb;      // [H][W][3] fp32
@@ -829,7 +1107,18 @@ GFPP_API int gfpp_sr_forward(const gfpp_sr_model *m, const gfpp_sr_ws *ws, const
         const int rc = check_launch("gfpp_sr_forward(block0.conv1 + torgb)");
         if (rc) return rc;
     }
-    {
+    if (m->w_up_poly && m->up_fir_g && tuning().sr_up_poly) {
+        SrUpArgs a{};
+        a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up_poly; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
+        a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;
+        a.g = (const _Float16 *)m->up_fir_g;
+        a.rng = rng_of(2);
+        a.prof = (unsigned long long *)ws->up_prof;
+        if (a.prof) hipLaunchKernelGGL(k_sr_up_poly<true>, dim3(R / kUpPW, (R + kUpPH - 1) / kUpPH, 2), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(k_sr_up_poly<false>, dim3(R / kUpPW, (R + kUpPH - 1) / kUpPH, 2), dim3(512), 0, st, a);
+        const int rc = check_launch("gfpp_sr_forward(block1.conv0 up, polyphase)");
+        if (rc) return rc;
+    } else {
         SrConvArgs a{};
         a.x = (const _Float16 *)ws->x1; a.w = (const uint4 *)m->w_up; a.noise = noise ? noise[2] : nullptr; a.noise_strength = m->noise_strength[2];
         a.bias = m->bias[2]; a.act_gain = gain; a.clamp = clamp; a.y = (_Float16 *)ws->x2; a.H = R; a.W = R;

@@ -31,12 +31,12 @@ def _as_i64(u):
 
 class SrModel(ctypes.Structure):
     _fields_ = [("w_first", c_p), ("w_b0c1", c_p), ("w_up", c_p), ("w_b1c1", c_p), ("bias", c_p * 4), ("noise_strength", c_f * 4),
-                ("rgb0_w", c_p), ("rgb0_b", c_p), ("rgb1_w", c_p), ("rgb1_b", c_p), ("fir", c_f * 4), ("conv_clamp", c_f)]
+                ("rgb0_w", c_p), ("rgb0_b", c_p), ("rgb1_w", c_p), ("rgb1_b", c_p), ("fir", c_f * 4), ("conv_clamp", c_f), ("w_up_poly", c_p), ("up_fir_g", c_p)]
 
 
 class SrWs(ctypes.Structure):
     _fields_ = [("x0", c_p), ("x1", c_p), ("x2", c_p), ("img256", c_p), ("rng_state", c_p), ("rng_seed", ctypes.c_uint64), ("clamp01", ctypes.c_uint32),
-                ("clip_job", c_p), ("clip_lane", ctypes.c_uint32), ("clip_sub", ctypes.c_uint32), ("clip_advance", ctypes.c_uint32)]
+                ("clip_job", c_p), ("clip_lane", ctypes.c_uint32), ("clip_sub", ctypes.c_uint32), ("clip_advance", ctypes.c_uint32), ("up_prof", c_p)]
 
 
 _lib.register("gfpp_sr_forward", [ctypes.POINTER(SrModel), ctypes.POINTER(SrWs), c_p, c_p, c_p, c_p])
@@ -142,6 +142,40 @@ def _pack_conv3(w_eff, nt):
     return w.reshape(cout // per_pass, 9, cin // 16, nt, 64, 8).to(torch.float16).contiguous()
 
 
+_POLY_TAPS = ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (1, 2), (2, 0), (2, 1), (2, 2))      # (ky, kx), grouped by the input shift they multiply (csrc/superres.hip::k_sr_up_poly)
+
+
+def _pack_up_poly(w_eff):
+    """[64, 128, 3, 3] -> f16 fragments [2 nt][2 ks][9 taps][4 steps][64 lanes][8]: lane (j, h) of step s holds W[32 nt + j][64 ks + 16 s + 8 h + e][ky][kx]."""
+    cout, cin = w_eff.shape[:2]
+    assert (cout, cin) == (64, 128)
+    w = w_eff.reshape(2, 32, 2, 4, 2, 8, 3, 3)                              # [nt, j, ks, s, h, e, ky, kx]
+    taps = torch.stack([w[..., ky, kx] for ky, kx in _POLY_TAPS], dim=0)    # [tap, nt, j, ks, s, h, e]
+    frag = taps.permute(1, 3, 0, 4, 5, 2, 6)                                # [nt, ks, tap, s, h, j, e]
+    return frag.reshape(2, 2, 9, 4, 64, 8).to(torch.float16).contiguous()
+
+
+def _fir_gemm_table(fir):
+    """The FIR of the polyphase up-sampling layer as a GEMM operand (gfpp_sr_model.up_fir_g): [2 pairs][5 steps][64 lanes][8] f16."""
+    g = torch.zeros(2, 5, 64, 8, dtype=torch.float64)
+    for pair, rows in enumerate(((1, 3), (0, 2))):
+        for s in range(5):
+            for lane in range(64):
+                j, h = lane & 31, lane >> 5
+                for e in range(8):
+                    k = 16 * s + 8 * h + e
+                    r, k36 = divmod(k, 36)
+                    if r >= 2:
+                        continue
+                    px, mx = divmod(k36, 18)
+                    t = 2 * (mx - 1) + px - (j - 1)
+                    if 0 <= t < 4:
+                        g[pair, s, lane, e] = float(fir[rows[r]]) * float(fir[t])
+    h16 = g.to(torch.float16)
+    assert torch.equal(h16.double(), g), "the FIR products must be exact in f16"
+    return h16.contiguous()
+
+
 def _pack_first(w_eff):
     """[128, 3, 3, 3] -> [2 steps, 4 tiles, 64, 8] f16 with k = 3 tap + channel (27 used of 32)."""
     flat = torch.zeros(128, 32, dtype=torch.float64, device=w_eff.device)
@@ -219,12 +253,13 @@ class Superresolution(nn.Module):
             "w_b0c1": _pack_conv3(b0.conv1.effective_weight(), 4).to(dev),
             "w_up": _pack_conv3(_compose_up_weights(b1.conv0.effective_weight(), self.resample_filter.detach().cpu()), 4).to(dev),
             "w_b1c1": _pack_conv3(b1.conv1.effective_weight(), 2).to(dev),
+            "w_up_poly": _pack_up_poly(b1.conv0.effective_weight()).to(dev),
             "bias": [l.bias.detach().float().contiguous() for l in (b0.conv0, b0.conv1, b1.conv0, b1.conv1)],
             "rgb0_w": b0.torgb.effective_weight().float().contiguous(), "rgb0_b": b0.torgb.bias.detach().float().contiguous(),
             "rgb1_w": b1.torgb.effective_weight().float().contiguous(), "rgb1_b": b1.torgb.bias.detach().float().contiguous(),
         }
         m = SrModel()
-        for k in ("w_first", "w_b0c1", "w_up", "w_b1c1", "rgb0_w", "rgb0_b", "rgb1_w", "rgb1_b"):
+        for k in ("w_first", "w_b0c1", "w_up", "w_b1c1", "w_up_poly", "rgb0_w", "rgb0_b", "rgb1_w", "rgb1_b"):
             setattr(m, k, keep[k].data_ptr())
         for i, l in enumerate((b0.conv0, b0.conv1, b1.conv0, b1.conv1)):
             m.bias[i] = keep["bias"][i].data_ptr()
@@ -235,6 +270,8 @@ class Superresolution(nn.Module):
             raise GfppError("Superresolution: resample_filter must be separable")
         for i in range(4):
             m.fir[i] = float(f1[i] * 2.0)                 # gain up^2 = 4 -> 2 per axis
+        keep["up_fir_g"] = _fir_gemm_table([float(f1[i] * 2.0) for i in range(4)]).to(dev)
+        m.up_fir_g = keep["up_fir_g"].data_ptr()
         m.conv_clamp = float(self.conv_clamp)
         self._packed = {"fp": fp, "keep": keep, "model": m, "ws": {}}
         return self._packed
@@ -340,6 +377,7 @@ class Superresolution(nn.Module):
         ws.rng_seed = bufs["rng_seed"]
         ws.clamp01 = 1 if clamp01 else 0
         ws.clip_job = None
+        ws.up_prof = self.up_prof.data_ptr() if getattr(self, "up_prof", None) is not None else None      # (tools/sr_up_phases.py)
         if self.clip_store is not None and clip_sub is not None and clamp01:
             from .. import tuning
             if tuning.LIB["sr_final_resident"]:

@@ -19,7 +19,7 @@ class GfppTuning(ctypes.Structure):
     """ctypes mirror of gfpp_tuning (size-checked against the library by _lib.lib())."""
     _fields_ = [("size", ctypes.c_uint32), ("trip_pool", ctypes.c_int32), ("lp_separate_trips", ctypes.c_int32), ("occ_clip", ctypes.c_int32),
                 ("barrier_spins", ctypes.c_uint32), ("persist_caps", ctypes.c_uint32), ("persist_xcd", ctypes.c_int32), ("torso_group_wgs", ctypes.c_int32),
-                ("sr_fuse_first", ctypes.c_int32), ("sr_final_resident", ctypes.c_int32), ("grid_bwd_scatter", ctypes.c_int32), ("wgrad_tr", ctypes.c_int32), ("grid_bwd_bins", ctypes.c_int32), ("march_fixed_step", ctypes.c_int32)]
+                ("sr_fuse_first", ctypes.c_int32), ("sr_final_resident", ctypes.c_int32), ("sr_up_poly", ctypes.c_int32), ("grid_bwd_scatter", ctypes.c_int32), ("wgrad_tr", ctypes.c_int32), ("grid_bwd_bins", ctypes.c_int32), ("march_fixed_step", ctypes.c_int32)]
 
 
 def _caps(text):
@@ -47,6 +47,7 @@ LIB = {
     "torso_group_wgs": _env("GFPP_TORSO_GROUP_WGS", 0, int),
     "sr_fuse_first": _env("GFPP_SR_FUSE_FIRST", 1, int),
     "sr_final_resident": _env("GFPP_SR_FINAL_RESIDENT", 1, int),
+    "sr_up_poly": _env("GFPP_SR_UP_POLY", 0, int),          # (off: the launch disturbs kernels that share a CU with it, see include/gfpp_radnerf.h)
     "grid_bwd_scatter": 1 if _env("GFPP_GRID_BWD", "").startswith("s") else 0,
     "wgrad_tr": _env("GFPP_WGRAD_TR", 1, int),
     "grid_bwd_bins": _env("GFPP_GRID_BWD_BINS", 1, int),

@@ -64,6 +64,11 @@ typedef struct gfpp_tuning {
     int32_t torso_group_wgs;     /* persistent workgroups per CU of the torso MLP group launch: 0 = default */
     int32_t sr_fuse_first;       /* block 0's first SR convolution inside the second one's halo load: 1 (default) / 0 */
     int32_t sr_final_resident;   /* last SR layer with LDS-resident weights: 1 (default) / 0 = one workgroup per patch */
+    int32_t sr_up_poly;          /* SR up-sampling layer in polyphase form + FIR GEMM (k_sr_up_poly) when the model carries w_up_poly: 0 (default) = the composed 3 x 3
+                                  * convolution.  OFF by default although it is 6 % faster per forward: while its MFMA phase shares a CU with OTHER kernels' wavefronts
+                                  * (a second clip lane's torso / pre-march launch) those kernels return different bits now and then -- 16 pixels of a torso pass off
+                                  * by 1e-3 .. 5e-2 in 2-40 % of the frames, never with the composed launch (tools/interference_probe.py, tools/clip_interference.py,
+                                  * docs/LAB_NOTEBOOK.md round 6).  Safe where nothing else runs beside it (one lane, plain launches). */
     int32_t grid_bwd_scatter;    /* table gradient: 0 = LDS ranges (default), 1 = device atomics (the round-2 path) */
     int32_t wgrad_tr;            /* transposing-read weight gradients: 1 (default) / 0 */
     int32_t grid_bwd_bins;       /* table gradient: ranges walk per-range point lists when the caller brings the `bins` scratch: 1 (default) / 0 = all points per range */
@@ -797,6 +802,16 @@ typedef struct gfpp_sr_model {
     const float *rgb1_w, *rgb1_b; /* block1.torgb: [64][3], [3] */
     float fir[4];          /* 1-D taps of the (separable) resample filter times the per-axis gain 2: [1,3,3,1]/8 * 2 */
     float conv_clamp;      /* 256 */
+    /* ABI 8: block1.conv0 in POLYPHASE form (NULL: only the composed `w_up` exists): the modulated / demodulated 3 x 3 weights themselves, [2 output-channel halves]
+     * [2 input-channel halves][9 taps][4 K steps][64 lanes][8] f16 with lane (j, h) of step s holding W[32 nt + j][64 ks + 16 s + 8 h + e][ky][kx], taps in the
+     * order (ky, kx) = (0,0) (0,1) (1,0) (1,1) | (0,2) (1,2) | (2,0) (2,1) | (2,2) -- grouped by the shift of the input they multiply.  The layer then runs as
+     * transposed convolution (9 tap products per pixel instead of the composed form's 36) + the FIR as a second small GEMM (gfpp_tuning.sr_up_poly). */
+    const void *w_up_poly;
+    /* ... and the FIR as the B operand of that GEMM: [2 row-tap pairs][5 K steps][64 lanes][8] f16.  A "run" is two consecutive T rows of one row phase (2 x 36
+     * entries [px][mx], mx = 0 the patch's halo column) + 8 entries of padding; lane (j, h) of step s holds the coefficients of run entries 16 s + 8 h .. + 7 for
+     * output column j of the patch: (pair 0: fir[1] for the run's first row, fir[3] for its second; pair 1: fir[0], fir[2]) x (fir[t] with t = 2 (mx - 1) + px -
+     * (j - 1) when 0 <= t < 4, else 0); padding entries 0.  With fir = [1,3,3,1]/4 every product is exact in f16. */
+    const void *up_fir_g;
 } gfpp_sr_model;
 
 typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
@@ -818,6 +833,8 @@ typedef struct gfpp_sr_ws { /* caller-allocated device workspace */
      * gfpp_clip_store_u8 launch behind the frame.  Needs the resident last layer (gfpp_tuning.sr_final_resident). */
     gfpp_clip_job *clip_job;
     uint32_t clip_lane, clip_sub, clip_advance;
+    uint64_t *up_prof;   /* NULL (production), or [704 workgroups][8] u64: the polyphase up-sampling launch runs its profiling instantiation and leaves thread 0's shader-clock
+                          * stamps at its phase boundaries there (tools/sr_up_phases.py) */
 } gfpp_sr_ws;
 
 /* replaces Superresolution.forward (radnerf_sr.py:30-43).  rgb_in [256][256][3] f32 (NHWC, values in [0,1]) -> rgb_out [512][512][3] f32.  noise: 4 device pointers to

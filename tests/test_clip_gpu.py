@@ -1,5 +1,7 @@
 """Clip renderer (genefaceplusplus_amd/clip.py): device-side ray generation + uint8 conversion + pinned async hand-off
 must deliver, frame for frame, the bytes that the reference-shaped per-frame call sequence delivers."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -206,6 +208,27 @@ def test_frame_groups_deliver_the_bytes_of_single_frames(dev, variant, HW, preci
     g, frames_ws, t = pipe.group_workspace(HW * HW, K, int(case["hp"]["max_steps"]))
     hist = t["counters"][:, 128:160].cpu().numpy()
     assert (hist.sum(axis=1) == HW * HW).all(), hist.sum(axis=1)
+
+
+def test_frames_do_not_depend_on_what_else_is_in_flight(dev):
+    """The same clip rendered 40 times by one renderer whose lanes overlap on the device (frame by frame, two lanes: a frame's torso and pre-march launches run beside
+    the other lane's SR launches): every render is the bytes of the first.  Round 6 found a launch for which that did NOT hold -- the polyphase up-sampling layer
+    (gfpp_tuning.sr_up_poly = 1; 2-40 % of the renders had a 32-pixel torso pass of the OTHER lane off by 1e-3 .. 5e-2 while its MFMA phase shared a CU with it,
+    tools/clip_interference.py) -- which is why it is off by default; this pins the shipped set of launches."""
+    from genefaceplusplus_amd import tuning
+    from genefaceplusplus_amd.clip import ClipRenderer
+    assert tuning.LIB["sr_up_poly"] == 0 or os.environ.get("GFPP_SR_UP_POLY"), "the polyphase up-sampling launch must stay opt-in (include/gfpp_radnerf.h)"
+    case = frame_case("may_torso_sr", 256)
+    model = build_model(case, dev, "fused")
+    model.precision = "fp16"
+    kw = dict(case["hp"], use_head_for_torso=True, sr_noise_mode="const")
+    batch = _clip_batch(case["hp"], 10)
+    for group, lanes in ((1, 2), (2, 3)):
+        cr = ClipRenderer(model, 256, 256, case["intr"], bg_img=torch.from_numpy(case["bg_color"]), T_thresh=case["T_thresh"], render_kwargs=kw, group=group, lanes=lanes)
+        clip = cr.prepare(batch, dev)
+        want = cr.render_to_device(clip).cpu().numpy()
+        for rep in range(40):
+            np.testing.assert_array_equal(cr.render_to_device(clip).cpu().numpy(), want, err_msg=f"group {group} lanes {lanes} render {rep}")
 
 
 def test_frame_groups_fall_back_where_they_are_not_supported(dev):

@@ -28,6 +28,10 @@ CEILINGS = [
     (r"k_head_frame_persistILi[23]EDF16[b_]Lb0ELb[01]ELb1E", 16), (r"k_head_trip_poolILi2EDF16[b_]Lb0E", 12),
     # super-resolution: the two K-sliced convolution instantiations without the fused first layer
     (r"k_sr_conv3ILi128ELi4ELi[12]ELi1ELi2ELb0E", 16),
+    # the polyphase up-sampling layer at the 128 registers that two workgroups per CU allow: four launch-lifetime values (tile origin, thread coordinates) parked
+    # across the products -- three scratch stores before the first MFMA, three loads behind the last barrier of a K slice, none inside an MFMA run; its
+    # phase-clock twin (tools/sr_up_phases.py only) parks the stamp address too
+    (r"k_sr_up_polyILb0E", 20), (r"k_sr_up_polyILb1E", 52),
 ]
 
 

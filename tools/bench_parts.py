@@ -699,8 +699,15 @@ def build(ctx):
                         e1.record()
                         torch.cuda.synchronize()
                         us = e0.elapsed_time(e1) / reps * 1e3
-                        gflop = 19.327 + 38.655 + 19.327
-                        sr_cfg["sr_stage"] = {"kernels": "k_sr_conv3<128,first fused> + k_sr_conv3<128,up> + k_sr_final_resident (3 launches; genefaceplusplus_amd/csrc/superres.hip)",
+                        # the up-sampling layer's arithmetic: composed into ONE 3 x 3 convolution with 4 x 64 outputs it is 38.655 GFLOP; in polyphase form
+                        # (k_sr_up_poly, gfpp_tuning.sr_up_poly = 1) it is the transposed convolution's 9 tap matrices per low-resolution pixel (9.664) + 16 FIR taps per
+                        # output value (0.537) -- what the FIR GEMM multiplies on top of that are zeros of its coefficient table and is not counted
+                        from genefaceplusplus_amd import tuning as _tuning
+                        poly = bool(_tuning.LIB.get("sr_up_poly", 0))
+                        gflop = 19.327 + (9.664 + 0.537 if poly else 38.655) + 19.327
+                        sr_cfg["sr_stage"] = {"kernels": ("k_sr_conv3<128,first fused> + " + ("k_sr_up_poly (transposed convolution + FIR as two GEMMs)" if poly else "k_sr_conv3<128,up>")
+                                                          + " + k_sr_final_resident (3 launches; genefaceplusplus_amd/csrc/superres.hip)"),
+                                              "up_layer": "polyphase" if poly else "composed",
                                               "us_per_forward": round(us, 2), "gflop_per_forward": round(gflop, 2), "bound": "mfma",
                                               "achieved": round(gflop / us * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gflop / us * 1e3 / 2500.0, 4),
                                               "sustained_clock_note": "the tap loops of these kernels run at 85-91 % MFMA-pipe occupancy in cycles, at the ~1.4 GHz the part sustains "
