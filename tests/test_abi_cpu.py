@@ -161,3 +161,9 @@ def test_tuning_record_round_trips_and_no_launch_path_reads_the_environment(buil
     for f in glob.glob(os.path.join(ROOT, "genefaceplusplus_amd", "csrc", "*.h*")):
         text = re.sub(r"//[^\n]*", "", open(f).read())
         assert "getenv" not in text, f
+    # the one switch whose faster value is NOT the default: the polyphase SR up-sampling launch makes other kernels' results depend on timing (round 6,
+    # include/gfpp_radnerf.h) -- off in the library's built-in record and in the binding's, unless the environment of this very run asks for it
+    if not os.environ.get("GFPP_SR_UP_POLY"):
+        assert tuning.LIB["sr_up_poly"] == 0 and got.sr_up_poly == 0
+    src = open(os.path.join(ROOT, "genefaceplusplus_amd", "csrc", "raymarch.hip")).read()
+    assert "t.sr_up_poly = 0;" in src, "the library's default record (default_tuning) must keep the polyphase launch off"
