@@ -1,6 +1,8 @@
 """Which hardware function of a wavefront goes wrong beside the polyphase SR launch?  Runs tools/probe/canary.hip (self-checking MFMA chains, vector ALU, LDS, global
 loads, shuffles, dot products -- each repetition compared with the wavefront's own first) on the main stream while a second stream keeps SR forwards in flight.
 
+STATUS: written at the end of round 6 and compiled for gfx950; GPU access closed before it ran once (docs/LAB_NOTEBOOK.md).  Treat it as unverified.
+
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o build/probe/libcanary.so tools/probe/canary.hip      (here; the .so travels with gpurun)
     python tools/canary.py [launches] [iters per launch] [workgroups]
 """
