@@ -19,7 +19,7 @@ from genefaceplusplus_amd import synthetic as syn, tuning                      #
 from genefaceplusplus_amd.radnerfs.superres import Superresolution             # noqa: E402
 
 TESTS = ("mfma chain, register operands", "mfma chain, A from LDS", "vector ALU chain", "LDS write / read back", "16-byte global loads", "lane shuffle",
-         "dot2 + permlane32_swap")
+         "dot2 + permlane32_swap", "mfma chain on an accumulator that starts as an LDS-read bias")
 
 
 def main():

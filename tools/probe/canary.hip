@@ -41,11 +41,13 @@ __device__ __forceinline__ f16x8 operand(int lane, int s, int mul, int mod, int 
 __global__ __launch_bounds__(256) void k_canary(CanaryArgs a) {
     __shared__ __attribute__((aligned(16))) f16x8 s_w[6 * 64];            // the A operands of test 1, as a weight image would sit in LDS
     __shared__ __attribute__((aligned(16))) float s_rw[4][64 * 4];        // test 3: one region per wavefront
+    __shared__ __attribute__((aligned(16))) float s_b[32];                // test 7: a layer's bias vector
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 6 * 64; i += 256) s_w[i] = operand(i & 63, i >> 6, 7, 17, 0);
+    if (tid < 32) s_b[tid] = (float)(tid * 3 - 40) * 0.0625f;
     __syncthreads();
 
-    v16f ref0, ref1;
+    v16f ref0, ref1, ref7;
     float ref2 = 0.0f, ref6 = 0.0f;
     for (uint32_t it = 0; it < a.iters; ++it) {
         int z = 0;
@@ -140,6 +142,31 @@ __global__ __launch_bounds__(256) void k_canary(CanaryArgs a) {
             const float sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             if (it == 0) ref6 = sum;
             report(a, 6, __float_as_uint(sum) != __float_as_uint(ref6), it, 0);
+        }
+        // ---- 7: the accumulator STARTS as a bias vector read from LDS (tl_load_bias of the torso kernels: the compiler loads it straight into the accumulator registers,
+        //         `ds_read_b128 a[0:3], ...; s_waitcnt lgkmcnt(0); v_mfma a[0:15], ..., a[0:15]`), then the chain of test 1 ------------------------------------------------
+        {
+            const int hi = lane >> 5;
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = s_b[(r & 3) + 8 * (r >> 2) + 4 * hi + z];
+            const f16x8 *p = s_w + lane + z;
+            f16x8 ring[3];
+            ring[0] = p[0]; ring[1] = p[64];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                if (s + 2 < 6) ring[(s + 2) % 3] = p[(s + 2) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s % 3], operand(lane, s, 5, 13, z), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it == 0) ref7 = acc;
+            bool bad = false;
+            uint32_t regs = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (__float_as_uint(acc[r]) != __float_as_uint(ref7[r])) { bad = true; regs |= 1u << r; }
+            report(a, 7, bad, it, regs);
         }
     }
 }
