@@ -9,6 +9,7 @@
 //   k_sr_conv3<128, up>      up-conv 128 -> 64, 256^2 -> 512^2: the transposed stride-2 convolution AND the [1,3,3,1] FIR of conv2d_resample.py:
 //                            117-133 composed on the host into one 3x3 convolution with 4 x 64 output channels (one set per output phase),
 //                            written depth-to-space                                                                              K = 1152, N = 256
+//                            (k_sr_up_poly: the same layer un-composed -- polyphase transposed convolution + the FIR as a second GEMM -- opt-in, see below)
 //   k_sr_final_resident      conv 3x3 64 -> 64 @ 512^2 + ToRGB 64 -> 3 + upsample2d(img256) fused -> rgb 512^2, one workgroup per CU with the layer's
 //                            72 KB of weights resident in LDS (k_sr_conv3<64, final> per patch: the parity partner, GFPP_SR_FINAL_RESIDENT=0)  K = 576
 // Activations travel as f16 NHWC (the reference runs both blocks in fp16 on the GPU, use_fp16=True), images as fp32; accumulation fp32.
@@ -689,12 +690,16 @@ __global__ __launch_bounds__(512, 2) void k_sr_final_resident(SrConvArgs a) {
 //   (2) T goes to LDS as f16 -- the reference's own intermediate is an fp16 tensor (x stays fp16 through conv_transpose2d and upfirdn2d) -- laid out
 //       [channel][py][my][px][mx] over the memory the halo patch and the weight chunks no longer need;
 //   (3) the FIR is a second GEMM: for one high-resolution output row, out[channel][column] = sum_k T[channel][k] G[k][column] over the two runs of two T rows
-//       (2 x (72 + 8 pad) entries) the row's four y taps touch; G holds the products of the taps {1/4, 3/4}^2 (exact in f16) and is built per lane in registers.
+//       (2 x (72 + 8 pad) entries) the row's four y taps touch; G holds the products of the taps {1/4, 3/4}^2 (exact in f16), a [2][5][64][8] table from the host
+//       (gfpp_sr_model.up_fir_g, radnerfs/superres.py::_fir_gemm_table) that a lane loads behind the products.
 //       A = T (a lane reads 8 consecutive entries of its channel: two ds_read_b64), B = G: D = channels x 32 output columns -- a lane holds one output pixel's 16
 //       channels, which is the layout the activation epilogue of the other layers works on.
 // MFMAs per low-resolution pixel: (9 x 8 x 8 tiles + 24 rows x 10) x 2 channel halves / 192 = 8.5 instead of 18; one workgroup = one 16 x 12 patch x 32 output
-// channels, 66 KB of LDS: two per CU.  Same noise / bias / activation / clamp expressions as k_sr_conv3's epilogue; not the same bits as the composed layer (T is
-// rounded to f16 here, and the sums associate differently): compared with it and with the oracle by tolerance (tests/test_kernels_gpu.py).
+// channels, 73.9 KB of LDS (the halo patch of one K slice + all nine tap matrices of the slice; T overlays both): two per CU.  Same noise / bias / activation / clamp
+// expressions as k_sr_conv3's epilogue; not the same bits as the composed layer (T is rounded to f16 here, and the sums associate differently): compared with it and with
+// the oracle by tolerance (tests/test_kernels_gpu.py); the host tables through a numpy restatement of this data flow: tests/test_sr_polyphase_cpu.py.
+// STATUS: opt-in (gfpp_tuning.sr_up_poly, default 0).  37-39 us against the composed launch's 38.6-43.7 -- but kernels of OTHER streams that share a CU with this launch's
+// MFMA phase were measured to return different bits now and then (include/gfpp_radnerf.h at the field, docs/LAB_NOTEBOOK.md round 6, tools/clip_interference.py).
 constexpr int kUpPW = 16, kUpPH = 12, kUpGW = kUpPW + 2, kUpGH = kUpPH + 2, kUpPos = kUpGW * kUpGH;      // 18 x 14 = 252 positions = 8 tiles of 32 (4 idle rows)
 constexpr int kUpRow = 2 * kUpGW;                        // one T row of a channel: [px][mx] = 36 entries
 constexpr int kUpChStride = 2056;                        // bytes between channels of T: 2 x 14 x 36 x 2 = 2016, padded so that 32 lanes' 8-byte reads hit 64 distinct banks
