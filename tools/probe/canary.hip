@@ -122,6 +122,15 @@ __global__ __launch_bounds__(256) void k_canary(CanaryArgs a) {
                 const f32x4_a8 g = *reinterpret_cast<const f32x4_a8 *>(a.tab + i);
                 bad = bad || g[0] != tab_value(i) || g[1] != tab_value(i + 1) || g[2] != tab_value(i + 2) || g[3] != tab_value(i + 3);
             }
+            // ... and dependent single-byte loads (the pre-march's bitfield probes)
+            uint32_t at = (uint32_t)((lane + z) * 53 + (int)(it % 89u) * 211 + (int)blockIdx.x * 17) % (4u * a.n_tab - 4u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t g = reinterpret_cast<const uint8_t *>(a.tab)[at];
+                const uint8_t want = (uint8_t)(__float_as_uint(tab_value(at >> 2)) >> (8u * (at & 3u)));
+                bad = bad || g != want;
+                at = (at * 5u + (uint32_t)g + 1u) % (4u * a.n_tab - 4u);          // the next address depends on the loaded byte
+            }
             report(a, 4, bad, it, 0);
         }
         // ---- 5: lane shuffles (ds_bpermute) -----------------------------------------------------------------------------------------------------------------
